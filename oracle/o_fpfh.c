@@ -1,0 +1,173 @@
+/*
+ * o_fpfh.c -- computeLocalDescriptors(FPFH) restated (TEST INFRASTRUCTURE).
+ *
+ * R/src/features.cpp:99-150 with the FPFH row of R/src/dispatch_descriptors.h:40
+ *   (pcl::FPFHEstimation<PointXYZRGB, Normal, FPFHSignature33>, setRadiusSearch,
+ *    setSearchSurface(points), setInputNormals, setInputCloud(keypoints)), then pruning of
+ *    descriptors with any non-finite bin together with their keypoints (:118-143).
+ * PCL 1.8.1 features/impl/fpfh.hpp: computeFeature, computeSPFHSignatures,
+ *   computePointSPFHSignature, weightPointSPFHSignature; features/src/pfh.cpp
+ *   pcl::computePairFeatures.  FPFHEstimation::computePairFeatures returns true
+ *   unconditionally, so a degenerate pair (f=0,0,0) is still binned.
+ */
+#include "mm3d_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NB 11
+
+static void pair_features(const mo_point *p1, const mo_normal *n1, const mo_point *p2,
+                          const mo_normal *n2, float *f1, float *f2, float *f3, float *f4)
+{
+  float d[3] = {p2->x - p1->x, p2->y - p1->y, p2->z - p1->z};
+  *f4 = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (*f4 == 0.0f) { *f1 = *f2 = *f3 = *f4 = 0.0f; return; }
+  float a[3] = {n1->nx, n1->ny, n1->nz}, b[3] = {n2->nx, n2->ny, n2->nz};
+  float angle1 = (a[0] * d[0] + a[1] * d[1] + a[2] * d[2]) / *f4;
+  float angle2 = (b[0] * d[0] + b[1] * d[1] + b[2] * d[2]) / *f4;
+  if (acos(fabs(angle1)) > acos(fabs(angle2))) {
+    /* switch p1 and p2 */
+    float t;
+    for (int i = 0; i < 3; ++i) { t = a[i]; a[i] = b[i]; b[i] = t; d[i] *= -1.0f; }
+    *f3 = -angle2;
+  } else {
+    *f3 = angle1;
+  }
+  /* v = d x n1 */
+  float v[3] = {d[1] * a[2] - d[2] * a[1], d[2] * a[0] - d[0] * a[2], d[0] * a[1] - d[1] * a[0]};
+  float v_norm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  if (v_norm == 0.0f) { *f1 = *f2 = *f3 = *f4 = 0.0f; return; }
+  v[0] /= v_norm; v[1] /= v_norm; v[2] /= v_norm;
+  /* w = n1 x v */
+  float w[3] = {a[1] * v[2] - a[2] * v[1], a[2] * v[0] - a[0] * v[2], a[0] * v[1] - a[1] * v[0]};
+  *f2 = v[0] * b[0] + v[1] * b[1] + v[2] * b[2];
+  *f1 = atan2f(w[0] * b[0] + w[1] * b[1] + w[2] * b[2], a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
+}
+
+/* static_cast<int>(floor(x)) with x86 cvttsd2si semantics for NaN/out-of-range (INT_MIN) */
+static inline int floor_to_int(double x)
+{
+  double f = floor(x);
+  if (!(f >= -2147483648.0 && f <= 2147483647.0)) return (-2147483647 - 1);
+  return (int)f;
+}
+
+static void point_spfh(const mo_point *cloud, const mo_normal *normals, int p_idx, const int *nbr,
+                       int cnt, float *hist /* 33 */)
+{
+  const float d_pi = 1.0f / (2.0f * (float)M_PI);
+  float hist_incr = 100.0f / (float)(cnt - 1);
+  for (int j = 0; j < cnt; ++j) {
+    if (p_idx == nbr[j]) continue;
+    float f1, f2, f3, f4;
+    pair_features(&cloud[p_idx], &normals[p_idx], &cloud[nbr[j]], &normals[nbr[j]], &f1, &f2, &f3, &f4);
+    int h = floor_to_int(NB * ((f1 + M_PI) * d_pi));
+    if (h < 0) h = 0;
+    if (h >= NB) h = NB - 1;
+    hist[h] += hist_incr;
+    h = floor_to_int(NB * ((f2 + 1.0) * 0.5));
+    if (h < 0) h = 0;
+    if (h >= NB) h = NB - 1;
+    hist[NB + h] += hist_incr;
+    h = floor_to_int(NB * ((f3 + 1.0) * 0.5));
+    if (h < 0) h = 0;
+    if (h >= NB) h = NB - 1;
+    hist[2 * NB + h] += hist_incr;
+  }
+}
+
+int mo_fpfh_raw(const mo_point *surface, const mo_normal *normals, int n,
+                const mo_point *keypoints, int n_kp, double radius, float *desc,
+                int *support_idx, float *spfh_out)
+{
+  mo_grid *g = mo_grid_build(surface, n, (float)(radius * 0.5));
+  const float r2 = (float)(radius * radius);
+  int cap = 4096;
+  int *idx = (int *)malloc(sizeof(int) * (size_t)cap);
+  float *d2 = (float *)malloc(sizeof(float) * (size_t)cap);
+#define SEARCH(qx, qy, qz, cntvar)                                                   \
+  do {                                                                               \
+    cntvar = mo_radius_search(g, qx, qy, qz, r2, idx, d2, cap);                      \
+    if (cntvar > cap) {                                                              \
+      cap = cntvar * 2;                                                              \
+      idx = (int *)realloc(idx, sizeof(int) * (size_t)cap);                          \
+      d2 = (float *)realloc(d2, sizeof(float) * (size_t)cap);                        \
+      cntvar = mo_radius_search(g, qx, qy, qz, r2, idx, d2, cap);                    \
+    }                                                                                \
+  } while (0)
+
+  /* computeSPFHSignatures: std::set of all neighbours of all keypoints (surface != input) */
+  unsigned char *in_set = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+  for (int k = 0; k < n_kp; ++k) {
+    int cnt;
+    SEARCH(keypoints[k].x, keypoints[k].y, keypoints[k].z, cnt);
+    for (int j = 0; j < cnt; ++j) in_set[idx[j]] = 1;
+  }
+  int *lookup = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  int ns = 0;
+  for (int i = 0; i < n; ++i) if (in_set[i]) lookup[i] = ns++; else lookup[i] = -1;
+  float *spfh = (float *)calloc((size_t)(ns > 0 ? ns : 1) * 33, sizeof(float));
+  for (int i = 0; i < n; ++i) {
+    if (!in_set[i]) continue;
+    if (support_idx) support_idx[lookup[i]] = i;
+    int cnt;
+    SEARCH(surface[i].x, surface[i].y, surface[i].z, cnt);
+    if (cnt == 0) continue;
+    point_spfh(surface, normals, i, idx, cnt, &spfh[(size_t)lookup[i] * 33]);
+  }
+  if (spfh_out) memcpy(spfh_out, spfh, sizeof(float) * (size_t)ns * 33);
+
+  /* computeFeature: weightPointSPFHSignature per keypoint */
+  for (int k = 0; k < n_kp; ++k) {
+    float *out = &desc[(size_t)k * 33];
+    int cnt;
+    SEARCH(keypoints[k].x, keypoints[k].y, keypoints[k].z, cnt);
+    if (cnt == 0) {
+      for (int b = 0; b < 33; ++b) out[b] = NAN;
+      continue;
+    }
+    double sum[3] = {0.0, 0.0, 0.0};
+    for (int b = 0; b < 33; ++b) out[b] = 0.0f;
+    for (int j = 0; j < cnt; ++j) {
+      if (d2[j] == 0) continue;            /* minus the query point itself */
+      float weight = 1.0f / d2[j];
+      const float *h = &spfh[(size_t)lookup[idx[j]] * 33];
+      for (int f = 0; f < 3; ++f)
+        for (int b = 0; b < NB; ++b) {
+          float val = h[f * NB + b] * weight;
+          sum[f] += val;
+          out[f * NB + b] += val;
+        }
+    }
+    for (int f = 0; f < 3; ++f) {
+      if (sum[f] != 0) sum[f] = 100.0 / sum[f];
+      for (int b = 0; b < NB; ++b) out[f * NB + b] *= (float)sum[f];
+    }
+  }
+#undef SEARCH
+  free(idx); free(d2); free(in_set); free(lookup); free(spfh);
+  mo_grid_free(g);
+  return ns;
+}
+
+int mo_descriptors_fpfh(const mo_point *surface, const mo_normal *normals, int n,
+                        mo_point *keypoints, int n_kp, double radius, float *desc)
+{
+  if (n_kp <= 0) return 0;
+  mo_fpfh_raw(surface, normals, n, keypoints, n_kp, radius, desc, NULL, NULL);
+  /* DefaultPointRepresentation<FPFHSignature33>::isValid: all 33 floats finite; prune both */
+  int m = 0;
+  for (int k = 0; k < n_kp; ++k) {
+    int valid = 1;
+    for (int b = 0; b < 33; ++b) if (!isfinite(desc[(size_t)k * 33 + b])) { valid = 0; break; }
+    if (!valid) continue;
+    if (m != k) {
+      memmove(&desc[(size_t)m * 33], &desc[(size_t)k * 33], sizeof(float) * 33);
+      keypoints[m] = keypoints[k];
+    }
+    ++m;
+  }
+  return m;
+}

@@ -1,0 +1,134 @@
+/*
+ * o_sift.c -- detectKeypoints(SIFT) restated (TEST INFRASTRUCTURE).
+ *
+ * R/src/features.cpp:45-62,85-96:
+ *   pcl::SIFTKeypoint<PointXYZRGB, PointWithScale>; setScales(resolution, 3, 3);
+ *   setMinimumContrast(threshold); result copied with pcl::copyPointCloud (xyz only, rgb = 0).
+ * PCL 1.8.1 keypoints/impl/sift_keypoint.hpp: detectKeypoints, detectKeypointsForOctave,
+ *   computeScaleSpace, findScaleSpaceExtrema; keypoints/sift_keypoint.h
+ *   SIFTKeypointFieldSelector<PointXYZRGB>: (299*r + 587*g + 114*b) / 1000.0f.
+ */
+#include "mm3d_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float intensity(const mo_point *p)
+{
+  int r = (int)((p->rgba >> 16) & 255u), g = (int)((p->rgba >> 8) & 255u), b = (int)(p->rgba & 255u);
+  return (float)(299 * r + 587 * g + 114 * b) / 1000.0f;
+}
+
+typedef struct { mo_point *pts; float *scales; int n, cap; } kp_vec;
+static void kp_push(kp_vec *v, float x, float y, float z, float scale)
+{
+  if (v->n == v->cap) {
+    v->cap = v->cap ? v->cap * 2 : 1024;
+    v->pts = (mo_point *)realloc(v->pts, sizeof(mo_point) * (size_t)v->cap);
+    v->scales = (float *)realloc(v->scales, sizeof(float) * (size_t)v->cap);
+  }
+  v->pts[v->n].x = x; v->pts[v->n].y = y; v->pts[v->n].z = z; v->pts[v->n].rgba = 0;
+  v->scales[v->n] = scale;
+  v->n++;
+}
+
+static void detect_octave(const mo_point *cloud, int n, float base_scale, int nr_scales_per_octave,
+                          float min_contrast, kp_vec *out)
+{
+  const int ns = nr_scales_per_octave + 3;
+  float *scales = (float *)malloc(sizeof(float) * (size_t)ns);
+  for (int i = 0; i < ns; ++i)
+    scales[i] = base_scale * powf(2.0f, (1.0f * (float)i - 1.0f) / (float)nr_scales_per_octave);
+  const int nd = ns - 1;                       /* DoG columns */
+  float *dog = (float *)malloc(sizeof(float) * (size_t)n * (size_t)nd);
+  const float max_radius = 3.0f * scales[ns - 1];
+  /* tree.radiusSearch(i_point, max_radius): KdTreeFLANN casts radius*radius (double) to float */
+  const float r2 = (float)((double)max_radius * (double)max_radius);
+  mo_grid *g = mo_grid_build(cloud, n, max_radius * 0.5f);
+
+  int cap = 4096;
+  int *idx = (int *)malloc(sizeof(int) * (size_t)cap);
+  float *d2 = (float *)malloc(sizeof(float) * (size_t)cap);
+  /* computeScaleSpace */
+  for (int i = 0; i < n; ++i) {
+    int cnt = mo_radius_search(g, cloud[i].x, cloud[i].y, cloud[i].z, r2, idx, d2, cap);
+    if (cnt > cap) {
+      cap = cnt * 2;
+      idx = (int *)realloc(idx, sizeof(int) * (size_t)cap);
+      d2 = (float *)realloc(d2, sizeof(float) * (size_t)cap);
+      cnt = mo_radius_search(g, cloud[i].x, cloud[i].y, cloud[i].z, r2, idx, d2, cap);
+    }
+    float filter_response = 0.0f, previous_filter_response;
+    for (int s = 0; s < ns; ++s) {
+      float sigma_sqr = powf(scales[s], 2.0f);
+      float numerator = 0.0f, denominator = 0.0f;
+      for (int j = 0; j < cnt; ++j) {
+        float value = intensity(&cloud[idx[j]]);
+        float dist_sqr = d2[j];
+        if (dist_sqr <= 9 * sigma_sqr) {
+          float w = expf(-0.5f * dist_sqr / sigma_sqr);
+          numerator += value * w;
+          denominator += w;
+        } else {
+          break;   /* sorted: beyond 3 sigma */
+        }
+      }
+      previous_filter_response = filter_response;
+      filter_response = numerator / denominator;
+      if (s > 0) dog[(size_t)i * nd + (s - 1)] = filter_response - previous_filter_response;
+    }
+  }
+  /* findScaleSpaceExtrema */
+  const int k = 25;
+  int nn_idx[25]; float nn_d2[25];
+  float *min_val = (float *)malloc(sizeof(float) * (size_t)nd), *max_val = (float *)malloc(sizeof(float) * (size_t)nd);
+  for (int i = 0; i < n; ++i) {
+    int nr_nn = mo_knn_search(g, cloud[i].x, cloud[i].y, cloud[i].z, k, INFINITY, nn_idx, nn_d2);
+    for (int s = 0; s < nd; ++s) {
+      min_val[s] = FLT_MAX; max_val[s] = -FLT_MAX;
+      for (int j = 0; j < nr_nn; ++j) {
+        float d = dog[(size_t)nn_idx[j] * nd + s];
+        /* std::min/std::max: NaN in d never replaces the running value */
+        min_val[s] = (d < min_val[s]) ? d : min_val[s];
+        max_val[s] = (max_val[s] < d) ? d : max_val[s];
+      }
+    }
+    for (int s = 1; s < nd - 1; ++s) {
+      float val = dog[(size_t)i * nd + s];
+      if (fabs(val) >= min_contrast) {
+        if ((val == min_val[s]) && (val <= min_val[s - 1]) && (val <= min_val[s + 1]))
+          kp_push(out, cloud[i].x, cloud[i].y, cloud[i].z, scales[s]);
+        else if ((val == max_val[s]) && (val >= max_val[s - 1]) && (val >= max_val[s + 1]))
+          kp_push(out, cloud[i].x, cloud[i].y, cloud[i].z, scales[s]);
+      }
+    }
+  }
+  free(min_val); free(max_val); free(idx); free(d2); free(dog); free(scales);
+  mo_grid_free(g);
+}
+
+int mo_keypoints_sift(const mo_point *in, int n, double min_scale, int nr_octaves,
+                      int nr_scales_per_octave, double min_contrast, mo_point **out,
+                      float **scales_out)
+{
+  kp_vec kv = {0, 0, 0, 0};
+  mo_point *cloud = (mo_point *)malloc(sizeof(mo_point) * (size_t)(n > 0 ? n : 1));
+  memcpy(cloud, in, sizeof(mo_point) * (size_t)(n > 0 ? n : 0));
+  int cn = n;
+  float scale = (float)min_scale;
+  for (int oct = 0; oct < nr_octaves; ++oct) {
+    const float s = 1.0f * scale;
+    mo_point *tmp = (mo_point *)malloc(sizeof(mo_point) * (size_t)(cn > 0 ? cn : 1));
+    int tn = mo_downsample(cloud, cn, (double)s, tmp);
+    free(cloud); cloud = tmp; cn = tn;
+    if (cn < 25) break;
+    detect_octave(cloud, cn, scale, nr_scales_per_octave, (float)min_contrast, &kv);
+    scale *= 2;
+  }
+  free(cloud);
+  *out = kv.pts;
+  if (scales_out) *scales_out = kv.scales; else free(kv.scales);
+  return kv.n;
+}

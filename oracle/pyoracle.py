@@ -1,0 +1,271 @@
+"""ctypes binding of the CPU oracle (liboracle_mm3d.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see oracle/mm3d_oracle.h).  The product package never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
+NORMAL = np.dtype([("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4"), ("curvature", "<f4")])
+CORR = np.dtype([("index_query", "<i4"), ("index_match", "<i4"), ("distance", "<f4")])
+ESTIMATE = np.dtype([("source_idx", "<u8"), ("target_idx", "<u8"), ("transform", "<f4", (16,)),
+                     ("confidence", "<f8")])
+
+
+class Params(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("descriptor_radius", C.c_double),
+                ("outliers_min_neighbours", C.c_int), ("normal_radius", C.c_double),
+                ("keypoint_type", C.c_int), ("keypoint_threshold", C.c_double),
+                ("descriptor_type", C.c_int), ("estimation_method", C.c_int),
+                ("refine_transform", C.c_int), ("inlier_threshold", C.c_double),
+                ("max_correspondence_distance", C.c_double), ("max_iterations", C.c_int),
+                ("matching_k", C.c_uint64), ("transform_epsilon", C.c_double),
+                ("confidence_threshold", C.c_double), ("output_resolution", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle_mm3d.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.mo_transform_score.restype = C.c_double
+        L.mo_mt19937_next.restype = C.c_uint32
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _pts(a):
+    a = np.ascontiguousarray(a, dtype=POINT)
+    return a
+
+
+def params_default() -> Params:
+    p = Params()
+    lib().mo_params_default(C.byref(p))
+    return p
+
+
+def downsample(pts, resolution):
+    pts = _pts(pts)
+    out = np.empty(len(pts), dtype=POINT)
+    n = lib().mo_downsample(_p(pts), len(pts), C.c_double(resolution), _p(out))
+    return out[:n].copy()
+
+
+def remove_outliers(pts, radius, min_neighbors):
+    pts = _pts(pts)
+    out = np.empty(len(pts), dtype=POINT)
+    n = lib().mo_remove_outliers(_p(pts), len(pts), C.c_double(radius), int(min_neighbors), _p(out))
+    return out[:n].copy()
+
+
+def normals(pts, radius):
+    pts = _pts(pts)
+    out = np.empty(len(pts), dtype=NORMAL)
+    lib().mo_normals(_p(pts), len(pts), C.c_double(radius), _p(out))
+    return out
+
+
+def keypoints_sift(pts, min_scale, nr_octaves=3, nr_scales=3, min_contrast=5.0):
+    pts = _pts(pts)
+    outp = C.c_void_p()
+    outs = C.c_void_p()
+    n = lib().mo_keypoints_sift(_p(pts), len(pts), C.c_double(min_scale), nr_octaves, nr_scales,
+                                C.c_double(min_contrast), C.byref(outp), C.byref(outs))
+    if n > 0:
+        kp = np.frombuffer((C.c_char * (16 * n)).from_address(outp.value), dtype=POINT).copy()
+        sc = np.frombuffer((C.c_char * (4 * n)).from_address(outs.value), dtype=np.float32).copy()
+    else:
+        kp = np.empty(0, dtype=POINT)
+        sc = np.empty(0, dtype=np.float32)
+    lib().mo_free(outp)
+    lib().mo_free(outs)
+    return kp, sc
+
+
+def fpfh_raw(surface, nrm, keypoints, radius):
+    surface = _pts(surface)
+    nrm = np.ascontiguousarray(nrm, dtype=NORMAL)
+    keypoints = _pts(keypoints)
+    desc = np.empty((len(keypoints), 33), dtype=np.float32)
+    support = np.empty(len(surface), dtype=np.int32)
+    spfh = np.empty((len(surface), 33), dtype=np.float32)
+    ns = lib().mo_fpfh_raw(_p(surface), _p(nrm), len(surface), _p(keypoints), len(keypoints),
+                           C.c_double(radius), _p(desc), _p(support), _p(spfh))
+    return desc, support[:ns].copy(), spfh[:ns].copy()
+
+
+def descriptors_fpfh(surface, nrm, keypoints, radius):
+    """Returns (pruned keypoints, descriptors) like computeLocalDescriptors (which mutates keypoints)."""
+    surface = _pts(surface)
+    nrm = np.ascontiguousarray(nrm, dtype=NORMAL)
+    kp = _pts(keypoints).copy()
+    desc = np.empty((max(len(kp), 1), 33), dtype=np.float32)
+    n = lib().mo_descriptors_fpfh(_p(surface), _p(nrm), len(surface), _p(kp), len(kp),
+                                  C.c_double(radius), _p(desc))
+    return kp[:n].copy(), desc[:n].copy()
+
+
+def desc_knn(a, b, k):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    idx = np.empty((len(a), k), dtype=np.int32)
+    d2 = np.empty((len(a), k), dtype=np.float32)
+    lib().mo_desc_knn(_p(a), len(a), _p(b), len(b), a.shape[1], k, _p(idx), _p(d2))
+    return idx, d2
+
+
+def find_correspondences(ds, dt, k=5):
+    ds = np.ascontiguousarray(ds, dtype=np.float32)
+    dt = np.ascontiguousarray(dt, dtype=np.float32)
+    out = np.empty(max(len(ds), 1), dtype=CORR)
+    n = lib().mo_find_correspondences(_p(ds), len(ds), _p(dt), len(dt), ds.shape[1] if ds.ndim == 2 else 33,
+                                      C.c_size_t(k), _p(out))
+    return out[:n].copy()
+
+
+def ransac(src_kp, tgt_kp, corr, inlier_threshold):
+    src_kp, tgt_kp = _pts(src_kp), _pts(tgt_kp)
+    corr = np.ascontiguousarray(corr, dtype=CORR)
+    T = np.zeros(16, dtype=np.float32)
+    inl = np.empty(max(len(corr), 1), dtype=CORR)
+    iters, best = C.c_int(), C.c_int()
+    n = lib().mo_ransac(_p(src_kp), len(src_kp), _p(tgt_kp), len(tgt_kp), _p(corr), len(corr),
+                        C.c_double(inlier_threshold), _p(T), _p(inl), C.byref(iters), C.byref(best))
+    return T.reshape(4, 4).T.copy(), inl[:n].copy(), iters.value, best.value
+
+
+def srand(seed):
+    lib().mo_srand(C.c_uint(seed))
+
+
+def rand():
+    return lib().mo_rand()
+
+
+def sac_ia(src_kp, src_desc, tgt_kp, tgt_desc, min_sample_distance, max_corr_dist, max_iterations):
+    src_kp, tgt_kp = _pts(src_kp), _pts(tgt_kp)
+    sd = np.ascontiguousarray(src_desc, dtype=np.float32)
+    td = np.ascontiguousarray(tgt_desc, dtype=np.float32)
+    T = np.zeros(16, dtype=np.float32)
+    bi, be = C.c_int(), C.c_float()
+    lib().mo_sac_ia(_p(src_kp), _p(sd), len(src_kp), _p(tgt_kp), _p(td), len(tgt_kp), sd.shape[1],
+                    C.c_double(min_sample_distance), C.c_double(max_corr_dist), int(max_iterations),
+                    _p(T), C.byref(bi), C.byref(be))
+    return T.reshape(4, 4).T.copy(), bi.value, be.value
+
+
+def icp(src, tgt, guess, max_corr_dist, outlier_thr, max_iterations, eps):
+    src, tgt = _pts(src), _pts(tgt)
+    g = np.ascontiguousarray(np.asarray(guess, dtype=np.float32).T.reshape(16))
+    T = np.zeros(16, dtype=np.float32)
+    it = C.c_int()
+    lib().mo_icp(_p(src), len(src), _p(tgt), len(tgt), _p(g), C.c_double(max_corr_dist),
+                 C.c_double(outlier_thr), int(max_iterations), C.c_double(eps), _p(T), C.byref(it))
+    return T.reshape(4, 4).T.copy(), it.value
+
+
+def transform_score(src, tgt, T, max_distance):
+    src, tgt = _pts(src), _pts(tgt)
+    t = np.ascontiguousarray(np.asarray(T, dtype=np.float32).T.reshape(16))
+    return lib().mo_transform_score(_p(src), len(src), _p(tgt), len(tgt), _p(t), C.c_double(max_distance))
+
+
+def umeyama_f32(src, dst):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    dst = np.ascontiguousarray(dst, dtype=np.float32)
+    T = np.zeros(16, dtype=np.float32)
+    lib().mo_umeyama_f32(_p(src), _p(dst), len(src), _p(T))
+    return T.reshape(4, 4).T.copy()
+
+
+def mat4_inverse(A):
+    a = np.ascontiguousarray(np.asarray(A, dtype=np.float32).T.reshape(16))
+    o = np.zeros(16, dtype=np.float32)
+    lib().mo_mat4_inverse(_p(a), _p(o))
+    return o.reshape(4, 4).T.copy()
+
+
+def make_estimates(pairs):
+    """pairs: iterable of (src, tgt, T 4x4 row/col numpy, confidence)."""
+    est = np.zeros(len(pairs), dtype=ESTIMATE)
+    for i, (s, t, T, c) in enumerate(pairs):
+        est[i]["source_idx"], est[i]["target_idx"], est[i]["confidence"] = s, t, c
+        est[i]["transform"] = np.asarray(T, dtype=np.float32).T.reshape(16)
+    return est
+
+
+def global_transforms(est, confidence_threshold, cap_nodes=None):
+    est = np.ascontiguousarray(est, dtype=ESTIMATE)
+    cap = cap_nodes or (int(max(est["source_idx"].max(initial=0), est["target_idx"].max(initial=0))) + 1
+                        if len(est) else 1)
+    out = np.zeros((cap, 16), dtype=np.float32)
+    n = lib().mo_global_transforms(_p(est), len(est), C.c_double(confidence_threshold), _p(out), cap)
+    return [out[i].reshape(4, 4).T.copy() for i in range(max(n, 0))]
+
+
+def largest_component(est, thr):
+    est = np.ascontiguousarray(est, dtype=ESTIMATE)
+    kept = np.zeros(max(len(est), 1), dtype=np.int32)
+    lib().mo_largest_component(_p(est), len(est), C.c_double(thr), _p(kept))
+    return kept[:len(est)].astype(bool)
+
+
+def spanning_tree_centers(est):
+    est = np.ascontiguousarray(est, dtype=ESTIMATE)
+    c = (C.c_size_t * 2)()
+    n = lib().mo_max_spanning_tree_centers(_p(est), len(est), c)
+    return [int(c[i]) for i in range(min(n, 2))], n
+
+
+def estimate_maps_transforms(clouds, params: Params):
+    clouds = [_pts(c) for c in clouds]
+    n = len(clouds)
+    ptrs = (C.c_void_p * max(n, 1))(*[c.ctypes.data for c in clouds])
+    sizes = (C.c_int * max(n, 1))(*[len(c) for c in clouds])
+    out = np.zeros((max(n, 1), 16), dtype=np.float32)
+    pairs = np.zeros(max(n * (n - 1) // 2, 1), dtype=ESTIMATE)
+    npairs = C.c_int()
+    m = lib().mo_estimate_maps_transforms(ptrs, sizes, n, C.byref(params), _p(out), _p(pairs), C.byref(npairs))
+    if m < 0:
+        raise RuntimeError(f"oracle estimate_maps_transforms failed: {m}")
+    return [out[i].reshape(4, 4).T.copy() for i in range(m)], pairs[:npairs.value].copy()
+
+
+def compose_maps(clouds, transforms, resolution):
+    clouds = [_pts(c) for c in clouds]
+    n = len(clouds)
+    ptrs = (C.c_void_p * max(n, 1))(*[c.ctypes.data for c in clouds])
+    sizes = (C.c_int * max(n, 1))(*[len(c) for c in clouds])
+    tr = np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float32).T.reshape(16) for T in transforms])
+                              if len(transforms) else np.zeros((0, 16), np.float32))
+    outp = C.c_void_p()
+    m = lib().mo_compose_maps(ptrs, sizes, n, _p(tr) if len(tr) else None, len(transforms),
+                              C.c_double(resolution), C.byref(outp))
+    if m == -1:
+        return None
+    if m == -2:
+        raise RuntimeError("composeMaps: clouds and transforms size must be the same.")
+    res = np.frombuffer((C.c_char * (16 * m)).from_address(outp.value), dtype=POINT).copy() if m > 0 \
+        else np.empty(0, dtype=POINT)
+    lib().mo_free(outp)
+    return res
