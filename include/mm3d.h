@@ -1,0 +1,228 @@
+/*
+ * mm3d.h -- C ABI of libmm3d.so, the MI355X (gfx950) registration engine that replaces the
+ * hot path of map_merge_3d (static library `map_merging`, R/CMakeLists.txt:67-74).
+ *
+ * The reference has no FFI: its seam is the C++ free-function API in
+ * R/include/map_merge_3d/{features,matching,map_merging}.h.  Every entry point below names the
+ * reference declaration it replaces; include/map_merge_3d_shim.hpp shows the C++ forwarding
+ * layer a maintainer links instead of the static library.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types; nothing throws across the boundary;
+ *     every function returns an mm3d_status (MM3D_OK == 0) and mm3d_last_error() gives text.
+ *   - "points" are pcl::PointXYZRGB payloads: float x,y,z at byte 0 and uint32 rgba
+ *     (0xAARRGGBB, PCL byte order b,g,r,a) at byte `rgba_offset`, `stride` bytes apart.
+ *     pcl::PointXYZRGB itself is stride 32 / rgba_offset 16; packed records are 16 / 12.
+ *     Source pointers may be host or device (HBM) addresses.
+ *   - 4x4 transforms are column-major float[16] (Eigen::Matrix4f storage); the all-zero matrix
+ *     is the reference's "could not be estimated" sentinel (matching.h:41-42, map_merging.h:81-83).
+ *   - enums carry the reference's integer values (features.h:20-24,49; matching.h:103).
+ *   - one estimation at a time per context (internally serialised); contexts are independent.
+ */
+#ifndef MM3D_H_
+#define MM3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MM3D_OK = 0,
+  MM3D_EINVAL = -1,        /* bad argument (also: unknown enum string, like enums::from_string) */
+  MM3D_EDEVICE = -2,       /* HIP runtime / device failure */
+  MM3D_ENOMEM = -3,
+  MM3D_EUNSUPPORTED = -4,  /* descriptor / keypoint type outside the implemented path */
+  MM3D_ECAPACITY = -5      /* caller buffer too small; required size is reported */
+} mm3d_status;
+
+/* R/include/map_merge_3d/features.h:20-24 (ENUM_CLASS(Descriptor, PFH, PFHRGB, FPFH, RSD, SHOT, SC3D)) */
+typedef enum { MM3D_DESC_PFH = 0, MM3D_DESC_PFHRGB, MM3D_DESC_FPFH, MM3D_DESC_RSD, MM3D_DESC_SHOT, MM3D_DESC_SC3D } mm3d_descriptor;
+/* R/include/map_merge_3d/features.h:49 */
+typedef enum { MM3D_KP_SIFT = 0, MM3D_KP_HARRIS } mm3d_keypoint;
+/* R/include/map_merge_3d/matching.h:103 */
+typedef enum { MM3D_EST_MATCHING = 0, MM3D_EST_SAC_IA } mm3d_estimation_method;
+
+/* enums::to_string / enums::from_string (R/include/map_merge_3d/enum.h:30-67) and the
+ * PointCloud2 field-name table of R/src/dispatch_descriptors.h:38-48. */
+const char *mm3d_descriptor_name(int d);              /* "PFH" ... or NULL */
+int mm3d_descriptor_from_string(const char *s);       /* value or MM3D_EINVAL */
+const char *mm3d_descriptor_field_name(int d);        /* "pfh","pfhrgb","fpfh","r_min","shot","shape_context" */
+int mm3d_descriptor_dim(int d);                       /* 125, 250, 33, 2, 1344, 1980 */
+const char *mm3d_keypoint_name(int k);
+int mm3d_keypoint_from_string(const char *s);
+const char *mm3d_estimation_method_name(int m);
+int mm3d_estimation_method_from_string(const char *s);
+
+/* MapMergingParams, field for field (R/include/map_merge_3d/map_merging.h:28-44). */
+typedef struct {
+  double resolution;
+  double descriptor_radius;
+  int outliers_min_neighbours;
+  double normal_radius;
+  int keypoint_type;
+  double keypoint_threshold;
+  int descriptor_type;
+  int estimation_method;
+  int refine_transform;
+  double inlier_threshold;
+  double max_correspondence_distance;
+  int max_iterations;
+  uint64_t matching_k;
+  double transform_epsilon;
+  double confidence_threshold;
+  double output_resolution;
+} mm3d_params;
+/* the defaults of map_merging.h:28-44 (dependent defaults evaluated from resolution = 0.1) */
+void mm3d_params_default(mm3d_params *p);
+/* MapMergingParams::fromCommandLine (R/src/map_merging.cpp:10-54): "--name value", unknown
+ * options ignored, matching_k applied only if > 0; bad enum string -> MM3D_EINVAL. */
+int mm3d_params_from_command_line(int argc, const char *const *argv, mm3d_params *p);
+/* operator<<(ostream, MapMergingParams) (R/src/map_merging.cpp:100-123); returns bytes needed. */
+size_t mm3d_params_to_string(const mm3d_params *p, char *buf, size_t cap);
+
+typedef struct { int32_t index_query, index_match; float distance; } mm3d_corr; /* pcl::Correspondence */
+
+typedef struct mm3d_ctx mm3d_ctx;
+typedef struct mm3d_cloud mm3d_cloud;      /* device-resident PointCloud<PointXYZRGB> */
+typedef struct mm3d_normals mm3d_normals;  /* device-resident PointCloud<Normal> */
+typedef struct mm3d_desc mm3d_desc;        /* device-resident descriptors (PCLPointCloud2 payload) */
+
+/* ---- context -------------------------------------------------------------------------- */
+int mm3d_create(int device, mm3d_ctx **out);
+void mm3d_destroy(mm3d_ctx *ctx);
+const char *mm3d_last_error(const mm3d_ctx *ctx);
+/* SAC-IA draws from libc rand() in the reference (process-global, glibc seed 1).  The context
+ * carries its own replay of that generator; mm3d_srand re-seeds it (srand semantics). */
+void mm3d_srand(mm3d_ctx *ctx, unsigned seed);
+
+/* ---- cloud objects -------------------------------------------------------------------- */
+int mm3d_cloud_create(mm3d_ctx *ctx, const void *points, size_t n, size_t stride, size_t rgba_offset,
+                      mm3d_cloud **out);
+size_t mm3d_cloud_size(const mm3d_cloud *c);
+int mm3d_cloud_download(mm3d_ctx *ctx, const mm3d_cloud *c, void *dst, size_t stride, size_t rgba_offset);
+void mm3d_cloud_free(mm3d_ctx *ctx, mm3d_cloud *c);
+size_t mm3d_normals_size(const mm3d_normals *n);
+/* 16-byte records nx,ny,nz,curvature (pcl::Normal payload) */
+int mm3d_normals_download(mm3d_ctx *ctx, const mm3d_normals *n, void *dst, size_t stride);
+int mm3d_normals_create(mm3d_ctx *ctx, const void *normals, size_t n, size_t stride, mm3d_normals **out);
+void mm3d_normals_free(mm3d_ctx *ctx, mm3d_normals *n);
+size_t mm3d_desc_size(const mm3d_desc *d);
+int mm3d_desc_dim(const mm3d_desc *d);
+int mm3d_desc_type(const mm3d_desc *d);
+int mm3d_desc_download(mm3d_ctx *ctx, const mm3d_desc *d, float *dst /* size*dim */);
+int mm3d_desc_create(mm3d_ctx *ctx, const float *data, size_t n, int descriptor_type, mm3d_desc **out);
+void mm3d_desc_free(mm3d_ctx *ctx, mm3d_desc *d);
+
+/* ---- features.h ----------------------------------------------------------------------- */
+/* downSample (R/include/map_merge_3d/features.h:34, R/src/features.cpp:17-27) */
+int mm3d_downsample(mm3d_ctx *ctx, const mm3d_cloud *in, double resolution, mm3d_cloud **out);
+/* removeOutliers (features.h:45, features.cpp:31-43) */
+int mm3d_remove_outliers(mm3d_ctx *ctx, const mm3d_cloud *in, double radius, int min_neighbours,
+                         mm3d_cloud **out);
+/* computeSurfaceNormals (features.h:97, features.cpp:168-179) */
+int mm3d_compute_normals(mm3d_ctx *ctx, const mm3d_cloud *in, double radius, mm3d_normals **out);
+/* detectKeypoints (features.h:65, features.cpp:85-96).  SIFT only; HARRIS -> MM3D_EUNSUPPORTED.
+ * An invalid enum is UB in the reference (falls off the switch); here MM3D_EINVAL. */
+int mm3d_detect_keypoints(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_normals *normals,
+                          int type, double threshold, double radius, double resolution,
+                          mm3d_cloud **keypoints);
+/* computeLocalDescriptors (features.h:83, features.cpp:99-166).  Like the reference it prunes
+ * keypoints whose descriptor is not finite: *keypoints is replaced IN PLACE by the pruned cloud.
+ * FPFH only; others -> MM3D_EUNSUPPORTED. */
+int mm3d_compute_descriptors(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_normals *normals,
+                             mm3d_cloud *keypoints, int descriptor, double feature_radius,
+                             mm3d_desc **out);
+
+/* ---- matching.h ----------------------------------------------------------------------- */
+/* findFeatureCorrespondences (matching.h:26, matching.cpp:31-108).  Two-call protocol: with
+ * out == NULL only *n is written. */
+int mm3d_find_correspondences(mm3d_ctx *ctx, const mm3d_desc *source, const mm3d_desc *target, size_t k,
+                              mm3d_corr *out, size_t cap, size_t *n);
+/* estimateTransformFromCorrespondences (matching.h:44, matching.cpp:110-140) */
+int mm3d_estimate_transform_from_correspondences(mm3d_ctx *ctx, const mm3d_cloud *source_keypoints,
+                                                 const mm3d_cloud *target_keypoints, const mm3d_corr *corr,
+                                                 size_t n_corr, double inlier_threshold, float T[16],
+                                                 mm3d_corr *inliers, size_t cap, size_t *n_inliers);
+/* estimateTransformFromDescriptorsSets, SAC-IA (matching.h:68, matching.cpp:142-194) */
+int mm3d_estimate_transform_from_descriptors(mm3d_ctx *ctx, const mm3d_cloud *source_keypoints,
+                                             const mm3d_desc *source_descriptors,
+                                             const mm3d_cloud *target_keypoints,
+                                             const mm3d_desc *target_descriptors, double min_sample_distance,
+                                             double max_correspondence_distance, int max_iterations,
+                                             float T[16]);
+/* estimateTransformICP (matching.h:94, matching.cpp:196-221) */
+int mm3d_estimate_transform_icp(mm3d_ctx *ctx, const mm3d_cloud *source, const mm3d_cloud *target,
+                                const float initial_guess[16], double max_correspondence_distance,
+                                double outlier_rejection_threshold, int max_iterations,
+                                double transformation_epsilon, float T[16]);
+/* estimateTransform (matching.h:129, matching.cpp:223-257) */
+int mm3d_estimate_transform(mm3d_ctx *ctx, const mm3d_cloud *source_points, const mm3d_cloud *source_keypoints,
+                            const mm3d_desc *source_descriptors, const mm3d_cloud *target_points,
+                            const mm3d_cloud *target_keypoints, const mm3d_desc *target_descriptors,
+                            int method, int refine, double inlier_threshold,
+                            double max_correspondence_distance, int max_iterations, size_t matching_k,
+                            double transform_epsilon, float T[16]);
+/* transformScore (matching.h:150, matching.cpp:259-268) */
+int mm3d_transform_score(mm3d_ctx *ctx, const mm3d_cloud *source, const mm3d_cloud *target,
+                         const float T[16], double max_distance, double *score);
+
+/* ---- map_merging.h -------------------------------------------------------------------- */
+typedef struct { const void *points; size_t n; size_t stride; size_t rgba_offset; } mm3d_cloud_view;
+/* TransformEstimate (R/src/graph.h:24-36) plus diagnostics */
+typedef struct {
+  uint64_t source_idx, target_idx;
+  float transform[16];
+  double confidence;
+  int32_t icp_iterations;
+  int32_t reserved;
+} mm3d_pair_result;
+
+/* estimateMapsTransforms (map_merging.h:85, map_merging.cpp:188-275).
+ * out_T has room for n*16 floats; *n_out = 0 for no cloud, 1 (identity) for one cloud,
+ * otherwise `max pair index + 1` like the reference (map_merging.cpp:168) -- or n with all-zero
+ * matrices when no pair survives (the reference is UB there).  pairs (optional, capacity
+ * n*(n-1)/2) receives the pairwise estimates in pair order. */
+int mm3d_estimate_maps_transforms(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n,
+                                  const mm3d_params *params, float *out_T, size_t *n_out,
+                                  mm3d_pair_result *pairs, size_t *n_pairs);
+/* composeMaps (map_merging.h:99, map_merging.cpp:277-305): *out = NULL for n == 0 (nullptr in
+ * the reference); n != n_transforms -> MM3D_EINVAL (the reference throws). */
+int mm3d_compose_maps(mm3d_ctx *ctx, const mm3d_cloud *const *clouds, size_t n, const float *transforms,
+                      size_t n_transforms, double resolution, mm3d_cloud **out);
+
+/* ---- the same path in shardable pieces (one process per GPU; see bench.py) -------------- */
+typedef struct mm3d_map mm3d_map;   /* per-map bundle: filtered cloud + keypoints + descriptors */
+/* the per-cloud loop body of map_merging.cpp:212-242 */
+int mm3d_map_features(mm3d_ctx *ctx, const mm3d_cloud *raw, const mm3d_params *params, mm3d_map **out);
+const mm3d_cloud *mm3d_map_points(const mm3d_map *m);
+const mm3d_cloud *mm3d_map_keypoints(const mm3d_map *m);
+const mm3d_desc *mm3d_map_descriptors(const mm3d_map *m);
+int mm3d_map_from_parts(mm3d_ctx *ctx, mm3d_cloud *points, mm3d_cloud *keypoints, mm3d_desc *desc,
+                        mm3d_map **out);            /* takes ownership (feature exchange between ranks) */
+void mm3d_map_free(mm3d_ctx *ctx, mm3d_map *m);
+/* the per-pair loop body of map_merging.cpp:256-269.  execute == 0 only advances the context's
+ * rand() replay exactly as the pair would (ranks that do not own the pair stay in lock-step with
+ * the reference's single global stream). */
+int mm3d_pair_estimate(mm3d_ctx *ctx, const mm3d_map *source, const mm3d_map *target,
+                       const mm3d_params *params, int execute, mm3d_pair_result *out);
+/* computeGlobalTransforms (map_merging.cpp:153-186 + graph.cpp); host only, needs no device. */
+int mm3d_global_transforms(const mm3d_pair_result *pairs, size_t n_pairs, double confidence_threshold,
+                           size_t n_clouds, float *out_T, size_t *n_out);
+
+/* ---- measurement ---------------------------------------------------------------------- */
+/* per-kernel HIP-event timing on the context's own stream (bench.py roofline leg) */
+int mm3d_profile_enable(mm3d_ctx *ctx, int on);
+void mm3d_profile_reset(mm3d_ctx *ctx);
+/* number of distinct kernels recorded; names via mm3d_profile_entry */
+int mm3d_profile_count(mm3d_ctx *ctx);
+int mm3d_profile_entry(mm3d_ctx *ctx, int i, const char **name, double *total_ms, uint64_t *launches,
+                       double *algorithmic_bytes);
+int mm3d_synchronize(mm3d_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM3D_H_ */

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds libmm3d.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+# -ffp-contract=off: float arithmetic must round exactly like the CPU path it is checked against;
+# kernels that may fuse say fmaf() explicitly.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-parameter"
+mkdir -p build
+SRCS="grid.hip filters.hip normals.hip sift.hip fpfh.hip desc_knn.hip registration.hip linalg.cpp host_pipeline.cpp capi.cpp"
+OBJS=""
+pids=()
+for s in $SRCS; do
+  o=build/${s%.*}.o
+  OBJS="$OBJS $o"
+  if [ ! -f "$o" ] || [ "csrc/$s" -nt "$o" ] || [ -n "$(find csrc ../include -name '*.h*' -newer "$o" 2>/dev/null)" ]; then
+    ( $HIPCC $FLAGS -x hip -c "csrc/$s" -o "$o" ${EXTRA:-} ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libmm3d.so $OBJS
+echo "built $(pwd)/libmm3d.so"

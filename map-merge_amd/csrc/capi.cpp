@@ -1,0 +1,596 @@
+// capi.cpp -- the extern "C" boundary of libmm3d.so (include/mm3d.h).  Nothing throws across it.
+#include <algorithm>
+#include <cstdlib>
+#include <functional>
+#include <sstream>
+#include <string>
+
+#include "device_util.hpp"
+
+using namespace mm3d;
+
+namespace {
+
+template <class F>
+int guarded(mm3d_ctx *ctx, F &&f)
+{
+  if (!ctx) return MM3D_EINVAL;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  try {
+    if (hipSetDevice(ctx->device) != hipSuccess) throw Error(MM3D_EDEVICE, "hipSetDevice failed");
+    f();
+    return MM3D_OK;
+  } catch (const Error &e) {
+    ctx->err = e.what();
+    return e.status;
+  } catch (const std::bad_alloc &) {
+    ctx->err = "out of host memory";
+    return MM3D_ENOMEM;
+  } catch (const std::exception &e) {
+    ctx->err = e.what();
+    return MM3D_EDEVICE;
+  } catch (...) {
+    ctx->err = "unknown error";
+    return MM3D_EDEVICE;
+  }
+}
+
+const char *kDescNames[] = {"PFH", "PFHRGB", "FPFH", "RSD", "SHOT", "SC3D"};
+const char *kDescFields[] = {"pfh", "pfhrgb", "fpfh", "r_min", "shot", "shape_context"};
+const int kDescDims[] = {125, 250, 33, 2, 1344, 1980};
+const char *kKpNames[] = {"SIFT", "HARRIS"};
+const char *kEstNames[] = {"MATCHING", "SAC_IA"};
+
+int from_string(const char *s, const char *const *names, int n)
+{
+  if (!s) return MM3D_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (std::string(names[i]) == s) return i;
+  return MM3D_EINVAL;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- enums / params
+const char *mm3d_descriptor_name(int d) { return (d >= 0 && d < 6) ? kDescNames[d] : nullptr; }
+int mm3d_descriptor_from_string(const char *s) { return from_string(s, kDescNames, 6); }
+const char *mm3d_descriptor_field_name(int d) { return (d >= 0 && d < 6) ? kDescFields[d] : nullptr; }
+int mm3d_descriptor_dim(int d) { return (d >= 0 && d < 6) ? kDescDims[d] : MM3D_EINVAL; }
+const char *mm3d_keypoint_name(int k) { return (k >= 0 && k < 2) ? kKpNames[k] : nullptr; }
+int mm3d_keypoint_from_string(const char *s) { return from_string(s, kKpNames, 2); }
+const char *mm3d_estimation_method_name(int m) { return (m >= 0 && m < 2) ? kEstNames[m] : nullptr; }
+int mm3d_estimation_method_from_string(const char *s) { return from_string(s, kEstNames, 2); }
+
+void mm3d_params_default(mm3d_params *p)
+{
+  if (!p) return;
+  p->resolution = 0.1;
+  p->descriptor_radius = p->resolution * 8.0;
+  p->outliers_min_neighbours = 50;
+  p->normal_radius = p->resolution * 6.0;
+  p->keypoint_type = MM3D_KP_SIFT;
+  p->keypoint_threshold = 5.0;
+  p->descriptor_type = MM3D_DESC_PFH;
+  p->estimation_method = MM3D_EST_MATCHING;
+  p->refine_transform = 1;
+  p->inlier_threshold = p->resolution * 5.0;
+  p->max_correspondence_distance = p->inlier_threshold * 2.0;
+  p->max_iterations = 500;
+  p->matching_k = 5;
+  p->transform_epsilon = 1e-2;
+  p->confidence_threshold = 0.0;
+  p->output_resolution = 0.05;
+}
+
+// pcl::console::parse_argument semantics: the first occurrence of "--name" (argv[1..]) followed by a
+// value is taken; unknown options are ignored; a bool is atoi(value) == 1.
+int mm3d_params_from_command_line(int argc, const char *const *argv, mm3d_params *p)
+{
+  if (!p || (argc > 0 && !argv)) return MM3D_EINVAL;
+  mm3d_params_default(p);
+  auto find = [&](const char *name) -> const char * {
+    for (int i = 1; i < argc; ++i)   // pcl::console::find_argument
+      if (argv[i] && std::string(argv[i]) == name) return (i + 1 < argc) ? argv[i + 1] : nullptr;
+    return nullptr;
+  };
+  auto get_d = [&](const char *name, double &v) { if (const char *s = find(name)) v = std::atof(s); };
+  auto get_i = [&](const char *name, int &v) { if (const char *s = find(name)) v = std::atoi(s); };
+  get_d("--resolution", p->resolution);
+  get_d("--descriptor_radius", p->descriptor_radius);
+  get_i("--outliers_min_neighbours", p->outliers_min_neighbours);
+  get_d("--normal_radius", p->normal_radius);
+  if (const char *s = find("--keypoint_type"); s && *s) {
+    int v = mm3d_keypoint_from_string(s);
+    if (v < 0) return MM3D_EINVAL;
+    p->keypoint_type = v;
+  }
+  get_d("--keypoint_threshold", p->keypoint_threshold);
+  if (const char *s = find("--descriptor_type"); s && *s) {
+    int v = mm3d_descriptor_from_string(s);
+    if (v < 0) return MM3D_EINVAL;
+    p->descriptor_type = v;
+  }
+  if (const char *s = find("--estimation_method"); s && *s) {
+    int v = mm3d_estimation_method_from_string(s);
+    if (v < 0) return MM3D_EINVAL;
+    p->estimation_method = v;
+  }
+  if (const char *s = find("--refine_transform")) p->refine_transform = std::atoi(s) == 1;   // parse_argument(bool&)
+  get_d("--inlier_threshold", p->inlier_threshold);
+  get_d("--max_correspondence_distance", p->max_correspondence_distance);
+  get_i("--max_iterations", p->max_iterations);
+  int matching_k = -1;
+  get_i("--matching_k", matching_k);
+  if (matching_k > 0) p->matching_k = (uint64_t)matching_k;
+  get_d("--transform_epsilon", p->transform_epsilon);
+  get_d("--confidence_threshold", p->confidence_threshold);
+  get_d("--output_resolution", p->output_resolution);
+  return MM3D_OK;
+}
+
+size_t mm3d_params_to_string(const mm3d_params *p, char *buf, size_t cap)
+{
+  if (!p) return 0;
+  std::ostringstream s;
+  s << "resolution: " << p->resolution << std::endl;
+  s << "descriptor_radius: " << p->descriptor_radius << std::endl;
+  s << "outliers_min_neighbours: " << p->outliers_min_neighbours << std::endl;
+  s << "normal_radius: " << p->normal_radius << std::endl;
+  s << "keypoint_type: " << (mm3d_keypoint_name(p->keypoint_type) ? mm3d_keypoint_name(p->keypoint_type) : "?") << std::endl;
+  s << "keypoint_threshold: " << p->keypoint_threshold << std::endl;
+  s << "descriptor_type: " << (mm3d_descriptor_name(p->descriptor_type) ? mm3d_descriptor_name(p->descriptor_type) : "?") << std::endl;
+  s << "estimation_method: "
+    << (mm3d_estimation_method_name(p->estimation_method) ? mm3d_estimation_method_name(p->estimation_method) : "?") << std::endl;
+  s << "refine_transform: " << (p->refine_transform ? 1 : 0) << std::endl;
+  s << "inlier_threshold: " << p->inlier_threshold << std::endl;
+  s << "max_correspondence_distance: " << p->max_correspondence_distance << std::endl;
+  s << "max_iterations: " << p->max_iterations << std::endl;
+  s << "matching_k: " << p->matching_k << std::endl;
+  s << "transform_epsilon: " << p->transform_epsilon << std::endl;
+  s << "confidence_threshold: " << p->confidence_threshold << std::endl;
+  s << "output_resolution: " << p->output_resolution << std::endl;
+  const std::string str = s.str();
+  if (buf && cap) {
+    size_t m = std::min(cap - 1, str.size());
+    std::memcpy(buf, str.data(), m);
+    buf[m] = 0;
+  }
+  return str.size() + 1;
+}
+
+// ---------------------------------------------------------------- context
+int mm3d_create(int device, mm3d_ctx **out)
+{
+  if (!out) return MM3D_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return MM3D_EDEVICE;
+  if (hipSetDevice(device) != hipSuccess) return MM3D_EDEVICE;
+  auto *c = new (std::nothrow) mm3d_ctx();
+  if (!c) return MM3D_ENOMEM;
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MM3D_EDEVICE; }
+  *out = c;
+  return MM3D_OK;
+}
+
+void mm3d_destroy(mm3d_ctx *ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  ctx->pool.trim();
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *mm3d_last_error(const mm3d_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+void mm3d_srand(mm3d_ctx *ctx, unsigned seed) { if (ctx) ctx->rnd.seed(seed); }
+int mm3d_synchronize(mm3d_ctx *ctx) { return guarded(ctx, [&] { ctx->sync(); }); }
+
+// ---------------------------------------------------------------- objects
+int mm3d_cloud_create(mm3d_ctx *ctx, const void *points, size_t n, size_t stride, size_t rgba_offset, mm3d_cloud **out)
+{
+  if (!out) return MM3D_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = cloud_from_memory(ctx, points, n, stride, rgba_offset); ctx->sync(); });
+}
+size_t mm3d_cloud_size(const mm3d_cloud *c) { return c ? c->n : 0; }
+int mm3d_cloud_download(mm3d_ctx *ctx, const mm3d_cloud *c, void *dst, size_t stride, size_t rgba_offset)
+{
+  if (!c || (!dst && c->n)) return MM3D_EINVAL;
+  return guarded(ctx, [&] { cloud_download(ctx, c, dst, stride, rgba_offset); });
+}
+void mm3d_cloud_free(mm3d_ctx *ctx, mm3d_cloud *c)
+{
+  if (!ctx || !c) return;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  (void)hipStreamSynchronize(ctx->stream);
+  delete c;
+}
+
+size_t mm3d_normals_size(const mm3d_normals *n) { return n ? n->n : 0; }
+int mm3d_normals_download(mm3d_ctx *ctx, const mm3d_normals *n, void *dst, size_t stride)
+{
+  if (!n || (!dst && n->n) || stride < 16 || stride % 4) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    if (!n->n) return;
+    MM3D_HIP(hipMemcpy2DAsync(dst, stride, n->nrm.get(), 16, 16, n->n, hipMemcpyDefault, ctx->stream));
+    ctx->sync();
+  });
+}
+int mm3d_normals_create(mm3d_ctx *ctx, const void *normals, size_t n, size_t stride, mm3d_normals **out)
+{
+  if (!out || stride < 16 || stride % 4 || (!normals && n)) return MM3D_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    auto *r = new mm3d_normals();
+    r->n = n;
+    r->nrm = DevBuf<float4>(ctx, n);
+    if (n) {
+      MM3D_HIP(hipMemcpy2DAsync(r->nrm.get(), 16, normals, stride, 16, n, hipMemcpyDefault, ctx->stream));
+      ctx->sync();
+    }
+    *out = r;
+  });
+}
+void mm3d_normals_free(mm3d_ctx *ctx, mm3d_normals *n)
+{
+  if (!ctx || !n) return;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  (void)hipStreamSynchronize(ctx->stream);
+  delete n;
+}
+
+size_t mm3d_desc_size(const mm3d_desc *d) { return d ? d->n : 0; }
+int mm3d_desc_dim(const mm3d_desc *d) { return d ? d->dim : 0; }
+int mm3d_desc_type(const mm3d_desc *d) { return d ? d->type : MM3D_EINVAL; }
+int mm3d_desc_download(mm3d_ctx *ctx, const mm3d_desc *d, float *dst)
+{
+  if (!d || (!dst && d->n)) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    if (!d->n) return;
+    MM3D_HIP(hipMemcpyAsync(dst, d->data.get(), d->n * d->dim * sizeof(float), hipMemcpyDefault, ctx->stream));
+    ctx->sync();
+  });
+}
+int mm3d_desc_create(mm3d_ctx *ctx, const float *data, size_t n, int descriptor_type, mm3d_desc **out)
+{
+  if (!out || (!data && n)) return MM3D_EINVAL;
+  *out = nullptr;
+  const int dim = mm3d_descriptor_dim(descriptor_type);
+  if (dim < 0) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    auto *r = new mm3d_desc();
+    r->n = n; r->dim = dim; r->type = descriptor_type;
+    r->data = DevBuf<float>(ctx, n * dim);
+    if (n) {
+      MM3D_HIP(hipMemcpyAsync(r->data.get(), data, n * dim * sizeof(float), hipMemcpyDefault, ctx->stream));
+      ctx->sync();
+    }
+    *out = r;
+  });
+}
+void mm3d_desc_free(mm3d_ctx *ctx, mm3d_desc *d)
+{
+  if (!ctx || !d) return;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  (void)hipStreamSynchronize(ctx->stream);
+  delete d;
+}
+
+// ---------------------------------------------------------------- features.h
+int mm3d_downsample(mm3d_ctx *ctx, const mm3d_cloud *in, double resolution, mm3d_cloud **out)
+{
+  if (!in || !out) return MM3D_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = downsample(ctx, in, resolution); });
+}
+
+int mm3d_remove_outliers(mm3d_ctx *ctx, const mm3d_cloud *in, double radius, int min_neighbours, mm3d_cloud **out)
+{
+  if (!in || !out) return MM3D_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = remove_outliers(ctx, in, radius, min_neighbours); });
+}
+
+int mm3d_compute_normals(mm3d_ctx *ctx, const mm3d_cloud *in, double radius, mm3d_normals **out)
+{
+  if (!in || !out) return MM3D_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = compute_normals(ctx, in, radius); ctx->sync(); });
+}
+
+int mm3d_detect_keypoints(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_normals *normals, int type, double threshold,
+                          double radius, double resolution, mm3d_cloud **keypoints)
+{
+  (void)normals; (void)radius;
+  if (!points || !keypoints) return MM3D_EINVAL;
+  *keypoints = nullptr;
+  return guarded(ctx, [&] {
+    if (type == MM3D_KP_SIFT) {
+      // detectKeypointsSIFT(points, resolution, 3, 3, threshold)  (features.cpp:92)
+      *keypoints = detect_keypoints_sift(ctx, points, resolution, 3, 3, threshold);
+    } else if (type == MM3D_KP_HARRIS) {
+      throw Error(MM3D_EUNSUPPORTED, "HARRIS keypoints are not built (outside the north-star path)");
+    } else {
+      throw Error(MM3D_EINVAL, "invalid keypoint type");
+    }
+  });
+}
+
+int mm3d_compute_descriptors(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_normals *normals, mm3d_cloud *keypoints,
+                             int descriptor, double feature_radius, mm3d_desc **out)
+{
+  if (!points || !normals || !keypoints || !out) return MM3D_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    if (descriptor == MM3D_DESC_FPFH) {
+      *out = compute_fpfh(ctx, points, normals, keypoints, feature_radius);
+    } else if (descriptor >= 0 && descriptor < 6) {
+      throw Error(MM3D_EUNSUPPORTED, std::string("descriptor ") + kDescNames[descriptor] + " is not built (only FPFH is)");
+    } else {
+      throw Error(MM3D_EINVAL, "unknown descriptor type");   // dispatch_descriptors.h:63
+    }
+  });
+}
+
+// ---------------------------------------------------------------- matching.h
+int mm3d_find_correspondences(mm3d_ctx *ctx, const mm3d_desc *source, const mm3d_desc *target, size_t k, mm3d_corr *out,
+                              size_t cap, size_t *n)
+{
+  if (!source || !target || !n) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    // assertDescriptorsPair / dispatch by field name: both sides must be the same descriptor kind
+    if (source->type != target->type) throw Error(MM3D_EINVAL, "descriptor types differ");
+    std::vector<mm3d_corr> v;
+    find_correspondences(ctx, source, target, k, v);
+    *n = v.size();
+    if (out) {
+      if (cap < v.size()) throw Error(MM3D_ECAPACITY, "correspondence buffer too small");
+      std::memcpy(out, v.data(), v.size() * sizeof(mm3d_corr));
+    }
+  });
+}
+
+int mm3d_estimate_transform_from_correspondences(mm3d_ctx *ctx, const mm3d_cloud *skp, const mm3d_cloud *tkp,
+                                                 const mm3d_corr *corr, size_t n_corr, double inlier_threshold, float T[16],
+                                                 mm3d_corr *inliers, size_t cap, size_t *n_inliers)
+{
+  if (!skp || !tkp || (!corr && n_corr) || !T) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    std::vector<mm3d_corr> inl;
+    ransac_transform(ctx, skp, tkp, corr, n_corr, inlier_threshold, T, inl);
+    if (n_inliers) *n_inliers = inl.size();
+    if (inliers) {
+      if (cap < inl.size()) throw Error(MM3D_ECAPACITY, "inlier buffer too small");
+      std::memcpy(inliers, inl.data(), inl.size() * sizeof(mm3d_corr));
+    }
+  });
+}
+
+int mm3d_estimate_transform_from_descriptors(mm3d_ctx *ctx, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tkp,
+                                             const mm3d_desc *td, double min_sample_distance, double max_corr_dist,
+                                             int max_iterations, float T[16])
+{
+  if (!skp || !sd || !tkp || !td || !T) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    if (sd->type != td->type) throw Error(MM3D_EINVAL, "descriptor types differ");
+    sac_ia(ctx, skp, sd, tkp, td, min_sample_distance, max_corr_dist, max_iterations, T, true);
+  });
+}
+
+int mm3d_estimate_transform_icp(mm3d_ctx *ctx, const mm3d_cloud *source, const mm3d_cloud *target, const float guess[16],
+                                double max_corr_dist, double outlier_rejection_threshold, int max_iterations, double eps,
+                                float T[16])
+{
+  (void)outlier_rejection_threshold;   // setRANSACOutlierRejectionThreshold: no rejector is registered in the reference
+  if (!source || !target || !guess || !T) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    IcpResult r = icp(ctx, source, target, guess, max_corr_dist, max_iterations, eps);
+    std::memcpy(T, r.T, sizeof(r.T));
+  });
+}
+
+int mm3d_estimate_transform(mm3d_ctx *ctx, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd,
+                            const mm3d_cloud *tp, const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine,
+                            double inlier_threshold, double max_corr_dist, int max_iterations, size_t matching_k, double eps,
+                            float T[16])
+{
+  if (!sp || !skp || !sd || !tp || !tkp || !td || !T) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    estimate_transform(ctx, sp, skp, sd, tp, tkp, td, method, refine, inlier_threshold, max_corr_dist, max_iterations,
+                       matching_k, eps, T, true);
+  });
+}
+
+int mm3d_transform_score(mm3d_ctx *ctx, const mm3d_cloud *source, const mm3d_cloud *target, const float T[16],
+                         double max_distance, double *score)
+{
+  if (!source || !target || !T || !score) return MM3D_EINVAL;
+  return guarded(ctx, [&] { *score = transform_score(ctx, source, target, T, max_distance); });
+}
+
+// ---------------------------------------------------------------- map bundles
+static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const mm3d_params *p)
+{
+  if (p->keypoint_type != MM3D_KP_SIFT) throw Error(p->keypoint_type == MM3D_KP_HARRIS ? MM3D_EUNSUPPORTED : MM3D_EINVAL,
+                                                   "only SIFT keypoints are built");
+  if (p->descriptor_type != MM3D_DESC_FPFH)
+    throw Error((p->descriptor_type >= 0 && p->descriptor_type < 6) ? MM3D_EUNSUPPORTED : MM3D_EINVAL,
+                "only FPFH descriptors are built");
+  std::unique_ptr<mm3d_cloud> down(downsample(ctx, raw, p->resolution));
+  // NB: the outlier radius is the DESCRIPTOR radius (map_merging.cpp:219-220)
+  std::unique_ptr<mm3d_cloud> filt(remove_outliers(ctx, down.get(), p->descriptor_radius, p->outliers_min_neighbours));
+  down.reset();
+  std::unique_ptr<mm3d_normals> nrm(compute_normals(ctx, filt.get(), p->normal_radius));
+  std::unique_ptr<mm3d_cloud> kp(detect_keypoints_sift(ctx, filt.get(), p->resolution, 3, 3, p->keypoint_threshold));
+  std::unique_ptr<mm3d_desc> desc(compute_fpfh(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius));
+  ctx->sync();
+  auto *m = new mm3d_map();
+  m->points = filt.release();
+  m->keypoints = kp.release();
+  m->desc = desc.release();
+  return m;
+}
+
+int mm3d_map_features(mm3d_ctx *ctx, const mm3d_cloud *raw, const mm3d_params *params, mm3d_map **out)
+{
+  if (!raw || !params || !out) return MM3D_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = map_features_impl(ctx, raw, params); });
+}
+
+const mm3d_cloud *mm3d_map_points(const mm3d_map *m) { return m ? m->points : nullptr; }
+const mm3d_cloud *mm3d_map_keypoints(const mm3d_map *m) { return m ? m->keypoints : nullptr; }
+const mm3d_desc *mm3d_map_descriptors(const mm3d_map *m) { return m ? m->desc : nullptr; }
+
+int mm3d_map_from_parts(mm3d_ctx *ctx, mm3d_cloud *points, mm3d_cloud *keypoints, mm3d_desc *desc, mm3d_map **out)
+{
+  if (!ctx || !points || !keypoints || !desc || !out) return MM3D_EINVAL;
+  if (keypoints->n != desc->n) return MM3D_EINVAL;
+  auto *m = new mm3d_map();
+  m->points = points; m->keypoints = keypoints; m->desc = desc;
+  *out = m;
+  return MM3D_OK;
+}
+
+void mm3d_map_free(mm3d_ctx *ctx, mm3d_map *m)
+{
+  if (!ctx || !m) return;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  (void)hipStreamSynchronize(ctx->stream);
+  delete m->points; delete m->keypoints; delete m->desc;
+  delete m;
+}
+
+static void pair_estimate_impl(mm3d_ctx *ctx, const mm3d_map *s, const mm3d_map *t, const mm3d_params *p, bool execute,
+                               mm3d_pair_result *out)
+{
+  std::memset(out->transform, 0, sizeof(out->transform));
+  out->confidence = 0.0;
+  out->icp_iterations = 0;
+  out->reserved = 0;
+  const int iters = estimate_transform(ctx, s->points, s->keypoints, s->desc, t->points, t->keypoints, t->desc,
+                                       p->estimation_method, p->refine_transform, p->inlier_threshold,
+                                       p->max_correspondence_distance, p->max_iterations, (size_t)p->matching_k,
+                                       p->transform_epsilon, out->transform, execute);
+  if (!execute) return;
+  out->icp_iterations = iters;
+  const double score = transform_score(ctx, s->points, t->points, out->transform, p->max_correspondence_distance);
+  out->confidence = 1.0 / score;
+}
+
+int mm3d_pair_estimate(mm3d_ctx *ctx, const mm3d_map *source, const mm3d_map *target, const mm3d_params *params, int execute,
+                       mm3d_pair_result *out)
+{
+  if (!source || !target || !params || !out) return MM3D_EINVAL;
+  return guarded(ctx, [&] { pair_estimate_impl(ctx, source, target, params, execute != 0, out); });
+}
+
+int mm3d_global_transforms(const mm3d_pair_result *pairs, size_t n_pairs, double confidence_threshold, size_t n_clouds,
+                           float *out_T, size_t *n_out)
+{
+  if ((!pairs && n_pairs) || !out_T || !n_out) return MM3D_EINVAL;
+  try {
+    return global_transforms(pairs, n_pairs, confidence_threshold, n_clouds, out_T, n_out);
+  } catch (...) {
+    return MM3D_ENOMEM;
+  }
+}
+
+// ---------------------------------------------------------------- map_merging.h
+int mm3d_estimate_maps_transforms(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, const mm3d_params *params,
+                                  float *out_T, size_t *n_out, mm3d_pair_result *pairs_out, size_t *n_pairs_out)
+{
+  if (!params || !n_out || (n && (!clouds || !out_T))) return MM3D_EINVAL;
+  if (n_pairs_out) *n_pairs_out = 0;
+  *n_out = 0;
+  if (n == 0) return MM3D_OK;                       // {} -> {}  (map_merging.cpp:192-194)
+  if (n == 1) {                                     // one cloud -> {Identity}, the cloud is not touched (:195-197)
+    std::memset(out_T, 0, sizeof(float) * 16);
+    out_T[0] = out_T[5] = out_T[10] = out_T[15] = 1.0f;
+    *n_out = 1;
+    return MM3D_OK;
+  }
+  return guarded(ctx, [&] {
+    std::vector<std::unique_ptr<mm3d_map, std::function<void(mm3d_map *)>>> maps;
+    auto del = [](mm3d_map *m) { if (m) { delete m->points; delete m->keypoints; delete m->desc; delete m; } };
+    for (size_t i = 0; i < n; ++i) {
+      // a null / empty map (robot subscribed but no message yet) counts as "no keypoints"
+      std::unique_ptr<mm3d_cloud> raw(cloud_from_memory(ctx, clouds[i].points, clouds[i].points ? clouds[i].n : 0,
+                                                        clouds[i].stride ? clouds[i].stride : 16,
+                                                        clouds[i].stride ? clouds[i].rgba_offset : 12));
+      maps.emplace_back(map_features_impl(ctx, raw.get(), params), del);
+    }
+    std::vector<mm3d_pair_result> pairs;
+    for (size_t i = 0; i + 1 < n; ++i)
+      for (size_t j = i + 1; j < n; ++j)
+        if (maps[i]->keypoints->n > 0 && maps[j]->keypoints->n > 0) {
+          mm3d_pair_result r;
+          std::memset(&r, 0, sizeof(r));
+          r.source_idx = i; r.target_idx = j;
+          pairs.push_back(r);
+        }
+    for (auto &r : pairs) pair_estimate_impl(ctx, maps[r.source_idx].get(), maps[r.target_idx].get(), params, true, &r);
+    if (pairs_out) std::memcpy(pairs_out, pairs.data(), pairs.size() * sizeof(mm3d_pair_result));
+    if (n_pairs_out) *n_pairs_out = pairs.size();
+    int st = global_transforms(pairs.data(), pairs.size(), params->confidence_threshold, n, out_T, n_out);
+    if (st != MM3D_OK) throw Error(st, "computeGlobalTransforms failed");
+  });
+}
+
+int mm3d_compose_maps(mm3d_ctx *ctx, const mm3d_cloud *const *clouds, size_t n, const float *transforms, size_t n_transforms,
+                      double resolution, mm3d_cloud **out)
+{
+  if (!out) return MM3D_EINVAL;
+  *out = nullptr;
+  if (n == 0) return MM3D_OK;                       // nullptr (map_merging.cpp:281-283)
+  if (n != n_transforms) {                          // the reference throws (map_merging.cpp:285-288)
+    if (ctx) ctx->err = "composeMaps: clouds and transforms size must be the same.";
+    return MM3D_EINVAL;
+  }
+  if (!clouds || !transforms) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    std::unique_ptr<mm3d_cloud> cat(transform_concat(ctx, clouds, n, transforms));
+    *out = downsample(ctx, cat.get(), resolution);
+  });
+}
+
+// ---------------------------------------------------------------- measurement
+int mm3d_profile_enable(mm3d_ctx *ctx, int on)
+{
+  return guarded(ctx, [&] { ctx->prof_resolve(); ctx->prof_on = on != 0; });
+}
+void mm3d_profile_reset(mm3d_ctx *ctx)
+{
+  if (!ctx) return;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  try { ctx->prof_resolve(); } catch (...) {}
+  for (auto &e : ctx->prof) e = ProfEntry();
+}
+int mm3d_profile_count(mm3d_ctx *ctx)
+{
+  if (!ctx) return 0;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  try { ctx->prof_resolve(); } catch (...) {}
+  return (int)ctx->prof.size();
+}
+int mm3d_profile_entry(mm3d_ctx *ctx, int i, const char **name, double *total_ms, uint64_t *launches, double *bytes)
+{
+  if (!ctx) return MM3D_EINVAL;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (i < 0 || i >= (int)ctx->prof.size()) return MM3D_EINVAL;
+  if (name) *name = ctx->prof_names[i].c_str();
+  if (total_ms) *total_ms = ctx->prof[i].ms;
+  if (launches) *launches = ctx->prof[i].launches;
+  if (bytes) *bytes = ctx->prof[i].bytes;
+  return MM3D_OK;
+}
+
+}  // extern "C"

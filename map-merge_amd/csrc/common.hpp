@@ -1,0 +1,195 @@
+// common.hpp -- shared host-side plumbing of libmm3d (context, device buffers, launch/profiling).
+//
+// MI355X-native (gfx950) only.  Device memory comes from a per-context size-class pool on top of
+// hipMalloc so the per-pair loop never hits the allocator; every kernel of a context runs on the
+// context's own stream.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mm3d.h"
+
+namespace mm3d {
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int s, const std::string &m) : std::runtime_error(m), status(s) {}
+};
+
+#define MM3D_HIP(expr)                                                                            \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      throw ::mm3d::Error(MM3D_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + \
+                                            __FILE__ + ":" + std::to_string(__LINE__) + ")");     \
+  } while (0)
+
+#define MM3D_REQUIRE(cond, msg)                                  \
+  do {                                                           \
+    if (!(cond)) throw ::mm3d::Error(MM3D_EINVAL, (msg));        \
+  } while (0)
+
+// ---- glibc rand() replay (TYPE_3 additive feedback; SAC-IA's getRandomIndex) -----------------
+struct GlibcRand {
+  uint32_t ring[31];
+  int f = 3, b = 0;
+  GlibcRand() { seed(1); }
+  void seed(unsigned s)
+  {
+    if (s == 0) s = 1;
+    int32_t r[31];
+    r[0] = (int32_t)s;
+    for (int i = 1; i < 31; ++i) {
+      long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+      long word = 16807 * lo - 2836 * hi;
+      if (word < 0) word += 2147483647;
+      r[i] = (int32_t)word;
+    }
+    for (int i = 0; i < 31; ++i) ring[i] = (uint32_t)r[i];
+    f = 3; b = 0;
+    for (int i = 0; i < 310; ++i) (void)next();
+  }
+  int next()
+  {
+    ring[f] += ring[b];
+    uint32_t res = ring[f] >> 1;
+    f = (f + 1) % 31;
+    b = (b + 1) % 31;
+    return (int)res;
+  }
+};
+
+// ---- boost::mt19937 (pcl::SampleConsensusModel::rnd) -----------------------------------------
+struct Mt19937 {
+  uint32_t s[624];
+  int pos = 624;
+  explicit Mt19937(uint32_t seed)
+  {
+    s[0] = seed;
+    for (int i = 1; i < 624; ++i) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + (uint32_t)i;
+  }
+  uint32_t next()
+  {
+    if (pos >= 624) {
+      for (int k = 0; k < 624; ++k) {
+        uint32_t y = (s[k] & 0x80000000u) | (s[(k + 1) % 624] & 0x7fffffffu);
+        s[k] = s[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      pos = 0;
+    }
+    uint32_t y = s[pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
+};
+
+// ---- profiling ----------------------------------------------------------------------------------
+struct ProfEntry {
+  double ms = 0.0;
+  uint64_t launches = 0;
+  double bytes = 0.0;
+};
+
+struct Context;
+
+// ---- device memory pool -------------------------------------------------------------------------
+class Pool {
+ public:
+  void *alloc(size_t bytes);
+  void release(void *p);
+  void trim();
+  ~Pool() { trim(); }
+
+ private:
+  static size_t size_class(size_t bytes);
+  std::unordered_map<size_t, std::vector<void *>> free_;
+  std::unordered_map<void *, size_t> live_;
+};
+
+struct Context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Pool pool;
+  std::string err;
+  std::mutex mu;
+  GlibcRand rnd;
+  // pinned host scratch for small D2H reads
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
+  // profiling
+  bool prof_on = false;
+  struct Pending { int slot; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+  std::vector<std::string> prof_names;
+  std::vector<ProfEntry> prof;
+  std::unordered_map<std::string, int> prof_index;
+
+  void *pin(size_t bytes);
+  void sync() { MM3D_HIP(hipStreamSynchronize(stream)); }
+  int prof_slot(const char *name);
+  void prof_resolve();
+};
+
+template <typename T>
+class DevBuf {
+ public:
+  DevBuf() = default;
+  DevBuf(Context *c, size_t n) : ctx_(c), n_(n) { p_ = n ? (T *)c->pool.alloc(n * sizeof(T)) : nullptr; }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : ctx_(o.ctx_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept
+  {
+    if (this != &o) { reset(); ctx_ = o.ctx_; p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
+    return *this;
+  }
+  ~DevBuf() { reset(); }
+  void reset()
+  {
+    if (p_) ctx_->pool.release(p_);
+    p_ = nullptr; n_ = 0;
+  }
+  T *get() const { return p_; }
+  size_t size() const { return n_; }
+
+ private:
+  Context *ctx_ = nullptr;
+  T *p_ = nullptr;
+  size_t n_ = 0;
+};
+
+// RAII kernel timer: HIP events on the context stream around one launch (only when profiling)
+struct KernelScope {
+  Context *c;
+  int slot = -1;
+  hipEvent_t a = nullptr, b = nullptr;
+  KernelScope(Context *ctx, const char *name, double bytes);
+  ~KernelScope();
+};
+
+#define MM3D_LAUNCH(ctx, name, bytes, kernel, grid, block, shmem, ...)                      \
+  do {                                                                                      \
+    ::mm3d::KernelScope ks_((ctx), (name), (double)(bytes));                                \
+    hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (ctx)->stream, __VA_ARGS__);       \
+    MM3D_HIP(hipGetLastError());                                                            \
+  } while (0)
+
+inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace mm3d

@@ -1,0 +1,185 @@
+// device_util.hpp -- device-side helpers shared by the gfx950 kernels.
+//
+// Arithmetic policy: the library is compiled with -ffp-contract=off, so a*b+c is two roundings
+// exactly like the CPU path it must agree with; kernels that are not bit-critical say fmaf()
+// explicitly.  Wave = 64 lanes (CDNA4); nothing here assumes 32.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "types.hpp"
+
+namespace mm3d {
+
+constexpr int kWave = 64;
+constexpr int kXcds = 8;   // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only)
+
+// XCD-aware block remap: give every XCD one contiguous slice of the (spatially sorted) work so
+// that each private 4 MiB L2 caches one region of the grid instead of all of it.  Bijective for
+// any grid size (cdna_hip_programming.md T1).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks)
+{
+  unsigned q = nblocks / kXcds, r = nblocks % kXcds;
+  unsigned xcd = bid % kXcds, k = bid / kXcds;
+  unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+__device__ __forceinline__ unsigned f2ord(float f)
+{
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(unsigned u)
+{
+  unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  f = __uint_as_float(v);
+#else
+  memcpy(&f, &v, 4);
+#endif
+  return f;
+}
+
+// FLANN L2_Simple order: ((dx*dx + dy*dy) + dz*dz), no contraction
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz)
+{
+  float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// pcl::transformPointCloud order: ((m0*x + m1*y) + m2*z) + m3, per row; T column-major
+__device__ __forceinline__ float3 xform(const float *T, float x, float y, float z)
+{
+  float3 r;
+  r.x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], x), __fmul_rn(T[4], y)), __fmul_rn(T[8], z)), T[12]);
+  r.y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[1], x), __fmul_rn(T[5], y)), __fmul_rn(T[9], z)), T[13]);
+  r.z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[2], x), __fmul_rn(T[6], y)), __fmul_rn(T[10], z)), T[14]);
+  return r;
+}
+
+__device__ __forceinline__ int cell_floor(float v, float mn, float inv)
+{
+  float f = floorf((v - mn) * inv);
+  f = fminf(fmaxf(f, -1048576.0f), 1048576.0f);
+  return (int)f;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Visit every point of the grid that can lie within `r` of q: (2s+1)^2 contiguous row spans.
+// f(const float4 &p) -> bool; returning false stops the walk early.
+template <class F>
+__device__ __forceinline__ void for_each_candidate(const GridView &g, float qx, float qy, float qz, float r, F &&f)
+{
+  const float ri = r * 1.0001f + 1e-4f;   // keeps the cell range conservative under float rounding
+  int x0 = clampi(cell_floor(qx - ri, g.minx, g.inv), 0, g.dx - 1);
+  int x1 = clampi(cell_floor(qx + ri, g.minx, g.inv), 0, g.dx - 1);
+  int y0 = cell_floor(qy - ri, g.miny, g.inv), y1 = cell_floor(qy + ri, g.miny, g.inv);
+  int z0 = cell_floor(qz - ri, g.minz, g.inv), z1 = cell_floor(qz + ri, g.minz, g.inv);
+  if (cell_floor(qx + ri, g.minx, g.inv) < 0 || cell_floor(qx - ri, g.minx, g.inv) > g.dx - 1) return;
+  y0 = y0 < 0 ? 0 : y0; z0 = z0 < 0 ? 0 : z0;
+  y1 = y1 > g.dy - 1 ? g.dy - 1 : y1; z1 = z1 > g.dz - 1 ? g.dz - 1 : z1;
+  for (int z = z0; z <= z1; ++z)
+    for (int y = y0; y <= y1; ++y) {
+      const int row = (z * g.dy + y) * g.dx;
+      const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+      for (int j = b; j < e; ++j)
+        if (!f(g.pts[j])) return;
+    }
+}
+
+// ---- wave / block reductions -------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+  return v;
+}
+
+// ---- pcl::eigen33 (common/impl/eigen.hpp) ------------------------------------------------------
+__host__ __device__ inline void compute_roots2(float b, float c, float *roots)
+{
+  roots[0] = 0.0f;
+  float d = (float)((double)(b * b) - 4.0 * (double)c);
+  if (d < 0.0f) d = 0.0f;
+  float sd = sqrtf(d);
+  roots[2] = 0.5f * (b + sd);
+  roots[1] = 0.5f * (b - sd);
+}
+
+__host__ __device__ inline void compute_roots(const float *m /* row-major symmetric 3x3 */, float *roots)
+{
+  float c0 = m[0] * m[4] * m[8] + 2.0f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] -
+             m[8] * m[1] * m[1];
+  float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+  float c2 = m[0] + m[4] + m[8];
+  if (fabsf(c0) < 1.1920929e-07f) {
+    compute_roots2(c2, c1, roots);
+  } else {
+    const float s_inv3 = (float)(1.0 / 3.0);
+    const float s_sqrt3 = 1.7320508f;
+    float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+    float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.0f) q = 0.0f;
+    float rho = sqrtf(-a_over_3);
+    float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+    float cos_theta = cosf(theta);
+    float sin_theta = sinf(theta);
+    roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
+    roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    float t;
+    if (roots[0] >= roots[1]) { t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+    if (roots[1] >= roots[2]) {
+      t = roots[1]; roots[1] = roots[2]; roots[2] = t;
+      if (roots[0] >= roots[1]) { t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+    }
+    if (roots[0] <= 0.0f) compute_roots2(c2, c1, roots);
+  }
+}
+
+// smallest eigenpair of a symmetric 3x3 given as {xx,xy,xz,yy,yz,zz}
+__host__ __device__ inline void eigen33_smallest(float xx, float xy, float xz, float yy, float yz, float zz,
+                                                 float *eigenvalue, float *v)
+{
+  float scale = fmaxf(fmaxf(fmaxf(fabsf(xx), fabsf(xy)), fmaxf(fabsf(xz), fabsf(yy))), fmaxf(fabsf(yz), fabsf(zz)));
+  if (scale <= 1.17549435e-38f) scale = 1.0f;
+  float m[9] = {xx / scale, xy / scale, xz / scale, xy / scale, yy / scale, yz / scale,
+                xz / scale, yz / scale, zz / scale};
+  float roots[3];
+  compute_roots(m, roots);
+  *eigenvalue = roots[0] * scale;
+  m[0] -= roots[0]; m[4] -= roots[0]; m[8] -= roots[0];
+  float v1[3] = {m[1] * m[5] - m[2] * m[4], m[2] * m[3] - m[0] * m[5], m[0] * m[4] - m[1] * m[3]};
+  float v2[3] = {m[1] * m[8] - m[2] * m[7], m[2] * m[6] - m[0] * m[8], m[0] * m[7] - m[1] * m[6]};
+  float v3[3] = {m[4] * m[8] - m[5] * m[7], m[5] * m[6] - m[3] * m[8], m[3] * m[7] - m[4] * m[6]};
+  float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+  float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+  float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+  const bool c1 = (l1 >= l2 && l1 >= l3);
+  const bool c2 = !c1 && (l2 >= l1 && l2 >= l3);
+  const float sx = c1 ? v1[0] : (c2 ? v2[0] : v3[0]);
+  const float sy = c1 ? v1[1] : (c2 ? v2[1] : v3[1]);
+  const float sz = c1 ? v1[2] : (c2 ? v2[2] : v3[2]);
+  const float n = sqrtf(c1 ? l1 : (c2 ? l2 : l3));
+  v[0] = sx / n; v[1] = sy / n; v[2] = sz / n;
+}
+
+}  // namespace mm3d

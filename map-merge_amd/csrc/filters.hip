@@ -1,0 +1,215 @@
+// filters.hip -- downSample / removeOutliers / composeMaps' transform+concatenate on gfx950.
+//
+// downSample      R/src/features.cpp:17-27  (pcl::VoxelGrid<PointXYZRGB>, cubic leaf)
+// removeOutliers  R/src/features.cpp:31-43  (pcl::RadiusOutlierRemoval, dense k-NN form:
+//                 keep p iff its (min_pts+1)-th nearest neighbour, self included, has d2 <= r*r)
+// composeMaps     R/src/map_merging.cpp:292-299 (transformPointCloud + operator+=)
+//
+// Both filters are HBM/L2-bound integer+float work (voxel 16 B read per raw point +
+// 16 B written per voxel; outlier filter 13 B per point); neither is reshaped into a GEMM.
+#include <algorithm>
+#include <climits>
+
+#include "device_util.hpp"
+
+namespace mm3d {
+
+// ---------------------------------------------------------------- voxel grid
+// key = i + j*div_x + k*div_x*div_y exactly as VoxelGrid computes it (float floor, int32)
+__global__ void k_voxel_keys(const float4 *__restrict__ pts, int n, float inv, int minbx, int minby, int minbz,
+                             int mul1, int mul2, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  vals[i] = (uint32_t)i;
+  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = 0xFFFFFFFFu; return; }
+  int ijk0 = (int)(floorf(__fmul_rn(p.x, inv)) - (float)minbx);
+  int ijk1 = (int)(floorf(__fmul_rn(p.y, inv)) - (float)minby);
+  int ijk2 = (int)(floorf(__fmul_rn(p.z, inv)) - (float)minbz);
+  keys[i] = (uint32_t)(ijk0 + ijk1 * mul1 + ijk2 * mul2);
+}
+
+__global__ void k_voxel_heads(const uint32_t *__restrict__ keys, int n, int *__restrict__ heads)
+{
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n) return;
+  if (j == n) { heads[j] = 0; return; }
+  uint32_t k = keys[j];
+  heads[j] = (k != 0xFFFFFFFFu && (j == 0 || keys[j - 1] != k)) ? 1 : 0;
+}
+
+__global__ void k_voxel_starts(const int *__restrict__ heads, const int *__restrict__ pos, int n,
+                               int *__restrict__ starts)
+{
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  if (heads[j]) starts[pos[j]] = j;
+}
+
+// One thread per voxel walks its (stable-sorted, i.e. ascending input index) members and sums in
+// float in that order: bit-identical to CentroidPoint on the CPU restatement.
+__global__ void k_voxel_centroid(const float4 *__restrict__ pts, const uint32_t *__restrict__ order,
+                                 const int *__restrict__ starts, int nvox, int nvalid, float4 *__restrict__ out)
+{
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  int b = starts[v], e = (v + 1 < nvox) ? starts[v + 1] : nvalid;
+  float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f;
+  for (int j = b; j < e; ++j) {
+    float4 p = pts[order[j]];
+    unsigned c = __float_as_uint(p.w);
+    sx += p.x; sy += p.y; sz += p.z;
+    sr += (float)((c >> 16) & 255u);
+    sg += (float)((c >> 8) & 255u);
+    sb += (float)(c & 255u);
+    sa += (float)((c >> 24) & 255u);
+  }
+  float cnt = (float)(e - b);
+  float4 o;
+  o.x = sx / cnt; o.y = sy / cnt; o.z = sz / cnt;
+  unsigned rgba = ((unsigned)(sa / cnt) << 24) | ((unsigned)(sr / cnt) << 16) | ((unsigned)(sg / cnt) << 8) |
+                  (unsigned)(sb / cnt);
+  o.w = __uint_as_float(rgba);
+  out[v] = o;
+}
+
+mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
+{
+  auto *in = const_cast<mm3d_cloud *>(in_);
+  cloud_bbox(c, in);
+  const int n = (int)in->n;
+  if (n == 0 || in->n_finite == 0) return cloud_from_device(c, DevBuf<float4>(c, 0), 0);
+  const float leaf = (float)resolution;
+  const float inv = 1.0f / leaf;
+  const float *mn = in->bmin, *mx = in->bmax;
+  // VoxelGrid's overflow guard: too many voxels => the input is returned unchanged
+  auto i64 = [](float v) -> int64_t {
+    if (!(v > -9.2e18f && v < 9.2e18f)) return INT64_MAX / 4;
+    return (int64_t)v;
+  };
+  int64_t dx = i64((mx[0] - mn[0]) * inv) + 1, dy = i64((mx[1] - mn[1]) * inv) + 1, dz = i64((mx[2] - mn[2]) * inv) + 1;
+  bool overflow = false;
+  {
+    long double prod = (long double)dx * (long double)dy * (long double)dz;
+    overflow = prod > (long double)INT32_MAX;
+  }
+  if (overflow || !(leaf > 0.0f)) {
+    DevBuf<float4> copy(c, in->n);
+    MM3D_HIP(hipMemcpyAsync(copy.get(), in->pts.get(), in->n * 16, hipMemcpyDeviceToDevice, c->stream));
+    return cloud_from_device(c, std::move(copy), in->n);
+  }
+  int min_b[3], div_b[3];
+  for (int a = 0; a < 3; ++a) {
+    min_b[a] = (int)std::floor(mn[a] * inv);
+    int max_b = (int)std::floor(mx[a] * inv);
+    div_b[a] = max_b - min_b[a] + 1;
+  }
+  const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+  DevBuf<uint32_t> keys(c, n), vals(c, n), keys2(c, n), vals2(c, n);
+  MM3D_LAUNCH(c, "voxel_keys", n * 24.0, k_voxel_keys, dim3(div_up(n, 256)), dim3(256), 0, in->pts.get(), n, inv,
+              min_b[0], min_b[1], min_b[2], mul1, mul2, keys.get(), vals.get());
+  sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), n, 32);
+  DevBuf<int> heads(c, n + 1), pos(c, n + 1);
+  MM3D_LAUNCH(c, "voxel_heads", n * 8.0, k_voxel_heads, dim3(div_up(n + 1, 256)), dim3(256), 0, keys2.get(), n, heads.get());
+  exclusive_scan_int(c, heads.get(), pos.get(), n + 1);
+  int *h = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(h, pos.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  const int nvox = h[0];
+  DevBuf<int> starts(c, nvox + 1);
+  MM3D_LAUNCH(c, "voxel_starts", n * 12.0, k_voxel_starts, dim3(div_up(n, 256)), dim3(256), 0, heads.get(), pos.get(), n, starts.get());
+  DevBuf<float4> out(c, nvox);
+  // 16 B read per raw point + 16 B written per voxel
+  MM3D_LAUNCH(c, "voxel_centroid", in->n_finite * 16.0 + nvox * 16.0, k_voxel_centroid, dim3(div_up(nvox, 256)), dim3(256), 0,
+              in->pts.get(), vals2.get(), starts.get(), nvox, (int)in->n_finite, out.get());
+  c->sync();
+  return cloud_from_device(c, std::move(out), (size_t)nvox);
+}
+
+// ---------------------------------------------------------------- radius outlier removal
+// One thread per (cell-sorted) query; counts candidates with d2 <= thr and stops at need.
+__global__ void __launch_bounds__(256)
+k_radius_count(GridView g, float radius, float thr, int need, int *__restrict__ keep /* by original index */)
+{
+  unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  int i = bid * blockDim.x + threadIdx.x;
+  if (i >= g.n) return;
+  float4 q = g.pts[i];
+  int cnt = 0;
+  for_each_candidate(g, q.x, q.y, q.z, radius, [&](const float4 &p) {
+    float d = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
+    cnt += (d <= thr) ? 1 : 0;
+    return cnt < need;
+  });
+  keep[__float_as_int(q.w)] = cnt >= need ? 1 : 0;
+}
+
+mm3d_cloud *remove_outliers(Context *c, const mm3d_cloud *in, double radius, int min_neighbours)
+{
+  const size_t n = in->n;
+  if (n == 0) return cloud_from_device(c, DevBuf<float4>(c, 0), 0);
+  // largest float whose double value does not exceed r*r: (double)d2 > r*r  <=>  d2 > thr
+  const double r2 = radius * radius;
+  float thr = (float)r2;
+  if ((double)thr > r2) thr = std::nextafterf(thr, -INFINITY);
+  const int need = min_neighbours + 1;
+  DevBuf<int> keep(c, n + 1);
+  if (need <= 0) {
+    // k == 0 neighbours requested: everything passes
+    std::vector<int> ones(n + 1, 1);
+    MM3D_HIP(hipMemcpyAsync(keep.get(), ones.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->sync();
+  } else {
+    MM3D_HIP(hipMemsetAsync(keep.get(), 0, (n + 1) * sizeof(int), c->stream));
+    const Grid &g = cloud_grid(c, in, (float)(radius * 0.5));
+    if (g.n) {
+      // 12 B read + 1 B mask per point (we read 16 and write a 4 B flag: 20 B)
+      MM3D_LAUNCH(c, "radius_outlier_count", g.n * 13.0, k_radius_count, dim3(div_up(g.n, 256)), dim3(256), 0,
+                  g.view(), (float)radius, thr, need, keep.get());
+    }
+  }
+  DevBuf<float4> out;
+  size_t m = compact_points(c, in->pts.get(), keep.get(), n, out);
+  return cloud_from_device(c, std::move(out), m);
+}
+
+// ---------------------------------------------------------------- composeMaps: transform + concat
+__global__ void k_transform_into(const float4 *__restrict__ in, size_t n, const float *__restrict__ T16,
+                                 float4 *__restrict__ out)
+{
+  __shared__ float T[16];
+  if (threadIdx.x < 16) T[threadIdx.x] = T16[threadIdx.x];
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = in[i];
+  float3 r = xform(T, p.x, p.y, p.z);
+  out[i] = make_float4(r.x, r.y, r.z, p.w);
+}
+
+mm3d_cloud *transform_concat(Context *c, const mm3d_cloud *const *clouds, size_t n, const float *T)
+{
+  size_t total = 0;
+  for (size_t i = 0; i < n; ++i) {
+    bool zero = true;
+    for (int k = 0; k < 16; ++k) zero = zero && (T[i * 16 + k] == 0.0f);
+    if (!zero && clouds[i]) total += clouds[i]->n;
+  }
+  DevBuf<float4> out(c, total);
+  DevBuf<float> dT(c, n * 16 + 16);
+  if (n) MM3D_HIP(hipMemcpyAsync(dT.get(), T, n * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  size_t off = 0;
+  for (size_t i = 0; i < n; ++i) {
+    bool zero = true;
+    for (int k = 0; k < 16; ++k) zero = zero && (T[i * 16 + k] == 0.0f);
+    if (zero || !clouds[i] || clouds[i]->n == 0) continue;
+    MM3D_LAUNCH(c, "transform_cloud", clouds[i]->n * 32.0, k_transform_into, dim3(div_up(clouds[i]->n, 256)), dim3(256), 0,
+                clouds[i]->pts.get(), clouds[i]->n, dT.get() + i * 16, out.get() + off);
+    off += clouds[i]->n;
+  }
+  c->sync();
+  return cloud_from_device(c, std::move(out), total);
+}
+
+}  // namespace mm3d

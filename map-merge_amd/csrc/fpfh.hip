@@ -1,0 +1,295 @@
+// fpfh.hip -- computeLocalDescriptors(FPFH) on gfx950 (K5/K6 in SURVEY 2.2).
+//
+// R/src/features.cpp:99-150 with R/src/dispatch_descriptors.h:40: pcl::FPFHEstimation with
+// setRadiusSearch(feature_radius), setSearchSurface(points), setInputNormals(normals),
+// setInputCloud(keypoints); descriptors with a non-finite bin are pruned together with their
+// keypoints (features.cpp:118-143).
+//   1. support set S = union of the keypoints' radius neighbourhoods (std::set order = index order)
+//   2. SPFH for every s in S over its own neighbourhood: Darboux pair features -> 3 x 11 bins,
+//      each hit adds 100/(|N(s)|-1)   (pfh.cpp computePairFeatures; FPFH's wrapper always bins)
+//   3. per keypoint: sum of SPFH rows weighted by 1/d2 (d2 == 0 skipped), each 11-bin block scaled
+//      to sum 100.
+// Algorithmic traffic: SPFH 156 B per support point; weighting 132 B per gathered row.
+#include "device_util.hpp"
+
+namespace mm3d {
+
+constexpr int kBins = 11;
+constexpr int kDim = 33;
+
+// same walk as for_each_candidate but the callback also receives the sorted position j
+template <class F>
+__device__ __forceinline__ void for_each_candidate_idx(const GridView &g, float qx, float qy, float qz, float r, F &&f)
+{
+  const float ri = r * 1.0001f + 1e-4f;
+  if (cell_floor(qx + ri, g.minx, g.inv) < 0 || cell_floor(qx - ri, g.minx, g.inv) > g.dx - 1) return;
+  const int x0 = clampi(cell_floor(qx - ri, g.minx, g.inv), 0, g.dx - 1), x1 = clampi(cell_floor(qx + ri, g.minx, g.inv), 0, g.dx - 1);
+  int y0 = cell_floor(qy - ri, g.miny, g.inv), y1 = cell_floor(qy + ri, g.miny, g.inv);
+  int z0 = cell_floor(qz - ri, g.minz, g.inv), z1 = cell_floor(qz + ri, g.minz, g.inv);
+  y0 = y0 < 0 ? 0 : y0; z0 = z0 < 0 ? 0 : z0;
+  y1 = y1 > g.dy - 1 ? g.dy - 1 : y1; z1 = z1 > g.dz - 1 ? g.dz - 1 : z1;
+  for (int z = z0; z <= z1; ++z)
+    for (int y = y0; y <= y1; ++y) {
+      const int row = (z * g.dy + y) * g.dx;
+      const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+      for (int j = b; j < e; ++j) f(j, g.pts[j]);
+    }
+}
+
+// 1. mark the support set (by sorted position) and count each keypoint's neighbours
+__global__ void __launch_bounds__(256)
+k_fpfh_mark(const float4 *__restrict__ kp, int nk, GridView g, float radius, float r2, int *__restrict__ in_set,
+            int *__restrict__ nbr_count)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nk) return;
+  const float4 q = kp[k];
+  int cnt = 0;
+  for_each_candidate_idx(g, q.x, q.y, q.z, radius, [&](int j, const float4 &p) {
+    if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) { in_set[__float_as_int(p.w)] = 1; ++cnt; }
+  });
+  nbr_count[k] = cnt;
+}
+
+__global__ void k_fpfh_support(const float4 *__restrict__ sorted, int n, const int *__restrict__ in_set,
+                               const int *__restrict__ pos, int *__restrict__ support_sorted /* by row */,
+                               int *__restrict__ row_of_sorted /* by sorted position, -1 if none */,
+                               const float4 *__restrict__ nrm, float4 *__restrict__ nrm_sorted)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int oi = __float_as_int(sorted[j].w);
+  nrm_sorted[j] = nrm[oi];
+  if (in_set[oi]) { support_sorted[pos[oi]] = j; row_of_sorted[j] = pos[oi]; }
+  else row_of_sorted[j] = -1;
+}
+
+// pcl::computePairFeatures (features/src/pfh.cpp); returns f1,f2,f3 (all 0 on the degenerate exits)
+__device__ __forceinline__ void pair_features(const float4 &p1, const float4 &n1, const float4 &p2, const float4 &n2,
+                                              float &f1, float &f2, float &f3)
+{
+  float dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
+  const float f4 = sqrtf(dx * dx + dy * dy + dz * dz);
+  if (f4 == 0.0f) { f1 = f2 = f3 = 0.0f; return; }
+  float ax = n1.x, ay = n1.y, az = n1.z, bx = n2.x, by = n2.y, bz = n2.z;
+  const float angle1 = (ax * dx + ay * dy + az * dz) / f4;
+  const float angle2 = (bx * dx + by * dy + bz * dz) / f4;
+  // acos(fabs(angle1)) > acos(fabs(angle2)) evaluated in double on the CPU; acos is strictly
+  // decreasing there, so the test is |angle1| < |angle2| (NaN -> false on both sides)
+  if (fabsf(angle1) < fabsf(angle2)) {
+    float t;
+    t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; t = az; az = bz; bz = t;
+    dx *= -1.0f; dy *= -1.0f; dz *= -1.0f;
+    f3 = -angle2;
+  } else {
+    f3 = angle1;
+  }
+  float vx = dy * az - dz * ay, vy = dz * ax - dx * az, vz = dx * ay - dy * ax;
+  const float v_norm = sqrtf(vx * vx + vy * vy + vz * vz);
+  if (v_norm == 0.0f) { f1 = f2 = f3 = 0.0f; return; }
+  vx /= v_norm; vy /= v_norm; vz /= v_norm;
+  const float wx = ay * vz - az * vy, wy = az * vx - ax * vz, wz = ax * vy - ay * vx;
+  f2 = vx * bx + vy * by + vz * bz;
+  f1 = atan2f(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);
+}
+
+// static_cast<int>(floor(x)) with x86 semantics for NaN / out of range (INT_MIN -> clamped to 0)
+__device__ __forceinline__ int bin_of(double x)
+{
+  const double f = floor(x);
+  int h = (f >= -2147483648.0 && f <= 2147483647.0) ? (int)f : (-2147483647 - 1);
+  h = h < 0 ? 0 : h;
+  return h >= kBins ? kBins - 1 : h;
+}
+
+// 2. SPFH: one thread per support point; histogram in LDS, bin-major so lane l hits bank l
+template <int BD>
+__global__ void __launch_bounds__(BD)
+k_spfh(GridView g, const float4 *__restrict__ nrm_sorted, const int *__restrict__ support_sorted, int ns, float radius,
+       float r2, float *__restrict__ spfh /* [ns][33] */)
+{
+  __shared__ float hist[kDim][BD];
+  const int t = threadIdx.x;
+  const int s = blockIdx.x * BD + t;
+  if (s >= ns) return;
+#pragma unroll
+  for (int b = 0; b < kDim; ++b) hist[b][t] = 0.0f;
+  const int js = support_sorted[s];
+  const float4 q = g.pts[js];
+  const float4 nq = nrm_sorted[js];
+  int cnt = 0;
+  for_each_candidate_idx(g, q.x, q.y, q.z, radius, [&](int j, const float4 &p) {
+    cnt += (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) ? 1 : 0;
+  });
+  const float hist_incr = 100.0f / (float)(cnt - 1);
+  const float d_pi = 1.0f / (2.0f * 3.14159274f);
+  for_each_candidate_idx(g, q.x, q.y, q.z, radius, [&](int j, const float4 &p) {
+    if (j == js) return;                                   // p_idx == indices[idx]
+    if (!(dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2)) return;
+    float f1, f2, f3;
+    pair_features(q, nq, p, nrm_sorted[j], f1, f2, f3);
+    const int h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
+    const int h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
+    const int h3 = bin_of(kBins * (((double)f3 + 1.0) * 0.5));
+    hist[h1][t] += hist_incr;
+    hist[kBins + h2][t] += hist_incr;
+    hist[2 * kBins + h3][t] += hist_incr;
+  });
+  float *o = spfh + (size_t)s * kDim;
+#pragma unroll
+  for (int b = 0; b < kDim; ++b) o[b] = hist[b][t];
+}
+
+// 3. weighting: one wave per keypoint.  Lanes scan 64 candidates at a time; for every hit the
+// first 33 lanes each accumulate their own bin of the neighbour's SPFH row (a coalesced 132 B read).
+__global__ void __launch_bounds__(256)
+k_fpfh_weight(const float4 *__restrict__ kp, int nk, GridView g, const int *__restrict__ row_of_sorted,
+              const float *__restrict__ spfh, float radius, float r2, float *__restrict__ desc /* [nk][33] */,
+              int *__restrict__ valid)
+{
+  const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (k >= nk) return;
+  const int lane = threadIdx.x & 63;
+  const float4 q = kp[k];
+  float acc = 0.0f;
+  double dsum = 0.0;
+  int total = 0;
+  const float ri = radius * 1.0001f + 1e-4f;
+  const bool xin = !(cell_floor(q.x + ri, g.minx, g.inv) < 0 || cell_floor(q.x - ri, g.minx, g.inv) > g.dx - 1);
+  const int x0 = clampi(cell_floor(q.x - ri, g.minx, g.inv), 0, g.dx - 1), x1 = clampi(cell_floor(q.x + ri, g.minx, g.inv), 0, g.dx - 1);
+  int y0 = cell_floor(q.y - ri, g.miny, g.inv), y1 = cell_floor(q.y + ri, g.miny, g.inv);
+  int z0 = cell_floor(q.z - ri, g.minz, g.inv), z1 = cell_floor(q.z + ri, g.minz, g.inv);
+  y0 = y0 < 0 ? 0 : y0; z0 = z0 < 0 ? 0 : z0;
+  y1 = y1 > g.dy - 1 ? g.dy - 1 : y1; z1 = z1 > g.dz - 1 ? g.dz - 1 : z1;
+  if (xin)
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        const int row = (z * g.dy + y) * g.dx;
+        const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
+        for (int j0 = b; j0 < e; j0 += kWave) {
+          const int j = j0 + lane;
+          float d2 = INFINITY;
+          int r = -1;
+          if (j < e) {
+            const float4 p = g.pts[j];
+            d2 = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
+            r = row_of_sorted[j];
+          }
+          const bool in = d2 < r2;
+          const unsigned long long m_in = __ballot(in);
+          total += __popcll(m_in);
+          unsigned long long m = __ballot(in && d2 != 0.0f);   // "minus the query point itself"
+          const float w = 1.0f / d2;
+          while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const float ws = __shfl(w, src, kWave);
+            const int rs = __shfl(r, src, kWave);
+            if (lane < kDim) {
+              const float val = spfh[(size_t)rs * kDim + lane] * ws;
+              dsum += (double)val;
+              acc += val;
+            }
+          }
+        }
+      }
+  // block sums over the three 11-bin groups
+  const int base = (lane < kDim) ? (lane / kBins) * kBins : 0;
+  double bs = 0.0;
+#pragma unroll
+  for (int b = 0; b < kBins; ++b) bs += __shfl(dsum, base + b, kWave);
+  if (lane < kDim) {
+    float out;
+    if (total == 0) {
+      out = __uint_as_float(0x7fc00000u);
+    } else {
+      if (bs != 0.0) bs = 100.0 / bs;
+      out = acc * (float)bs;
+    }
+    desc[(size_t)k * kDim + lane] = out;
+  }
+  if (lane == 0) valid[k] = total != 0 ? 1 : 0;
+}
+
+__global__ void k_compact_rows(const float *__restrict__ in, const int *__restrict__ flags, const int *__restrict__ pos,
+                               int n, int dim, float *__restrict__ out)
+{
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n * dim) return;
+  const int r = (int)(e / dim), cidx = (int)(e % dim);
+  if (flags[r]) out[(size_t)pos[r] * dim + cidx] = in[e];
+}
+
+mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, mm3d_cloud *keypoints,
+                        double radius)
+{
+  MM3D_REQUIRE(normals->n == points->n, "computeLocalDescriptors: normals and points differ in size");
+  auto *res = new mm3d_desc();
+  res->dim = kDim;
+  res->type = MM3D_DESC_FPFH;
+  const int nk = (int)keypoints->n;
+  if (nk == 0) { res->n = 0; res->data = DevBuf<float>(c, 0); return res; }
+  const float r2 = (float)(radius * radius);
+  const Grid &g = cloud_grid(c, points, (float)(radius * 0.5));
+  const int n = (int)points->n;
+  DevBuf<float> raw(c, (size_t)nk * kDim);
+  DevBuf<int> valid(c, (size_t)nk + 1);
+  MM3D_HIP(hipMemsetAsync(valid.get(), 0, ((size_t)nk + 1) * sizeof(int), c->stream));
+  if (g.n == 0) {
+    // no surface: every descriptor is NaN and gets pruned
+    res->n = 0; res->data = DevBuf<float>(c, 0);
+    keypoints->pts = DevBuf<float4>(c, 0); keypoints->n = 0; keypoints->grids.clear(); keypoints->host.clear();
+    keypoints->have_bbox = false;
+    return res;
+  }
+  DevBuf<int> in_set(c, (size_t)n + 1), pos(c, (size_t)n + 1), nbr(c, nk);
+  MM3D_HIP(hipMemsetAsync(in_set.get(), 0, ((size_t)n + 1) * sizeof(int), c->stream));
+  MM3D_LAUNCH(c, "fpfh_mark", nk * 16.0, k_fpfh_mark, dim3(div_up(nk, 256)), dim3(256), 0, keypoints->pts.get(), nk, g.view(),
+              (float)radius, r2, in_set.get(), nbr.get());
+  exclusive_scan_int(c, in_set.get(), pos.get(), (size_t)n + 1);
+  int *h = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(h, pos.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  const int ns = h[0];
+  DevBuf<int> support(c, ns > 0 ? ns : 1), row_of(c, g.n);
+  DevBuf<float4> nrm_sorted(c, g.n);
+  MM3D_LAUNCH(c, "fpfh_support", g.n * 48.0, k_fpfh_support, dim3(div_up(g.n, 256)), dim3(256), 0, g.sorted.get(), g.n,
+              in_set.get(), pos.get(), support.get(), row_of.get(), normals->nrm.get(), nrm_sorted.get());
+  DevBuf<float> spfh(c, (size_t)(ns > 0 ? ns : 1) * kDim);
+  if (ns > 0)
+    MM3D_LAUNCH(c, "spfh", ns * 156.0, (k_spfh<128>), dim3(div_up(ns, 128)), dim3(128), 0, g.view(),
+                (const float4 *)nrm_sorted.get(), (const int *)support.get(), ns, (float)radius, r2, spfh.get());
+  MM3D_LAUNCH(c, "fpfh_weight", (double)ns * 132.0 + nk * 132.0, k_fpfh_weight, dim3(div_up(nk, 4)), dim3(256), 0,
+              keypoints->pts.get(), nk, g.view(), (const int *)row_of.get(), (const float *)spfh.get(), (float)radius, r2,
+              raw.get(), valid.get());
+  // prune invalid descriptors and the same keypoints (features.cpp:118-143)
+  DevBuf<int> vpos(c, (size_t)nk + 1);
+  exclusive_scan_int(c, valid.get(), vpos.get(), (size_t)nk + 1);
+  MM3D_HIP(hipMemcpyAsync(h, vpos.get() + nk, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  const int nv = h[0];
+  res->n = (size_t)nv;
+  if (nv == nk) {
+    res->data = std::move(raw);
+  } else {
+    res->data = DevBuf<float>(c, (size_t)nv * kDim);
+    DevBuf<float4> kp2(c, nv);
+    if (nv) {
+      MM3D_LAUNCH(c, "compact_rows", nk * 264.0, k_compact_rows, dim3(div_up((size_t)nk * kDim, 256)), dim3(256), 0,
+                  (const float *)raw.get(), (const int *)valid.get(), (const int *)vpos.get(), nk, kDim, res->data.get());
+      MM3D_LAUNCH(c, "compact_rows", nk * 32.0, k_compact_rows, dim3(div_up((size_t)nk * 4, 256)), dim3(256), 0,
+                  (const float *)keypoints->pts.get(), (const int *)valid.get(), (const int *)vpos.get(), nk, 4,
+                  (float *)kp2.get());
+    }
+    c->sync();
+    keypoints->pts = std::move(kp2);
+    keypoints->n = (size_t)nv;
+    keypoints->grids.clear();
+    keypoints->host.clear();
+    keypoints->have_bbox = false;
+  }
+  c->sync();
+  return res;
+}
+
+}  // namespace mm3d

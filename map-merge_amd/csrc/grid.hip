@@ -1,0 +1,387 @@
+// grid.hip -- context plumbing, cloud objects and the device-built uniform grid (K1 in SURVEY 2.2).
+//
+// The grid replaces every kd-tree the reference builds through PCL (normals, outlier filter,
+// FPFH, SIFT, ICP target, SAC-IA target, transformScore target: R/src/features.cpp:34,50,105,171,
+// R/src/matching.cpp:159,204,263).  It is built once per (cloud, cell size) and cached on the
+// cloud; PCL rebuilds its tree per call and per pair.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "device_util.hpp"
+
+namespace mm3d {
+
+// ---------------------------------------------------------------- pool / context
+size_t Pool::size_class(size_t bytes)
+{
+  if (bytes <= 256) return 256;
+  size_t p = 256;
+  while (p * 2 <= bytes) p *= 2;        // p <= bytes < 2p
+  if (bytes == p) return p;
+  size_t step = p / 4;
+  return p + ((bytes - p + step - 1) / step) * step;
+}
+
+void *Pool::alloc(size_t bytes)
+{
+  size_t cls = size_class(bytes);
+  auto it = free_.find(cls);
+  void *p = nullptr;
+  if (it != free_.end() && !it->second.empty()) {
+    p = it->second.back();
+    it->second.pop_back();
+  } else {
+    hipError_t e = hipMalloc(&p, cls);
+    if (e != hipSuccess) {
+      trim();
+      e = hipMalloc(&p, cls);
+      if (e != hipSuccess) throw Error(MM3D_ENOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    }
+  }
+  live_[p] = cls;
+  return p;
+}
+
+void Pool::release(void *p)
+{
+  auto it = live_.find(p);
+  if (it == live_.end()) return;
+  free_[it->second].push_back(p);
+  live_.erase(it);
+}
+
+void Pool::trim()
+{
+  for (auto &kv : free_)
+    for (void *p : kv.second) (void)hipFree(p);
+  free_.clear();
+}
+
+void *Context::pin(size_t bytes)
+{
+  if (bytes > pinned_bytes) {
+    if (pinned) (void)hipHostFree(pinned);
+    pinned_bytes = bytes < 4096 ? 4096 : bytes * 2;
+    MM3D_HIP(hipHostMalloc(&pinned, pinned_bytes));
+  }
+  return pinned;
+}
+
+int Context::prof_slot(const char *name)
+{
+  auto it = prof_index.find(name);
+  if (it != prof_index.end()) return it->second;
+  int s = (int)prof.size();
+  prof_index[name] = s;
+  prof_names.emplace_back(name);
+  prof.emplace_back();
+  return s;
+}
+
+void Context::prof_resolve()
+{
+  if (pending.empty()) return;
+  MM3D_HIP(hipStreamSynchronize(stream));
+  for (auto &p : pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) prof[p.slot].ms += ms;
+    event_pool.push_back(p.a);
+    event_pool.push_back(p.b);
+  }
+  pending.clear();
+}
+
+KernelScope::KernelScope(Context *ctx, const char *name, double bytes) : c(ctx)
+{
+  if (!c->prof_on) return;
+  slot = c->prof_slot(name);
+  c->prof[slot].launches++;
+  c->prof[slot].bytes += bytes;
+  auto get = [&]() {
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    MM3D_HIP(hipEventCreate(&e));
+    return e;
+  };
+  a = get(); b = get();
+  (void)hipEventRecord(a, c->stream);
+}
+
+KernelScope::~KernelScope()
+{
+  if (slot < 0) return;
+  (void)hipEventRecord(b, c->stream);
+  c->pending.push_back({slot, a, b});
+  if (c->pending.size() > 8192) {
+    try { c->prof_resolve(); } catch (...) {}
+  }
+}
+
+// ---------------------------------------------------------------- rocPRIM-backed primitives
+void exclusive_scan_int(Context *c, const int *in, int *out, size_t n)
+{
+  if (n == 0) return;
+  size_t tmp_bytes = 0;
+  MM3D_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, 0, n, rocprim::plus<int>(), c->stream));
+  DevBuf<char> tmp(c, tmp_bytes ? tmp_bytes : 1);
+  KernelScope ks(c, "rocprim_exclusive_scan", (double)n * 8.0);
+  MM3D_HIP(rocprim::exclusive_scan(tmp.get(), tmp_bytes, in, out, 0, n, rocprim::plus<int>(), c->stream));
+}
+
+void sort_pairs_u32(Context *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                    size_t n, int end_bit)
+{
+  if (n == 0) return;
+  size_t tmp_bytes = 0;
+  MM3D_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, c->stream));
+  DevBuf<char> tmp(c, tmp_bytes ? tmp_bytes : 1);
+  KernelScope ks(c, "rocprim_radix_sort_pairs", (double)n * 16.0);
+  MM3D_HIP(rocprim::radix_sort_pairs(tmp.get(), tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, c->stream));
+}
+
+// ---------------------------------------------------------------- cloud objects
+__global__ void k_repack(const unsigned char *__restrict__ src, size_t n, size_t stride, size_t rgba_off,
+                         float4 *__restrict__ dst)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char *p = src + i * stride;
+  const float *f = reinterpret_cast<const float *>(p);
+  float4 o;
+  o.x = f[0]; o.y = f[1]; o.z = f[2];
+  o.w = __uint_as_float(*reinterpret_cast<const unsigned *>(p + rgba_off));
+  dst[i] = o;
+}
+
+__global__ void k_unpack(const float4 *__restrict__ src, size_t n, size_t stride, size_t rgba_off,
+                         unsigned char *__restrict__ dst)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned char *p = dst + i * stride;
+  float4 v = src[i];
+  float *f = reinterpret_cast<float *>(p);
+  f[0] = v.x; f[1] = v.y; f[2] = v.z;
+  if (rgba_off != 12 && stride >= 16) f[3] = 1.0f;   // PCL's data[3]
+  *reinterpret_cast<unsigned *>(p + rgba_off) = __float_as_uint(v.w);
+}
+
+mm3d_cloud *cloud_from_device(Context *c, DevBuf<float4> &&pts, size_t n)
+{
+  auto *cl = new mm3d_cloud();
+  cl->pts = std::move(pts);
+  cl->n = n;
+  return cl;
+}
+
+mm3d_cloud *cloud_from_memory(Context *c, const void *src, size_t n, size_t stride, size_t rgba_off)
+{
+  MM3D_REQUIRE(stride >= 16 && stride % 4 == 0 && rgba_off % 4 == 0 && rgba_off >= 12 && rgba_off + 4 <= stride,
+               "mm3d_cloud_create: stride/rgba_offset do not describe an x,y,z,rgba record");
+  DevBuf<float4> pts(c, n);
+  if (n) {
+    MM3D_REQUIRE(src != nullptr, "mm3d_cloud_create: null points with n > 0");
+    if (stride == 16 && rgba_off == 12) {
+      MM3D_HIP(hipMemcpyAsync(pts.get(), src, n * 16, hipMemcpyDefault, c->stream));
+    } else {
+      DevBuf<unsigned char> stage(c, n * stride);
+      MM3D_HIP(hipMemcpyAsync(stage.get(), src, n * stride, hipMemcpyDefault, c->stream));
+      MM3D_LAUNCH(c, "repack", 0, k_repack, dim3(div_up(n, 256)), dim3(256), 0, stage.get(), n, stride, rgba_off, pts.get());
+      c->sync();   // stage goes back to the pool only after the kernel is done with it
+    }
+  }
+  return cloud_from_device(c, std::move(pts), n);
+}
+
+void cloud_download(Context *c, const mm3d_cloud *cl, void *dst, size_t stride, size_t rgba_off)
+{
+  MM3D_REQUIRE(stride >= 16 && stride % 4 == 0 && rgba_off % 4 == 0 && rgba_off >= 12 && rgba_off + 4 <= stride,
+               "mm3d_cloud_download: stride/rgba_offset do not describe an x,y,z,rgba record");
+  if (cl->n == 0) return;
+  if (stride == 16 && rgba_off == 12) {
+    MM3D_HIP(hipMemcpyAsync(dst, cl->pts.get(), cl->n * 16, hipMemcpyDefault, c->stream));
+    c->sync();
+    return;
+  }
+  DevBuf<unsigned char> stage(c, cl->n * stride);
+  MM3D_HIP(hipMemsetAsync(stage.get(), 0, cl->n * stride, c->stream));
+  MM3D_LAUNCH(c, "unpack", 0, k_unpack, dim3(div_up(cl->n, 256)), dim3(256), 0, cl->pts.get(), cl->n, stride, rgba_off, stage.get());
+  MM3D_HIP(hipMemcpyAsync(dst, stage.get(), cl->n * stride, hipMemcpyDefault, c->stream));
+  c->sync();
+}
+
+const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl)
+{
+  auto *m = const_cast<mm3d_cloud *>(cl);
+  if (m->host.size() != m->n) {
+    m->host.resize(m->n);
+    if (m->n) {
+      MM3D_HIP(hipMemcpyAsync(m->host.data(), m->pts.get(), m->n * 16, hipMemcpyDeviceToHost, c->stream));
+      c->sync();
+    }
+  }
+  return m->host;
+}
+
+// ---------------------------------------------------------------- bounding box (finite points)
+__global__ void k_bbox(const float4 *__restrict__ pts, size_t n, unsigned *__restrict__ out /* 6 ord + count */)
+{
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int cnt = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float4 p = pts[i];
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+      mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+      mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+      ++cnt;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_down(mn[a], o, kWave));
+      mx[a] = fmaxf(mx[a], __shfl_down(mx[a], o, kWave));
+    }
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) {
+    for (int a = 0; a < 3; ++a) {
+      atomicMin(&out[a], f2ord(mn[a]));
+      atomicMax(&out[3 + a], f2ord(mx[a]));
+    }
+    atomicAdd(&out[6], (unsigned)cnt);
+  }
+}
+
+void cloud_bbox(Context *c, mm3d_cloud *cl)
+{
+  if (cl->have_bbox) return;
+  cl->have_bbox = true;
+  cl->n_finite = 0;
+  if (cl->n == 0) return;
+  DevBuf<unsigned> d(c, 8);
+  unsigned init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+  unsigned *h = (unsigned *)c->pin(64);
+  memcpy(h, init, sizeof(init));
+  MM3D_HIP(hipMemcpyAsync(d.get(), h, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  unsigned blocks = std::min<unsigned>(div_up(cl->n, 256), 2048);
+  MM3D_LAUNCH(c, "bbox", cl->n * 16.0, k_bbox, dim3(blocks), dim3(256), 0, cl->pts.get(), cl->n, d.get());
+  MM3D_HIP(hipMemcpyAsync(h, d.get(), sizeof(init), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  cl->n_finite = h[6];
+  if (cl->n_finite) {
+    for (int a = 0; a < 3; ++a) { cl->bmin[a] = ord2f(h[a]); cl->bmax[a] = ord2f(h[3 + a]); }
+  }
+}
+
+// ---------------------------------------------------------------- grid build
+__global__ void k_cell_keys(const float4 *__restrict__ pts, int n, float minx, float miny, float minz, float inv,
+                            int dx, int dy, int dz, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                            int *__restrict__ counts, uint32_t invalid_key)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  vals[i] = (uint32_t)i;
+  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = invalid_key; return; }
+  int cx = clampi(cell_floor(p.x, minx, inv), 0, dx - 1);
+  int cy = clampi(cell_floor(p.y, miny, inv), 0, dy - 1);
+  int cz = clampi(cell_floor(p.z, minz, inv), 0, dz - 1);
+  uint32_t key = (uint32_t)((cz * dy + cy) * dx + cx);
+  keys[i] = key;
+  atomicAdd(&counts[key], 1);
+}
+
+__global__ void k_gather_sorted(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, int n,
+                                float4 *__restrict__ out)
+{
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  uint32_t i = order[j];
+  float4 p = pts[i];
+  p.w = __int_as_float((int)i);
+  out[j] = p;
+}
+
+const Grid &cloud_grid(Context *c, const mm3d_cloud *cl_, float cell)
+{
+  auto *cl = const_cast<mm3d_cloud *>(cl_);
+  MM3D_REQUIRE(cell > 0.f && std::isfinite(cell), "grid cell size must be positive");
+  int key = (int)std::lround((double)cell * 1e4);
+  auto it = cl->grids.find(key);
+  if (it != cl->grids.end()) return *it->second;
+  cloud_bbox(c, cl);
+  auto g = std::make_unique<Grid>();
+  g->cell = cell;
+  const size_t nfin = cl->n_finite;
+  if (nfin == 0) {
+    g->n = 0;
+    g->cell_start = DevBuf<int>(c, 2);
+    MM3D_HIP(hipMemsetAsync(g->cell_start.get(), 0, 8, c->stream));
+    g->sorted = DevBuf<float4>(c, 1);
+  } else {
+    // bounded table: grow the cell when the box is huge (correctness does not depend on the size)
+    for (;;) {
+      double inv = 1.0 / (double)g->cell;
+      double ex = std::floor(((double)cl->bmax[0] - cl->bmin[0]) * inv) + 2;
+      double ey = std::floor(((double)cl->bmax[1] - cl->bmin[1]) * inv) + 2;
+      double ez = std::floor(((double)cl->bmax[2] - cl->bmin[2]) * inv) + 2;
+      if (ex * ey * ez <= 2.0e8) { g->dims[0] = (int)ex; g->dims[1] = (int)ey; g->dims[2] = (int)ez; break; }
+      g->cell *= 1.5f;
+    }
+    for (int a = 0; a < 3; ++a) g->mn[a] = cl->bmin[a];
+    const size_t ncell = (size_t)g->dims[0] * g->dims[1] * g->dims[2];
+    const int n = (int)cl->n;
+    DevBuf<int> counts(c, ncell + 1);
+    MM3D_HIP(hipMemsetAsync(counts.get(), 0, (ncell + 1) * sizeof(int), c->stream));
+    DevBuf<uint32_t> keys(c, n), vals(c, n), keys2(c, n), vals2(c, n);
+    const uint32_t invalid = (uint32_t)ncell;   // sorts after every real cell
+    MM3D_LAUNCH(c, "grid_cell_keys", n * 24.0, k_cell_keys, dim3(div_up(n, 256)), dim3(256), 0, cl->pts.get(), n,
+                g->mn[0], g->mn[1], g->mn[2], 1.0f / g->cell, g->dims[0], g->dims[1], g->dims[2], keys.get(),
+                vals.get(), counts.get(), invalid);
+    int bits = 1;
+    while (((size_t)1 << bits) <= ncell) ++bits;
+    sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), n, bits);
+    g->cell_start = DevBuf<int>(c, ncell + 1);
+    exclusive_scan_int(c, counts.get(), g->cell_start.get(), ncell + 1);
+    g->sorted = DevBuf<float4>(c, nfin);
+    MM3D_LAUNCH(c, "grid_gather", nfin * 36.0, k_gather_sorted, dim3(div_up(nfin, 256)), dim3(256), 0, cl->pts.get(),
+                vals2.get(), (int)nfin, g->sorted.get());
+    g->n = (int)nfin;
+    c->sync();   // temporaries return to the pool after the stream is done with them
+  }
+  auto &ref = *g;
+  cl->grids[key] = std::move(g);
+  return ref;
+}
+
+// ---------------------------------------------------------------- ordered compaction
+__global__ void k_compact(const float4 *__restrict__ in, const int *__restrict__ flags, const int *__restrict__ pos,
+                          size_t n, float4 *__restrict__ out)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (flags[i]) out[pos[i]] = in[i];
+}
+
+size_t compact_points(Context *c, const float4 *in, const int *flags, size_t n, DevBuf<float4> &out)
+{
+  if (n == 0) { out = DevBuf<float4>(c, 0); return 0; }
+  DevBuf<int> pos(c, n + 1);
+  // scan n+1 entries so pos[n] is the total (flags has n+1 readable entries: see callers)
+  exclusive_scan_int(c, flags, pos.get(), n + 1);
+  int *h = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(h, pos.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  size_t m = (size_t)h[0];
+  out = DevBuf<float4>(c, m);
+  if (m) {
+    MM3D_LAUNCH(c, "compact", n * 24.0, k_compact, dim3(div_up(n, 256)), dim3(256), 0, in, flags, pos.get(), n, out.get());
+    c->sync();
+  }
+  return m;
+}
+
+}  // namespace mm3d

@@ -1,0 +1,147 @@
+// types.hpp -- device-resident objects behind the opaque C handles, and the stage entry points
+// shared between the translation units of libmm3d.
+//
+// HBM layout:
+//   cloud points   float4 {x, y, z, rgba-bits}            16 B / point, reference order
+//   normals        float4 {nx, ny, nz, curvature}         16 B / point, same order
+//   descriptors    float  [n][dim] row-major              (FPFH: 132 B / keypoint)
+//   grid           cell_start int32[dx*dy*dz + 1] (x fastest) + a cell-sorted copy of the points
+//                  whose .w carries the ORIGINAL index, so a (y,z) row of cells is one contiguous
+//                  span of candidates.
+#pragma once
+
+#include "common.hpp"
+
+// the opaque C handles are these structs
+struct mm3d_ctx : mm3d::Context {};
+
+namespace mm3d {
+
+struct GridView {
+  float minx, miny, minz;
+  float inv;   // 1 / cell
+  float cell;
+  int dx, dy, dz;
+  const int *cell_start;
+  const float4 *pts;   // cell-sorted; .w = original index bits
+  int n;
+};
+
+struct Grid {
+  float cell = 0.f;
+  float mn[3] = {0, 0, 0};
+  int dims[3] = {1, 1, 1};
+  DevBuf<int> cell_start;
+  DevBuf<float4> sorted;
+  int n = 0;
+  GridView view() const
+  {
+    GridView v;
+    v.minx = mn[0]; v.miny = mn[1]; v.minz = mn[2];
+    v.inv = 1.0f / cell; v.cell = cell;
+    v.dx = dims[0]; v.dy = dims[1]; v.dz = dims[2];
+    v.cell_start = cell_start.get(); v.pts = sorted.get(); v.n = n;
+    return v;
+  }
+};
+
+}  // namespace mm3d
+
+struct mm3d_cloud {
+  mm3d::DevBuf<float4> pts;
+  size_t n = 0;
+  // lazily computed
+  bool have_bbox = false;
+  float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+  size_t n_finite = 0;
+  std::map<int, std::unique_ptr<mm3d::Grid>> grids;   // key: cell size in units of 1e-4 m
+  std::vector<float4> host;                            // host copy (keypoint clouds only)
+};
+
+struct mm3d_normals {
+  mm3d::DevBuf<float4> nrm;
+  size_t n = 0;
+};
+
+struct mm3d_desc {
+  mm3d::DevBuf<float> data;
+  size_t n = 0;
+  int dim = 0;
+  int type = 0;
+};
+
+struct mm3d_map {
+  mm3d_cloud *points = nullptr;
+  mm3d_cloud *keypoints = nullptr;
+  mm3d_desc *desc = nullptr;
+};
+
+namespace mm3d {
+
+// grid.hip
+void cloud_bbox(Context *c, mm3d_cloud *cl);
+const Grid &cloud_grid(Context *c, const mm3d_cloud *cl, float cell);
+mm3d_cloud *cloud_from_device(Context *c, DevBuf<float4> &&pts, size_t n);
+mm3d_cloud *cloud_from_memory(Context *c, const void *src, size_t n, size_t stride, size_t rgba_off);
+void cloud_download(Context *c, const mm3d_cloud *cl, void *dst, size_t stride, size_t rgba_off);
+const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl);
+// ordered compaction: keeps in[i] where flags[i] != 0, preserving order; returns kept count
+size_t compact_points(Context *c, const float4 *in, const int *flags, size_t n, DevBuf<float4> &out);
+void exclusive_scan_int(Context *c, const int *in, int *out, size_t n);
+void sort_pairs_u32(Context *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                    size_t n, int end_bit);
+
+// filters.hip
+mm3d_cloud *downsample(Context *c, const mm3d_cloud *in, double resolution);
+mm3d_cloud *remove_outliers(Context *c, const mm3d_cloud *in, double radius, int min_neighbours);
+mm3d_cloud *transform_concat(Context *c, const mm3d_cloud *const *clouds, size_t n, const float *T);
+
+// normals.hip
+mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius);
+
+// sift.hip
+mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double min_scale, int nr_octaves,
+                                  int nr_scales, double min_contrast);
+
+// fpfh.hip
+mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,
+                        mm3d_cloud *keypoints, double radius);
+
+// desc_knn.hip
+// k nearest rows of B for every row of A (squared L2, FLANN accumulation order); idx -1 padded
+void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2);
+
+// registration.hip
+struct IcpResult { float T[16]; int iterations; int converged; };
+IcpResult icp(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float guess[16],
+              double max_corr_dist, int max_iterations, double eps);
+double transform_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float T[16],
+                       double max_distance);
+// hypothesis scoring
+void ransac_count(Context *c, const float4 *src_kp, const float4 *tgt_kp, const int *idx_src,
+                  const int *idx_tgt, int n_corr, const float *T_all /* H*16 device */, int H,
+                  double thr2, int *counts /* device H */);
+void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const float *T_all /* H*16 dev */,
+                  int H, float corr_thresh, float *errors /* device H */);
+
+// host_pipeline.cpp
+size_t find_correspondences(Context *c, const mm3d_desc *s, const mm3d_desc *t, size_t k, std::vector<mm3d_corr> &out);
+size_t ransac_transform(Context *c, const mm3d_cloud *skp, const mm3d_cloud *tkp, const mm3d_corr *corr,
+                        size_t n_corr, double inlier_threshold, float T[16], std::vector<mm3d_corr> &inliers);
+void sac_ia(Context *c, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tkp, const mm3d_desc *td,
+            double min_sample_distance, double max_corr_dist, int max_iterations, float T[16], bool execute);
+int estimate_transform(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd,
+                       const mm3d_cloud *tp, const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine,
+                       double inlier_threshold, double max_corr_dist, int max_iterations, size_t matching_k,
+                       double eps, float T[16], bool execute);
+int global_transforms(const mm3d_pair_result *pairs, size_t n_pairs, double thr, size_t n_clouds, float *out,
+                      size_t *n_out);
+
+// linalg (host)
+void umeyama_f32(const float *src, const float *dst, int n, float T[16]);
+void umeyama_f64(const double *src, const double *dst, int n, double T[16]);
+void mat4_mul(const float A[16], const float B[16], float out[16]);
+void mat4_inverse(const float A[16], float out[16]);
+void eigen33_values(const float cov[9], float evals[3]);
+
+}  // namespace mm3d

@@ -1,0 +1,279 @@
+"""GPU parity: every stage of the HIP path against the CPU oracle on identical seeded inputs.
+
+All calls go through the C ABI (libmm3d.so via map_merge_amd).  Integer/index results must be
+bit-exact; floating-point stages carry their tolerance in the test.  Run with `-m gpu` on the
+MI355X box.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_RAW = 12000
+RES, R_DESC, R_NRM, MIN_NB = 0.1, 0.8, 0.6, 50
+
+
+def xyz(a):
+    return np.stack([a["x"], a["y"], a["z"]], axis=1)
+
+
+@pytest.fixture(scope="module")
+def scene(po, synth):
+    """Two overlapping synthetic maps and every oracle stage on them."""
+    world, maps = synth.synth_maps(2, N_RAW, overlap_step=0.35)
+    out = []
+    for x, c, T in maps:
+        raw = synth.pack_points(x, c)
+        down = po.downsample(raw, RES)
+        filt = po.remove_outliers(down, R_DESC, MIN_NB)
+        nrm = po.normals(filt, R_NRM)
+        kp_raw, scales = po.keypoints_sift(filt, RES, 3, 3, 5.0)
+        kp, desc = po.descriptors_fpfh(filt, nrm, kp_raw, R_DESC)
+        out.append(dict(raw=raw, down=down, filt=filt, nrm=nrm, kp_raw=kp_raw, kp=kp, desc=desc, T=T))
+    return out
+
+
+def test_downsample_bit_exact(ctx, scene):
+    for m in scene:
+        got = ctx.downSample(ctx.cloud(m["raw"]), RES).numpy()
+        assert got.shape == m["down"].shape
+        assert np.array_equal(got.view(np.uint32), m["down"].view(np.uint32))
+
+
+def test_downsample_edge_cases(ctx, po, mm):
+    empty = np.empty(0, dtype=mm.POINT)
+    assert len(ctx.downSample(ctx.cloud(empty), 0.1)) == 0
+    one = np.zeros(1, dtype=mm.POINT); one["x"] = 1.5; one["rgba"] = 0xFF102030
+    got = ctx.downSample(ctx.cloud(one), 0.1).numpy()
+    assert np.array_equal(got, po.downsample(one, 0.1))
+    # leaf too small for int32 voxel indices: VoxelGrid returns the input unchanged
+    far = np.zeros(3, dtype=mm.POINT); far["x"] = [0, 1000, 2000]; far["y"] = [0, 1500, 3000]; far["z"] = [0, 500, 900]
+    got = ctx.downSample(ctx.cloud(far), 0.001).numpy()
+    assert np.array_equal(got, far) and np.array_equal(po.downsample(far, 0.001), far)
+    # non-finite points are skipped
+    nf = np.zeros(4, dtype=mm.POINT); nf["x"] = [0.01, np.nan, 0.02, np.inf]; nf["rgba"] = 0xFF646464
+    assert np.array_equal(ctx.downSample(ctx.cloud(nf), 0.1).numpy().view(np.uint32),
+                          po.downsample(nf, 0.1).view(np.uint32))
+
+
+def test_remove_outliers_exact(ctx, scene):
+    for m in scene:
+        got = ctx.removeOutliers(ctx.cloud(m["down"]), R_DESC, MIN_NB).numpy()
+        assert np.array_equal(got.view(np.uint32), m["filt"].view(np.uint32))
+
+
+def test_remove_outliers_thresholds(ctx, po, scene):
+    d = scene[0]["down"][:3000]
+    for radius, k in [(0.3, 5), (0.5, 20), (0.8, 200), (0.2, 0)]:
+        got = ctx.removeOutliers(ctx.cloud(d), radius, k).numpy()
+        assert np.array_equal(got.view(np.uint32), po.remove_outliers(d, radius, k).view(np.uint32)), (radius, k)
+
+
+def test_normals(ctx, scene):
+    for m in scene:
+        got = ctx.computeSurfaceNormals(ctx.cloud(m["filt"]), R_NRM).numpy()
+        ref = m["nrm"]
+        assert np.array_equal(np.isnan(got["nx"]), np.isnan(ref["nx"]))
+        ok = ~np.isnan(ref["nx"])
+        dot = got["nx"][ok] * ref["nx"][ok] + got["ny"][ok] * ref["ny"][ok] + got["nz"][ok] * ref["nz"][ok]
+        ang = np.arccos(np.clip(dot, -1, 1))
+        # tolerance: 3e-3 rad on >= 99.5 % of the points (the oracle's float raw-moment covariance
+        # carries ~1e-3 rad of its own noise a few tens of metres from the origin; sign must agree)
+        assert np.mean(ang <= 3e-3) >= 0.995, np.percentile(ang, [50, 99, 99.9, 100])
+        # unit length
+        nn = np.sqrt(got["nx"][ok] ** 2 + got["ny"][ok] ** 2 + got["nz"][ok] ** 2)
+        assert np.allclose(nn, 1.0, atol=1e-5)
+
+
+def test_sift_keypoints(ctx, scene):
+    for m in scene:
+        got = ctx.detectKeypoints(ctx.cloud(m["filt"]), None, 0, 5.0, R_NRM, RES).numpy()
+        ref = m["kp_raw"]
+        a = {tuple(r) for r in xyz(got).view(np.uint32).tolist()}
+        b = {tuple(r) for r in xyz(ref).view(np.uint32).tolist()}
+        jac = len(a & b) / max(1, len(a | b))
+        # expf differs by an ulp between glibc and the device: extrema decisions may flip on exact ties
+        assert jac >= 0.99, (len(got), len(ref), jac)
+        if len(got) == len(ref):
+            same = np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
+            assert same or jac < 1.0   # identical sets must come in the identical (octave, index, scale) order
+        assert (got["rgba"] == 0).all()
+
+
+def test_fpfh(ctx, scene):
+    for m in scene:
+        pts, nrm = ctx.cloud(m["filt"]), ctx.normals(m["nrm"])
+        kp = ctx.cloud(m["kp_raw"])
+        desc = ctx.computeLocalDescriptors(pts, nrm, kp, 2, R_DESC)
+        got, ref = desc.numpy(), m["desc"]
+        assert got.shape == ref.shape
+        assert np.array_equal(kp.numpy().view(np.uint32), m["kp"].view(np.uint32))   # same pruning
+        # each 11-bin block sums to 100
+        assert np.allclose(got.reshape(len(got), 3, 11).sum(axis=2), 100.0, atol=1e-2)
+        err = np.abs(got - ref).max(axis=1)
+        # tolerance: 1e-2 on >= 99 % of descriptors (atan2f ulp differences can move one pair across
+        # a bin edge; summation order differs), hard cap 1.0 on the rest
+        assert np.mean(err <= 1e-2) >= 0.99, np.percentile(err, [50, 99, 100])
+        assert err.max() <= 1.0
+
+
+def test_fpfh_prunes_isolated_keypoints(ctx, po, scene, mm):
+    m = scene[0]
+    kp = m["kp_raw"][:50].copy()
+    kp["x"][7] += 500.0          # no surface point within the radius -> NaN descriptor -> pruned
+    kp["z"][20] -= 300.0
+    kp_ref, desc_ref = po.descriptors_fpfh(m["filt"], m["nrm"], kp, R_DESC)
+    k = ctx.cloud(kp)
+    desc = ctx.computeLocalDescriptors(ctx.cloud(m["filt"]), ctx.normals(m["nrm"]), k, 2, R_DESC)
+    assert len(desc) == len(desc_ref) == 48
+    assert np.array_equal(k.numpy().view(np.uint32), kp_ref.view(np.uint32))
+
+
+def test_correspondences_exact(ctx, scene):
+    a, b = scene
+    da, db = ctx.descriptors(a["desc"]), ctx.descriptors(b["desc"])
+    for k in (1, 5, 10):
+        got = ctx.findFeatureCorrespondences(da, db, k)
+        import __graft_entry__ as ge
+        ref = ge.load_oracle().find_correspondences(a["desc"], b["desc"], k)
+        assert np.array_equal(got["index_query"], ref["index_query"])
+        assert np.array_equal(got["index_match"], ref["index_match"])
+        assert np.array_equal(got["distance"].view(np.uint32), ref["distance"].view(np.uint32))
+
+
+def test_ransac_exact(ctx, po, scene):
+    a, b = scene
+    corr = po.find_correspondences(a["desc"], b["desc"], 5)
+    T_ref, inl_ref, iters, best = po.ransac(a["kp"], b["kp"], corr, 0.5)
+    T, inl = ctx.estimateTransformFromCorrespondences(ctx.cloud(a["kp"]), ctx.cloud(b["kp"]), corr, 0.5)
+    assert len(inl) == len(inl_ref)                       # inlier count exact
+    assert np.array_equal(inl["index_query"], inl_ref["index_query"])
+    assert np.array_equal(T.view(np.uint32), T_ref.view(np.uint32))
+    # self-registration: a rigid copy must be recovered with every correspondence an inlier
+    R = np.array([[0.8, -0.6, 0], [0.6, 0.8, 0], [0, 0, 1.0]])
+    moved = a["kp"].copy()
+    p = xyz(a["kp"]).astype(np.float64) @ R.T + np.array([1.0, -2.0, 0.5])
+    moved["x"], moved["y"], moved["z"] = p[:, 0], p[:, 1], p[:, 2]
+    ident = np.zeros(len(moved), dtype=corr.dtype)
+    ident["index_query"] = ident["index_match"] = np.arange(len(moved))
+    T2, inl2 = ctx.estimateTransformFromCorrespondences(ctx.cloud(a["kp"]), ctx.cloud(moved), ident, 0.5)
+    T2r, inl2r, _, _ = po.ransac(a["kp"], moved, ident, 0.5)
+    assert len(inl2) == len(inl2r) == len(moved)
+    assert np.array_equal(T2.view(np.uint32), T2r.view(np.uint32))
+    assert np.allclose(T2[:3, :3], R, atol=1e-4)
+    # too few correspondences -> zero matrix, no inliers (R/src/matching.cpp:128-133)
+    T3, inl3 = ctx.estimateTransformFromCorrespondences(ctx.cloud(a["kp"]), ctx.cloud(b["kp"]), corr[:2], 0.5)
+    assert not T3.any() and len(inl3) == 0
+
+
+def test_sac_ia_exact(ctx, po, scene):
+    a, b = scene
+    po.srand(1)
+    T_ref, best_it, best_err = po.sac_ia(a["kp"], a["desc"], b["kp"], b["desc"], 0.5, 1.0, 500)
+    ctx.srand(1)
+    T = ctx.estimateTransformFromDescriptorsSets(ctx.cloud(a["kp"]), ctx.descriptors(a["desc"]), ctx.cloud(b["kp"]),
+                                                 ctx.descriptors(b["desc"]), 0.5, 1.0, 500)
+    assert np.array_equal(T.view(np.uint32), T_ref.view(np.uint32))   # same best hypothesis, same floats
+    # the generator state advanced identically: a second run continues the stream on both sides
+    T_ref2, _, _ = po.sac_ia(a["kp"], a["desc"], b["kp"], b["desc"], 0.5, 1.0, 50)
+    T2 = ctx.estimateTransformFromDescriptorsSets(ctx.cloud(a["kp"]), ctx.descriptors(a["desc"]), ctx.cloud(b["kp"]),
+                                                  ctx.descriptors(b["desc"]), 0.5, 1.0, 50)
+    assert np.array_equal(T2.view(np.uint32), T_ref2.view(np.uint32))
+
+
+def _small_rot(ax, ay, az, t):
+    cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = t
+    return T
+
+
+def test_transform_score(ctx, po, scene, synth):
+    a, b = scene
+    gt = synth.relative_gt(a["T"], b["T"]).astype(np.float32)
+    ca, cb = ctx.cloud(a["filt"]), ctx.cloud(b["filt"])
+    for T in (gt, np.eye(4, dtype=np.float32), (gt @ _small_rot(0.02, -0.01, 0.05, [0.2, 0.1, 0.0])).astype(np.float32)):
+        ref = po.transform_score(a["filt"], b["filt"], T, 1.0)
+        got = ctx.transformScore(ca, cb, T, 1.0)
+        assert got == pytest.approx(ref, rel=1e-6), (got, ref)   # double sum of identical float d2
+    # nothing in range -> DBL_MAX; zero transform is scored like any other matrix
+    far = np.eye(4, dtype=np.float32); far[0, 3] = 1e4
+    assert ctx.transformScore(ca, cb, far, 1.0) == po.transform_score(a["filt"], b["filt"], far, 1.0) == np.finfo(np.float64).max
+    z = np.zeros((4, 4), dtype=np.float32)
+    assert ctx.transformScore(ca, cb, z, 1.0) == pytest.approx(po.transform_score(a["filt"], b["filt"], z, 1.0), rel=1e-6)
+
+
+def test_icp(ctx, po, scene, synth):
+    a, b = scene
+    gt = synth.relative_gt(a["T"], b["T"])
+    ca, cb = ctx.cloud(a["filt"]), ctx.cloud(b["filt"])
+    for k, pert in enumerate([_small_rot(0.03, -0.02, 0.06, [0.3, -0.2, 0.1]), _small_rot(-0.01, 0.02, -0.1, [-0.4, 0.3, -0.05]),
+                              np.eye(4)]):
+        guess = (gt @ pert).astype(np.float32)
+        for eps, iters in ((1e-2, 500), (1e-6, 30)):
+            T_ref, it_ref = po.icp(a["filt"], b["filt"], guess, 1.0, 0.5, iters, eps)
+            T = ctx.estimateTransformICP(ca, cb, guess, 1.0, 0.5, iters, eps)
+            # tolerance: Frobenius 1e-3 (rotation part 2e-4): the device reduces in double, the oracle in
+            # float like Eigen, and applies the accumulated transform instead of re-transforming the cloud
+            assert np.linalg.norm(T - T_ref) <= 1e-3, (k, eps, np.linalg.norm(T - T_ref))
+            assert np.linalg.norm(T[:3, :3] - T_ref[:3, :3]) <= 2e-4
+            if eps == 1e-6:
+                # tight run moves towards the ground truth
+                assert np.linalg.norm(T - gt) < np.linalg.norm(guess - gt) + 1e-3
+    # zero initial guess stays zero (no guard before ICP in the reference, matching.cpp:250)
+    z = np.zeros((4, 4), dtype=np.float32)
+    assert not ctx.estimateTransformICP(ca, cb, z, 1.0, 0.5, 20, 1e-2).any()
+    assert not po.icp(a["filt"], b["filt"], z, 1.0, 0.5, 20, 1e-2)[0].any()
+
+
+def test_estimate_maps_transforms_end_to_end(ctx, po, mm, scene):
+    a, b = scene
+    params = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
+    op = po.params_default(); op.descriptor_type = 2; op.estimation_method = 1
+    po.srand(1); ctx.srand(1)
+    ref_T, ref_pairs = po.estimate_maps_transforms([a["raw"], b["raw"]], op)
+    T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
+    assert len(T) == len(ref_T) == 2 and len(pairs) == len(ref_pairs) == 1
+    pt = pairs[0]["transform"].reshape(4, 4).T
+    rt = ref_pairs[0]["transform"].reshape(4, 4).T
+    # whole-pipeline tolerance (only meaningful when both sides found the same keypoints, which the
+    # stage tests above establish on this scene): Frobenius 1e-3 on the pair transform
+    assert np.linalg.norm(pt - rt) <= 1e-3, np.linalg.norm(pt - rt)
+    assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=1e-3)
+    for g, r in zip(T, ref_T):
+        assert np.linalg.norm(g - r) <= 2e-3
+    # MATCHING + RANSAC path
+    params.estimation_method = 0; op.estimation_method = 0
+    ref_T, ref_pairs = po.estimate_maps_transforms([a["raw"], b["raw"]], op)
+    T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
+    assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= 1e-3
+
+
+def test_reference_gtests(ctx, mm):
+    """R/test/test_map_merging.cpp:9-40 through the ABI."""
+    P = mm.MapMergingParams()
+    assert ctx.estimateMapsTransforms([], P) == []                                  # estimateMapsTransforms.empty
+    r = ctx.estimateMapsTransforms([np.empty(0, dtype=mm.POINT)], P)                # estimateMapsTransforms.one
+    assert len(r) == 1 and np.array_equal(r[0], np.eye(4, dtype=np.float32))
+    assert ctx.composeMaps([], [], 0.0) is None                                     # composeMaps.empty
+    with pytest.raises(Exception):                                                  # composeMaps.wrongSizes
+        ctx.composeMaps([ctx.cloud(np.empty(0, dtype=mm.POINT))], [], 0.0)
+    res = ctx.composeMaps([ctx.cloud(np.empty(0, dtype=mm.POINT))], [np.eye(4)], 0.0)   # composeMaps.one
+    assert res is not None and len(res) == 0
+
+
+def test_compose_maps(ctx, po, scene):
+    a, b = scene
+    T = [np.eye(4, dtype=np.float32), _small_rot(0.0, 0.0, 0.3, [1, 2, 0]).astype(np.float32)]
+    ref = po.compose_maps([a["filt"], b["filt"]], T, 0.05)
+    got = ctx.composeMaps([ctx.cloud(a["filt"]), ctx.cloud(b["filt"])], T, 0.05).numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # zero transforms are skipped
+    T[1] = np.zeros((4, 4), dtype=np.float32)
+    ref = po.compose_maps([a["filt"], b["filt"]], T, 0.05)
+    got = ctx.composeMaps([ctx.cloud(a["filt"]), ctx.cloud(b["filt"])], T, 0.05).numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
