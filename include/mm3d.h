@@ -94,6 +94,9 @@ typedef struct mm3d_desc mm3d_desc;        /* device-resident descriptors (PCLPo
 int mm3d_create(int device, mm3d_ctx **out);
 void mm3d_destroy(mm3d_ctx *ctx);
 const char *mm3d_last_error(const mm3d_ctx *ctx);
+/* diagnostics of the most recent ICP run on this context (pcl::Registration::nr_iterations_, converged_) */
+int mm3d_last_icp_iterations(const mm3d_ctx *ctx);
+int mm3d_last_icp_converged(const mm3d_ctx *ctx);
 /* SAC-IA draws from libc rand() in the reference (process-global, glibc seed 1).  The context
  * carries its own replay of that generator; mm3d_srand re-seeds it (srand semantics). */
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed);

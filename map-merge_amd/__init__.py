@@ -262,6 +262,7 @@ class Context:
             self._h, source_points._h, target_points._h, g.ctypes.data_as(C.c_void_p),
             C.c_double(max_correspondence_distance), C.c_double(outlier_rejection_threshold), int(max_iterations),
             C.c_double(transformation_epsilon), T.ctypes.data_as(C.c_void_p)))
+        self.last_icp_iterations = lib().mm3d_last_icp_iterations(self._h)
         return _Tout(T)
 
     def estimateTransform(self, source_points, source_keypoints, source_descriptors, target_points,

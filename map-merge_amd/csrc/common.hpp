@@ -128,6 +128,7 @@ struct Context {
   std::string err;
   std::mutex mu;
   GlibcRand rnd;
+  int last_icp_iterations = 0, last_icp_converged = 0;
   // pinned host scratch for small D2H reads
   void *pinned = nullptr;
   size_t pinned_bytes = 0;

@@ -57,9 +57,11 @@ k_knn_exact(const float *__restrict__ A, int na, const float *__restrict__ B, in
       if (r < bd[kMaxK - 1]) {
         float cd = r;
         int ci = j0 + jj;
+        bool carrying = false;   // once an entry is displaced it keeps its place ahead of equal successors
 #pragma unroll
         for (int s = 0; s < kMaxK; ++s) {
-          const bool sw = cd < bd[s];
+          const bool sw = carrying || cd < bd[s];
+          carrying = sw;
           const float td = bd[s];
           const int ti = bi[s];
           bd[s] = sw ? cd : td; bi[s] = sw ? ci : ti;

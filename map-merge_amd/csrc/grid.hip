@@ -246,12 +246,25 @@ __global__ void k_bbox(const float4 *__restrict__ pts, size_t n, unsigned *__res
       mx[a] = fmaxf(mx[a], __shfl_down(mx[a], o, kWave));
     }
   cnt = wave_sum(cnt);
-  if ((threadIdx.x & 63) == 0) {
-    for (int a = 0; a < 3; ++a) {
-      atomicMin(&out[a], f2ord(mn[a]));
-      atomicMax(&out[3 + a], f2ord(mx[a]));
+  // one set of atomics per block (the seven words are shared by the whole grid)
+  __shared__ float smn[4][3], smx[4][3];
+  __shared__ int scnt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    for (int a = 0; a < 3; ++a) { smn[wave][a] = mn[a]; smx[wave][a] = mx[a]; }
+    scnt[wave] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      for (int a = 0; a < 3; ++a) { smn[0][a] = fminf(smn[0][a], smn[w][a]); smx[0][a] = fmaxf(smx[0][a], smx[w][a]); }
+      scnt[0] += scnt[w];
     }
-    atomicAdd(&out[6], (unsigned)cnt);
+    for (int a = 0; a < 3; ++a) {
+      atomicMin(&out[a], f2ord(smn[0][a]));
+      atomicMax(&out[3 + a], f2ord(smx[0][a]));
+    }
+    atomicAdd(&out[6], (unsigned)scnt[0]);
   }
 }
 
@@ -266,7 +279,7 @@ void cloud_bbox(Context *c, mm3d_cloud *cl)
   unsigned *h = (unsigned *)c->pin(64);
   memcpy(h, init, sizeof(init));
   MM3D_HIP(hipMemcpyAsync(d.get(), h, sizeof(init), hipMemcpyHostToDevice, c->stream));
-  unsigned blocks = std::min<unsigned>(div_up(cl->n, 256), 2048);
+  unsigned blocks = std::min<unsigned>(div_up(cl->n, 256 * 8), 512);   // 256 threads, k_bbox assumes 4 waves
   MM3D_LAUNCH(c, "bbox", cl->n * 16.0, k_bbox, dim3(blocks), dim3(256), 0, cl->pts.get(), cl->n, d.get());
   MM3D_HIP(hipMemcpyAsync(h, d.get(), sizeof(init), hipMemcpyDeviceToHost, c->stream));
   c->sync();

@@ -348,6 +348,8 @@ IcpResult icp(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const fl
   memcpy(res.T, hp->T, sizeof(res.T));
   res.iterations = hp->iters;
   res.converged = hp->converged;
+  c->last_icp_iterations = res.iterations;
+  c->last_icp_converged = res.converged;
   return res;
 }
 
@@ -442,7 +444,7 @@ k_sacia_err(const float4 *__restrict__ skp, int ns, GridView g, const float *__r
 {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)ns * H) return;
-  const int i = (int)(t / H), h = (int)(t % H);
+  const int h = (int)(t / ns), i = (int)(t % ns);   // row h of E is contiguous over the keypoints
   const float *T = T_all + (size_t)h * 16;
   float Tl[16];
 #pragma unroll
@@ -462,8 +464,18 @@ __global__ void k_seq_sum(const float *__restrict__ E, int ns, int H, float *__r
 {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
+  const float *row = E + (size_t)h * ns;
   float e = 0.0f;
-  for (int i = 0; i < ns; ++i) e += E[(size_t)i * H + h];
+  int i = 0;
+  // the additions stay strictly sequential; only the loads are batched (8 in flight per thread)
+  for (; i + 8 <= ns; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = row[i + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e += v[k];
+  }
+  for (; i < ns; ++i) e += row[i];
   err[h] = e;
 }
 
