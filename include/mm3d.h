@@ -97,6 +97,11 @@ const char *mm3d_last_error(const mm3d_ctx *ctx);
 /* diagnostics of the most recent ICP run on this context (pcl::Registration::nr_iterations_, converged_) */
 int mm3d_last_icp_iterations(const mm3d_ctx *ctx);
 int mm3d_last_icp_converged(const mm3d_ctx *ctx);
+/* debug counters (cost a host sync per call when on): descriptor k-NN rows that failed the MFMA
+ * certificate and were redone by the exact kernel, out of all rows, since the last reset */
+void mm3d_set_debug(mm3d_ctx *ctx, int on);
+long long mm3d_debug_knn_fallback_rows(mm3d_ctx *ctx);
+long long mm3d_debug_knn_rows(mm3d_ctx *ctx);
 /* SAC-IA draws from libc rand() in the reference (process-global, glibc seed 1).  The context
  * carries its own replay of that generator; mm3d_srand re-seeds it (srand semantics). */
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed);

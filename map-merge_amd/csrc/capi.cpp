@@ -192,6 +192,14 @@ void mm3d_destroy(mm3d_ctx *ctx)
 const char *mm3d_last_error(const mm3d_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int mm3d_last_icp_iterations(const mm3d_ctx *ctx) { return ctx ? ctx->last_icp_iterations : 0; }
 int mm3d_last_icp_converged(const mm3d_ctx *ctx) { return ctx ? ctx->last_icp_converged : 0; }
+void mm3d_set_debug(mm3d_ctx *ctx, int on)
+{
+  if (!ctx) return;
+  ctx->debug = on != 0;
+  ctx->knn_fallback_rows = ctx->knn_rows = 0;
+}
+long long mm3d_debug_knn_fallback_rows(mm3d_ctx *ctx) { return ctx ? ctx->knn_fallback_rows : 0; }
+long long mm3d_debug_knn_rows(mm3d_ctx *ctx) { return ctx ? ctx->knn_rows : 0; }
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed) { if (ctx) ctx->rnd.seed(seed); }
 int mm3d_synchronize(mm3d_ctx *ctx) { return guarded(ctx, [&] { ctx->sync(); }); }
 

@@ -129,6 +129,8 @@ struct Context {
   std::mutex mu;
   GlibcRand rnd;
   int last_icp_iterations = 0, last_icp_converged = 0;
+  bool debug = false;            // mm3d_set_debug: collect counters that cost a host sync
+  long long knn_fallback_rows = 0, knn_rows = 0;
   // pinned host scratch for small D2H reads
   void *pinned = nullptr;
   size_t pinned_bytes = 0;

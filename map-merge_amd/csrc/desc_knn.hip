@@ -5,31 +5,46 @@
 //   SAC-IA findSimilarFeatures   R/src/matching.cpp:159-173 (k_correspondences_ = 10)
 // A kd-tree in 33+ dimensions degenerates to a linear scan; here it IS a linear scan, tiled.
 //
-// Two stages:
-//   1. candidate generation on the matrix cores: G = A * B^T with v_mfma_f32_32x32x2_f32 (exact
-//      f32 FMA chains), approximate distance |a|^2 + |b|^2 - 2G, per-row top-(kCand) kept in LDS;
-//   2. exact re-rank of the candidates with FLANN's L2_Simple accumulation (diff*diff summed in
-//      dimension order, no FMA) -- the ONLY distances that leave the kernel -- plus a certificate:
-//      the row is accepted only if the worst kept candidate's approximate distance clears the
-//      k-th exact distance by more than the expansion's error bound; otherwise the row is redone by
-//      the exact brute-force kernel.  The result is the exact k-NN, ties to the lower index.
+// Three stages (desc_knn below):
+//   1. knn_prep: descriptors -> augmented, MFMA-ordered operands.  Query  a' = [a, |a|^2, 1, 0],
+//      target b' = [-2b, 1, |b|^2, 0]  (36 wide), so a'.b' = |a|^2 + |b|^2 - 2 a.b directly.
+//   2. knn_mfma: the one genuine dense contraction of the pipeline on the matrix cores,
+//      v_mfma_f32_32x32x2_f32 (exact f32 FMA chains, 157 TF peak).  One wave owns 32 queries as the
+//      COLUMNS of the product, so each lane sees 16 target rows of one query per tile and keeps a
+//      register-resident sorted list of the 16 best approximate distances.
+//   3. knn_rerank: the candidates (2 lane halves x 4 target slices x 16) are re-ranked with FLANN's
+//      L2_Simple accumulation (diff*diff summed in dimension order, no FMA) -- the ONLY distances
+//      that leave this file -- and certified: the k-th exact distance must clear the smallest
+//      "worst kept approximate distance" of any full list by more than the expansion's rounding
+//      bound.  Rows that fail go through the exact brute-force kernel.  The result is therefore the
+//      exact k-NN with ties to the lower index, bit-identical to the CPU path.
 #include "device_util.hpp"
 
 namespace mm3d {
 
 constexpr int kMaxK = 16;
+constexpr int kD = 33;
+constexpr int kKP = 36;          // padded contraction length
+constexpr int kSteps = kKP / 2;  // 32x32x2 MFMA steps
+constexpr int kSlices = 4;       // waves per query tile, each scanning a quarter of the targets
+constexpr int kLists = 2 * kSlices;
+constexpr int kCand = kLists * kMaxK;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------- exact brute force (VALU)
 // one thread per query row (registers), target rows staged through LDS in tiles of 64 and
-// broadcast-read by every lane.
+// broadcast-read by every lane.  Used for small problems and for rows that fail the certificate.
 template <int D>
 __global__ void __launch_bounds__(128)
 k_knn_exact(const float *__restrict__ A, int na, const float *__restrict__ B, int nb, int k,
-            const int *__restrict__ rows /* optional subset of A rows */, int nrows, int *__restrict__ idx,
-            float *__restrict__ d2out)
+            const int *__restrict__ rows /* optional subset of A rows */, const int *__restrict__ nrows_dev, int nrows_host,
+            int *__restrict__ idx, float *__restrict__ d2out)
 {
   constexpr int TB = 64;
   __shared__ float tile[TB][D + 1];
+  const int nrows = nrows_dev ? *nrows_dev : nrows_host;
+  if ((int)(blockIdx.x * blockDim.x) >= nrows) return;   // uniform per block
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = t < nrows;
   const int row = active ? (rows ? rows[t] : t) : 0;
@@ -79,26 +94,219 @@ k_knn_exact(const float *__restrict__ A, int na, const float *__restrict__ B, in
     }
 }
 
-// The insertion network above keeps kMaxK entries; only the first k are reported, which is the
-// exact top-k because the list is the exact sorted top-kMaxK.
+// ---------------------------------------------------------------- stage 1: operand preparation
+// Xp[(tile * kSteps + s) * 64 + lane] = x'[tile*32 + (lane & 31)][2*s + (lane >> 5)]: one coalesced
+// 256-byte wave load per MFMA step.
+__global__ void k_knn_prep(const float *__restrict__ X, int n, int ntiles, int is_target, float *__restrict__ Xp,
+                           unsigned *__restrict__ norm2max_ord)
+{
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)ntiles * kSteps * 64) return;
+  const int lane = (int)(e & 63);
+  const int s = (int)((e >> 6) % kSteps);
+  const int tile = (int)(e / (64 * kSteps));
+  const int row = tile * 32 + (lane & 31);
+  const int kk = 2 * s + (lane >> 5);
+  float v = 0.0f;
+  if (row < n) {
+    const float *x = X + (size_t)row * kD;
+    if (kk < kD) {
+      v = is_target ? -2.0f * x[kk] : x[kk];
+    } else if (kk == kD || kk == kD + 1) {
+      const bool want_norm = is_target ? (kk == kD + 1) : (kk == kD);
+      if (want_norm) {
+        float nrm = 0.0f;
+        for (int d = 0; d < kD; ++d) nrm = fmaf(x[d], x[d], nrm);
+        v = nrm;
+        if (is_target) atomicMax(norm2max_ord, f2ord(nrm));
+      } else {
+        v = 1.0f;
+      }
+    }
+  } else if (is_target) {
+    // padding targets: a'.b' = 1e30, never a candidate ahead of a real row
+    v = (kk == kD + 1) ? 1e30f : 0.0f;
+  }
+  Xp[e] = v;
+}
+
+// ---------------------------------------------------------------- stage 2: MFMA distance tiles
+// block = one tile of 32 queries; its 4 waves scan disjoint quarters of the target tiles.
+__global__ void __launch_bounds__(256)
+k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, int nb, int nb_tiles,
+           float *__restrict__ cand_d, int *__restrict__ cand_i)
+{
+  const int lane = threadIdx.x & 63;
+  const int slice = threadIdx.x >> 6;
+  const int tile_a = blockIdx.x;
+  float af[kSteps];
+#pragma unroll
+  for (int s = 0; s < kSteps; ++s) af[s] = Ap[((size_t)tile_a * kSteps + s) * 64 + lane];
+  float ld[kMaxK];
+  int li[kMaxK];
+#pragma unroll
+  for (int s = 0; s < kMaxK; ++s) { ld[s] = INFINITY; li[s] = -1; }
+  const int c0 = (int)(((long long)nb_tiles * slice) / kSlices), c1 = (int)(((long long)nb_tiles * (slice + 1)) / kSlices);
+  float bf[kSteps], bn[kSteps];
+  if (c0 < c1) {
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) bf[s] = Bp[((size_t)c0 * kSteps + s) * 64 + lane];
+  }
+  for (int c = c0; c < c1; ++c) {
+    // prefetch the next target tile while the matrix core works on this one
+    const int cn = (c + 1 < c1) ? c + 1 : c;
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) bn[s] = Bp[((size_t)cn * kSteps + s) * 64 + lane];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // rows of the product = targets (A operand), columns = queries (B operand)
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc, 0, 0, 0);
+    const int rbase = c * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[r];
+      if (v < ld[kMaxK - 1]) {
+        float cd = v;
+        int ci = rbase + (r & 3) + 8 * (r >> 2);
+        bool carrying = false;
+#pragma unroll
+        for (int s = 0; s < kMaxK; ++s) {
+          const bool sw = carrying || cd < ld[s];
+          carrying = sw;
+          const float td = ld[s];
+          const int ti = li[s];
+          ld[s] = sw ? cd : td; li[s] = sw ? ci : ti;
+          cd = sw ? td : cd; ci = sw ? ti : ci;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) bf[s] = bn[s];
+  }
+  const int a = tile_a * 32 + (lane & 31);
+  if (a >= na) return;
+  const int list = (lane >> 5) * kSlices + slice;
+  float *od = cand_d + ((size_t)a * kLists + list) * kMaxK;
+  int *oi = cand_i + ((size_t)a * kLists + list) * kMaxK;
+#pragma unroll
+  for (int s = 0; s < kMaxK; ++s) {
+    const bool real = li[s] >= 0 && li[s] < nb;
+    od[s] = real ? ld[s] : INFINITY;
+    oi[s] = real ? li[s] : -1;
+  }
+}
+
+// ---------------------------------------------------------------- stage 3: exact re-rank + certificate
+__global__ void __launch_bounds__(128)
+k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, int nb, int k,
+             const float *__restrict__ cand_d, const int *__restrict__ cand_i, const unsigned *__restrict__ norm2max_ord,
+             int *__restrict__ idx, float *__restrict__ d2out, int *__restrict__ fb_rows, int *__restrict__ fb_count)
+{
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= na) return;
+  float x[kD];
+  float na2 = 0.0f;
+#pragma unroll
+  for (int d = 0; d < kD; ++d) { x[d] = A[(size_t)a * kD + d]; na2 = fmaf(x[d], x[d], na2); }
+  float bd[kMaxK];
+  int bi[kMaxK];
+#pragma unroll
+  for (int s = 0; s < kMaxK; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
+  float tau = INFINITY;
+  for (int l = 0; l < kLists; ++l) {
+    const float *cd_ = cand_d + ((size_t)a * kLists + l) * kMaxK;
+    const int *ci_ = cand_i + ((size_t)a * kLists + l) * kMaxK;
+    // a full list hides targets whose approximate distance is >= its worst entry
+    if (ci_[kMaxK - 1] >= 0) tau = fminf(tau, cd_[kMaxK - 1]);
+    for (int s = 0; s < kMaxK; ++s) {
+      const int j = ci_[s];
+      if (j < 0) break;
+      const float *b = B + (size_t)j * kD;
+      float r = 0.0f;
+#pragma unroll
+      for (int d = 0; d < kD; ++d) {
+        const float df = x[d] - b[d];
+        r = __fadd_rn(r, __fmul_rn(df, df));
+      }
+      if (r < bd[kMaxK - 1] || (r == bd[kMaxK - 1] && j < bi[kMaxK - 1])) {
+        float cd = r;
+        int ci = j;
+        bool carrying = false;
+#pragma unroll
+        for (int t = 0; t < kMaxK; ++t) {
+          const bool sw = carrying || cd < bd[t] || (cd == bd[t] && ci < bi[t]);
+          carrying = sw;
+          const float td = bd[t];
+          const int ti = bi[t];
+          bd[t] = sw ? cd : td; bi[t] = sw ? ci : ti;
+          cd = sw ? td : cd; ci = sw ? ti : ci;
+        }
+      }
+    }
+  }
+  // |approx - exact| <= ~1.05e-5 (|a|^2 + |b|^2) for a 36-term f32 FMA chain plus the 33-term exact
+  // sum (header comment of DESIGN.md section 5); 2e-5 keeps a 2x margin
+  const float eps = 2e-5f * (na2 + ord2f(*norm2max_ord));
+  float kth = INFINITY;
+#pragma unroll
+  for (int s = 0; s < kMaxK; ++s)
+    if (s == k - 1) kth = bd[s];
+  const bool certified = !(tau < INFINITY) || (kth < tau - eps);
+#pragma unroll
+  for (int s = 0; s < kMaxK; ++s)
+    if (s < k) {
+      const bool have = bd[s] < INFINITY;
+      idx[(size_t)a * k + s] = have ? bi[s] : -1;
+      d2out[(size_t)a * k + s] = bd[s];
+    }
+  if (!certified) fb_rows[atomicAdd(fb_count, 1)] = a;
+}
 
 void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2)
 {
   MM3D_REQUIRE(A->dim == B->dim, "descriptor dimensions differ");
   MM3D_REQUIRE(k >= 1, "k must be positive");
   if (k > kMaxK) throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN supports k <= 16");
+  if (A->dim != kD) throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for FPFH (dim 33) only");
   const int na = (int)A->n, nb = (int)B->n;
   idx = DevBuf<int>(c, (size_t)na * k);
   d2 = DevBuf<float>(c, (size_t)na * k);
   if (na == 0) return;
-  const double flops = 2.0 * na * (double)nb * A->dim;
-  (void)flops;
-  if (A->dim == 33) {
-    MM3D_LAUNCH(c, "desc_knn_exact", ((double)na + nb) * 132.0, (k_knn_exact<33>), dim3(div_up(na, 128)), dim3(128), 0,
-                (const float *)A->data.get(), na, (const float *)B->data.get(), nb, k, (const int *)nullptr, na, idx.get(),
-                d2.get());
-  } else {
-    throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for FPFH (dim 33) only");
+  const float *Ad = A->data.get(), *Bd = B->data.get();
+  if ((double)na * nb < 65536.0 || nb < 64) {
+    MM3D_LAUNCH(c, "desc_knn_exact", ((double)na + nb) * 132.0, (k_knn_exact<kD>), dim3(div_up(na, 128)), dim3(128), 0, Ad, na,
+                Bd, nb, k, (const int *)nullptr, (const int *)nullptr, na, idx.get(), d2.get());
+    return;
+  }
+  const int na_tiles = (na + 31) / 32, nb_tiles = (nb + 31) / 32;
+  DevBuf<float> Ap(c, (size_t)na_tiles * kSteps * 64), Bp(c, (size_t)nb_tiles * kSteps * 64);
+  DevBuf<unsigned> meta(c, 4);   // [0] max |b|^2 (ordered bits), [1] fallback count
+  MM3D_HIP(hipMemsetAsync(meta.get(), 0, 16, c->stream));
+  MM3D_LAUNCH(c, "desc_knn_prep", na * 276.0, k_knn_prep, dim3(div_up((size_t)na_tiles * kSteps * 64, 256)), dim3(256), 0, Ad, na,
+              na_tiles, 0, Ap.get(), meta.get());
+  MM3D_LAUNCH(c, "desc_knn_prep", nb * 276.0, k_knn_prep, dim3(div_up((size_t)nb_tiles * kSteps * 64, 256)), dim3(256), 0, Bd, nb,
+              nb_tiles, 1, Bp.get(), meta.get());
+  DevBuf<float> cand_d(c, (size_t)na * kCand);
+  DevBuf<int> cand_i(c, (size_t)na * kCand);
+  // roofline unit for this kernel is FLOPs (2 * na * nb * 36 per launch), reported as such by bench.py
+  MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, k_knn_mfma, dim3(na_tiles), dim3(256), 0,
+              (const float *)Ap.get(), na, (const float *)Bp.get(), nb, nb_tiles, cand_d.get(), cand_i.get());
+  DevBuf<int> fb_rows(c, na);
+  MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(kCand * 140 + 132), k_knn_rerank, dim3(div_up(na, 128)), dim3(128), 0, Ad, na, Bd,
+              nb, k, (const float *)cand_d.get(), (const int *)cand_i.get(), (const unsigned *)meta.get(), idx.get(), d2.get(),
+              fb_rows.get(), (int *)(meta.get() + 1));
+  // rows without a certificate: exact brute force (the grid is sized for the worst case; blocks
+  // beyond the device-side count exit at once)
+  MM3D_LAUNCH(c, "desc_knn_exact", 0.0, (k_knn_exact<kD>), dim3(div_up(na, 128)), dim3(128), 0, Ad, na, Bd, nb, k,
+              (const int *)fb_rows.get(), (const int *)(meta.get() + 1), 0, idx.get(), d2.get());
+  if (c->debug) {
+    unsigned *h = (unsigned *)c->pin(64);
+    MM3D_HIP(hipMemcpyAsync(h, meta.get(), 16, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    c->knn_fallback_rows += (long long)h[1];
+    c->knn_rows += na;
   }
 }
 

@@ -174,6 +174,32 @@ def test_correspondences_exact(ctx, scene):
         assert np.array_equal(got["distance"].view(np.uint32), ref["distance"].view(np.uint32))
 
 
+def test_desc_knn_mfma_path_exact(ctx, po, mm, scene):
+    """Large enough for the matrix-core candidate stage; results must still be the exact FLANN-order
+    k-NN (indices and distance bits), and almost no row may need the exact fallback."""
+    rng = np.random.default_rng(7)
+    base = np.concatenate([scene[0]["desc"], scene[1]["desc"]])
+    # FPFH-like rows: resample real descriptors with small perturbations, plus exact duplicates (ties)
+    A = base[rng.integers(0, len(base), 1500)] + rng.normal(0, 0.3, (1500, 33)).astype(np.float32)
+    B = base[rng.integers(0, len(base), 2100)] + rng.normal(0, 0.3, (2100, 33)).astype(np.float32)
+    B[100:140] = B[200:240]                      # duplicated targets: ties must go to the lower index
+    A[:20] = B[300:320]                          # zero distances
+    A, B = A.astype(np.float32), B.astype(np.float32)
+    L = mm.lib()
+    L.mm3d_debug_knn_fallback_rows.restype = L.mm3d_debug_knn_rows.restype = __import__("ctypes").c_longlong
+    L.mm3d_set_debug(ctx._h, 1)
+    da, db = ctx.descriptors(A), ctx.descriptors(B)
+    for k in (1, 5, 10, 16):
+        got = ctx.findFeatureCorrespondences(da, db, k)
+        ref = po.find_correspondences(A, B, k)
+        assert np.array_equal(got["index_query"], ref["index_query"]), k
+        assert np.array_equal(got["index_match"], ref["index_match"]), k
+        assert np.array_equal(got["distance"].view(np.uint32), ref["distance"].view(np.uint32)), k
+    rows, fb = L.mm3d_debug_knn_rows(ctx._h), L.mm3d_debug_knn_fallback_rows(ctx._h)
+    L.mm3d_set_debug(ctx._h, 0)
+    assert rows > 0 and fb <= 0.05 * rows, (rows, fb)   # the certificate holds for nearly every row
+
+
 def test_ransac_exact(ctx, po, scene):
     a, b = scene
     corr = po.find_correspondences(a["desc"], b["desc"], 5)
