@@ -79,6 +79,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     mm = ge.load()
+    from map_merge_amd import sharding
     ctx = mm.Context(local_rank)
     params = mm.MapMergingParams(descriptor_type=mm.Descriptor.FPFH, estimation_method=mm.EstimationMethod.SAC_IA,
                                  refine_transform=1)
@@ -138,30 +139,20 @@ def main():
         ctx.synchronize()
         t1 = time.perf_counter()
         for i in range(n_maps):
-            maps[i] = bcast_map(i % world, maps[i])
+            maps[i] = bcast_map(sharding.map_owner(i, world), maps[i])
         kn = [len(m.keypoints) for m in maps]
-        live = [(i, j) for (i, j) in pairs_idx if kn[i] > 0 and kn[j] > 0]
+        live = sharding.live_pairs(n_maps, kn)
         t2 = time.perf_counter()
         mine = np.zeros(len(live), dtype=mm.PAIR)
         for p, (i, j) in enumerate(live):
-            r = ctx.pairEstimate(maps[i], maps[j], params, execute=(p % world == rank))
+            # non-owners only replay the pair's rand() draws (mm3d_pair_estimate, execute = 0)
+            r = ctx.pairEstimate(maps[i], maps[j], params, execute=(sharding.pair_owner(p, world) == rank))
             r["source_idx"], r["target_idx"] = i, j
             mine[p] = r
         ctx.synchronize()
         t3 = time.perf_counter()
-        if world > 1:
-            # C1: all-gather of the fixed-size pair records; slot p is valid on rank p % world
-            buf = torch.from_numpy(mine.view(np.uint8).reshape(len(live), -1).copy()).to(dev)
-            allb = [torch.empty_like(buf) for _ in range(world)]
-            dist.all_gather(allb, buf)
-            merged = mine.copy()
-            for r in range(world):
-                if r == rank:
-                    continue
-                other = allb[r].cpu().numpy().view(mm.PAIR).reshape(-1)
-                sel = np.arange(len(live)) % world == r
-                merged[sel] = other[sel]
-            mine = merged
+        # C1: all-gather of the fixed-size pair records over RCCL
+        mine = sharding.gather_pair_records(mine, world, rank, dist if world > 1 else None, dev)
         T = mm.globalTransforms(mine, params.confidence_threshold, n_maps)
         t4 = time.perf_counter()
         stats.update(dict(n_pairs=len(live), t_features=t1 - t0, t_exchange=t2 - t1, t_pairs=t3 - t2, t_gather_graph=t4 - t3,
