@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA (v_mfma_f32_32x32x2_f32)
+MFMA_KERNELS = {"desc_knn_mfma"}   # kernels whose profile "bytes" field carries FLOPs (csrc/desc_knn.hip)
 
 
 def make_workload(n_maps, n_points, cache=True):
@@ -197,12 +199,18 @@ def main():
         if dom[0]:
             k = dom[1]
             avg_ms = k["ms"] / max(k["launches"], 1)
-            bytes_per_launch = k["bytes"] / max(k["launches"], 1)
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            roofline = {"kernel": dom[0], "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                        "avg_launch_us": round(avg_ms * 1e3, 3), "launches_per_step": k["launches"] / max(args.steps, 1),
-                        "algorithmic_bytes_per_launch": round(bytes_per_launch, 1)}
+            work_per_launch = k["bytes"] / max(k["launches"], 1)   # bytes, or FLOPs for the MFMA kernel
+            rate = work_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+            if dom[0] in MFMA_KERNELS:
+                roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(rate / 1e12, 4), "peak": MFMA_F32_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(rate / 1e12 / MFMA_F32_PEAK_TFLOPS, 6), "traffic": None,
+                            "avg_launch_us": round(avg_ms * 1e3, 3), "launches_per_step": k["launches"] / max(args.steps, 1),
+                            "algorithmic_flops_per_launch": round(work_per_launch, 1)}
+            else:
+                roofline = {"kernel": dom[0], "bound": "hbm", "achieved": round(rate / 1e9, 3), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(rate / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                            "avg_launch_us": round(avg_ms * 1e3, 3), "launches_per_step": k["launches"] / max(args.steps, 1),
+                            "algorithmic_bytes_per_launch": round(work_per_launch, 1)}
         top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:8]
         npts_f = stats["pts_filtered"]
         icp_pts = sum(npts_f[i] * it for (i, j), it in zip([(i, j) for (i, j) in pairs_idx], stats["icp_iters"]))

@@ -370,6 +370,66 @@ const Grid &cloud_grid(Context *c, const mm3d_cloud *cl_, float cell)
   return ref;
 }
 
+// ---------------------------------------------------------------- Chebyshev distance transform
+// dt[c] = distance in cells (max-norm) from cell c to the nearest occupied cell, 255 if > R.
+// The max-norm separates exactly: f1 = 1-D distance along x, f2 = min_dy max(f1, |dy|), f3 likewise
+// along z.  A 1-NN query reads ONE byte to learn which ring of cells to start at, or that nothing
+// lies within range at all (most source points of a non-overlapping map pair).
+__global__ void k_dt_x(const int *__restrict__ cell_start, int dx, int dy, int dz, int R, unsigned char *__restrict__ out)
+{
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nc = (size_t)dx * dy * dz;
+  if (c >= nc) return;
+  const int x = (int)(c % dx);
+  const size_t row = c - x;
+  int best = 255;
+  for (int d = 0; d <= R && best == 255; ++d) {
+    const int xl = x - d, xr = x + d;
+    if (xl >= 0 && cell_start[row + xl + 1] > cell_start[row + xl]) best = d;
+    else if (xr < dx && cell_start[row + xr + 1] > cell_start[row + xr]) best = d;
+  }
+  out[c] = (unsigned char)best;
+}
+
+__global__ void k_dt_axis(const unsigned char *__restrict__ in, int dx, int dy, int dz, int axis, int R,
+                          unsigned char *__restrict__ out)
+{
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nc = (size_t)dx * dy * dz;
+  if (c >= nc) return;
+  const int x = (int)(c % dx), y = (int)((c / dx) % dy), z = (int)(c / ((size_t)dx * dy));
+  const int pos = axis == 1 ? y : z, lim = axis == 1 ? dy : dz;
+  const size_t stride = axis == 1 ? (size_t)dx : (size_t)dx * dy;
+  int best = 255;
+  for (int d = -R; d <= R; ++d) {
+    const int q = pos + d;
+    if (q < 0 || q >= lim) continue;
+    const int v = in[c + (long long)d * (long long)stride];
+    const int a = d < 0 ? -d : d;
+    const int m = v > a ? v : a;
+    best = m < best ? m : best;
+  }
+  out[c] = (unsigned char)(best > R ? 255 : best);
+}
+
+void grid_ensure_dt(Context *c, const Grid &g_, int R)
+{
+  Grid &g = const_cast<Grid &>(g_);
+  if (R > 250) R = 250;
+  if (g.dt.get() && g.dt_cap >= R) return;
+  const size_t nc = (size_t)g.dims[0] * g.dims[1] * g.dims[2];
+  DevBuf<unsigned char> a(c, nc), b(c, nc);
+  const unsigned blocks = div_up(nc, 256);
+  MM3D_LAUNCH(c, "grid_dt", nc * 5.0, k_dt_x, dim3(blocks), dim3(256), 0, (const int *)g.cell_start.get(), g.dims[0], g.dims[1],
+              g.dims[2], R, a.get());
+  MM3D_LAUNCH(c, "grid_dt", nc * 2.0, k_dt_axis, dim3(blocks), dim3(256), 0, (const unsigned char *)a.get(), g.dims[0], g.dims[1],
+              g.dims[2], 1, R, b.get());
+  MM3D_LAUNCH(c, "grid_dt", nc * 2.0, k_dt_axis, dim3(blocks), dim3(256), 0, (const unsigned char *)b.get(), g.dims[0], g.dims[1],
+              g.dims[2], 2, R, a.get());
+  g.dt = std::move(a);
+  g.dt_cap = R;
+}
+
 // ---------------------------------------------------------------- ordered compaction
 __global__ void k_compact(const float4 *__restrict__ in, const int *__restrict__ flags, const int *__restrict__ pos,
                           size_t n, float4 *__restrict__ out)

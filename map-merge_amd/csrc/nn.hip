@@ -1,0 +1,619 @@
+// nn.hip -- ICP and transformScore: exact 1-NN of every (transformed) source point in the target
+// grid, fused with the reduction the caller needs (K12/K13 in SURVEY 2.2).
+//
+// estimateTransformICP  R/src/matching.cpp:196-221 -> pcl::IterativeClosestPoint (point-to-point,
+//                       TransformationEstimationSVD/Umeyama, DefaultConvergenceCriteria)
+// transformScore        R/src/matching.cpp:259-268 -> TransformationValidationEuclidean
+//
+// Wave-cooperative search.  A wave owns 64 consecutive source points in Morton order (a compact
+// patch), so the cells its queries can touch form a small box of the target grid.  The wave
+//   1. reads one distance-transform byte per lane (how many cells to the nearest occupied cell;
+//      out of range -> that lane is done),
+//   2. takes the bounding box of its lanes' cells, grows it by the largest radius any lane needs,
+//   3. streams the box's rows (contiguous spans of the cell-sorted target) through LDS with
+//      coalesced 16-byte loads, 512 points per tile,
+//   4. every lane scans the tile out of LDS (same address for all lanes = broadcast reads),
+//   5. a lane is finished when its best distance is within what the box provably covers; otherwise
+//      the box grows once more to the radius that lane needs.
+// Candidate traffic is therefore LDS traffic; HBM sees the source once (16 B/point) and each target
+// span once per wave.  The ICP iteration stays two launches and no host round trip:
+// icp_corr_reduce (this search + 17 double partial sums per block through wave shuffles) and
+// icp_finalize (Umeyama by 3x3 Jacobi SVD, accumulate, PCL's convergence tests, all on the device).
+// Algorithmic traffic: 12 B per source point per iteration.
+#include <cfloat>
+
+#include "device_util.hpp"
+
+namespace mm3d {
+
+constexpr int kAcc = 17;     // sum p(3) | sum q(3) | sum q p^T (9, row = q) | sum d2 | count
+constexpr int kTile = 512;   // staged target points per wave and tile (8 KiB of LDS)
+
+#ifdef MM3D_NN_STATS
+__device__ unsigned long long g_nn_stats[8];   // 0 waves, 1 passes, 2 row chunks, 3 staged points, 4 active lanes at pass, 5 rows
+#define MM3D_STAT(i_, v_) do { if (lane == 0) atomicAdd(&g_nn_stats[i_], (unsigned long long)(v_)); } while (0)
+#else
+#define MM3D_STAT(i_, v_)
+#endif
+
+struct IcpState {
+  float T[16];      // cumulative transform applied to the original source points (starts at the guess)
+  float Tinc[16];
+  double prev_mse;
+  double rot_thresh, trans_thresh;
+  int iters, done, converged, n_corr, max_iter, pad;
+};
+
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+// LDS written by some lanes of a wave and read by others: order the accesses for the compiler;
+// the hardware executes one wave's DS operations in order.
+__device__ __forceinline__ void wave_lds_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// MODE 0: ICP (transform from the device state, accumulate Umeyama moments)
+// MODE 1: transformScore (transform from Tc, accumulate sum d2 / count for d2 <= max_d2)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_items, GridView g,
+          const float4 *__restrict__ tgt_ref /* target points in reference order */,
+          const IcpState *__restrict__ st, const float *__restrict__ Tc, float max_d2, float rmax, int max_ring,
+          double *__restrict__ partials)
+{
+  __shared__ float Ts[16];
+  __shared__ double red[4][kAcc];
+  __shared__ float4 s_pts[4][kTile];
+  __shared__ int s_off[4][64];
+  __shared__ int s_beg[4][64];
+  if (MODE == 0 && st->done) return;
+  if (threadIdx.x < 16) Ts[threadIdx.x] = (MODE == 0) ? st->T[threadIdx.x] : Tc[threadIdx.x];
+  __syncthreads();
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = bid * 4 + wave;                       // one work item (<= 64 points of one coarse block) per wave
+  const int2 it = item < n_items ? items[item] : make_int2(0, 0);
+  const int i = it.x + lane;
+  const bool valid = lane < it.y;
+  float3 p = make_float3(0.f, 0.f, 0.f);
+  if (valid) {
+    const float4 s = src[i];
+    p = xform(Ts, s.x, s.y, s.z);
+  }
+  const int cx = cell_floor(p.x, g.minx, g.inv), cy = cell_floor(p.y, g.miny, g.inv), cz = cell_floor(p.z, g.minz, g.inv);
+  bool active = valid;
+  int need = max_ring;          // radius (in cells around the lane's own cell) the lane wants scanned
+  if (active) {
+    const bool inside = cx >= 0 && cx < g.dx && cy >= 0 && cy < g.dy && cz >= 0 && cz < g.dz;
+    if (inside) {
+      const int d0 = g.dt[((size_t)cz * g.dy + cy) * g.dx + cx];
+      if (d0 > max_ring) active = false;          // nothing within range of this cell
+      need = d0 > 1 ? d0 : 1;
+    } else {
+      // outside the grid: farther than rmax from its box means no neighbour in range
+      const float ex = fmaxf(fmaxf(g.minx - p.x, p.x - (g.minx + g.dx * g.cell)), 0.0f);
+      const float ey = fmaxf(fmaxf(g.miny - p.y, p.y - (g.miny + g.dy * g.cell)), 0.0f);
+      const float ez = fmaxf(fmaxf(g.minz - p.z, p.z - (g.minz + g.dz * g.cell)), 0.0f);
+      if (!(fmaxf(ex, fmaxf(ey, ez)) <= rmax)) active = false;
+    }
+  }
+  // (d2 bits, original index) as one 64-bit key: d2 >= 0 so its bits order like the value, and the
+  // low word breaks ties towards the lower original index, like the CPU path
+  unsigned long long bkey = ~0ull;
+  float best = INFINITY;
+
+  for (int pass = 0; pass < 64; ++pass) {
+    if (!__ballot(active)) break;
+    MM3D_STAT(1, 1);
+    MM3D_STAT(4, __popcll(__ballot(active)));
+    if (pass == 0) MM3D_STAT(0, 1);
+    // box = bounding box of the active lanes' cells, grown by the largest radius any of them needs
+    const int E = wave_max_i(active ? need : 0);
+    const int lx = wave_min_i(active ? cx : 0x7fffffff), hx = wave_max_i(active ? cx : -0x7fffffff);
+    const int ly = wave_min_i(active ? cy : 0x7fffffff), hy = wave_max_i(active ? cy : -0x7fffffff);
+    const int lz = wave_min_i(active ? cz : 0x7fffffff), hz = wave_max_i(active ? cz : -0x7fffffff);
+    const int x0 = max(lx - E, 0), x1 = min(hx + E, g.dx - 1);
+    const int y0 = max(ly - E, 0), y1 = min(hy + E, g.dy - 1);
+    const int z0 = max(lz - E, 0), z1 = min(hz + E, g.dz - 1);
+    const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    const int nrows = (x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
+    for (int r0 = 0; r0 < nrows; r0 += kWave) {
+      // one row header per lane, exclusive scan of the span lengths
+      const int r = r0 + lane;
+      int b = 0, len = 0;
+      if (r < nrows) {
+        const int z = z0 + r / ny, y = y0 + r % ny;
+        const int row = (z * g.dy + y) * g.dx;
+        b = g.cell_start[row + x0];
+        len = g.cell_start[row + x1 + 1] - b;
+      }
+      int incl = len;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const int t = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += t;
+      }
+      const int total = __shfl(incl, kWave - 1, kWave);
+      MM3D_STAT(2, 1);
+      MM3D_STAT(3, total);
+      MM3D_STAT(5, min(nrows - r0, kWave));
+      wave_lds_sync();                 // previous tile's readers are done
+      s_off[wave][lane] = incl - len;
+      s_beg[wave][lane] = b;
+      wave_lds_sync();
+      for (int t0 = 0; t0 < total; t0 += kTile) {
+        const int cnt = min(kTile, total - t0);
+        // stage: slot -> (row by binary search over the 64 offsets) -> sorted target index
+        // (all of a lane's gathers are issued before the first LDS store: one memory round trip per tile)
+        float4 stage[kTile / kWave];
+#pragma unroll
+        for (int u = 0; u < kTile / kWave; ++u) {
+          const int s = lane + u * kWave;
+          const int slot = t0 + (s < cnt ? s : 0);
+          int lo = 0;
+#pragma unroll
+          for (int step = 32; step > 0; step >>= 1)
+            if (s_off[wave][lo + step] <= slot) lo += step;   // offsets are non-decreasing; empty rows collapse
+#if defined(MM3D_ABL) && MM3D_ABL == 2
+          stage[u] = make_float4((float)lo, (float)slot, 0.f, 0.f);
+#else
+          stage[u] = g.pts[s_beg[wave][lo] + (slot - s_off[wave][lo])];
+#endif
+        }
+#pragma unroll
+        for (int u = 0; u < kTile / kWave; ++u) {
+          const int s = lane + u * kWave;
+          if (s < cnt) s_pts[wave][s] = stage[u];
+        }
+        wave_lds_sync();
+#if defined(MM3D_ABL) && MM3D_ABL == 1
+        if (active && cnt < 0) {
+#else
+        if (active) {
+#endif
+#pragma unroll 4
+          for (int k = 0; k < cnt; ++k) {
+            const float4 q = s_pts[wave][k];
+            const float d = dist2(p.x, p.y, p.z, q.x, q.y, q.z);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_uint(q.w);
+            bkey = key < bkey ? key : bkey;
+          }
+        }
+        wave_lds_sync();
+      }
+    }
+    // what the scanned box proves: every target point closer than `guard` to this lane has been seen
+    best = (bkey == ~0ull) ? INFINITY : __uint_as_float((unsigned)(bkey >> 32));
+    if (active) {
+      const float gx0 = (lx - E > 0) ? p.x - (g.minx + (float)(lx - E) * g.cell) : INFINITY;
+      const float gx1 = (hx + E < g.dx - 1) ? (g.minx + (float)(hx + E + 1) * g.cell) - p.x : INFINITY;
+      const float gy0 = (ly - E > 0) ? p.y - (g.miny + (float)(ly - E) * g.cell) : INFINITY;
+      const float gy1 = (hy + E < g.dy - 1) ? (g.miny + (float)(hy + E + 1) * g.cell) - p.y : INFINITY;
+      const float gz0 = (lz - E > 0) ? p.z - (g.minz + (float)(lz - E) * g.cell) : INFINITY;
+      const float gz1 = (hz + E < g.dz - 1) ? (g.minz + (float)(hz + E + 1) * g.cell) - p.z : INFINITY;
+      const float guard = fminf(fminf(fminf(gx0, gx1), fminf(gy0, gy1)), fminf(gz0, gz1)) * 0.9999f - 1e-5f;
+      if (guard >= rmax || best <= guard * guard) {
+        active = false;
+      } else {
+        const float reach = best < INFINITY ? fminf(sqrtf(best), rmax) : rmax;
+        const int want = (int)ceilf(reach * g.inv * 1.001f + 0.01f);   // guard >= want*cell*0.9999 - 1e-5 >= reach
+        need = min(max(want, E + 1), max_ring + pass + 1);
+      }
+    }
+  }
+
+  double acc[kAcc];
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+  if (valid && best <= max_d2) {   // false for INFINITY / NaN
+    if (MODE == 0) {
+      const float4 bq = tgt_ref[(unsigned)(bkey & 0xffffffffull)];
+      const float bqx = bq.x, bqy = bq.y, bqz = bq.z;
+      acc[0] = p.x; acc[1] = p.y; acc[2] = p.z;
+      acc[3] = bqx; acc[4] = bqy; acc[5] = bqz;
+      acc[6] = (double)bqx * p.x; acc[7] = (double)bqx * p.y; acc[8] = (double)bqx * p.z;
+      acc[9] = (double)bqy * p.x; acc[10] = (double)bqy * p.y; acc[11] = (double)bqy * p.z;
+      acc[12] = (double)bqz * p.x; acc[13] = (double)bqz * p.y; acc[14] = (double)bqz * p.z;
+    }
+    acc[15] = best;
+    acc[16] = 1.0;
+  }
+#pragma unroll
+  for (int k = (MODE == 0 ? 0 : 15); k < kAcc; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAcc) {
+    const int k = threadIdx.x;
+    double v = 0.0;
+    if (MODE == 0 || k >= 15) v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    partials[(size_t)bid * kAcc + k] = v;
+  }
+}
+
+// ---- 3x3 SVD (one-sided Jacobi, double) and Umeyama on the device ------------------------------
+__device__ void svd3(const double *A, double *U, double *S, double *V)
+{
+  double B[9];
+  for (int i = 0; i < 9; ++i) { B[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    int rotated = 0;
+    for (int k = 0; k < 3; ++k) {
+      const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2;
+      double alpha = 0, beta = 0, gamma = 0;
+      for (int i = 0; i < 3; ++i) {
+        alpha += B[i * 3 + p] * B[i * 3 + p];
+        beta += B[i * 3 + q] * B[i * 3 + q];
+        gamma += B[i * 3 + p] * B[i * 3 + q];
+      }
+      if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+      rotated = 1;
+      const double zeta = (beta - alpha) / (2.0 * gamma);
+      const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+      const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+      for (int i = 0; i < 3; ++i) {
+        const double bp = B[i * 3 + p], bq = B[i * 3 + q];
+        B[i * 3 + p] = c * bp - s * bq;
+        B[i * 3 + q] = s * bp + c * bq;
+        const double vp = V[i * 3 + p], vq = V[i * 3 + q];
+        V[i * 3 + p] = c * vp - s * vq;
+        V[i * 3 + q] = s * vp + c * vq;
+      }
+    }
+    if (!rotated) break;
+  }
+  double nrm[3];
+  for (int j = 0; j < 3; ++j) nrm[j] = sqrt(B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j]);
+  int o0 = 0, o1 = 1, o2 = 2, t;
+  if (nrm[o1] > nrm[o0]) { t = o0; o0 = o1; o1 = t; }
+  if (nrm[o2] > nrm[o0]) { t = o0; o0 = o2; o2 = t; }
+  if (nrm[o2] > nrm[o1]) { t = o1; o1 = o2; o2 = t; }
+  const int ord[3] = {o0, o1, o2};
+  double Vs[9];
+  for (int j = 0; j < 3; ++j) {
+    S[j] = nrm[ord[j]];
+    for (int i = 0; i < 3; ++i) {
+      Vs[i * 3 + j] = V[i * 3 + ord[j]];
+      U[i * 3 + j] = (S[j] > 0.0) ? B[i * 3 + ord[j]] / S[j] : 0.0;
+    }
+  }
+  for (int i = 0; i < 9; ++i) V[i] = Vs[i];
+  const double tiny = 1e-14 * (S[0] > 0 ? S[0] : 1.0);
+  if (S[0] <= 0.0) {
+    for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    return;
+  }
+  if (S[1] <= tiny) {
+    const double u0[3] = {U[0], U[3], U[6]};
+    const int m = fabs(u0[0]) < fabs(u0[1]) ? (fabs(u0[0]) < fabs(u0[2]) ? 0 : 2) : (fabs(u0[1]) < fabs(u0[2]) ? 1 : 2);
+    double e[3] = {0, 0, 0};
+    e[m] = 1.0;
+    const double d = u0[m];
+    const double v[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
+    const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    U[1] = v[0] / n; U[4] = v[1] / n; U[7] = v[2] / n;
+  }
+  if (S[2] <= tiny) {
+    const double a[3] = {U[0], U[3], U[6]}, b[3] = {U[1], U[4], U[7]};
+    U[2] = a[1] * b[2] - a[2] * b[1];
+    U[5] = a[2] * b[0] - a[0] * b[2];
+    U[8] = a[0] * b[1] - a[1] * b[0];
+  }
+}
+
+__device__ inline double det3(const double *M)
+{
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// one block: reduce partials, Umeyama, accumulate, convergence (DefaultConvergenceCriteria)
+__global__ void __launch_bounds__(256) k_icp_finalize(const double *__restrict__ partials, int nblocks, IcpState *st)
+{
+  __shared__ double red[4][kAcc];
+  __shared__ double tot[kAcc];
+  if (st->done) return;
+  double acc[kAcc];
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) acc[k] += partials[(size_t)b * kAcc + k];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAcc) tot[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+
+  const double cnt = tot[16];
+  st->n_corr = (int)cnt;
+  if (cnt < 3.0) {   // min_number_correspondences_: "Not enough correspondences" -> not converged, stop
+    st->converged = 0;
+    st->done = 1;
+    return;
+  }
+  const double inv = 1.0 / cnt;
+  double mp[3] = {tot[0] * inv, tot[1] * inv, tot[2] * inv}, mq[3] = {tot[3] * inv, tot[4] * inv, tot[5] * inv};
+  double sigma[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) sigma[r * 3 + c] = tot[6 + r * 3 + c] * inv - mq[r] * mp[c];
+  double U[9], S[3], V[9];
+  svd3(sigma, U, S, V);
+  double Sd[3] = {1.0, 1.0, 1.0};
+  if (det3(sigma) < 0) Sd[2] = -1.0;
+  int rank = 0;
+  for (int i = 0; i < 3; ++i)
+    if (!(fabs(S[i]) <= fabs(S[0]) * 1e-5)) ++rank;
+  if (rank == 2) Sd[2] = (det3(U) * det3(V) > 0) ? 1.0 : -1.0;
+  float Ti[16];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += U[r * 3 + k] * Sd[k] * V[c * 3 + k];
+      Ti[c * 4 + r] = (float)a;
+    }
+  for (int r = 0; r < 3; ++r) {
+    // t = dst_mean - R * src_mean (with the float R, like Eigen's float instantiation)
+    const double a = mq[r] - ((double)Ti[0 * 4 + r] * mp[0] + (double)Ti[1 * 4 + r] * mp[1] + (double)Ti[2 * 4 + r] * mp[2]);
+    Ti[12 + r] = (float)a;
+  }
+  Ti[3] = Ti[7] = Ti[11] = 0.0f;
+  Ti[15] = 1.0f;
+  // final = Tinc * final
+  float Tn[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      float a = 0.0f;
+      for (int k = 0; k < 4; ++k) a += Ti[k * 4 + r] * st->T[c * 4 + k];
+      Tn[c * 4 + r] = a;
+    }
+  for (int i = 0; i < 16; ++i) { st->T[i] = Tn[i]; st->Tinc[i] = Ti[i]; }
+  const int iters = ++st->iters;
+  // DefaultConvergenceCriteria::hasConverged
+  if (iters >= st->max_iter) { st->converged = 1; st->done = 1; return; }
+  const double cos_angle = 0.5 * ((double)Ti[0] + (double)Ti[5] + (double)Ti[10] - 1.0);
+  const double translation_sqr = (double)Ti[12] * Ti[12] + (double)Ti[13] * Ti[13] + (double)Ti[14] * Ti[14];
+  if (cos_angle >= st->rot_thresh && translation_sqr <= st->trans_thresh) { st->converged = 1; st->done = 1; return; }
+  const double mse = tot[15] * inv;
+  if (fabs(mse - st->prev_mse) < 1e-12) { st->converged = 1; st->done = 1; return; }
+  st->prev_mse = mse;
+}
+
+__global__ void __launch_bounds__(256) k_score_finalize(const double *__restrict__ partials, int nblocks, double *out)
+{
+  __shared__ double red[4][2];
+  double s = 0.0, n = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    s += partials[(size_t)b * kAcc + 15];
+    n += partials[(size_t)b * kAcc + 16];
+  }
+  s = wave_sum(s); n = wave_sum(n);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = s; red[wave][1] = n; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    out[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+  }
+}
+
+// ---------------------------------------------------------------- Morton-ordered source copy
+// 64 consecutive points of this order form a compact patch, so a wave's box of target cells is small.
+__device__ __forceinline__ unsigned spread3(unsigned v)   // 10 bits -> every third bit
+{
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__global__ void k_morton_keys(const float4 *__restrict__ pts, int n, float minx, float miny, float minz, float inv,
+                              uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  vals[i] = (uint32_t)i;
+  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = 0xFFFFFFFFu; return; }
+  unsigned x = (unsigned)clampi(cell_floor(p.x, minx, inv), 0, 1023);
+  unsigned y = (unsigned)clampi(cell_floor(p.y, miny, inv), 0, 1023);
+  const unsigned z = (unsigned)clampi(cell_floor(p.z, minz, inv), 0, 1023);
+  // Hilbert index of the (x, y) column (no jumps: consecutive columns share an edge), z below it
+  unsigned d = 0;
+  for (unsigned sft = 512; sft > 0; sft >>= 1) {
+    const unsigned rx = (x & sft) ? 1u : 0u, ry = (y & sft) ? 1u : 0u;
+    d += sft * sft * ((3u * rx) ^ ry);
+    if (ry == 0) {
+      if (rx == 1) { x = 1023u - x; y = 1023u - y; }
+      const unsigned t = x; x = y; y = t;
+    }
+  }
+  keys[i] = (d << 10) | z;
+}
+
+__global__ void k_gather_pts(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, int n, float4 *__restrict__ out)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) out[j] = pts[order[j]];
+}
+
+// an item starts at every coarse-block change (key >> 6: 4x4x4 Morton cells) and at every multiple
+// of 64, so it holds at most 64 points of ONE coarse block
+__global__ void k_item_heads(const uint32_t *__restrict__ keys, int n, int *__restrict__ heads)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n) return;
+  // chunks of 64 that never straddle a 2 m x 2 m column block (8x8 Hilbert cells = key >> 16): the curve may
+  // leave the occupied area and re-enter far away, but never inside one block
+  heads[j] = (j < n && (j == 0 || (keys[j] >> 16) != (keys[j - 1] >> 16) || (j & 63) == 0)) ? 1 : 0;
+}
+
+__global__ void k_item_fill(const int *__restrict__ heads, const int *__restrict__ pos, int n, int2 *__restrict__ items)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || !heads[j]) return;
+  int cnt = 1;
+  while (cnt < 64 && j + cnt < n && !heads[j + cnt]) ++cnt;
+  items[pos[j]] = make_int2(j, cnt);
+}
+
+static const float4 *morton_source(Context *c, const mm3d_cloud *src_, int &n)
+{
+  auto *src = const_cast<mm3d_cloud *>(src_);
+  cloud_bbox(c, src);
+  n = (int)src->n_finite;
+  if (src->morton.get() || n == 0) return src->morton.get();
+  const int total = (int)src->n;
+  // cell so that the larger box side spans at most 1024 cells, but never finer than 0.25 m
+  float ext = 0.f;
+  for (int a = 0; a < 3; ++a) ext = std::fmax(ext, src->bmax[a] - src->bmin[a]);
+  const float cell = std::fmax(0.25f, ext / 1023.0f);
+  DevBuf<uint32_t> keys(c, total), vals(c, total), keys2(c, total), vals2(c, total);
+  MM3D_LAUNCH(c, "morton_keys", total * 24.0, k_morton_keys, dim3(div_up(total, 256)), dim3(256), 0, src->pts.get(), total,
+              src->bmin[0], src->bmin[1], src->bmin[2], 1.0f / cell, keys.get(), vals.get());
+  sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), total, 32);
+  src->morton = DevBuf<float4>(c, n);
+  MM3D_LAUNCH(c, "morton_gather", n * 36.0, k_gather_pts, dim3(div_up(n, 256)), dim3(256), 0, src->pts.get(),
+              (const uint32_t *)vals2.get(), n, src->morton.get());
+  // wave work items: a wave never straddles a coarse block (4x4x4 Morton cells = key >> 6), so its
+  // queries always form a compact patch even where the Z-curve jumps
+  DevBuf<int> heads(c, (size_t)n + 1), blk(c, (size_t)n + 1);
+  MM3D_LAUNCH(c, "morton_items", n * 8.0, k_item_heads, dim3(div_up(n + 1, 256)), dim3(256), 0, (const uint32_t *)keys2.get(), n,
+              heads.get());
+  exclusive_scan_int(c, heads.get(), blk.get(), (size_t)n + 1);     // blk[j] = items before point j; blk[n] = total
+  int *h = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(h, blk.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  src->n_wave_items = h[0];
+  src->wave_items = DevBuf<int2>(c, (size_t)h[0]);
+  MM3D_LAUNCH(c, "morton_items", n * 12.0, k_item_fill, dim3(div_up(n, 256)), dim3(256), 0, (const int *)heads.get(),
+              (const int *)blk.get(), n, src->wave_items.get());
+  c->sync();
+  return src->morton.get();
+}
+
+static float nn_cell_for(double radius)
+{
+  float cell = (float)(radius * 0.25);
+  if (!(cell > 1e-3f)) cell = 0.25f;
+  return cell;
+}
+
+IcpResult icp(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float guess[16],
+              double max_corr_dist, int max_iterations, double eps)
+{
+  IcpResult res;
+  memcpy(res.T, guess, sizeof(res.T));   // Identity * guess when nothing runs
+  res.iterations = 0;
+  res.converged = 0;
+  c->last_icp_iterations = 0;
+  c->last_icp_converged = 0;
+  if (src->n == 0 || tgt->n == 0) return res;
+  const Grid &tg = cloud_grid(c, tgt, nn_cell_for(max_corr_dist));
+  int ns = 0;
+  const float4 *sp = morton_source(c, src, ns);
+  if (ns == 0 || tg.n == 0) return res;
+  const double max_dist_sqr = max_corr_dist * max_corr_dist;
+  // (double)d2 > max_dist_sqr rejects: accept d2 <= largest float not above max_dist_sqr
+  float max_d2 = (float)max_dist_sqr;
+  if ((double)max_d2 > max_dist_sqr) max_d2 = std::nextafterf(max_d2, -INFINITY);
+  const float rmax = (float)(max_corr_dist * 1.0001 + 1e-5);
+  const int max_ring = (int)std::ceil(rmax / tg.cell) + 1;
+  grid_ensure_dt(c, tg, max_ring);
+
+  IcpState h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.T, guess, sizeof(h.T));
+  h.prev_mse = DBL_MAX;
+  h.rot_thresh = 1.0 - eps;
+  h.trans_thresh = eps;
+  h.max_iter = max_iterations;
+  IcpState *hp = (IcpState *)c->pin(sizeof(IcpState));
+  *hp = h;
+  DevBuf<IcpState> st(c, 1);
+  MM3D_HIP(hipMemcpyAsync(st.get(), hp, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
+  const int n_items = src->n_wave_items;
+  const unsigned nblocks = div_up(n_items, 4);
+  DevBuf<double> partials(c, (size_t)nblocks * kAcc);
+  const GridView gv = tg.view();
+  const int chunk = 4;
+  for (;;) {
+    for (int k = 0; k < chunk; ++k) {
+      MM3D_LAUNCH(c, "icp_corr_reduce", ns * 12.0, k_nn_wave<0>, dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items, gv, (const float4 *)tgt->pts.get(),
+                  (const IcpState *)st.get(), (const float *)nullptr, max_d2, rmax, max_ring, partials.get());
+      MM3D_LAUNCH(c, "icp_finalize", nblocks * kAcc * 8.0, k_icp_finalize, dim3(1), dim3(256), 0, (const double *)partials.get(),
+                  (int)nblocks, st.get());
+    }
+    MM3D_HIP(hipMemcpyAsync(hp, st.get(), sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    if (hp->done) break;
+  }
+  memcpy(res.T, hp->T, sizeof(res.T));
+  res.iterations = hp->iters;
+  res.converged = hp->converged;
+  c->last_icp_iterations = res.iterations;
+  c->last_icp_converged = res.converged;
+  return res;
+}
+
+double transform_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float T[16], double max_distance)
+{
+  if (src->n == 0 || tgt->n == 0) return DBL_MAX;
+  // max_range_ is compared with the SQUARED distance (PCL quirk): search radius sqrt(max_distance)
+  const double radius = std::sqrt(max_distance > 0 ? max_distance : 0.0);
+  const Grid &tg = cloud_grid(c, tgt, nn_cell_for(radius));
+  int ns = 0;
+  const float4 *sp = morton_source(c, src, ns);
+  if (ns == 0 || tg.n == 0) return DBL_MAX;
+  float max_d2 = (float)max_distance;
+  if ((double)max_d2 > max_distance) max_d2 = std::nextafterf(max_d2, -INFINITY);
+  const float rmax = (float)(radius * 1.0001 + 1e-5);
+  const int max_ring = (int)std::ceil(rmax / tg.cell) + 1;
+  grid_ensure_dt(c, tg, max_ring);
+  const int n_items = src->n_wave_items;
+  const unsigned nblocks = div_up(n_items, 4);
+  DevBuf<double> partials(c, (size_t)nblocks * kAcc);
+  DevBuf<float> dT(c, 16);
+  DevBuf<double> out(c, 2);
+  float *hT = (float *)c->pin(256);
+  memcpy(hT, T, 64);
+  MM3D_HIP(hipMemcpyAsync(dT.get(), hT, 64, hipMemcpyHostToDevice, c->stream));
+  MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + tg.n * 12.0, k_nn_wave<1>, dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items, tg.view(), (const float4 *)tgt->pts.get(),
+              (const IcpState *)nullptr, (const float *)dT.get(), max_d2, rmax, max_ring, partials.get());
+  MM3D_LAUNCH(c, "score_finalize", 0, k_score_finalize, dim3(1), dim3(256), 0, (const double *)partials.get(), (int)nblocks, out.get());
+  double *ho = (double *)((char *)c->pin(256) + 128);
+  MM3D_HIP(hipMemcpyAsync(ho, out.get(), 16, hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  return ho[1] > 0.0 ? ho[0] / ho[1] : DBL_MAX;
+}
+
+#ifdef MM3D_NN_STATS
+extern "C" void mm3d_debug_nn_stats(unsigned long long *out, int reset)
+{
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stats), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof(z)); }
+}
+#endif
+
+}  // namespace mm3d

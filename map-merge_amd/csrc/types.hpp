@@ -25,6 +25,8 @@ struct GridView {
   const int *cell_start;
   const float4 *pts;   // cell-sorted; .w = original index bits
   int n;
+  const unsigned char *dt;   // optional: Chebyshev distance (in cells, capped) to the nearest occupied cell
+  int dt_cap;                // values > dt_cap are stored as 255
 };
 
 struct Grid {
@@ -34,6 +36,8 @@ struct Grid {
   DevBuf<int> cell_start;
   DevBuf<float4> sorted;
   int n = 0;
+  DevBuf<unsigned char> dt;   // built on demand by grid_ensure_dt
+  int dt_cap = 0;
   GridView view() const
   {
     GridView v;
@@ -41,6 +45,7 @@ struct Grid {
     v.inv = 1.0f / cell; v.cell = cell;
     v.dx = dims[0]; v.dy = dims[1]; v.dz = dims[2];
     v.cell_start = cell_start.get(); v.pts = sorted.get(); v.n = n;
+    v.dt = dt.get(); v.dt_cap = dt_cap;
     return v;
   }
 };
@@ -56,6 +61,9 @@ struct mm3d_cloud {
   size_t n_finite = 0;
   std::map<int, std::unique_ptr<mm3d::Grid>> grids;   // key: cell size in units of 1e-4 m
   std::vector<float4> host;                            // host copy (keypoint clouds only)
+  mm3d::DevBuf<float4> morton;                         // finite points in Morton order (ICP / score source)
+  mm3d::DevBuf<int2> wave_items;                       // {first point, count <= 64}: one coarse Morton block per wave
+  int n_wave_items = 0;
 };
 
 struct mm3d_normals {
@@ -81,6 +89,8 @@ namespace mm3d {
 // grid.hip
 void cloud_bbox(Context *c, mm3d_cloud *cl);
 const Grid &cloud_grid(Context *c, const mm3d_cloud *cl, float cell);
+// per-cell Chebyshev distance transform (capped at R cells), cached on the grid
+void grid_ensure_dt(Context *c, const Grid &g, int R);
 mm3d_cloud *cloud_from_device(Context *c, DevBuf<float4> &&pts, size_t n);
 mm3d_cloud *cloud_from_memory(Context *c, const void *src, size_t n, size_t stride, size_t rgba_off);
 void cloud_download(Context *c, const mm3d_cloud *cl, void *dst, size_t stride, size_t rgba_off);
