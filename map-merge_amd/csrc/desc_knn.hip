@@ -11,8 +11,8 @@
 //   2. knn_mfma: the one genuine dense contraction of the pipeline on the matrix cores,
 //      v_mfma_f32_32x32x2_f32 (exact f32 FMA chains, 157 TF peak).  One wave owns 32 queries as the
 //      COLUMNS of the product, so each lane sees 16 target rows of one query per tile and keeps a
-//      register-resident sorted list of the 16 best approximate distances.
-//   3. knn_rerank: the candidates (2 lane halves x 4 target slices x 16) are re-ranked with FLANN's
+//      register-resident sorted list of the 8 best approximate distances.
+//   3. knn_rerank: the candidates (2 lane halves x 4 target slices x 8) are re-ranked with FLANN's
 //      L2_Simple accumulation (diff*diff summed in dimension order, no FMA) -- the ONLY distances
 //      that leave this file -- and certified: the k-th exact distance must clear the smallest
 //      "worst kept approximate distance" of any full list by more than the expansion's rounding
@@ -28,7 +28,8 @@ constexpr int kKP = 36;          // padded contraction length
 constexpr int kSteps = kKP / 2;  // 32x32x2 MFMA steps
 constexpr int kSlices = 4;       // waves per query tile, each scanning a quarter of the targets
 constexpr int kLists = 2 * kSlices;
-constexpr int kCand = kLists * kMaxK;
+constexpr int kListLen = 8;      // per-lane candidate list of the MFMA stage (8 lists x 8 = 64 candidates per query)
+constexpr int kCand = kLists * kListLen;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -97,8 +98,99 @@ k_knn_exact(const float *__restrict__ A, int na, const float *__restrict__ B, in
 // ---------------------------------------------------------------- stage 1: operand preparation
 // Xp[(tile * kSteps + s) * 64 + lane] = x'[tile*32 + (lane & 31)][2*s + (lane >> 5)]: one coalesced
 // 256-byte wave load per MFMA step.
-__global__ void k_knn_prep(const float *__restrict__ X, int n, int ntiles, int is_target, float *__restrict__ Xp,
-                           unsigned *__restrict__ norm2max_ord)
+// Exact k-NN for the (few) rows that miss the certificate: one WAVE per row.  Lanes stride over the
+// targets (64-row tiles staged through LDS with coalesced loads), each keeps its own sorted top-16 in
+// registers, and the k winners are drawn by repeated wave-wide minimum over (distance, index) keys.
+__global__ void __launch_bounds__(256)
+k_knn_exact_wave(const float *__restrict__ A, const float *__restrict__ B, int nb, int k, const int *__restrict__ rows,
+                 const int *__restrict__ nrows_dev, int *__restrict__ idx, float *__restrict__ d2out)
+{
+  __shared__ float tile[4][64][kD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrows = *nrows_dev;
+  const int t = blockIdx.x * 4 + wave;
+  if (blockIdx.x * 4 >= nrows) return;          // uniform per block
+  const bool live = t < nrows;                    // uniform per wave
+  const int row = live ? rows[t] : rows[0];
+  float a[kD];
+#pragma unroll
+  for (int d = 0; d < kD; ++d) a[d] = A[(size_t)row * kD + d];
+  float bd[kMaxK];
+  int bi[kMaxK];
+#pragma unroll
+  for (int s = 0; s < kMaxK; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
+  for (int j0 = 0; j0 < nb; j0 += 64) {
+    const int tn = min(64, nb - j0);
+    // coalesced copy of tn x 33 floats; a wave only ever touches its own LDS slab
+    for (int e = lane; e < tn * kD; e += 64) (&tile[wave][0][0])[e] = B[(size_t)j0 * kD + e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < tn) {
+      float r = 0.0f;
+#pragma unroll
+      for (int d = 0; d < kD; ++d) {
+        const float df = a[d] - tile[wave][lane][d];
+        r = __fadd_rn(r, __fmul_rn(df, df));
+      }
+      const int j = j0 + lane;
+      if (r < bd[kMaxK - 1]) {     // a lane sees its targets in ascending index order: strict < keeps the lower index
+        float cd = r;
+        int ci = j;
+        bool carrying = false;
+#pragma unroll
+        for (int s = 0; s < kMaxK; ++s) {
+          const bool sw = carrying || cd < bd[s];
+          carrying = sw;
+          const float td = bd[s];
+          const int ti = bi[s];
+          bd[s] = sw ? cd : td; bi[s] = sw ? ci : ti;
+          cd = sw ? td : cd; ci = sw ? ti : ci;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // merge the 64 sorted lists: k rounds of "smallest head wins" on (distance bits, index) keys
+  for (int o = 0; o < k; ++o) {
+    const unsigned long long key = ((unsigned long long)__float_as_uint(bd[0]) << 32) | (unsigned)bi[0];
+    unsigned long long best = key;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const unsigned long long other = __shfl_xor(best, s, kWave);
+      best = other < best ? other : best;
+    }
+    if (live && lane == 0) {
+      const float d = __uint_as_float((unsigned)(best >> 32));
+      const bool have = d < INFINITY;
+      idx[(size_t)row * k + o] = have ? (int)(unsigned)(best & 0xffffffffull) : -1;
+      d2out[(size_t)row * k + o] = d;
+    }
+    if (key == best && bd[0] < INFINITY) {   // pop (indices are unique, so exactly one lane matches)
+#pragma unroll
+      for (int s = 0; s + 1 < kMaxK; ++s) { bd[s] = bd[s + 1]; bi[s] = bi[s + 1]; }
+      bd[kMaxK - 1] = INFINITY; bi[kMaxK - 1] = 0x7fffffff;
+    }
+  }
+}
+
+// column sums of the targets (33 floats) -> mu = sum / n.  Distances do not change when both sides
+// are shifted by the same vector, but the rounding error of the |a|^2 + |b|^2 - 2ab expansion does:
+// FPFH rows share a large common component, and centred rows make the certificate below tight.
+__global__ void k_knn_colsum(const float *__restrict__ X, int n, float *__restrict__ sum)
+{
+  const int d = threadIdx.x & 63;
+  const int part = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nparts = gridDim.x * (blockDim.x >> 6);
+  if (d >= kD) return;
+  float acc = 0.0f;
+  for (int r = part; r < n; r += nparts) acc += X[(size_t)r * kD + d];
+  atomicAdd(&sum[d], acc);
+}
+
+__global__ void k_knn_prep(const float *__restrict__ X, int n, int ntiles, int is_target, const float *__restrict__ colsum,
+                           float inv_nb, float *__restrict__ Xp)
 {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)ntiles * kSteps * 64) return;
@@ -111,14 +203,14 @@ __global__ void k_knn_prep(const float *__restrict__ X, int n, int ntiles, int i
   if (row < n) {
     const float *x = X + (size_t)row * kD;
     if (kk < kD) {
-      v = is_target ? -2.0f * x[kk] : x[kk];
+      const float xc = x[kk] - colsum[kk] * inv_nb;
+      v = is_target ? -2.0f * xc : xc;
     } else if (kk == kD || kk == kD + 1) {
       const bool want_norm = is_target ? (kk == kD + 1) : (kk == kD);
       if (want_norm) {
         float nrm = 0.0f;
-        for (int d = 0; d < kD; ++d) nrm = fmaf(x[d], x[d], nrm);
+        for (int d = 0; d < kD; ++d) { const float xc = x[d] - colsum[d] * inv_nb; nrm = fmaf(xc, xc, nrm); }
         v = nrm;
-        if (is_target) atomicMax(norm2max_ord, f2ord(nrm));
       } else {
         v = 1.0f;
       }
@@ -142,19 +234,22 @@ k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, i
   float af[kSteps];
 #pragma unroll
   for (int s = 0; s < kSteps; ++s) af[s] = Ap[((size_t)tile_a * kSteps + s) * 64 + lane];
-  float ld[kMaxK];
-  int li[kMaxK];
+  float ld[kListLen];
+  int li[kListLen];
 #pragma unroll
-  for (int s = 0; s < kMaxK; ++s) { ld[s] = INFINITY; li[s] = -1; }
-  const int c0 = (int)(((long long)nb_tiles * slice) / kSlices), c1 = (int)(((long long)nb_tiles * (slice + 1)) / kSlices);
+  for (int s = 0; s < kListLen; ++s) { ld[s] = INFINITY; li[s] = -1; }
+  // slices interleave the target tiles (tile c belongs to slice c % kSlices): similar descriptors sit at
+  // nearby indices (same keypoint at several scales, spatial neighbours), and interleaving spreads a
+  // query's true neighbours evenly over the 8 lists, which is what keeps short lists certifiable
+  const int c0 = slice, c1 = nb_tiles;
   float bf[kSteps], bn[kSteps];
   if (c0 < c1) {
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) bf[s] = Bp[((size_t)c0 * kSteps + s) * 64 + lane];
   }
-  for (int c = c0; c < c1; ++c) {
+  for (int c = c0; c < c1; c += kSlices) {
     // prefetch the next target tile while the matrix core works on this one
-    const int cn = (c + 1 < c1) ? c + 1 : c;
+    const int cn = (c + kSlices < c1) ? c + kSlices : c;
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) bn[s] = Bp[((size_t)cn * kSteps + s) * 64 + lane];
     f32x16 acc;
@@ -164,15 +259,19 @@ k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, i
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc, 0, 0, 0);
     const int rbase = c * 32 + 4 * (lane >> 5);
+    float tmin = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmin = fminf(tmin, acc[r]);
+    if (__any(tmin < ld[kListLen - 1]))   // wave-uniform: most late tiles improve no lane's list
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float v = acc[r];
-      if (v < ld[kMaxK - 1]) {
+      if (v < ld[kListLen - 1]) {
         float cd = v;
         int ci = rbase + (r & 3) + 8 * (r >> 2);
         bool carrying = false;
 #pragma unroll
-        for (int s = 0; s < kMaxK; ++s) {
+        for (int s = 0; s < kListLen; ++s) {
           const bool sw = carrying || cd < ld[s];
           carrying = sw;
           const float td = ld[s];
@@ -188,10 +287,10 @@ k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, i
   const int a = tile_a * 32 + (lane & 31);
   if (a >= na) return;
   const int list = (lane >> 5) * kSlices + slice;
-  float *od = cand_d + ((size_t)a * kLists + list) * kMaxK;
-  int *oi = cand_i + ((size_t)a * kLists + list) * kMaxK;
+  float *od = cand_d + ((size_t)a * kLists + list) * kListLen;
+  int *oi = cand_i + ((size_t)a * kLists + list) * kListLen;
 #pragma unroll
-  for (int s = 0; s < kMaxK; ++s) {
+  for (int s = 0; s < kListLen; ++s) {
     const bool real = li[s] >= 0 && li[s] < nb;
     od[s] = real ? ld[s] : INFINITY;
     oi[s] = real ? li[s] : -1;
@@ -201,7 +300,7 @@ k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, i
 // ---------------------------------------------------------------- stage 3: exact re-rank + certificate
 __global__ void __launch_bounds__(128)
 k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, int nb, int k,
-             const float *__restrict__ cand_d, const int *__restrict__ cand_i, const unsigned *__restrict__ norm2max_ord,
+             const float *__restrict__ cand_d, const int *__restrict__ cand_i, const float *__restrict__ colsum, float inv_nb,
              int *__restrict__ idx, float *__restrict__ d2out, int *__restrict__ fb_rows, int *__restrict__ fb_count)
 {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -209,18 +308,22 @@ k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, i
   float x[kD];
   float na2 = 0.0f;
 #pragma unroll
-  for (int d = 0; d < kD; ++d) { x[d] = A[(size_t)a * kD + d]; na2 = fmaf(x[d], x[d], na2); }
+  for (int d = 0; d < kD; ++d) {
+    x[d] = A[(size_t)a * kD + d];
+    const float xc = x[d] - colsum[d] * inv_nb;
+    na2 = fmaf(xc, xc, na2);       // |a - mu|^2
+  }
   float bd[kMaxK];
   int bi[kMaxK];
 #pragma unroll
   for (int s = 0; s < kMaxK; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
   float tau = INFINITY;
   for (int l = 0; l < kLists; ++l) {
-    const float *cd_ = cand_d + ((size_t)a * kLists + l) * kMaxK;
-    const int *ci_ = cand_i + ((size_t)a * kLists + l) * kMaxK;
+    const float *cd_ = cand_d + ((size_t)a * kLists + l) * kListLen;
+    const int *ci_ = cand_i + ((size_t)a * kLists + l) * kListLen;
     // a full list hides targets whose approximate distance is >= its worst entry
-    if (ci_[kMaxK - 1] >= 0) tau = fminf(tau, cd_[kMaxK - 1]);
-    for (int s = 0; s < kMaxK; ++s) {
+    if (ci_[kListLen - 1] >= 0) tau = fminf(tau, cd_[kListLen - 1]);
+    for (int s = 0; s < kListLen; ++s) {
       const int j = ci_[s];
       if (j < 0) break;
       const float *b = B + (size_t)j * kD;
@@ -246,13 +349,18 @@ k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, i
       }
     }
   }
-  // |approx - exact| <= ~1.05e-5 (|a|^2 + |b|^2) for a 36-term f32 FMA chain plus the 33-term exact
-  // sum (header comment of DESIGN.md section 5); 2e-5 keeps a 2x margin
-  const float eps = 2e-5f * (na2 + ord2f(*norm2max_ord));
+  // Certificate.  A target b outside the candidate lists has approx(b) >= tau.  If |b - mu| > rho :=
+  // |a - mu| + sqrt(kth) (plus slack) then |a - b|^2 > kth by the triangle inequality, so only
+  // targets with |b - mu| <= rho matter, and for those the expansion's rounding error is bounded by
+  // ~5e-6 (|a-mu| + |b-mu|)^2 + 2e-6 kth  (36-term f32 FMA chain on the centred operands, the two
+  // norms, the centring itself, and the 33-term exact sum).  2e-5 (|a-mu|^2 + rho^2) + 1e-5 kth
+  // doubles that bound.
   float kth = INFINITY;
 #pragma unroll
   for (int s = 0; s < kMaxK; ++s)
     if (s == k - 1) kth = bd[s];
+  const float rho = (sqrtf(na2) + sqrtf(kth)) * 1.001f + 1e-3f;
+  const float eps = 2e-5f * (na2 + rho * rho) + 1e-5f * kth;
   const bool certified = !(tau < INFINITY) || (kth < tau - eps);
 #pragma unroll
   for (int s = 0; s < kMaxK; ++s)
@@ -282,12 +390,16 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
   }
   const int na_tiles = (na + 31) / 32, nb_tiles = (nb + 31) / 32;
   DevBuf<float> Ap(c, (size_t)na_tiles * kSteps * 64), Bp(c, (size_t)nb_tiles * kSteps * 64);
-  DevBuf<unsigned> meta(c, 4);   // [0] max |b|^2 (ordered bits), [1] fallback count
+  DevBuf<unsigned> meta(c, 4);   // [1] fallback count
   MM3D_HIP(hipMemsetAsync(meta.get(), 0, 16, c->stream));
+  DevBuf<float> colsum(c, 64);
+  MM3D_HIP(hipMemsetAsync(colsum.get(), 0, 64 * sizeof(float), c->stream));
+  MM3D_LAUNCH(c, "desc_knn_prep", nb * 132.0, k_knn_colsum, dim3(64), dim3(256), 0, Bd, nb, colsum.get());
+  const float inv_nb = 1.0f / (float)nb;
   MM3D_LAUNCH(c, "desc_knn_prep", na * 276.0, k_knn_prep, dim3(div_up((size_t)na_tiles * kSteps * 64, 256)), dim3(256), 0, Ad, na,
-              na_tiles, 0, Ap.get(), meta.get());
+              na_tiles, 0, (const float *)colsum.get(), inv_nb, Ap.get());
   MM3D_LAUNCH(c, "desc_knn_prep", nb * 276.0, k_knn_prep, dim3(div_up((size_t)nb_tiles * kSteps * 64, 256)), dim3(256), 0, Bd, nb,
-              nb_tiles, 1, Bp.get(), meta.get());
+              nb_tiles, 1, (const float *)colsum.get(), inv_nb, Bp.get());
   DevBuf<float> cand_d(c, (size_t)na * kCand);
   DevBuf<int> cand_i(c, (size_t)na * kCand);
   // roofline unit for this kernel is FLOPs (2 * na * nb * 36 per launch), reported as such by bench.py
@@ -295,12 +407,12 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
               (const float *)Ap.get(), na, (const float *)Bp.get(), nb, nb_tiles, cand_d.get(), cand_i.get());
   DevBuf<int> fb_rows(c, na);
   MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(kCand * 140 + 132), k_knn_rerank, dim3(div_up(na, 128)), dim3(128), 0, Ad, na, Bd,
-              nb, k, (const float *)cand_d.get(), (const int *)cand_i.get(), (const unsigned *)meta.get(), idx.get(), d2.get(),
+              nb, k, (const float *)cand_d.get(), (const int *)cand_i.get(), (const float *)colsum.get(), inv_nb, idx.get(), d2.get(),
               fb_rows.get(), (int *)(meta.get() + 1));
   // rows without a certificate: exact brute force (the grid is sized for the worst case; blocks
   // beyond the device-side count exit at once)
-  MM3D_LAUNCH(c, "desc_knn_exact", 0.0, (k_knn_exact<kD>), dim3(div_up(na, 128)), dim3(128), 0, Ad, na, Bd, nb, k,
-              (const int *)fb_rows.get(), (const int *)(meta.get() + 1), 0, idx.get(), d2.get());
+  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, k_knn_exact_wave, dim3(div_up(na, 4)), dim3(256), 0, Ad, Bd, nb, k,
+              (const int *)fb_rows.get(), (const int *)(meta.get() + 1), idx.get(), d2.get());
   if (c->debug) {
     unsigned *h = (unsigned *)c->pin(64);
     MM3D_HIP(hipMemcpyAsync(h, meta.get(), 16, hipMemcpyDeviceToHost, c->stream));

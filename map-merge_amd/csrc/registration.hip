@@ -66,10 +66,16 @@ k_sacia_err(const float4 *__restrict__ skp, int ns, int ns_pad, GridView g, cons
   const float4 s = skp[i];
   const float3 p = xform(Tl, s.x, s.y, s.z);
   float best = INFINITY;
-  for_each_candidate(g, p.x, p.y, p.z, radius, [&](const float4 &q) {
-    best = fminf(best, dist2(p.x, p.y, p.z, q.x, q.y, q.z));
-    return true;
-  });
+  // most hypotheses are wrong and throw the keypoint far from every target keypoint: one byte of
+  // the distance transform (cell = search radius, so "no occupied cell within 1" = out of range)
+  const int cx = cell_floor(p.x, g.minx, g.inv), cy = cell_floor(p.y, g.miny, g.inv), cz = cell_floor(p.z, g.minz, g.inv);
+  const bool inside = cx >= 0 && cx < g.dx && cy >= 0 && cy < g.dy && cz >= 0 && cz < g.dz;
+  if (!inside || g.dt[((size_t)cz * g.dy + cy) * g.dx + cx] <= 1) {
+    for_each_candidate(g, p.x, p.y, p.z, radius, [&](const float4 &q) {
+      best = fminf(best, dist2(p.x, p.y, p.z, q.x, q.y, q.z));
+      return true;
+    });
+  }
   E[(size_t)h * ns_pad + i] = (best <= thresh) ? best / thresh : 1.0f;
 }
 
@@ -120,8 +126,11 @@ void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp
   const int ns = (int)src_kp->n;
   const int ns_pad = (ns + 3) & ~3;
   float radius = std::sqrt(corr_thresh > 0.f ? corr_thresh : 0.f);
-  float cell = radius > 0.25f ? radius : 0.25f;
+  // cell a hair larger than the search radius: anything two cells away is strictly out of range,
+  // which is what makes the distance-transform test in k_sacia_err exact
+  float cell = radius * 1.001f > 0.25f ? radius * 1.001f : 0.25f;
   const Grid &g = cloud_grid(c, tgt_kp, cell);
+  grid_ensure_dt(c, g, 1);
   DevBuf<float> E(c, (size_t)ns_pad * H);
   const size_t total = (size_t)ns * H;
   MM3D_LAUNCH(c, "sacia_err", total * 4.0 + ns * 16.0, k_sacia_err, dim3(div_up(total, 256)), dim3(256), 0, src_kp->pts.get(), ns,
