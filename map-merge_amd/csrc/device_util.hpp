@@ -110,6 +110,97 @@ __device__ __forceinline__ int wave_sum(int v)
   return v;
 }
 
+__device__ __forceinline__ int wave_min_int(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+__device__ __forceinline__ int wave_max_int(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
+// LDS written by some lanes of a wave and read by others of the SAME wave: order the accesses for
+// the compiler; the hardware executes one wave's DS operations in order.
+__device__ __forceinline__ void wave_lds_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- wave-cooperative neighbourhood staging --------------------------------------------------------
+// A wave whose 64 queries form a compact patch streams the box of grid cells those queries can
+// reach through its private LDS slab: row headers one per lane, exclusive scan of the span lengths,
+// then TILE points at a time with coalesced 16-byte gathers (all of a lane's loads are issued before
+// its first LDS store, so a tile costs one memory round trip).  `scan(cnt)` is called with the tile
+// in s_pts[0..cnt) (and NX extra float4 per point in s_x[e*TILE + slot], produced by load_x from the
+// sorted index): every lane then reads the SAME LDS address, i.e. broadcast reads, no global
+// traffic.  Must be called by all 64 lanes with wave-uniform box arguments.
+template <int TILE, int NX, class LoadX, class Scan>
+__device__ __forceinline__ void wave_stream_box(const GridView &g, int x0, int x1, int y0, int y1, int z0, int z1,
+                                                float4 *s_pts, float4 *s_x, int *s_off, int *s_beg, int lane,
+                                                LoadX &&load_x, Scan &&scan)
+{
+  constexpr int PER = TILE / kWave;
+  constexpr int NXA = NX > 0 ? NX : 1;
+  const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+  const int nrows = (x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
+  for (int r0 = 0; r0 < nrows; r0 += kWave) {
+    const int r = r0 + lane;
+    int b = 0, len = 0;
+    if (r < nrows) {
+      const int z = z0 + r / ny, y = y0 + r % ny;
+      const int row = (z * g.dy + y) * g.dx;
+      b = g.cell_start[row + x0];
+      len = g.cell_start[row + x1 + 1] - b;
+    }
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const int t = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, kWave - 1, kWave);
+    wave_lds_fence();                 // readers of the previous tile / offsets are done
+    s_off[lane] = incl - len;
+    s_beg[lane] = b;
+    wave_lds_fence();
+    for (int t0 = 0; t0 < total; t0 += TILE) {
+      const int cnt = min(TILE, total - t0);
+      float4 st[PER];
+      float4 sx[PER][NXA];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int s = lane + u * kWave;
+        const int slot = t0 + (s < cnt ? s : 0);
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+          if (s_off[lo + step] <= slot) lo += step;   // offsets are non-decreasing; empty rows collapse
+        const int j = s_beg[lo] + (slot - s_off[lo]);
+        st[u] = g.pts[j];
+        if (NX > 0) load_x(j, sx[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int s = lane + u * kWave;
+        if (s < cnt) {
+          s_pts[s] = st[u];
+#pragma unroll
+          for (int e = 0; e < NX; ++e) s_x[e * TILE + s] = sx[u][e];
+        }
+      }
+      wave_lds_fence();
+      scan(cnt);
+      wave_lds_fence();
+    }
+  }
+}
+
 // ---- pcl::eigen33 (common/impl/eigen.hpp) ------------------------------------------------------
 __host__ __device__ inline void compute_roots2(float b, float c, float *roots)
 {

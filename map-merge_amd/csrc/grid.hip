@@ -430,6 +430,93 @@ void grid_ensure_dt(Context *c, const Grid &g_, int R)
   g.dt_cap = R;
 }
 
+// ---------------------------------------------------------------- Hilbert order + wave work items
+// Queries that run 64 to a wave should form a compact patch, so that the cells they can reach are a
+// small box (wave_stream_box).  Points are ordered by the Hilbert index of their (x, y) column with
+// z below it; a work item is a run of at most 64 consecutive points that never straddles a
+// 2 m x 2 m column block (8 x 8 Hilbert cells): the curve may leave the occupied area and re-enter
+// far away, but never inside one block.
+__global__ void k_hilbert_keys(const float4 *__restrict__ pts, int n, float minx, float miny, float minz, float inv,
+                               uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  vals[i] = (uint32_t)i;
+  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = 0xFFFFFFFFu; return; }
+  unsigned x = (unsigned)clampi(cell_floor(p.x, minx, inv), 0, 1023);
+  unsigned y = (unsigned)clampi(cell_floor(p.y, miny, inv), 0, 1023);
+  const unsigned z = (unsigned)clampi(cell_floor(p.z, minz, inv), 0, 1023);
+  unsigned d = 0;
+  for (unsigned sft = 512; sft > 0; sft >>= 1) {
+    const unsigned rx = (x & sft) ? 1u : 0u, ry = (y & sft) ? 1u : 0u;
+    d += sft * sft * ((3u * rx) ^ ry);
+    if (ry == 0) {
+      if (rx == 1) { x = 1023u - x; y = 1023u - y; }
+      const unsigned t = x; x = y; y = t;
+    }
+  }
+  keys[i] = (d << 10) | z;
+}
+
+__global__ void k_hilbert_gather(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, int n, float4 *__restrict__ out)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t i = order[j];
+  float4 p = pts[i];
+  p.w = __int_as_float((int)i);
+  out[j] = p;
+}
+
+__global__ void k_item_heads(const uint32_t *__restrict__ keys, int n, int *__restrict__ heads)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n) return;
+  heads[j] = (j < n && (j == 0 || (keys[j] >> 16) != (keys[j - 1] >> 16) || (j & 63) == 0)) ? 1 : 0;
+}
+
+__global__ void k_item_fill(const int *__restrict__ heads, const int *__restrict__ pos, int n, int2 *__restrict__ items)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || !heads[j]) return;
+  int cnt = 1;
+  while (cnt < 64 && j + cnt < n && !heads[j + cnt]) ++cnt;
+  items[pos[j]] = make_int2(j, cnt);
+}
+
+void cloud_hilbert(Context *c, const mm3d_cloud *cl_)
+{
+  auto *cl = const_cast<mm3d_cloud *>(cl_);
+  cloud_bbox(c, cl);
+  const int n = (int)cl->n_finite;
+  if (cl->hil_pts.get() || n == 0) return;
+  const int total = (int)cl->n;
+  // cell so that the larger box side spans at most 1024 cells, but never finer than 0.25 m
+  float ext = 0.f;
+  for (int a = 0; a < 3; ++a) ext = std::fmax(ext, cl->bmax[a] - cl->bmin[a]);
+  const float cell = std::fmax(0.25f, ext / 1023.0f);
+  DevBuf<uint32_t> keys(c, total), vals(c, total), keys2(c, total), vals2(c, total);
+  MM3D_LAUNCH(c, "hilbert_keys", total * 24.0, k_hilbert_keys, dim3(div_up(total, 256)), dim3(256), 0, cl->pts.get(), total,
+              cl->bmin[0], cl->bmin[1], cl->bmin[2], 1.0f / cell, keys.get(), vals.get());
+  sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), total, 32);
+  cl->hil_pts = DevBuf<float4>(c, n);
+  MM3D_LAUNCH(c, "hilbert_gather", n * 36.0, k_hilbert_gather, dim3(div_up(n, 256)), dim3(256), 0, cl->pts.get(),
+              (const uint32_t *)vals2.get(), n, cl->hil_pts.get());
+  DevBuf<int> heads(c, (size_t)n + 1), blk(c, (size_t)n + 1);
+  MM3D_LAUNCH(c, "hilbert_items", n * 8.0, k_item_heads, dim3(div_up(n + 1, 256)), dim3(256), 0, (const uint32_t *)keys2.get(), n,
+              heads.get());
+  exclusive_scan_int(c, heads.get(), blk.get(), (size_t)n + 1);
+  int *h = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(h, blk.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  cl->n_wave_items = h[0];
+  cl->wave_items = DevBuf<int2>(c, (size_t)h[0]);
+  MM3D_LAUNCH(c, "hilbert_items", n * 12.0, k_item_fill, dim3(div_up(n, 256)), dim3(256), 0, (const int *)heads.get(),
+              (const int *)blk.get(), n, cl->wave_items.get());
+  c->sync();
+}
+
 // ---------------------------------------------------------------- ordered compaction
 __global__ void k_compact(const float4 *__restrict__ in, const int *__restrict__ flags, const int *__restrict__ pos,
                           size_t n, float4 *__restrict__ out)

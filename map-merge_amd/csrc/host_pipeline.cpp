@@ -255,12 +255,12 @@ void sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
     desc_knn(c, sd, td, k_corr, d_nn, d_nd);
     download(c, d_nn.get(), nn, (size_t)ns * k_corr);
   }
-  const std::vector<float4> *tkp = execute ? &cloud_host(c, tkp_) : nullptr;
-
   const int H = max_iterations > 0 ? max_iterations : 0;
-  std::vector<float> T_all((size_t)H * 16);
+  // the host only replays the sample stream (rand() draws and the distance tests on source keypoints);
+  // the 500 three-point Umeyama models are built on the device from the sampled indices
+  std::vector<int> samp((size_t)H * 3), corr((size_t)H * 3);
   for (int it = 0; it < H; ++it) {
-    int sample[3], corr_idx[3];
+    int *sample = &samp[(size_t)it * 3];
     // selectSamples
     {
       int cnt = 0, without = 0;
@@ -283,20 +283,15 @@ void sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
     for (int i = 0; i < nr_samples; ++i) {
       int rc = get_random_index(k_corr);
       if (rc >= kk) rc = kk - 1;     // the reference indexes past the resized result when nt < 10 (UB)
-      corr_idx[i] = execute ? nn[(size_t)sample[i] * k_corr + rc] : 0;
+      corr[(size_t)it * 3 + i] = execute ? nn[(size_t)sample[i] * k_corr + rc] : 0;
     }
-    if (!execute) continue;
-    float s[9], d[9];
-    for (int i = 0; i < 3; ++i) {
-      const float4 &p = skp[sample[i]], &q = (*tkp)[corr_idx[i]];
-      s[i * 3] = p.x; s[i * 3 + 1] = p.y; s[i * 3 + 2] = p.z;
-      d[i * 3] = q.x; d[i * 3 + 1] = q.y; d[i * 3 + 2] = q.z;
-    }
-    umeyama_f32(s, d, 3, &T_all[(size_t)it * 16]);
   }
   if (!execute || H == 0) return;
-  DevBuf<float> d_T, d_err(c, H);
-  upload(c, d_T, T_all);
+  DevBuf<int> d_samp, d_corr;
+  DevBuf<float> d_T(c, (size_t)H * 16), d_err(c, H);
+  upload(c, d_samp, samp);
+  upload(c, d_corr, corr);
+  sacia_models(c, skp_, tkp_, d_samp.get(), d_corr.get(), H, d_T.get());
   sacia_errors(c, skp_, tkp_, d_T.get(), H, corr_thresh, d_err.get());
   std::vector<float> err;
   download(c, d_err.get(), err, (size_t)H);
@@ -304,7 +299,8 @@ void sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
   float lowest = err[0];
   for (int i = 1; i < H; ++i)
     if (err[i] < lowest) { lowest = err[i]; best = i; }
-  std::memcpy(T, &T_all[(size_t)best * 16], sizeof(float) * 16);
+  MM3D_HIP(hipMemcpyAsync(T, d_T.get() + (size_t)best * 16, sizeof(float) * 16, hipMemcpyDeviceToHost, c->stream));
+  c->sync();
 }
 
 // ---------------------------------------------------------------- estimateTransform

@@ -23,6 +23,7 @@
 #include <cfloat>
 
 #include "device_util.hpp"
+#include "linalg_shared.hpp"
 
 namespace mm3d {
 
@@ -245,81 +246,6 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
   }
 }
 
-// ---- 3x3 SVD (one-sided Jacobi, double) and Umeyama on the device ------------------------------
-__device__ void svd3(const double *A, double *U, double *S, double *V)
-{
-  double B[9];
-  for (int i = 0; i < 9; ++i) { B[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    int rotated = 0;
-    for (int k = 0; k < 3; ++k) {
-      const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2;
-      double alpha = 0, beta = 0, gamma = 0;
-      for (int i = 0; i < 3; ++i) {
-        alpha += B[i * 3 + p] * B[i * 3 + p];
-        beta += B[i * 3 + q] * B[i * 3 + q];
-        gamma += B[i * 3 + p] * B[i * 3 + q];
-      }
-      if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
-      rotated = 1;
-      const double zeta = (beta - alpha) / (2.0 * gamma);
-      const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-      const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-      for (int i = 0; i < 3; ++i) {
-        const double bp = B[i * 3 + p], bq = B[i * 3 + q];
-        B[i * 3 + p] = c * bp - s * bq;
-        B[i * 3 + q] = s * bp + c * bq;
-        const double vp = V[i * 3 + p], vq = V[i * 3 + q];
-        V[i * 3 + p] = c * vp - s * vq;
-        V[i * 3 + q] = s * vp + c * vq;
-      }
-    }
-    if (!rotated) break;
-  }
-  double nrm[3];
-  for (int j = 0; j < 3; ++j) nrm[j] = sqrt(B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j]);
-  int o0 = 0, o1 = 1, o2 = 2, t;
-  if (nrm[o1] > nrm[o0]) { t = o0; o0 = o1; o1 = t; }
-  if (nrm[o2] > nrm[o0]) { t = o0; o0 = o2; o2 = t; }
-  if (nrm[o2] > nrm[o1]) { t = o1; o1 = o2; o2 = t; }
-  const int ord[3] = {o0, o1, o2};
-  double Vs[9];
-  for (int j = 0; j < 3; ++j) {
-    S[j] = nrm[ord[j]];
-    for (int i = 0; i < 3; ++i) {
-      Vs[i * 3 + j] = V[i * 3 + ord[j]];
-      U[i * 3 + j] = (S[j] > 0.0) ? B[i * 3 + ord[j]] / S[j] : 0.0;
-    }
-  }
-  for (int i = 0; i < 9; ++i) V[i] = Vs[i];
-  const double tiny = 1e-14 * (S[0] > 0 ? S[0] : 1.0);
-  if (S[0] <= 0.0) {
-    for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0;
-    return;
-  }
-  if (S[1] <= tiny) {
-    const double u0[3] = {U[0], U[3], U[6]};
-    const int m = fabs(u0[0]) < fabs(u0[1]) ? (fabs(u0[0]) < fabs(u0[2]) ? 0 : 2) : (fabs(u0[1]) < fabs(u0[2]) ? 1 : 2);
-    double e[3] = {0, 0, 0};
-    e[m] = 1.0;
-    const double d = u0[m];
-    const double v[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
-    const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    U[1] = v[0] / n; U[4] = v[1] / n; U[7] = v[2] / n;
-  }
-  if (S[2] <= tiny) {
-    const double a[3] = {U[0], U[3], U[6]}, b[3] = {U[1], U[4], U[7]};
-    U[2] = a[1] * b[2] - a[2] * b[1];
-    U[5] = a[2] * b[0] - a[0] * b[2];
-    U[8] = a[0] * b[1] - a[1] * b[0];
-  }
-}
-
-__device__ inline double det3(const double *M)
-{
-  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
-}
-
 // one block: reduce partials, Umeyama, accumulate, convergence (DefaultConvergenceCriteria)
 __global__ void __launch_bounds__(256) k_icp_finalize(const double *__restrict__ partials, int nblocks, IcpState *st)
 {
@@ -356,13 +282,13 @@ __global__ void __launch_bounds__(256) k_icp_finalize(const double *__restrict__
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 3; ++c) sigma[r * 3 + c] = tot[6 + r * 3 + c] * inv - mq[r] * mp[c];
   double U[9], S[3], V[9];
-  svd3(sigma, U, S, V);
+  svd3_shared(sigma, U, S, V);
   double Sd[3] = {1.0, 1.0, 1.0};
-  if (det3(sigma) < 0) Sd[2] = -1.0;
+  if (det3_shared(sigma) < 0) Sd[2] = -1.0;
   int rank = 0;
   for (int i = 0; i < 3; ++i)
     if (!(fabs(S[i]) <= fabs(S[0]) * 1e-5)) ++rank;
-  if (rank == 2) Sd[2] = (det3(U) * det3(V) > 0) ? 1.0 : -1.0;
+  if (rank == 2) Sd[2] = (det3_shared(U) * det3_shared(V) > 0) ? 1.0 : -1.0;
   float Ti[16];
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 3; ++c) {
@@ -415,101 +341,12 @@ __global__ void __launch_bounds__(256) k_score_finalize(const double *__restrict
   }
 }
 
-// ---------------------------------------------------------------- Morton-ordered source copy
-// 64 consecutive points of this order form a compact patch, so a wave's box of target cells is small.
-__device__ __forceinline__ unsigned spread3(unsigned v)   // 10 bits -> every third bit
+// the source runs in the cloud's Hilbert order, one compact work item (<= 64 points) per wave (grid.hip)
+static const float4 *morton_source(Context *c, const mm3d_cloud *src, int &n)
 {
-  v &= 0x3ffu;
-  v = (v | (v << 16)) & 0x030000ffu;
-  v = (v | (v << 8)) & 0x0300f00fu;
-  v = (v | (v << 4)) & 0x030c30c3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
-
-__global__ void k_morton_keys(const float4 *__restrict__ pts, int n, float minx, float miny, float minz, float inv,
-                              uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
-  vals[i] = (uint32_t)i;
-  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = 0xFFFFFFFFu; return; }
-  unsigned x = (unsigned)clampi(cell_floor(p.x, minx, inv), 0, 1023);
-  unsigned y = (unsigned)clampi(cell_floor(p.y, miny, inv), 0, 1023);
-  const unsigned z = (unsigned)clampi(cell_floor(p.z, minz, inv), 0, 1023);
-  // Hilbert index of the (x, y) column (no jumps: consecutive columns share an edge), z below it
-  unsigned d = 0;
-  for (unsigned sft = 512; sft > 0; sft >>= 1) {
-    const unsigned rx = (x & sft) ? 1u : 0u, ry = (y & sft) ? 1u : 0u;
-    d += sft * sft * ((3u * rx) ^ ry);
-    if (ry == 0) {
-      if (rx == 1) { x = 1023u - x; y = 1023u - y; }
-      const unsigned t = x; x = y; y = t;
-    }
-  }
-  keys[i] = (d << 10) | z;
-}
-
-__global__ void k_gather_pts(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, int n, float4 *__restrict__ out)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) out[j] = pts[order[j]];
-}
-
-// an item starts at every coarse-block change (key >> 6: 4x4x4 Morton cells) and at every multiple
-// of 64, so it holds at most 64 points of ONE coarse block
-__global__ void k_item_heads(const uint32_t *__restrict__ keys, int n, int *__restrict__ heads)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > n) return;
-  // chunks of 64 that never straddle a 2 m x 2 m column block (8x8 Hilbert cells = key >> 16): the curve may
-  // leave the occupied area and re-enter far away, but never inside one block
-  heads[j] = (j < n && (j == 0 || (keys[j] >> 16) != (keys[j - 1] >> 16) || (j & 63) == 0)) ? 1 : 0;
-}
-
-__global__ void k_item_fill(const int *__restrict__ heads, const int *__restrict__ pos, int n, int2 *__restrict__ items)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n || !heads[j]) return;
-  int cnt = 1;
-  while (cnt < 64 && j + cnt < n && !heads[j + cnt]) ++cnt;
-  items[pos[j]] = make_int2(j, cnt);
-}
-
-static const float4 *morton_source(Context *c, const mm3d_cloud *src_, int &n)
-{
-  auto *src = const_cast<mm3d_cloud *>(src_);
-  cloud_bbox(c, src);
+  cloud_hilbert(c, src);
   n = (int)src->n_finite;
-  if (src->morton.get() || n == 0) return src->morton.get();
-  const int total = (int)src->n;
-  // cell so that the larger box side spans at most 1024 cells, but never finer than 0.25 m
-  float ext = 0.f;
-  for (int a = 0; a < 3; ++a) ext = std::fmax(ext, src->bmax[a] - src->bmin[a]);
-  const float cell = std::fmax(0.25f, ext / 1023.0f);
-  DevBuf<uint32_t> keys(c, total), vals(c, total), keys2(c, total), vals2(c, total);
-  MM3D_LAUNCH(c, "morton_keys", total * 24.0, k_morton_keys, dim3(div_up(total, 256)), dim3(256), 0, src->pts.get(), total,
-              src->bmin[0], src->bmin[1], src->bmin[2], 1.0f / cell, keys.get(), vals.get());
-  sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), total, 32);
-  src->morton = DevBuf<float4>(c, n);
-  MM3D_LAUNCH(c, "morton_gather", n * 36.0, k_gather_pts, dim3(div_up(n, 256)), dim3(256), 0, src->pts.get(),
-              (const uint32_t *)vals2.get(), n, src->morton.get());
-  // wave work items: a wave never straddles a coarse block (4x4x4 Morton cells = key >> 6), so its
-  // queries always form a compact patch even where the Z-curve jumps
-  DevBuf<int> heads(c, (size_t)n + 1), blk(c, (size_t)n + 1);
-  MM3D_LAUNCH(c, "morton_items", n * 8.0, k_item_heads, dim3(div_up(n + 1, 256)), dim3(256), 0, (const uint32_t *)keys2.get(), n,
-              heads.get());
-  exclusive_scan_int(c, heads.get(), blk.get(), (size_t)n + 1);     // blk[j] = items before point j; blk[n] = total
-  int *h = (int *)c->pin(64);
-  MM3D_HIP(hipMemcpyAsync(h, blk.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  c->sync();
-  src->n_wave_items = h[0];
-  src->wave_items = DevBuf<int2>(c, (size_t)h[0]);
-  MM3D_LAUNCH(c, "morton_items", n * 12.0, k_item_fill, dim3(div_up(n, 256)), dim3(256), 0, (const int *)heads.get(),
-              (const int *)blk.get(), n, src->wave_items.get());
-  c->sync();
-  return src->morton.get();
+  return src->hil_pts.get();
 }
 
 static float nn_cell_for(double radius)

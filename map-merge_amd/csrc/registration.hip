@@ -11,6 +11,7 @@
 #include <cfloat>
 
 #include "device_util.hpp"
+#include "linalg_shared.hpp"
 
 namespace mm3d {
 
@@ -47,6 +48,33 @@ void ransac_count(Context *c, const float4 *src_kp, const float4 *tgt_kp, const 
   if ((double)thr_le >= thr2) thr_le = std::nextafterf(thr_le, -INFINITY);
   MM3D_LAUNCH(c, "ransac_count", (double)H * n_corr * 8.0, k_ransac_count, dim3(div_up(H, 4)), dim3(256), 0, src_kp, tgt_kp,
               idx_src, idx_tgt, n_corr, T_all, H, thr_le, counts);
+}
+
+// ---------------------------------------------------------------- SAC-IA hypothesis models
+// TransformationEstimationSVD on the 3 sampled pairs of every hypothesis: one thread each, the same
+// host+device source the CPU side uses (linalg_shared.hpp), so T is bit-identical to a host build.
+__global__ void k_sacia_models(const float4 *__restrict__ skp, const float4 *__restrict__ tkp, const int *__restrict__ samp,
+                               const int *__restrict__ corr, int H, float *__restrict__ T_all)
+{
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  float s[9], d[9], T[16];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float4 p = skp[samp[h * 3 + i]], q = tkp[corr[h * 3 + i]];
+    s[i * 3] = p.x; s[i * 3 + 1] = p.y; s[i * 3 + 2] = p.z;
+    d[i * 3] = q.x; d[i * 3 + 1] = q.y; d[i * 3 + 2] = q.z;
+  }
+  umeyama_f32_shared(s, d, 3, T);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T_all[(size_t)h * 16 + i] = T[i];
+}
+
+void sacia_models(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const int *samp, const int *corr, int H,
+                  float *T_all)
+{
+  MM3D_LAUNCH(c, "sacia_models", H * 88.0, k_sacia_models, dim3(div_up(H, 64)), dim3(64), 0, (const float4 *)src_kp->pts.get(),
+              (const float4 *)tgt_kp->pts.get(), samp, corr, H, T_all);
 }
 
 // ---------------------------------------------------------------- SAC-IA hypothesis scoring

@@ -5,6 +5,16 @@
 // is copied with pcl::copyPointCloud, i.e. only x,y,z survive (rgb = 0).
 // Per octave: VoxelGrid(leaf = scale) of the previous octave's cloud -> DoG scale space over a
 // radius search of 3*sigma_max -> extrema over the 25 nearest neighbours and 3 adjacent scales.
+//
+// Both kernels are wave-cooperative (device_util.hpp::wave_stream_box): a wave owns one compact
+// patch of <= 64 points (Hilbert order of the octave cloud), streams the box of grid cells its
+// lanes can reach through LDS with coalesced loads, and every lane filters the staged candidates
+// by its own distance test.
+//
+// The 25-NN extremum test never materialises the 25 neighbours.  A point fails "minimum at scale
+// s" iff some neighbour q among its 25 nearest has DoG(q, s-1|s|s+1) < val: so it suffices to find
+// the NEAREST such violator (one min-reduction over (distance, index) keys) and count how many
+// points are closer than it (>= 25 <=> the violator is not among the 25 nearest).
 #include <cfloat>
 
 #include "device_util.hpp"
@@ -14,6 +24,7 @@ namespace mm3d {
 constexpr int kScales = 6;      // nr_scales_per_octave (3) + 3
 constexpr int kDog = 5;
 constexpr int kKnn = 25;
+constexpr int kSiftTile = 256;
 
 struct SiftScales {
   float sigma_sqr[kScales];
@@ -27,51 +38,76 @@ __device__ __forceinline__ float intensity_of(float w)
   return (float)(299 * r + 587 * g + 114 * b) / 1000.0f;
 }
 
-// intensity per sorted grid entry (so the DoG walk reads 4 B instead of decoding rgba each time)
-__global__ void k_sift_intensity(const float4 *__restrict__ sorted, const float4 *__restrict__ pts, int n,
-                                 float *__restrict__ val)
+__device__ __forceinline__ float wave_min_f(float v)
 {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
+// grid-sorted (x, y, z, intensity): what the scale-space walk reads
+__global__ void k_sift_pack(const float4 *__restrict__ sorted, const float4 *__restrict__ pts, int n, float4 *__restrict__ pv)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  val[j] = intensity_of(pts[__float_as_int(sorted[j].w)].w);
+  float4 s = sorted[j];
+  s.w = intensity_of(pts[__float_as_int(s.w)].w);
+  pv[j] = s;
 }
 
 // computeScaleSpace: Gaussian-weighted mean intensity at 6 scales -> 5 differences
 __global__ void __launch_bounds__(256)
-k_sift_dog(GridView g, const float *__restrict__ val, float radius, float r2, SiftScales sc,
-           float *__restrict__ dog /* [n][5] by original index */)
+k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* pts = (xyz, intensity) */,
+           float radius, float r2, SiftScales sc, float *__restrict__ dog /* [n][5] by original index */)
 {
+  __shared__ float4 s_pts[4][kSiftTile];
+  __shared__ int s_off[4][64];
+  __shared__ int s_beg[4][64];
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int i = bid * blockDim.x + threadIdx.x;
-  if (i >= g.n) return;
-  const float4 q = g.pts[i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = bid * 4 + wave;
+  const int2 it = item < n_items ? items[item] : make_int2(0, 0);
+  const bool valid = lane < it.y;
+  if (it.y == 0) return;                      // wave-uniform
+  const float4 q = q_pts[it.x + (valid ? lane : 0)];
+  // box of cells the wave's queries can reach
+  const float ri = radius * 1.0001f + 1e-4f;
+  const float lx = wave_min_f(valid ? q.x : INFINITY), hx = wave_max_f(valid ? q.x : -INFINITY);
+  const float ly = wave_min_f(valid ? q.y : INFINITY), hy = wave_max_f(valid ? q.y : -INFINITY);
+  const float lz = wave_min_f(valid ? q.z : INFINITY), hz = wave_max_f(valid ? q.z : -INFINITY);
+  const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
+  const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
+  const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
   float num[kScales], den[kScales];
 #pragma unroll
   for (int s = 0; s < kScales; ++s) { num[s] = 0.f; den[s] = 0.f; }
-  const float ri = radius * 1.0001f + 1e-4f;
-  const int x0 = clampi(cell_floor(q.x - ri, g.minx, g.inv), 0, g.dx - 1), x1 = clampi(cell_floor(q.x + ri, g.minx, g.inv), 0, g.dx - 1);
-  const int y0 = clampi(cell_floor(q.y - ri, g.miny, g.inv), 0, g.dy - 1), y1 = clampi(cell_floor(q.y + ri, g.miny, g.inv), 0, g.dy - 1);
-  const int z0 = clampi(cell_floor(q.z - ri, g.minz, g.inv), 0, g.dz - 1), z1 = clampi(cell_floor(q.z + ri, g.minz, g.inv), 0, g.dz - 1);
-  for (int z = z0; z <= z1; ++z)
-    for (int y = y0; y <= y1; ++y) {
-      const int row = (z * g.dy + y) * g.dx;
-      const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
-      for (int j = b; j < e; ++j) {
-        const float4 p = g.pts[j];
-        const float d2 = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
-        if (d2 < r2) {
-          const float v = val[j];
+  const float4 *sp = s_pts[wave];
+  wave_stream_box<kSiftTile, 0>(g, x0, x1, y0, y1, z0, z1, s_pts[wave], (float4 *)nullptr, s_off[wave], s_beg[wave], lane,
+                                [](int, float4 (&)[1]) {},
+                                [&](int cnt) {
+                                  if (!valid) return;
+                                  for (int k = 0; k < cnt; ++k) {
+                                    const float4 c = sp[k];
+                                    const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
+                                    if (d2 < r2) {
 #pragma unroll
-          for (int s = 0; s < kScales; ++s) {
-            if (d2 <= sc.thr9[s]) {
-              const float w = expf(-0.5f * d2 / sc.sigma_sqr[s]);
-              num[s] += v * w;
-              den[s] += w;
-            }
-          }
-        }
-      }
-    }
+                                      for (int s = 0; s < kScales; ++s) {
+                                        if (d2 <= sc.thr9[s]) {
+                                          const float w = expf(-0.5f * d2 / sc.sigma_sqr[s]);
+                                          num[s] += c.w * w;
+                                          den[s] += w;
+                                        }
+                                      }
+                                    }
+                                  }
+                                });
+  if (!valid) return;
   float prev = num[0] / den[0];
   float *o = dog + (size_t)__float_as_int(q.w) * kDog;
 #pragma unroll
@@ -82,93 +118,140 @@ k_sift_dog(GridView g, const float *__restrict__ val, float radius, float r2, Si
   }
 }
 
-// findScaleSpaceExtrema: exact 25-NN (self included) by ring expansion, then min/max of the DoG
-// over that set at every scale.  The per-thread sorted candidate list lives in LDS, slot-major so
-// that lane l touches bank l.
-template <int BD>
-__global__ void __launch_bounds__(BD)
-k_sift_extrema(GridView g, const float *__restrict__ dog, float min_contrast, int *__restrict__ flags /* [n*3] */)
+// DoG rows in the extrema grid's sorted order, two float4 per point: (d0,d1,d2,d3) and (d4,-,-,-)
+__global__ void k_sift_dogx(const float4 *__restrict__ sorted, const float *__restrict__ dog, int n, float4 *__restrict__ dogx)
 {
-  __shared__ float s_d[kKnn][BD];
-  __shared__ int s_i[kKnn][BD];
-  const int t = threadIdx.x;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const float *d = dog + (size_t)__float_as_int(sorted[j].w) * kDog;
+  dogx[j] = make_float4(d[0], d[1], d[2], d[3]);
+  dogx[n + j] = make_float4(d[4], 0.f, 0.f, 0.f);
+}
+
+// findScaleSpaceExtrema
+__global__ void __launch_bounds__(256)
+k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* .w = original index */,
+               const float4 *__restrict__ dogx, const float *__restrict__ dog, float min_contrast, int *__restrict__ flags /* [n*3] */)
+{
+  __shared__ float4 s_pts[4][kSiftTile];
+  __shared__ float4 s_x[4][2 * kSiftTile];
+  __shared__ int s_off[4][64];
+  __shared__ int s_beg[4][64];
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int i = bid * BD + t;
-  if (i >= g.n) return;
-  const float4 q = g.pts[i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = bid * 4 + wave;
+  const int2 it = item < n_items ? items[item] : make_int2(0, 0);
+  const bool valid = lane < it.y;
+  if (it.y == 0) return;                      // wave-uniform
+  const float4 q = q_pts[it.x + (valid ? lane : 0)];
   const int self = __float_as_int(q.w);
-  const int kk = g.n < kKnn ? g.n : kKnn;
-  int m = 0;
+  float v[3];
+  unsigned live = 0;                          // bit s-1: |DoG(self, s)| passes the contrast test
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    v[s] = valid ? dog[(size_t)self * kDog + s + 1] : 0.0f;
+    if (valid && fabsf(v[s]) >= min_contrast) live |= 1u << s;
+  }
+  bool active = live != 0;
+  bool is_min[3] = {false, false, false}, is_max[3] = {false, false, false};
   const int cx = cell_floor(q.x, g.minx, g.inv), cy = cell_floor(q.y, g.miny, g.inv), cz = cell_floor(q.z, g.minz, g.inv);
-  int maxring = max(max(max(cx, g.dx - 1 - cx), max(cy, g.dy - 1 - cy)), max(cz, g.dz - 1 - cz));
-  for (int ring = 0; ring <= maxring; ++ring) {
-    if (ring >= 2 && m == kk) {
-      const float guard = (float)(ring - 1) * g.cell;
-      if (s_d[kk - 1][t] <= guard * guard * 0.99999f) break;
-    }
-    const int z0 = cz - ring, z1 = cz + ring, y0 = cy - ring, y1 = cy + ring, xa = cx - ring, xb = cx + ring;
-    for (int z = z0 < 0 ? 0 : z0; z <= (z1 >= g.dz ? g.dz - 1 : z1); ++z) {
-      const bool zs = (z == z0 || z == z1);
-      for (int y = y0 < 0 ? 0 : y0; y <= (y1 >= g.dy ? g.dy - 1 : y1); ++y) {
-        const bool shell = zs || y == y0 || y == y1;
-        const int row = (z * g.dy + y) * g.dx;
-        const int npass = (shell || ring == 0) ? 1 : 2;
-        for (int pass = 0; pass < npass; ++pass) {
-          int lo, hi;
-          if (npass == 1) { lo = xa; hi = xb; }
-          else if (pass == 0) { lo = xa; hi = xa; }
-          else { lo = xb; hi = xb; }
-          lo = lo < 0 ? 0 : lo;
-          hi = hi >= g.dx ? g.dx - 1 : hi;
-          if (lo > hi) continue;
-          const int b = g.cell_start[row + lo], e = g.cell_start[row + hi + 1];
-          for (int j = b; j < e; ++j) {
-            const float4 p = g.pts[j];
-            const float d = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
-            const int oi = __float_as_int(p.w);
-            int pos = m;
-            if (m == kk) {
-              const float wd = s_d[kk - 1][t];
-              if (d > wd || (d == wd && oi > s_i[kk - 1][t])) continue;
-              pos = kk - 1;
-            } else {
-              ++m;
+  const int n_total = g.n;
+  const int max_e = max(max(g.dx, g.dy), g.dz) + 1;
+  int need = 1;
+  const float4 *sp = s_pts[wave];
+  const float4 *sx = s_x[wave];
+  const int ngrid = g.n;
+  for (int pass = 0; pass < 4096; ++pass) {
+    if (!__ballot(active)) break;
+    const int E = wave_max_int(active ? need : 0);
+    const int lx = wave_min_int(active ? cx : 0x7fffffff), hx = wave_max_int(active ? cx : -0x7fffffff);
+    const int ly = wave_min_int(active ? cy : 0x7fffffff), hy = wave_max_int(active ? cy : -0x7fffffff);
+    const int lz = wave_min_int(active ? cz : 0x7fffffff), hz = wave_max_int(active ? cz : -0x7fffffff);
+    const int x0 = max(lx - E, 0), x1 = min(hx + E, g.dx - 1);
+    const int y0 = max(ly - E, 0), y1 = min(hy + E, g.dy - 1);
+    const int z0 = max(lz - E, 0), z1 = min(hz + E, g.dz - 1);
+    // what this box proves for the lane: every point closer than `guard` has been staged
+    const float gx0 = (lx - E > 0) ? q.x - (g.minx + (float)(lx - E) * g.cell) : INFINITY;
+    const float gx1 = (hx + E < g.dx - 1) ? (g.minx + (float)(hx + E + 1) * g.cell) - q.x : INFINITY;
+    const float gy0 = (ly - E > 0) ? q.y - (g.miny + (float)(ly - E) * g.cell) : INFINITY;
+    const float gy1 = (hy + E < g.dy - 1) ? (g.miny + (float)(hy + E + 1) * g.cell) - q.y : INFINITY;
+    const float gz0 = (lz - E > 0) ? q.z - (g.minz + (float)(lz - E) * g.cell) : INFINITY;
+    const float gz1 = (hz + E < g.dz - 1) ? (g.minz + (float)(hz + E + 1) * g.cell) - q.z : INFINITY;
+    const float guard = fmaxf(fminf(fminf(fminf(gx0, gx1), fminf(gy0, gy1)), fminf(gz0, gz1)) * 0.9999f - 1e-5f, 0.0f);
+    const float guard2 = guard * guard;
+    // scan 1: nearest violator of every live (scale, min|max) test
+    unsigned long long vmin[3], vmax[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { vmin[s] = ~0ull; vmax[s] = ~0ull; }
+    wave_stream_box<kSiftTile, 2>(
+        g, x0, x1, y0, y1, z0, z1, s_pts[wave], s_x[wave], s_off[wave], s_beg[wave], lane,
+        [&](int j, float4 (&out)[2]) { out[0] = dogx[j]; out[1] = dogx[ngrid + j]; },
+        [&](int cnt) {
+          if (!active) return;
+          for (int k = 0; k < cnt; ++k) {
+            const float4 c = sp[k];
+            const float4 a = sx[k];
+            const float d4 = sx[kSiftTile + k].x;
+            const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_uint(c.w);
+            // min / max of the candidate's DoG over scales s-1, s, s+1 for s = 1, 2, 3
+            const float mn[3] = {fminf(fminf(a.x, a.y), a.z), fminf(fminf(a.y, a.z), a.w), fminf(fminf(a.z, a.w), d4)};
+            const float mx[3] = {fmaxf(fmaxf(a.x, a.y), a.z), fmaxf(fmaxf(a.y, a.z), a.w), fmaxf(fmaxf(a.z, a.w), d4)};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+              if (mn[s] < v[s] && key < vmin[s]) vmin[s] = key;
+              if (mx[s] > v[s] && key < vmax[s]) vmax[s] = key;
             }
-            while (pos > 0) {
-              const float pd = s_d[pos - 1][t];
-              const int pi = s_i[pos - 1][t];
-              if (pd > d || (pd == d && pi > oi)) { s_d[pos][t] = pd; s_i[pos][t] = pi; --pos; }
-              else break;
-            }
-            s_d[pos][t] = d; s_i[pos][t] = oi;
           }
+        });
+    // scan 2: how many points are closer than each nearest violator, and how many lie within guard
+    int cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0}, cg = 0;
+    wave_stream_box<kSiftTile, 0>(g, x0, x1, y0, y1, z0, z1, s_pts[wave], (float4 *)nullptr, s_off[wave], s_beg[wave], lane,
+                                  [](int, float4 (&)[1]) {},
+                                  [&](int cnt) {
+                                    if (!active) return;
+                                    for (int k = 0; k < cnt; ++k) {
+                                      const float4 c = sp[k];
+                                      const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
+                                      const unsigned long long key =
+                                          ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_uint(c.w);
+                                      cg += (d2 <= guard2) ? 1 : 0;
+#pragma unroll
+                                      for (int s = 0; s < 3; ++s) {
+                                        cmin[s] += (key < vmin[s]) ? 1 : 0;
+                                        cmax[s] += (key < vmax[s]) ? 1 : 0;
+                                      }
+                                    }
+                                  });
+    if (active) {
+      const int kk = n_total < kKnn ? n_total : kKnn;
+      const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dx - 1 && y1 == g.dy - 1 && z1 == g.dz - 1;
+      bool all_done = true;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        if (!(live & (1u << s))) continue;
+        // minimum test
+        {
+          const float vd2 = __uint_as_float((unsigned)(vmin[s] >> 32));
+          if (vmin[s] != ~0ull && (vd2 <= guard2 || whole)) is_min[s] = cmin[s] >= kk;   // violator seen in the proven zone
+          else if (cg >= kk || whole) is_min[s] = true;                                  // 25 proven-nearest, none violates
+          else all_done = false;
+        }
+        {
+          const float vd2 = __uint_as_float((unsigned)(vmax[s] >> 32));
+          if (vmax[s] != ~0ull && (vd2 <= guard2 || whole)) is_max[s] = cmax[s] >= kk;
+          else if (cg >= kk || whole) is_max[s] = true;
+          else all_done = false;
         }
       }
+      if (all_done) active = false;
+      else need = min(E + 1, max_e);
     }
   }
-  float mn[kDog], mx[kDog];
+  if (!valid) return;
 #pragma unroll
-  for (int s = 0; s < kDog; ++s) { mn[s] = FLT_MAX; mx[s] = -FLT_MAX; }
-  for (int k = 0; k < m; ++k) {
-    const float *d = dog + (size_t)s_i[k][t] * kDog;
-#pragma unroll
-    for (int s = 0; s < kDog; ++s) {
-      const float v = d[s];
-      mn[s] = (v < mn[s]) ? v : mn[s];     // std::min(a, b): b < a ? b : a
-      mx[s] = (mx[s] < v) ? v : mx[s];     // std::max(a, b): a < b ? b : a
-    }
-  }
-  const float *dv = dog + (size_t)self * kDog;
-#pragma unroll
-  for (int s = 1; s < kDog - 1; ++s) {
-    const float v = dv[s];
-    int f = 0;
-    if (fabsf(v) >= min_contrast) {
-      if ((v == mn[s]) && (v <= mn[s - 1]) && (v <= mn[s + 1])) f = 1;
-      else if ((v == mx[s]) && (v >= mx[s - 1]) && (v >= mx[s + 1])) f = 1;
-    }
-    flags[(size_t)self * 3 + (s - 1)] = f;
-  }
+  for (int s = 0; s < 3; ++s)
+    if (live & (1u << s)) flags[(size_t)self * 3 + s] = (is_min[s] || is_max[s]) ? 1 : 0;
 }
 
 __global__ void k_sift_emit(const float4 *__restrict__ pts, const int *__restrict__ flags, const int *__restrict__ pos,
@@ -204,20 +287,29 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     const float max_radius = 3.0f * scales[kScales - 1];
     const float r2 = (float)((double)max_radius * (double)max_radius);
     const int n = (int)cur->n;
+    cloud_hilbert(c, cur.get());                       // query order + wave work items
+    const int n_items = cur->n_wave_items;
+    const unsigned nblocks = div_up(n_items, 4);
     // scale space on a grid with cell = r/2
     const Grid &gr = cloud_grid(c, cur.get(), max_radius * 0.5f);
-    DevBuf<float> val(c, gr.n);
+    DevBuf<float4> pv(c, gr.n);
     DevBuf<float> dog(c, (size_t)n * kDog);
-    MM3D_LAUNCH(c, "sift_intensity", gr.n * 24.0, k_sift_intensity, dim3(div_up(gr.n, 256)), dim3(256), 0, gr.sorted.get(),
-                cur->pts.get(), gr.n, val.get());
-    MM3D_LAUNCH(c, "sift_dog", gr.n * 36.0, k_sift_dog, dim3(div_up(gr.n, 256)), dim3(256), 0, gr.view(), val.get(),
-                max_radius, r2, sc, dog.get());
+    MM3D_LAUNCH(c, "sift_pack", gr.n * 36.0, k_sift_pack, dim3(div_up(gr.n, 256)), dim3(256), 0, (const float4 *)gr.sorted.get(),
+                (const float4 *)cur->pts.get(), gr.n, pv.get());
+    GridView gvr = gr.view();
+    gvr.pts = pv.get();
+    MM3D_LAUNCH(c, "sift_dog", gr.n * 36.0, k_sift_dog, dim3(nblocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
+                (const int2 *)cur->wave_items.get(), n_items, gvr, max_radius, r2, sc, dog.get());
     // extrema on a finer grid (25 neighbours lie within ~3 leaf sizes on a surface)
     const Grid &gk = cloud_grid(c, cur.get(), 3.0f * scale);
+    DevBuf<float4> dogx(c, (size_t)gk.n * 2);
+    MM3D_LAUNCH(c, "sift_pack", gk.n * 48.0, k_sift_dogx, dim3(div_up(gk.n, 256)), dim3(256), 0, (const float4 *)gk.sorted.get(),
+                (const float *)dog.get(), gk.n, dogx.get());
     DevBuf<int> flags(c, (size_t)n * 3 + 1);
     MM3D_HIP(hipMemsetAsync(flags.get(), 0, ((size_t)n * 3 + 1) * sizeof(int), c->stream));
-    MM3D_LAUNCH(c, "sift_extrema", gk.n * 48.0, (k_sift_extrema<128>), dim3(div_up(gk.n, 128)), dim3(128), 0, gk.view(),
-                (const float *)dog.get(), (float)min_contrast, flags.get());
+    MM3D_LAUNCH(c, "sift_extrema", gk.n * 48.0, k_sift_extrema, dim3(nblocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
+                (const int2 *)cur->wave_items.get(), n_items, gk.view(), (const float4 *)dogx.get(), (const float *)dog.get(),
+                (float)min_contrast, flags.get());
     DevBuf<int> pos(c, (size_t)n * 3 + 1);
     exclusive_scan_int(c, flags.get(), pos.get(), (size_t)n * 3 + 1);
     int *h = (int *)c->pin(64);

@@ -61,8 +61,8 @@ struct mm3d_cloud {
   size_t n_finite = 0;
   std::map<int, std::unique_ptr<mm3d::Grid>> grids;   // key: cell size in units of 1e-4 m
   std::vector<float4> host;                            // host copy (keypoint clouds only)
-  mm3d::DevBuf<float4> morton;                         // finite points in Morton order (ICP / score source)
-  mm3d::DevBuf<int2> wave_items;                       // {first point, count <= 64}: one coarse Morton block per wave
+  mm3d::DevBuf<float4> hil_pts;                        // finite points in Hilbert order, .w = original index
+  mm3d::DevBuf<int2> wave_items;                       // {first point, count <= 64}: one compact patch per wave
   int n_wave_items = 0;
 };
 
@@ -91,6 +91,8 @@ void cloud_bbox(Context *c, mm3d_cloud *cl);
 const Grid &cloud_grid(Context *c, const mm3d_cloud *cl, float cell);
 // per-cell Chebyshev distance transform (capped at R cells), cached on the grid
 void grid_ensure_dt(Context *c, const Grid &g, int R);
+// Hilbert-ordered copy of the finite points (.w = original index) + wave work items, cached on the cloud
+void cloud_hilbert(Context *c, const mm3d_cloud *cl);
 mm3d_cloud *cloud_from_device(Context *c, DevBuf<float4> &&pts, size_t n);
 mm3d_cloud *cloud_from_memory(Context *c, const void *src, size_t n, size_t stride, size_t rgba_off);
 void cloud_download(Context *c, const mm3d_cloud *cl, void *dst, size_t stride, size_t rgba_off);
@@ -131,6 +133,8 @@ double transform_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt,
 void ransac_count(Context *c, const float4 *src_kp, const float4 *tgt_kp, const int *idx_src,
                   const int *idx_tgt, int n_corr, const float *T_all /* H*16 device */, int H,
                   double thr2, int *counts /* device H */);
+void sacia_models(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const int *samp /* H*3 dev */,
+                  const int *corr /* H*3 dev */, int H, float *T_all /* H*16 dev */);
 void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const float *T_all /* H*16 dev */,
                   int H, float corr_thresh, float *errors /* device H */);
 
