@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--points", type=int, default=500000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache", action="store_true")
+    ap.add_argument("--kernel-table", default=None, help="write rank 0's full per-kernel HIP-event table (CSV) here")
     args = ap.parse_args()
 
     import torch
@@ -211,7 +212,16 @@ def main():
                             "unit": "GB/s", "frac": round(rate / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                             "avg_launch_us": round(avg_ms * 1e3, 3), "launches_per_step": k["launches"] / max(args.steps, 1),
                             "algorithmic_bytes_per_launch": round(work_per_launch, 1)}
-        top = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:8]
+        ranked = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])
+        top = ranked[:8]
+        if args.kernel_table:
+            with open(args.kernel_table, "w") as f:
+                f.write("kernel,launches_per_step,ms_per_step,avg_launch_us,algorithmic_bytes_or_flops_per_launch\n")
+                for k, v in ranked:
+                    f.write("%s,%.1f,%.3f,%.2f,%.0f\n" % (k, v["launches"] / max(args.steps, 1), v["ms"] / max(args.steps, 1),
+                                                         1e3 * v["ms"] / max(v["launches"], 1), v["bytes"] / max(v["launches"], 1)))
+                f.write("TOTAL,%.1f,%.3f,,\n" % (sum(v["launches"] for _, v in ranked) / max(args.steps, 1),
+                                                 sum(v["ms"] for _, v in ranked) / max(args.steps, 1)))
         npts_f = stats["pts_filtered"]
         icp_pts = sum(npts_f[i] * it for (i, j), it in zip([(i, j) for (i, j) in pairs_idx], stats["icp_iters"]))
         out = {

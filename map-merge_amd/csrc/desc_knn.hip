@@ -28,8 +28,7 @@ constexpr int kKP = 36;          // padded contraction length
 constexpr int kSteps = kKP / 2;  // 32x32x2 MFMA steps
 constexpr int kSlices = 4;       // waves per query tile, each scanning a quarter of the targets
 constexpr int kLists = 2 * kSlices;
-constexpr int kListLen = 8;      // per-lane candidate list of the MFMA stage (8 lists x 8 = 64 candidates per query)
-constexpr int kCand = kLists * kListLen;
+constexpr int kListLen = 8;      // per-lane candidate list of the MFMA stage (8 lists x 8 = 64 candidates per query and part)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -95,9 +94,6 @@ k_knn_exact(const float *__restrict__ A, int na, const float *__restrict__ B, in
     }
 }
 
-// ---------------------------------------------------------------- stage 1: operand preparation
-// Xp[(tile * kSteps + s) * 64 + lane] = x'[tile*32 + (lane & 31)][2*s + (lane >> 5)]: one coalesced
-// 256-byte wave load per MFMA step.
 // Exact k-NN for the (few) rows that miss the certificate: one WAVE per row.  Lanes stride over the
 // targets (64-row tiles staged through LDS with coalesced loads), each keeps its own sorted top-16 in
 // registers, and the k winners are drawn by repeated wave-wide minimum over (distance, index) keys.
@@ -176,6 +172,10 @@ k_knn_exact_wave(const float *__restrict__ A, const float *__restrict__ B, int n
   }
 }
 
+// ---------------------------------------------------------------- stage 1: operand preparation
+// Xp[(tile * kSteps + s) * 64 + lane] = x'[tile*32 + (lane & 31)][2*s + (lane >> 5)]: one coalesced
+// 256-byte wave load per MFMA step.
+//
 // column sums of the targets (33 floats) -> mu = sum / n.  Distances do not change when both sides
 // are shifted by the same vector, but the rounding error of the |a|^2 + |b|^2 - 2ab expansion does:
 // FPFH rows share a large common component, and centred rows make the certificate below tight.
@@ -238,18 +238,21 @@ k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, i
   int li[kListLen];
 #pragma unroll
   for (int s = 0; s < kListLen; ++s) { ld[s] = INFINITY; li[s] = -1; }
-  // slices interleave the target tiles (tile c belongs to slice c % kSlices): similar descriptors sit at
-  // nearby indices (same keypoint at several scales, spatial neighbours), and interleaving spreads a
-  // query's true neighbours evenly over the 8 lists, which is what keeps short lists certifiable
-  const int c0 = slice, c1 = nb_tiles;
+  // (part, slice) interleave the target tiles (tile c belongs to unit c % (parts * kSlices)): similar
+  // descriptors sit at nearby indices (same keypoint at several scales, spatial neighbours), and
+  // interleaving spreads a query's true neighbours evenly over the lists, which is what keeps short
+  // lists certifiable.  gridDim.y = parts > 1 when there are few query tiles (SAC-IA only looks up
+  // its sampled rows): the targets are then split over more blocks so the launch still fills the chip.
+  const int part = blockIdx.y, stride = kSlices * (int)gridDim.y;
+  const int c0 = part * kSlices + slice, c1 = nb_tiles;
   float bf[kSteps], bn[kSteps];
   if (c0 < c1) {
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) bf[s] = Bp[((size_t)c0 * kSteps + s) * 64 + lane];
   }
-  for (int c = c0; c < c1; c += kSlices) {
+  for (int c = c0; c < c1; c += stride) {
     // prefetch the next target tile while the matrix core works on this one
-    const int cn = (c + kSlices < c1) ? c + kSlices : c;
+    const int cn = (c + stride < c1) ? c + stride : c;
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) bn[s] = Bp[((size_t)cn * kSteps + s) * 64 + lane];
     f32x16 acc;
@@ -286,9 +289,10 @@ k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, i
   }
   const int a = tile_a * 32 + (lane & 31);
   if (a >= na) return;
-  const int list = (lane >> 5) * kSlices + slice;
-  float *od = cand_d + ((size_t)a * kLists + list) * kListLen;
-  int *oi = cand_i + ((size_t)a * kLists + list) * kListLen;
+  const int n_lists = kLists * (int)gridDim.y;
+  const int list = part * kLists + (lane >> 5) * kSlices + slice;
+  float *od = cand_d + ((size_t)a * n_lists + list) * kListLen;
+  int *oi = cand_i + ((size_t)a * n_lists + list) * kListLen;
 #pragma unroll
   for (int s = 0; s < kListLen; ++s) {
     const bool real = li[s] >= 0 && li[s] < nb;
@@ -298,55 +302,82 @@ k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, i
 }
 
 // ---------------------------------------------------------------- stage 3: exact re-rank + certificate
-__global__ void __launch_bounds__(128)
-k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, int nb, int k,
+// One WAVE per query row: the lanes split the row's candidates (n_lists x kListLen of them: 64 for a
+// full table, several hundred when the targets were split over parts), each re-ranks its share with
+// FLANN's accumulation order into a private sorted list, and the k winners are drawn by repeated
+// wave-wide minimum over (distance bits, index) keys -- i.e. ties go to the lower index.
+__global__ void __launch_bounds__(256)
+k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, int nb, int k, int n_lists,
              const float *__restrict__ cand_d, const int *__restrict__ cand_i, const float *__restrict__ colsum, float inv_nb,
              int *__restrict__ idx, float *__restrict__ d2out, int *__restrict__ fb_rows, int *__restrict__ fb_count)
 {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= na) return;
+  const int lane = threadIdx.x & 63;
+  const int a = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (a >= na) return;               // wave-uniform
   float x[kD];
   float na2 = 0.0f;
 #pragma unroll
   for (int d = 0; d < kD; ++d) {
     x[d] = A[(size_t)a * kD + d];
     const float xc = x[d] - colsum[d] * inv_nb;
-    na2 = fmaf(xc, xc, na2);       // |a - mu|^2
+    na2 = fmaf(xc, xc, na2);         // |a - mu|^2
   }
   float bd[kMaxK];
   int bi[kMaxK];
 #pragma unroll
   for (int s = 0; s < kMaxK; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
   float tau = INFINITY;
-  for (int l = 0; l < kLists; ++l) {
-    const float *cd_ = cand_d + ((size_t)a * kLists + l) * kListLen;
-    const int *ci_ = cand_i + ((size_t)a * kLists + l) * kListLen;
-    // a full list hides targets whose approximate distance is >= its worst entry
-    if (ci_[kListLen - 1] >= 0) tau = fminf(tau, cd_[kListLen - 1]);
-    for (int s = 0; s < kListLen; ++s) {
-      const int j = ci_[s];
-      if (j < 0) break;
-      const float *b = B + (size_t)j * kD;
-      float r = 0.0f;
+  const int n_cand = n_lists * kListLen;
+  const float *cd_ = cand_d + (size_t)a * n_cand;
+  const int *ci_ = cand_i + (size_t)a * n_cand;
+  for (int e = lane; e < n_cand; e += kWave) {
+    const int j = ci_[e];
+    if (j < 0) continue;
+    // a full list hides targets whose approximate distance is >= its worst (last) entry
+    if ((e & (kListLen - 1)) == kListLen - 1) tau = fminf(tau, cd_[e]);
+    const float *b = B + (size_t)j * kD;
+    float r = 0.0f;
 #pragma unroll
-      for (int d = 0; d < kD; ++d) {
-        const float df = x[d] - b[d];
-        r = __fadd_rn(r, __fmul_rn(df, df));
-      }
-      if (r < bd[kMaxK - 1] || (r == bd[kMaxK - 1] && j < bi[kMaxK - 1])) {
-        float cd = r;
-        int ci = j;
-        bool carrying = false;
+    for (int d = 0; d < kD; ++d) {
+      const float df = x[d] - b[d];
+      r = __fadd_rn(r, __fmul_rn(df, df));
+    }
+    if (r < bd[kMaxK - 1] || (r == bd[kMaxK - 1] && j < bi[kMaxK - 1])) {
+      float cd = r;
+      int ci = j;
+      bool carrying = false;
 #pragma unroll
-        for (int t = 0; t < kMaxK; ++t) {
-          const bool sw = carrying || cd < bd[t] || (cd == bd[t] && ci < bi[t]);
-          carrying = sw;
-          const float td = bd[t];
-          const int ti = bi[t];
-          bd[t] = sw ? cd : td; bi[t] = sw ? ci : ti;
-          cd = sw ? td : cd; ci = sw ? ti : ci;
-        }
+      for (int t = 0; t < kMaxK; ++t) {
+        const bool sw = carrying || cd < bd[t] || (cd == bd[t] && ci < bi[t]);
+        carrying = sw;
+        const float td = bd[t];
+        const int ti = bi[t];
+        bd[t] = sw ? cd : td; bi[t] = sw ? ci : ti;
+        cd = sw ? td : cd; ci = sw ? ti : ci;
       }
+    }
+  }
+  tau = wave_min_f(tau);
+  // merge the 64 sorted lists (the lists partition the targets, so every index occurs once)
+  float kth = INFINITY;
+  for (int o = 0; o < k; ++o) {
+    const unsigned long long key = ((unsigned long long)__float_as_uint(bd[0]) << 32) | (unsigned)bi[0];
+    unsigned long long best = key;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const unsigned long long other = __shfl_xor(best, s, kWave);
+      best = other < best ? other : best;
+    }
+    const float d = __uint_as_float((unsigned)(best >> 32));
+    if (lane == 0) {
+      idx[(size_t)a * k + o] = d < INFINITY ? (int)(unsigned)(best & 0xffffffffull) : -1;
+      d2out[(size_t)a * k + o] = d;
+    }
+    if (o == k - 1) kth = d;
+    if (key == best && bd[0] < INFINITY) {
+#pragma unroll
+      for (int s = 0; s + 1 < kMaxK; ++s) { bd[s] = bd[s + 1]; bi[s] = bi[s + 1]; }
+      bd[kMaxK - 1] = INFINITY; bi[kMaxK - 1] = 0x7fffffff;
     }
   }
   // Certificate.  A target b outside the candidate lists has approx(b) >= tau.  If |b - mu| > rho :=
@@ -355,21 +386,10 @@ k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, i
   // ~5e-6 (|a-mu| + |b-mu|)^2 + 2e-6 kth  (36-term f32 FMA chain on the centred operands, the two
   // norms, the centring itself, and the 33-term exact sum).  2e-5 (|a-mu|^2 + rho^2) + 1e-5 kth
   // doubles that bound.
-  float kth = INFINITY;
-#pragma unroll
-  for (int s = 0; s < kMaxK; ++s)
-    if (s == k - 1) kth = bd[s];
   const float rho = (sqrtf(na2) + sqrtf(kth)) * 1.001f + 1e-3f;
   const float eps = 2e-5f * (na2 + rho * rho) + 1e-5f * kth;
   const bool certified = !(tau < INFINITY) || (kth < tau - eps);
-#pragma unroll
-  for (int s = 0; s < kMaxK; ++s)
-    if (s < k) {
-      const bool have = bd[s] < INFINITY;
-      idx[(size_t)a * k + s] = have ? bi[s] : -1;
-      d2out[(size_t)a * k + s] = bd[s];
-    }
-  if (!certified) fb_rows[atomicAdd(fb_count, 1)] = a;
+  if (!certified && lane == 0) fb_rows[atomicAdd(fb_count, 1)] = a;
 }
 
 void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2)
@@ -400,15 +420,20 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
               na_tiles, 0, (const float *)colsum.get(), inv_nb, Ap.get());
   MM3D_LAUNCH(c, "desc_knn_prep", nb * 276.0, k_knn_prep, dim3(div_up((size_t)nb_tiles * kSteps * 64, 256)), dim3(256), 0, Bd, nb,
               nb_tiles, 1, (const float *)colsum.get(), inv_nb, Bp.get());
-  DevBuf<float> cand_d(c, (size_t)na * kCand);
-  DevBuf<int> cand_i(c, (size_t)na * kCand);
+  // few query tiles (SAC-IA's sampled rows): split the targets over `parts` blocks per query tile so
+  // that the launch still has >= 2 blocks per CU; each part keeps its own 8 lists per query
+  int parts = 1;
+  while (parts < 16 && na_tiles * parts < 512 && nb_tiles / (kSlices * parts * 2) >= 4) parts *= 2;
+  const int n_lists = kLists * parts;
+  DevBuf<float> cand_d(c, (size_t)na * n_lists * kListLen);
+  DevBuf<int> cand_i(c, (size_t)na * n_lists * kListLen);
   // roofline unit for this kernel is FLOPs (2 * na * nb * 36 per launch), reported as such by bench.py
-  MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, k_knn_mfma, dim3(na_tiles), dim3(256), 0,
-              (const float *)Ap.get(), na, (const float *)Bp.get(), nb, nb_tiles, cand_d.get(), cand_i.get());
+  MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, k_knn_mfma, dim3(na_tiles, parts),
+              dim3(256), 0, (const float *)Ap.get(), na, (const float *)Bp.get(), nb, nb_tiles, cand_d.get(), cand_i.get());
   DevBuf<int> fb_rows(c, na);
-  MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(kCand * 140 + 132), k_knn_rerank, dim3(div_up(na, 128)), dim3(128), 0, Ad, na, Bd,
-              nb, k, (const float *)cand_d.get(), (const int *)cand_i.get(), (const float *)colsum.get(), inv_nb, idx.get(), d2.get(),
-              fb_rows.get(), (int *)(meta.get() + 1));
+  MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * 140 + 132), k_knn_rerank, dim3(div_up(na, 4)), dim3(256), 0,
+              Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), (const float *)colsum.get(), inv_nb,
+              idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
   // rows without a certificate: exact brute force (the grid is sized for the worst case; blocks
   // beyond the device-side count exit at once)
   MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, k_knn_exact_wave, dim3(div_up(na, 4)), dim3(256), 0, Ad, Bd, nb, k,
@@ -420,6 +445,29 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
     c->knn_fallback_rows += (long long)h[1];
     c->knn_rows += na;
   }
+}
+
+__global__ void k_gather_desc_rows(const float *__restrict__ X, const int *__restrict__ rows, int n_rows, int dim,
+                                   float *__restrict__ out)
+{
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n_rows * dim) return;
+  out[e] = X[(size_t)rows[e / dim] * dim + e % dim];
+}
+
+// k-NN of a subset of A's rows (device index list); result row r belongs to rows[r]
+void desc_knn_rows(Context *c, const mm3d_desc *A, const int *rows_dev, int n_rows, const mm3d_desc *B, int k, DevBuf<int> &idx,
+                   DevBuf<float> &d2)
+{
+  mm3d_desc sub;
+  sub.dim = A->dim;
+  sub.type = A->type;
+  sub.n = (size_t)n_rows;
+  sub.data = DevBuf<float>(c, (size_t)n_rows * A->dim);
+  if (n_rows > 0)
+    MM3D_LAUNCH(c, "desc_knn_prep", n_rows * A->dim * 8.0, k_gather_desc_rows, dim3(div_up((size_t)n_rows * A->dim, 256)), dim3(256), 0,
+                (const float *)A->data.get(), rows_dev, n_rows, A->dim, sub.data.get());
+  desc_knn(c, &sub, B, k, idx, d2);
 }
 
 }  // namespace mm3d

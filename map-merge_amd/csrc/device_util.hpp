@@ -123,6 +123,19 @@ __device__ __forceinline__ int wave_max_int(int v)
   return v;
 }
 
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
 // LDS written by some lanes of a wave and read by others of the SAME wave: order the accesses for
 // the compiler; the hardware executes one wave's DS operations in order.
 __device__ __forceinline__ void wave_lds_fence()
@@ -198,6 +211,46 @@ __device__ __forceinline__ void wave_stream_box(const GridView &g, int x0, int x
       scan(cnt);
       wave_lds_fence();
     }
+  }
+}
+
+// Hit compaction for a staged tile.  The cheap part (is candidate k within r2 of MY query?) runs
+// for all candidates with broadcast LDS reads and leaves a per-lane bitset; the expensive part then
+// runs only over each lane's own set bits, in increasing k (the staged order), so the wave's trip
+// count is the maximum hit count over its lanes instead of the tile size.
+template <int TILE>
+__device__ __forceinline__ void tile_hit_mask(const float4 *sp, int cnt, float qx, float qy, float qz, float r2, bool live,
+                                              unsigned (&m)[TILE / 32])
+{
+#pragma unroll
+  for (int gq = 0; gq < TILE / 32; ++gq) {
+    unsigned bits = 0;
+    if (gq * 32 < cnt) {                      // wave-uniform
+#pragma unroll 4
+      for (int b = 0; b < 32; ++b) {
+        const float4 p = sp[gq * 32 + b];     // slots >= cnt hold stale points: masked off below
+        bits |= (dist2(qx, qy, qz, p.x, p.y, p.z) < r2) ? (1u << b) : 0u;
+      }
+      const int rem = cnt - gq * 32;
+      if (rem < 32) bits &= (1u << rem) - 1u;
+    }
+    m[gq] = live ? bits : 0u;
+  }
+}
+
+template <int G, class F>
+__device__ __forceinline__ void for_each_hit(unsigned (&m)[G], F &&f)
+{
+  for (;;) {
+    int k = -1;
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq)
+      if (k < 0 && m[gq]) {
+        k = gq * 32 + __ffs((int)m[gq]) - 1;
+        m[gq] &= m[gq] - 1u;
+      }
+    if (k < 0) break;
+    f(k);
   }
 }
 

@@ -52,16 +52,14 @@ k_fpfh_mark(const float4 *__restrict__ kp, int nk, GridView g, float radius, flo
 }
 
 __global__ void k_fpfh_support(const float4 *__restrict__ sorted, int n, const int *__restrict__ in_set,
-                               const int *__restrict__ pos, int *__restrict__ support_sorted /* by row */,
-                               int *__restrict__ row_of_sorted /* by sorted position, -1 if none */,
+                               const int *__restrict__ pos, int *__restrict__ row_of_sorted /* by sorted position, -1 if none */,
                                const float4 *__restrict__ nrm, float4 *__restrict__ nrm_sorted)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int oi = __float_as_int(sorted[j].w);
   nrm_sorted[j] = nrm[oi];
-  if (in_set[oi]) { support_sorted[pos[oi]] = j; row_of_sorted[j] = pos[oi]; }
-  else row_of_sorted[j] = -1;
+  row_of_sorted[j] = in_set[oi] ? pos[oi] : -1;
 }
 
 // pcl::computePairFeatures (features/src/pfh.cpp); returns f1,f2,f3 (all 0 on the degenerate exits)
@@ -102,42 +100,79 @@ __device__ __forceinline__ int bin_of(double x)
   return h >= kBins ? kBins - 1 : h;
 }
 
-// 2. SPFH: one thread per support point; histogram in LDS, bin-major so lane l hits bank l
-template <int BD>
-__global__ void __launch_bounds__(BD)
-k_spfh(GridView g, const float4 *__restrict__ nrm_sorted, const int *__restrict__ support_sorted, int ns, float radius,
-       float r2, float *__restrict__ spfh /* [ns][33] */)
+// 2. SPFH, wave-cooperative: a wave owns one compact patch of the surface (<= 64 points in Hilbert
+// order, the lanes that belong to the support set are live), streams the box of cells those lanes
+// can reach through LDS together with the candidates' normals, and every live lane bins the pairs
+// inside its own radius.  Every hit of one point adds the SAME float 100/(|N|-1), so a bin's value
+// depends only on its hit count: the scan counts in integers (LDS, bin-major so lane l owns bank
+// l) in whatever order the tiles arrive, and the float chain "0 + incr + incr + ..." of the CPU
+// loop is replayed once per bin at the end, bit for bit.
+constexpr int kSpfhTile = 128;
+__global__ void __launch_bounds__(256)
+k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g,
+       const float4 *__restrict__ nrm /* original order */, const float4 *__restrict__ nrm_sorted,
+       const int *__restrict__ in_set, const int *__restrict__ pos, float radius, float r2, float *__restrict__ spfh /* [ns][33] */)
 {
-  __shared__ float hist[kDim][BD];
-  const int t = threadIdx.x;
-  const int s = blockIdx.x * BD + t;
-  if (s >= ns) return;
+  __shared__ float4 s_pts[4][kSpfhTile];
+  __shared__ float4 s_nrm[4][kSpfhTile];
+  __shared__ int s_off[4][64];
+  __shared__ int s_beg[4][64];
+  __shared__ unsigned hist[4][kDim][64];
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = bid * 4 + wave;
+  const int2 it = item < n_items ? items[item] : make_int2(0, 0);
+  const bool valid = lane < it.y;
+  if (it.y == 0) return;                      // wave-uniform
+  const float4 q = q_pts[it.x + (valid ? lane : 0)];
+  const int self = __float_as_int(q.w);
+  const bool live = valid && in_set[self] != 0;
+  if (!__ballot(live)) return;                // wave-uniform: no support point in this patch
+  const float4 nq = nrm[self];
 #pragma unroll
-  for (int b = 0; b < kDim; ++b) hist[b][t] = 0.0f;
-  const int js = support_sorted[s];
-  const float4 q = g.pts[js];
-  const float4 nq = nrm_sorted[js];
-  int cnt = 0;
-  for_each_candidate_idx(g, q.x, q.y, q.z, radius, [&](int j, const float4 &p) {
-    cnt += (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) ? 1 : 0;
-  });
-  const float hist_incr = 100.0f / (float)(cnt - 1);
+  for (int b = 0; b < kDim; ++b) hist[wave][b][lane] = 0u;
+  const float ri = radius * 1.0001f + 1e-4f;
+  const float lx = wave_min_f(live ? q.x : INFINITY), hx = wave_max_f(live ? q.x : -INFINITY);
+  const float ly = wave_min_f(live ? q.y : INFINITY), hy = wave_max_f(live ? q.y : -INFINITY);
+  const float lz = wave_min_f(live ? q.z : INFINITY), hz = wave_max_f(live ? q.z : -INFINITY);
+  const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
+  const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
+  const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
   const float d_pi = 1.0f / (2.0f * 3.14159274f);
-  for_each_candidate_idx(g, q.x, q.y, q.z, radius, [&](int j, const float4 &p) {
-    if (j == js) return;                                   // p_idx == indices[idx]
-    if (!(dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2)) return;
-    float f1, f2, f3;
-    pair_features(q, nq, p, nrm_sorted[j], f1, f2, f3);
-    const int h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
-    const int h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
-    const int h3 = bin_of(kBins * (((double)f3 + 1.0) * 0.5));
-    hist[h1][t] += hist_incr;
-    hist[kBins + h2][t] += hist_incr;
-    hist[2 * kBins + h3][t] += hist_incr;
-  });
-  float *o = spfh + (size_t)s * kDim;
+  int cnt = 0;
+  const float4 *sp = s_pts[wave];
+  const float4 *sn = s_nrm[wave];
+  unsigned(*hw)[64] = hist[wave];
+  wave_stream_box<kSpfhTile, 1>(
+      g, x0, x1, y0, y1, z0, z1, s_pts[wave], s_nrm[wave], s_off[wave], s_beg[wave], lane,
+      [&](int j, float4 (&out)[1]) { out[0] = nrm_sorted[j]; },
+      [&](int n_tile) {
+        unsigned hits[kSpfhTile / 32];
+        tile_hit_mask<kSpfhTile>(sp, n_tile, q.x, q.y, q.z, r2, live, hits);
 #pragma unroll
-  for (int b = 0; b < kDim; ++b) o[b] = hist[b][t];
+        for (int gq = 0; gq < kSpfhTile / 32; ++gq) cnt += __popc(hits[gq]);
+        for_each_hit(hits, [&](int k) {
+          const float4 p = sp[k];
+          if (__float_as_int(p.w) == self) return;           // p_idx == indices[idx]
+          float f1, f2, f3;
+          pair_features(q, nq, p, sn[k], f1, f2, f3);
+          const int h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
+          const int h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
+          const int h3 = bin_of(kBins * (((double)f3 + 1.0) * 0.5));
+          hw[h1][lane] += 1u;
+          hw[kBins + h2][lane] += 1u;
+          hw[2 * kBins + h3][lane] += 1u;
+        });
+      });
+  if (!live) return;
+  const float hist_incr = 100.0f / (float)(cnt - 1);
+  float *o = spfh + (size_t)pos[self] * kDim;
+  for (int b = 0; b < kDim; ++b) {
+    const unsigned hits = hw[b][lane];
+    float v = 0.0f;
+    for (unsigned i = 0; i < hits; ++i) v += hist_incr;
+    o[b] = v;
+  }
 }
 
 // 3. weighting: one wave per keypoint.  Lanes scan 64 candidates at a time; for every hit the
@@ -251,14 +286,18 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
   MM3D_HIP(hipMemcpyAsync(h, pos.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   c->sync();
   const int ns = h[0];
-  DevBuf<int> support(c, ns > 0 ? ns : 1), row_of(c, g.n);
+  DevBuf<int> row_of(c, g.n);
   DevBuf<float4> nrm_sorted(c, g.n);
-  MM3D_LAUNCH(c, "fpfh_support", g.n * 48.0, k_fpfh_support, dim3(div_up(g.n, 256)), dim3(256), 0, g.sorted.get(), g.n,
-              in_set.get(), pos.get(), support.get(), row_of.get(), normals->nrm.get(), nrm_sorted.get());
+  MM3D_LAUNCH(c, "fpfh_support", g.n * 44.0, k_fpfh_support, dim3(div_up(g.n, 256)), dim3(256), 0, g.sorted.get(), g.n,
+              in_set.get(), pos.get(), row_of.get(), normals->nrm.get(), nrm_sorted.get());
   DevBuf<float> spfh(c, (size_t)(ns > 0 ? ns : 1) * kDim);
-  if (ns > 0)
-    MM3D_LAUNCH(c, "spfh", ns * 156.0, (k_spfh<128>), dim3(div_up(ns, 128)), dim3(128), 0, g.view(),
-                (const float4 *)nrm_sorted.get(), (const int *)support.get(), ns, (float)radius, r2, spfh.get());
+  if (ns > 0) {
+    cloud_hilbert(c, points);                            // query order + wave work items (shared with ICP / score)
+    const int n_items = points->n_wave_items;
+    MM3D_LAUNCH(c, "spfh", ns * 156.0, k_spfh, dim3(div_up(n_items, 4)), dim3(256), 0, (const float4 *)points->hil_pts.get(),
+                (const int2 *)points->wave_items.get(), n_items, g.view(), (const float4 *)normals->nrm.get(),
+                (const float4 *)nrm_sorted.get(), (const int *)in_set.get(), (const int *)pos.get(), (float)radius, r2, spfh.get());
+  }
   MM3D_LAUNCH(c, "fpfh_weight", (double)ns * 132.0 + nk * 132.0, k_fpfh_weight, dim3(div_up(nk, 4)), dim3(256), 0,
               keypoints->pts.get(), nk, g.view(), (const int *)row_of.get(), (const float *)spfh.get(), (float)radius, r2,
               raw.get(), valid.get());

@@ -4,8 +4,9 @@
 // RANSAC (pcl::RandomSampleConsensus) and SAC-IA are sequential loops whose SAMPLE stream depends
 // only on the random generator and on geometry of the source keypoints, never on hypothesis
 // scores.  So the host replays the exact sample stream (boost::mt19937 seed 12345 / glibc rand()),
-// builds every hypothesis, the device scores them all in one launch, and the host replays the
-// accept / early-termination logic over the returned scores: identical to the sequential loop.
+// the hypotheses are built (RANSAC: on the host, SAC-IA: on the device) and scored on the device
+// all in one launch, and the host replays the accept / early-termination logic over the returned
+// scores: identical to the sequential loop.
 #include <algorithm>
 #include <cfloat>
 #include <climits>
@@ -247,18 +248,14 @@ void sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
   const std::vector<float4> &skp = cloud_host(c, skp_);
   auto get_random_index = [&](int n) { return (int)(n * (c->rnd.next() / (2147483647 + 1.0))); };
 
-  std::vector<int> nn;
   const int kk = std::min(k_corr, nt);
-  if (execute) {
-    DevBuf<int> d_nn;
-    DevBuf<float> d_nd;
-    desc_knn(c, sd, td, k_corr, d_nn, d_nd);
-    download(c, d_nn.get(), nn, (size_t)ns * k_corr);
-  }
   const int H = max_iterations > 0 ? max_iterations : 0;
-  // the host only replays the sample stream (rand() draws and the distance tests on source keypoints);
-  // the 500 three-point Umeyama models are built on the device from the sampled indices
-  std::vector<int> samp((size_t)H * 3), corr((size_t)H * 3);
+  // The host only replays the sample stream: the rand() draws and the distance tests on source
+  // keypoints.  Nothing in that stream depends on the descriptor search (findSimilarFeatures draws
+  // one rand() per sample whatever the neighbours are), so the whole stream is replayed FIRST, the
+  // k-NN is then computed for the sampled rows only (<= 3 * 500 of ~16k), and the device looks the
+  // replayed picks up in its own table and builds the 500 three-point Umeyama models.
+  std::vector<int> samp((size_t)H * 3), pick((size_t)H * 3);
   for (int it = 0; it < H; ++it) {
     int *sample = &samp[(size_t)it * 3];
     // selectSamples
@@ -283,15 +280,24 @@ void sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
     for (int i = 0; i < nr_samples; ++i) {
       int rc = get_random_index(k_corr);
       if (rc >= kk) rc = kk - 1;     // the reference indexes past the resized result when nt < 10 (UB)
-      corr[(size_t)it * 3 + i] = execute ? nn[(size_t)sample[i] * k_corr + rc] : 0;
+      pick[(size_t)it * 3 + i] = rc;
     }
   }
   if (!execute || H == 0) return;
-  DevBuf<int> d_samp, d_corr;
-  DevBuf<float> d_T(c, (size_t)H * 16), d_err(c, H);
+  // distinct sampled rows -> position in the subset table
+  std::vector<int> rows, row_pos((size_t)ns, -1), corr_ref((size_t)H * 3);
+  for (size_t e = 0; e < samp.size(); ++e) {
+    int &pos = row_pos[samp[e]];
+    if (pos < 0) { pos = (int)rows.size(); rows.push_back(samp[e]); }
+    corr_ref[e] = pos * k_corr + pick[e];
+  }
+  DevBuf<int> d_samp, d_ref, d_rows, d_nn;
+  DevBuf<float> d_nd, d_T(c, (size_t)H * 16), d_err(c, H);
   upload(c, d_samp, samp);
-  upload(c, d_corr, corr);
-  sacia_models(c, skp_, tkp_, d_samp.get(), d_corr.get(), H, d_T.get());
+  upload(c, d_ref, corr_ref);
+  upload(c, d_rows, rows);
+  desc_knn_rows(c, sd, d_rows.get(), (int)rows.size(), td, k_corr, d_nn, d_nd);
+  sacia_models(c, skp_, tkp_, d_samp.get(), d_ref.get(), d_nn.get(), H, d_T.get());
   sacia_errors(c, skp_, tkp_, d_T.get(), H, corr_thresh, d_err.get());
   std::vector<float> err;
   download(c, d_err.get(), err, (size_t)H);

@@ -17,7 +17,13 @@ namespace mm3d {
 __host__ __device__ inline void svd3_shared(const double *A, double *U, double *S, double *V)
 {
   double B[9];
-  for (int i = 0; i < 9; ++i) { B[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  double frob2 = 0.0;
+  for (int i = 0; i < 9; ++i) { B[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; frob2 += A[i] * A[i]; }
+  // Eigen's JacobiSVD leaves a 2x2 block alone once its off-diagonals are <= 2 eps * (largest
+  // diagonal entry); for the one-sided form that is |col_p . col_q| <= 2 eps |A| max(|col_p|, |col_q|).
+  // (A threshold relative to |col_p| |col_q| never settles on the rank-2 matrices three-point
+  // samples produce: the null column is pure rounding noise.)
+  const double thr = 2.0 * 2.220446049250313e-16 * sqrt(frob2);
   for (int sweep = 0; sweep < 60; ++sweep) {
     int rotated = 0;
     for (int k = 0; k < 3; ++k) {
@@ -28,7 +34,7 @@ __host__ __device__ inline void svd3_shared(const double *A, double *U, double *
         beta += B[i * 3 + q] * B[i * 3 + q];
         gamma += B[i * 3 + p] * B[i * 3 + q];
       }
-      if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+      if (gamma == 0.0 || fabs(gamma) <= thr * sqrt(alpha > beta ? alpha : beta)) continue;
       rotated = 1;
       const double zeta = (beta - alpha) / (2.0 * gamma);
       const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

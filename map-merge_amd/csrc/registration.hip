@@ -4,10 +4,11 @@
 //                  CorrespondenceRejectorSampleConsensus (R/src/matching.cpp:119-124)
 // SAC-IA scoring   SampleConsensusInitialAlignment::computeErrorMetric (R/src/matching.cpp:159-173)
 //
-// The host replays the reference's random sample stream and builds every hypothesis
-// (host_pipeline.cpp); these kernels score all of them in one launch with exactly the float
-// predicate / float summation order of the sequential CPU loop, so the host's replay of the
-// accept logic picks the same hypothesis.  (ICP and transformScore live in nn.hip.)
+// The host replays the reference's random sample stream (host_pipeline.cpp) and hands over the
+// sampled indices of ALL hypotheses; these kernels build the models (SAC-IA) and score every
+// hypothesis in one launch with exactly the float predicate / float summation order of the
+// sequential CPU loop, so the host's replay of the accept logic picks the same hypothesis.
+// (ICP and transformScore live in nn.hip.)
 #include <cfloat>
 
 #include "device_util.hpp"
@@ -53,15 +54,17 @@ void ransac_count(Context *c, const float4 *src_kp, const float4 *tgt_kp, const 
 // ---------------------------------------------------------------- SAC-IA hypothesis models
 // TransformationEstimationSVD on the 3 sampled pairs of every hypothesis: one thread each, the same
 // host+device source the CPU side uses (linalg_shared.hpp), so T is bit-identical to a host build.
+// corr_ref[e] indexes the k-NN table of the sampled rows (row * k + the replayed random pick), so the
+// correspondence itself never travels to the host.
 __global__ void k_sacia_models(const float4 *__restrict__ skp, const float4 *__restrict__ tkp, const int *__restrict__ samp,
-                               const int *__restrict__ corr, int H, float *__restrict__ T_all)
+                               const int *__restrict__ corr_ref, const int *__restrict__ nn, int H, float *__restrict__ T_all)
 {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
   float s[9], d[9], T[16];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const float4 p = skp[samp[h * 3 + i]], q = tkp[corr[h * 3 + i]];
+    const float4 p = skp[samp[h * 3 + i]], q = tkp[nn[corr_ref[h * 3 + i]]];
     s[i * 3] = p.x; s[i * 3 + 1] = p.y; s[i * 3 + 2] = p.z;
     d[i * 3] = q.x; d[i * 3 + 1] = q.y; d[i * 3 + 2] = q.z;
   }
@@ -70,11 +73,11 @@ __global__ void k_sacia_models(const float4 *__restrict__ skp, const float4 *__r
   for (int i = 0; i < 16; ++i) T_all[(size_t)h * 16 + i] = T[i];
 }
 
-void sacia_models(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const int *samp, const int *corr, int H,
-                  float *T_all)
+void sacia_models(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const int *samp, const int *corr_ref,
+                  const int *nn, int H, float *T_all)
 {
   MM3D_LAUNCH(c, "sacia_models", H * 88.0, k_sacia_models, dim3(div_up(H, 64)), dim3(64), 0, (const float4 *)src_kp->pts.get(),
-              (const float4 *)tgt_kp->pts.get(), samp, corr, H, T_all);
+              (const float4 *)tgt_kp->pts.get(), samp, corr_ref, nn, H, T_all);
 }
 
 // ---------------------------------------------------------------- SAC-IA hypothesis scoring
@@ -94,11 +97,36 @@ k_sacia_err(const float4 *__restrict__ skp, int ns, int ns_pad, GridView g, cons
   const float4 s = skp[i];
   const float3 p = xform(Tl, s.x, s.y, s.z);
   float best = INFINITY;
-  // most hypotheses are wrong and throw the keypoint far from every target keypoint: one byte of
-  // the distance transform (cell = search radius, so "no occupied cell within 1" = out of range)
+  // hypotheses that throw the keypoint far from every target keypoint cost one byte of the distance
+  // transform (cell a hair larger than the search radius, so "no occupied cell within 1" = out of range)
   const int cx = cell_floor(p.x, g.minx, g.inv), cy = cell_floor(p.y, g.miny, g.inv), cz = cell_floor(p.z, g.minz, g.inv);
   const bool inside = cx >= 0 && cx < g.dx && cy >= 0 && cy < g.dy && cz >= 0 && cz < g.dz;
-  if (!inside || g.dt[((size_t)cz * g.dy + cy) * g.dx + cx] <= 1) {
+  if (inside) {
+    if (g.dt[((size_t)cz * g.dy + cy) * g.dx + cx] <= 1) {
+      // the 3x3x3 block holds every point in range: nine row spans, all eighteen headers fetched
+      // before the first candidate
+      int bb[9], ee[9];
+      const int lo = cx > 0 ? cx - 1 : 0, hi = cx + 1 < g.dx ? cx + 1 : g.dx - 1;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        const bool ok = z >= 0 && z < g.dz && y >= 0 && y < g.dy;
+        const int row = ok ? (z * g.dy + y) * g.dx : 0;
+        bb[r] = ok ? g.cell_start[row + lo] : 0;
+        ee[r] = ok ? g.cell_start[row + hi + 1] : 0;
+      }
+      // (measured: the kernel is VALU-bound on these short, ragged row loops -- ~26 wave instructions
+      // per query; compacting the survivors of the DT test through LDS and 4-wide packed candidate
+      // loads were both slower than this plain loop)
+#pragma unroll
+      for (int r = 0; r < 9; ++r)
+        for (int j = bb[r]; j < ee[r]; ++j) {
+          const float4 q = g.pts[j];
+          best = fminf(best, dist2(p.x, p.y, p.z, q.x, q.y, q.z));
+        }
+    }
+  } else {
+    // outside the grid the distance transform says nothing: clipped walk
     for_each_candidate(g, p.x, p.y, p.z, radius, [&](const float4 &q) {
       best = fminf(best, dist2(p.x, p.y, p.z, q.x, q.y, q.z));
       return true;

@@ -25,6 +25,7 @@ constexpr int kScales = 6;      // nr_scales_per_octave (3) + 3
 constexpr int kDog = 5;
 constexpr int kKnn = 25;
 constexpr int kSiftTile = 256;
+constexpr int kDogTile = 256;
 
 struct SiftScales {
   float sigma_sqr[kScales];
@@ -36,19 +37,6 @@ __device__ __forceinline__ float intensity_of(float w)
   const unsigned c = __float_as_uint(w);
   const int r = (int)((c >> 16) & 255u), g = (int)((c >> 8) & 255u), b = (int)(c & 255u);
   return (float)(299 * r + 587 * g + 114 * b) / 1000.0f;
-}
-
-__device__ __forceinline__ float wave_min_f(float v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave));
-  return v;
-}
-__device__ __forceinline__ float wave_max_f(float v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
-  return v;
 }
 
 // grid-sorted (x, y, z, intensity): what the scale-space walk reads
@@ -66,7 +54,7 @@ __global__ void __launch_bounds__(256)
 k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* pts = (xyz, intensity) */,
            float radius, float r2, SiftScales sc, float *__restrict__ dog /* [n][5] by original index */)
 {
-  __shared__ float4 s_pts[4][kSiftTile];
+  __shared__ float4 s_pts[4][kDogTile];
   __shared__ int s_off[4][64];
   __shared__ int s_beg[4][64];
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -88,22 +76,26 @@ k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int
 #pragma unroll
   for (int s = 0; s < kScales; ++s) { num[s] = 0.f; den[s] = 0.f; }
   const float4 *sp = s_pts[wave];
-  wave_stream_box<kSiftTile, 0>(g, x0, x1, y0, y1, z0, z1, s_pts[wave], (float4 *)nullptr, s_off[wave], s_beg[wave], lane,
+  wave_stream_box<kDogTile, 0>(g, x0, x1, y0, y1, z0, z1, s_pts[wave], (float4 *)nullptr, s_off[wave], s_beg[wave], lane,
                                 [](int, float4 (&)[1]) {},
                                 [&](int cnt) {
+                                  // All lanes look at the same staged candidate (broadcast LDS read).  The
+                                  // supports are nested (3 sigma_s grows with s), so the scales are visited
+                                  // from the widest down and a candidate outside scale s skips the narrower
+                                  // ones; the wave leaves the chain as soon as no lane is inside.  (Per-lane
+                                  // hit bitsets were measured slower here: 90 instructions per gathered hit
+                                  // against ~35 per scale in this loop.)
                                   if (!valid) return;
                                   for (int k = 0; k < cnt; ++k) {
                                     const float4 c = sp[k];
                                     const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
-                                    if (d2 < r2) {
+                                    if (!(d2 < r2)) continue;
 #pragma unroll
-                                      for (int s = 0; s < kScales; ++s) {
-                                        if (d2 <= sc.thr9[s]) {
-                                          const float w = expf(-0.5f * d2 / sc.sigma_sqr[s]);
-                                          num[s] += c.w * w;
-                                          den[s] += w;
-                                        }
-                                      }
+                                    for (int s = kScales - 1; s >= 0; --s) {
+                                      if (!(d2 <= sc.thr9[s])) break;
+                                      const float w = expf(-0.5f * d2 / sc.sigma_sqr[s]);
+                                      num[s] += c.w * w;
+                                      den[s] += w;
                                     }
                                   }
                                 });

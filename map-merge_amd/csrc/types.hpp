@@ -122,6 +122,9 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
 // desc_knn.hip
 // k nearest rows of B for every row of A (squared L2, FLANN accumulation order); idx -1 padded
 void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2);
+// the same for a subset of A's rows given as a device index list; result row r belongs to rows[r]
+void desc_knn_rows(Context *c, const mm3d_desc *A, const int *rows_dev, int n_rows, const mm3d_desc *B, int k,
+                   DevBuf<int> &idx, DevBuf<float> &d2);
 
 // registration.hip
 struct IcpResult { float T[16]; int iterations; int converged; };
@@ -134,7 +137,8 @@ void ransac_count(Context *c, const float4 *src_kp, const float4 *tgt_kp, const 
                   const int *idx_tgt, int n_corr, const float *T_all /* H*16 device */, int H,
                   double thr2, int *counts /* device H */);
 void sacia_models(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const int *samp /* H*3 dev */,
-                  const int *corr /* H*3 dev */, int H, float *T_all /* H*16 dev */);
+                  const int *corr_ref /* H*3 dev: index into nn */, const int *nn /* dev k-NN table */, int H,
+                  float *T_all /* H*16 dev */);
 void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const float *T_all /* H*16 dev */,
                   int H, float corr_thresh, float *errors /* device H */);
 

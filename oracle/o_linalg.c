@@ -20,7 +20,11 @@ static void svd3(const double A[9], double U[9], double S[3], double V[9])
 {
   double B[9];
   memcpy(B, A, sizeof(B));
-  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  double frob2 = 0.0;
+  for (int i = 0; i < 9; ++i) { V[i] = (i % 4 == 0) ? 1.0 : 0.0; frob2 += A[i] * A[i]; }
+  /* Eigen's JacobiSVD stops rotating a 2x2 block once its off-diagonals are <= 2 eps * (largest
+   * diagonal entry); one-sided equivalent: |col_p . col_q| <= 2 eps |A| max(|col_p|, |col_q|) */
+  const double thr = 2.0 * 2.220446049250313e-16 * sqrt(frob2);
   static const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
   for (int sweep = 0; sweep < 60; ++sweep) {
     int rotated = 0;
@@ -32,7 +36,7 @@ static void svd3(const double A[9], double U[9], double S[3], double V[9])
         beta += B[i * 3 + q] * B[i * 3 + q];
         gamma += B[i * 3 + p] * B[i * 3 + q];
       }
-      if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+      if (gamma == 0.0 || fabs(gamma) <= thr * sqrt(alpha > beta ? alpha : beta)) continue;
       rotated = 1;
       double zeta = (beta - alpha) / (2.0 * gamma);
       double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Sum rocprofv3 --pmc counter_collection.csv rows per kernel: usage pmc_summary.py file.csv [file2.csv ...]"""
+import csv, sys, collections, re
+
+def short(name):
+    m = re.search(r"mm3d::(\w+)", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"(\w+)<", name)
+    return (m.group(1) if m else name)[:40]
+
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(set)
+for path in sys.argv[1:]:
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            k = short(row["Kernel_Name"])
+            acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            disp[k].add((path, row["Dispatch_Id"]))
+names = sorted({c for k in acc for c in acc[k]})
+print("kernel,dispatches," + ",".join(names))
+for k in sorted(acc, key=lambda k: -acc[k].get("SQ_WAVE_CYCLES", acc[k].get("SQ_ACTIVE_INST_ANY", 0))):
+    print(k + "," + str(len(disp[k]) // max(len(sys.argv) - 1, 1)) + "," + ",".join("%.4g" % acc[k].get(c, float("nan")) for c in names))
