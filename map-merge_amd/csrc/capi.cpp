@@ -1,5 +1,6 @@
 // capi.cpp -- the extern "C" boundary of libmm3d.so (include/mm3d.h).  Nothing throws across it.
 #include <algorithm>
+#include <cfloat>
 #include <cstdlib>
 #include <functional>
 #include <sstream>
@@ -486,13 +487,15 @@ static void pair_estimate_impl(mm3d_ctx *ctx, const mm3d_map *s, const mm3d_map 
   out->confidence = 0.0;
   out->icp_iterations = 0;
   out->reserved = 0;
-  const int iters = estimate_transform(ctx, s->points, s->keypoints, s->desc, t->points, t->keypoints, t->desc,
-                                       p->estimation_method, p->refine_transform, p->inlier_threshold,
-                                       p->max_correspondence_distance, p->max_iterations, (size_t)p->matching_k,
-                                       p->transform_epsilon, out->transform, execute);
+  // estimateTransform and transformScore of its result (R/src/map_merging.cpp:91-107) as one device
+  // pipeline: the transform never visits the host in between
+  double score = DBL_MAX;
+  const int iters = estimate_pair(ctx, s->points, s->keypoints, s->desc, t->points, t->keypoints, t->desc,
+                                  p->estimation_method, p->refine_transform, p->inlier_threshold,
+                                  p->max_correspondence_distance, p->max_iterations, (size_t)p->matching_k,
+                                  p->transform_epsilon, out->transform, execute, true, p->max_correspondence_distance, &score);
   if (!execute) return;
   out->icp_iterations = iters;
-  const double score = transform_score(ctx, s->points, t->points, out->transform, p->max_correspondence_distance);
   out->confidence = 1.0 / score;
 }
 

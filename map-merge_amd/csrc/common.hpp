@@ -131,9 +131,11 @@ struct Context {
   int last_icp_iterations = 0, last_icp_converged = 0;
   bool debug = false;            // mm3d_set_debug: collect counters that cost a host sync
   long long knn_fallback_rows = 0, knn_rows = 0;
-  // pinned host scratch for small D2H reads
+  // pinned host arena for small asynchronous H2D / D2H copies: pin() bumps through it, so regions
+  // handed out earlier stay untouched while their copies are in flight; the stream is drained
+  // before the arena wraps around or is replaced
   void *pinned = nullptr;
-  size_t pinned_bytes = 0;
+  size_t pinned_bytes = 0, pinned_off = 0;
   // profiling
   bool prof_on = false;
   struct Pending { int slot; hipEvent_t a, b; };

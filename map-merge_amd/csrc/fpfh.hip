@@ -17,38 +17,31 @@ namespace mm3d {
 constexpr int kBins = 11;
 constexpr int kDim = 33;
 
-// same walk as for_each_candidate but the callback also receives the sorted position j
-template <class F>
-__device__ __forceinline__ void for_each_candidate_idx(const GridView &g, float qx, float qy, float qz, float r, F &&f)
+// 1. mark the support set (by original index): one wave per keypoint, lanes stride over the
+// candidate row spans (coalesced 16-byte loads)
+__global__ void __launch_bounds__(256)
+k_fpfh_mark(const float4 *__restrict__ kp, int nk, GridView g, float radius, float r2, int *__restrict__ in_set)
 {
-  const float ri = r * 1.0001f + 1e-4f;
-  if (cell_floor(qx + ri, g.minx, g.inv) < 0 || cell_floor(qx - ri, g.minx, g.inv) > g.dx - 1) return;
-  const int x0 = clampi(cell_floor(qx - ri, g.minx, g.inv), 0, g.dx - 1), x1 = clampi(cell_floor(qx + ri, g.minx, g.inv), 0, g.dx - 1);
-  int y0 = cell_floor(qy - ri, g.miny, g.inv), y1 = cell_floor(qy + ri, g.miny, g.inv);
-  int z0 = cell_floor(qz - ri, g.minz, g.inv), z1 = cell_floor(qz + ri, g.minz, g.inv);
+  const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (k >= nk) return;
+  const int lane = threadIdx.x & 63;
+  const float4 q = kp[k];
+  const float ri = radius * 1.0001f + 1e-4f;
+  if (cell_floor(q.x + ri, g.minx, g.inv) < 0 || cell_floor(q.x - ri, g.minx, g.inv) > g.dx - 1) return;
+  const int x0 = clampi(cell_floor(q.x - ri, g.minx, g.inv), 0, g.dx - 1), x1 = clampi(cell_floor(q.x + ri, g.minx, g.inv), 0, g.dx - 1);
+  int y0 = cell_floor(q.y - ri, g.miny, g.inv), y1 = cell_floor(q.y + ri, g.miny, g.inv);
+  int z0 = cell_floor(q.z - ri, g.minz, g.inv), z1 = cell_floor(q.z + ri, g.minz, g.inv);
   y0 = y0 < 0 ? 0 : y0; z0 = z0 < 0 ? 0 : z0;
   y1 = y1 > g.dy - 1 ? g.dy - 1 : y1; z1 = z1 > g.dz - 1 ? g.dz - 1 : z1;
   for (int z = z0; z <= z1; ++z)
     for (int y = y0; y <= y1; ++y) {
       const int row = (z * g.dy + y) * g.dx;
       const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
-      for (int j = b; j < e; ++j) f(j, g.pts[j]);
+      for (int j = b + lane; j < e; j += kWave) {
+        const float4 p = g.pts[j];
+        if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) in_set[__float_as_int(p.w)] = 1;
+      }
     }
-}
-
-// 1. mark the support set (by sorted position) and count each keypoint's neighbours
-__global__ void __launch_bounds__(256)
-k_fpfh_mark(const float4 *__restrict__ kp, int nk, GridView g, float radius, float r2, int *__restrict__ in_set,
-            int *__restrict__ nbr_count)
-{
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nk) return;
-  const float4 q = kp[k];
-  int cnt = 0;
-  for_each_candidate_idx(g, q.x, q.y, q.z, radius, [&](int j, const float4 &p) {
-    if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) { in_set[__float_as_int(p.w)] = 1; ++cnt; }
-  });
-  nbr_count[k] = cnt;
 }
 
 __global__ void k_fpfh_support(const float4 *__restrict__ sorted, int n, const int *__restrict__ in_set,
@@ -277,10 +270,10 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
     keypoints->have_bbox = false;
     return res;
   }
-  DevBuf<int> in_set(c, (size_t)n + 1), pos(c, (size_t)n + 1), nbr(c, nk);
+  DevBuf<int> in_set(c, (size_t)n + 1), pos(c, (size_t)n + 1);
   MM3D_HIP(hipMemsetAsync(in_set.get(), 0, ((size_t)n + 1) * sizeof(int), c->stream));
-  MM3D_LAUNCH(c, "fpfh_mark", nk * 16.0, k_fpfh_mark, dim3(div_up(nk, 256)), dim3(256), 0, keypoints->pts.get(), nk, g.view(),
-              (float)radius, r2, in_set.get(), nbr.get());
+  MM3D_LAUNCH(c, "fpfh_mark", nk * 16.0, k_fpfh_mark, dim3(div_up(nk, 4)), dim3(256), 0, keypoints->pts.get(), nk, g.view(),
+              (float)radius, r2, in_set.get());
   exclusive_scan_int(c, in_set.get(), pos.get(), (size_t)n + 1);
   int *h = (int *)c->pin(64);
   MM3D_HIP(hipMemcpyAsync(h, pos.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));

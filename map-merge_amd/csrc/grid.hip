@@ -62,12 +62,20 @@ void Pool::trim()
 
 void *Context::pin(size_t bytes)
 {
+  bytes = (bytes + 255) & ~(size_t)255;
   if (bytes > pinned_bytes) {
-    if (pinned) (void)hipHostFree(pinned);
-    pinned_bytes = bytes < 4096 ? 4096 : bytes * 2;
+    if (pinned) { sync(); (void)hipHostFree(pinned); pinned = nullptr; }
+    pinned_bytes = bytes * 2 < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes * 2;
     MM3D_HIP(hipHostMalloc(&pinned, pinned_bytes));
+    pinned_off = 0;
   }
-  return pinned;
+  if (pinned_off + bytes > pinned_bytes) {
+    sync();                       // every copy that used the arena has drained
+    pinned_off = 0;
+  }
+  void *p = (char *)pinned + pinned_off;
+  pinned_off += bytes;
+  return p;
 }
 
 int Context::prof_slot(const char *name)

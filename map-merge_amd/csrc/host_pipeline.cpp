@@ -234,14 +234,15 @@ size_t ransac_transform(Context *c, const mm3d_cloud *skp_, const mm3d_cloud *tk
 // ---------------------------------------------------------------- SAC-IA
 // R/src/matching.cpp:142-194 -> pcl::SampleConsensusInitialAlignment (nr_samples 3,
 // k_correspondences 10, TruncatedError(max_correspondence_distance)).
-void sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_cloud *tkp_, const mm3d_desc *td,
-            double min_sample_distance_d, double max_corr_dist, int max_iterations, float T[16], bool execute)
+bool sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_cloud *tkp_, const mm3d_desc *td,
+            double min_sample_distance_d, double max_corr_dist, int max_iterations, float T[16], bool execute,
+            DevBuf<float> *T_dev)
 {
   std::memset(T, 0, sizeof(float) * 16);
   T[0] = T[5] = T[10] = T[15] = 1.0f;   // final_transformation_ = guess = Identity
   const int ns = (int)skp_->n, nt = (int)tkp_->n;
   const int nr_samples = 3, k_corr = 10;
-  if (ns < nr_samples || nt < 1) return;
+  if (ns < nr_samples || nt < 1) return false;
   MM3D_REQUIRE(sd->n == (size_t)ns && td->n == (size_t)nt, "SAC-IA: keypoints and descriptors differ in size");
   float min_sample_distance = (float)min_sample_distance_d;
   const float corr_thresh = (float)max_corr_dist;
@@ -283,7 +284,7 @@ void sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
       pick[(size_t)it * 3 + i] = rc;
     }
   }
-  if (!execute || H == 0) return;
+  if (!execute || H == 0) return false;
   // distinct sampled rows -> position in the subset table
   std::vector<int> rows, row_pos((size_t)ns, -1), corr_ref((size_t)H * 3);
   for (size_t e = 0; e < samp.size(); ++e) {
@@ -291,33 +292,43 @@ void sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
     if (pos < 0) { pos = (int)rows.size(); rows.push_back(samp[e]); }
     corr_ref[e] = pos * k_corr + pick[e];
   }
-  DevBuf<int> d_samp, d_ref, d_rows, d_nn;
-  DevBuf<float> d_nd, d_T(c, (size_t)H * 16), d_err(c, H);
-  upload(c, d_samp, samp);
-  upload(c, d_ref, corr_ref);
-  upload(c, d_rows, rows);
-  desc_knn_rows(c, sd, d_rows.get(), (int)rows.size(), td, k_corr, d_nn, d_nd);
-  sacia_models(c, skp_, tkp_, d_samp.get(), d_ref.get(), d_nn.get(), H, d_T.get());
+  // one pinned upload for the three index lists
+  const size_t n3 = (size_t)H * 3, nr = rows.size();
+  int *hp = (int *)c->pin((2 * n3 + nr) * sizeof(int));
+  std::memcpy(hp, samp.data(), n3 * sizeof(int));
+  std::memcpy(hp + n3, corr_ref.data(), n3 * sizeof(int));
+  std::memcpy(hp + 2 * n3, rows.data(), nr * sizeof(int));
+  DevBuf<int> d_idx(c, 2 * n3 + nr), d_nn;
+  MM3D_HIP(hipMemcpyAsync(d_idx.get(), hp, (2 * n3 + nr) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  const int *d_samp = d_idx.get(), *d_ref = d_idx.get() + n3, *d_rows = d_idx.get() + 2 * n3;
+  DevBuf<float> d_nd, d_T(c, (size_t)H * 16), d_err(c, H), d_best(c, 16);
+  desc_knn_rows(c, sd, d_rows, (int)nr, td, k_corr, d_nn, d_nd);
+  sacia_models(c, skp_, tkp_, d_samp, d_ref, d_nn.get(), H, d_T.get());
   sacia_errors(c, skp_, tkp_, d_T.get(), H, corr_thresh, d_err.get());
-  std::vector<float> err;
-  download(c, d_err.get(), err, (size_t)H);
-  int best = 0;
-  float lowest = err[0];
-  for (int i = 1; i < H; ++i)
-    if (err[i] < lowest) { lowest = err[i]; best = i; }
-  MM3D_HIP(hipMemcpyAsync(T, d_T.get() + (size_t)best * 16, sizeof(float) * 16, hipMemcpyDeviceToHost, c->stream));
+  // "if (i_iter == 0 || error < lowest_error)": the first minimum, picked on the device
+  sacia_pick(c, d_err.get(), H, d_T.get(), d_best.get());
+  if (T_dev) {
+    *T_dev = std::move(d_best);      // the caller keeps going on the device (ICP reads it there)
+    return true;
+  }
+  float *hT = (float *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(hT, d_best.get(), sizeof(float) * 16, hipMemcpyDeviceToHost, c->stream));
   c->sync();
+  std::memcpy(T, hT, sizeof(float) * 16);
+  return false;
 }
 
 // ---------------------------------------------------------------- estimateTransform
 // R/src/matching.cpp:223-257
-int estimate_transform(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tp,
-                       const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine, double inlier_threshold,
-                       double max_corr_dist, int max_iterations, size_t matching_k, double eps, float T[16], bool execute)
+int estimate_pair(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tp,
+                  const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine, double inlier_threshold,
+                  double max_corr_dist, int max_iterations, size_t matching_k, double eps, float T[16], bool execute,
+                  bool want_score, double score_max_distance, double *score)
 {
   float T0[16];
   std::memset(T0, 0, sizeof(T0));
-  int icp_iters = 0;
+  DevBuf<float> dT0;
+  bool on_device = false;
   if (method == MM3D_EST_MATCHING) {
     if (execute) {
       std::vector<mm3d_corr> corr, inl;
@@ -326,20 +337,25 @@ int estimate_transform(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, 
     }
   } else if (method == MM3D_EST_SAC_IA) {
     // argument mapping of matching.cpp:243-246: min_sample_distance := inlier_threshold
-    sac_ia(c, skp, sd, tkp, td, inlier_threshold, max_corr_dist, max_iterations, T0, execute);
+    on_device = sac_ia(c, skp, sd, tkp, td, inlier_threshold, max_corr_dist, max_iterations, T0, execute, &dT0);
   } else {
     throw Error(MM3D_EINVAL, "unknown estimation method");
   }
   if (!execute) { std::memset(T, 0, sizeof(float) * 16); return 0; }
-  if (refine) {
-    // no guard in the reference: ICP also runs from a zero matrix (and returns zero)
-    IcpResult r = icp(c, sp, tp, T0, max_corr_dist, max_iterations, eps);
-    std::memcpy(T, r.T, sizeof(r.T));
-    icp_iters = r.iterations;
-  } else {
-    std::memcpy(T, T0, sizeof(T0));
-  }
-  return icp_iters;
+  // no guard in the reference: ICP also runs from a zero matrix (and returns zero)
+  const PairTail r = icp_score(c, sp, tp, on_device ? dT0.get() : nullptr, T0, refine != 0, max_corr_dist, max_iterations, eps,
+                               want_score, score_max_distance);
+  std::memcpy(T, r.T, sizeof(r.T));
+  if (score) *score = r.score;
+  return r.iterations;
+}
+
+int estimate_transform(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tp,
+                       const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine, double inlier_threshold,
+                       double max_corr_dist, int max_iterations, size_t matching_k, double eps, float T[16], bool execute)
+{
+  return estimate_pair(c, sp, skp, sd, tp, tkp, td, method, refine, inlier_threshold, max_corr_dist, max_iterations, matching_k,
+                       eps, T, execute, false, 0.0, nullptr);
 }
 
 // ---------------------------------------------------------------- pose graph (host only)

@@ -21,6 +21,7 @@
 // icp_finalize (Umeyama by 3x3 Jacobi SVD, accumulate, PCL's convergence tests, all on the device).
 // Algorithmic traffic: 12 B per source point per iteration.
 #include <cfloat>
+#include <cstddef>
 
 #include "device_util.hpp"
 #include "linalg_shared.hpp"
@@ -356,50 +357,90 @@ static float nn_cell_for(double radius)
   return cell;
 }
 
-IcpResult icp(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float guess[16],
-              double max_corr_dist, int max_iterations, double eps)
+// ICP from `guess` and, if wanted, transformScore of the result -- the tail of every pair estimate --
+// with ONE host synchronisation: the guess may already live on the device (SAC-IA's winning
+// hypothesis), the score kernel reads the transform straight out of the ICP state, and state + score
+// come back in one copy.  The score is launched speculatively after each chunk of iterations; it is
+// only kept when ICP has finished (it nearly always has: the reference's epsilon is loose).
+PairTail icp_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float *guess_dev, const float guess_host[16],
+                   bool run_icp, double max_corr_dist, int max_iterations, double eps, bool want_score, double score_max_distance)
 {
-  IcpResult res;
-  memcpy(res.T, guess, sizeof(res.T));   // Identity * guess when nothing runs
+  static_assert(offsetof(IcpState, T) == 0, "the score kernel reads T at the head of the state");
+  PairTail res;
   res.iterations = 0;
   res.converged = 0;
+  res.score = DBL_MAX;
   c->last_icp_iterations = 0;
   c->last_icp_converged = 0;
-  if (src->n == 0 || tgt->n == 0) return res;
-  const Grid &tg = cloud_grid(c, tgt, nn_cell_for(max_corr_dist));
   int ns = 0;
-  const float4 *sp = morton_source(c, src, ns);
-  if (ns == 0 || tg.n == 0) return res;
+  const float4 *sp = (src->n && tgt->n) ? morton_source(c, src, ns) : nullptr;
+  const Grid *tg = (ns && run_icp) ? &cloud_grid(c, tgt, nn_cell_for(max_corr_dist)) : nullptr;
+  const double score_radius = std::sqrt(score_max_distance > 0 ? score_max_distance : 0.0);
+  const Grid *sg = (ns && want_score) ? &cloud_grid(c, tgt, nn_cell_for(score_radius)) : nullptr;
+  if (ns == 0 || (tg && tg->n == 0) || (sg && sg->n == 0) || (!tg && !sg)) {
+    // nothing to search: Identity * guess, and the score of an empty search
+    if (guess_dev) {
+      float *hT = (float *)c->pin(256);
+      MM3D_HIP(hipMemcpyAsync(hT, guess_dev, 64, hipMemcpyDeviceToHost, c->stream));
+      c->sync();
+      memcpy(res.T, hT, sizeof(res.T));
+    } else {
+      memcpy(res.T, guess_host, sizeof(res.T));
+    }
+    return res;
+  }
+  // ICP search parameters
   const double max_dist_sqr = max_corr_dist * max_corr_dist;
   // (double)d2 > max_dist_sqr rejects: accept d2 <= largest float not above max_dist_sqr
   float max_d2 = (float)max_dist_sqr;
   if ((double)max_d2 > max_dist_sqr) max_d2 = std::nextafterf(max_d2, -INFINITY);
   const float rmax = (float)(max_corr_dist * 1.0001 + 1e-5);
-  const int max_ring = (int)std::ceil(rmax / tg.cell) + 1;
-  grid_ensure_dt(c, tg, max_ring);
+  const int max_ring = tg ? (int)std::ceil(rmax / tg->cell) + 1 : 0;
+  if (tg) grid_ensure_dt(c, *tg, max_ring);
+  // score search parameters: max_range_ is compared with the SQUARED distance (PCL quirk), so the
+  // search radius is sqrt(max_distance)
+  float s_max_d2 = (float)score_max_distance;
+  if ((double)s_max_d2 > score_max_distance) s_max_d2 = std::nextafterf(s_max_d2, -INFINITY);
+  const float s_rmax = (float)(score_radius * 1.0001 + 1e-5);
+  const int s_ring = sg ? (int)std::ceil(s_rmax / sg->cell) + 1 : 0;
+  if (sg) grid_ensure_dt(c, *sg, s_ring);
 
+  char *pinned = (char *)c->pin(1024);
+  IcpState *hp = (IcpState *)pinned;
+  double *ho = (double *)(pinned + 512);
   IcpState h;
   memset(&h, 0, sizeof(h));
-  memcpy(h.T, guess, sizeof(h.T));
+  if (!guess_dev) memcpy(h.T, guess_host, sizeof(h.T));
   h.prev_mse = DBL_MAX;
   h.rot_thresh = 1.0 - eps;
   h.trans_thresh = eps;
   h.max_iter = max_iterations;
-  IcpState *hp = (IcpState *)c->pin(sizeof(IcpState));
+  h.done = run_icp ? 0 : 1;
   *hp = h;
   DevBuf<IcpState> st(c, 1);
   MM3D_HIP(hipMemcpyAsync(st.get(), hp, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
+  if (guess_dev) MM3D_HIP(hipMemcpyAsync(st.get(), guess_dev, 64, hipMemcpyDeviceToDevice, c->stream));
   const int n_items = src->n_wave_items;
   const unsigned nblocks = div_up(n_items, 4);
-  DevBuf<double> partials(c, (size_t)nblocks * kAcc);
-  const GridView gv = tg.view();
+  DevBuf<double> partials(c, (size_t)nblocks * kAcc), s_partials(c, want_score ? (size_t)nblocks * kAcc : 1);
+  DevBuf<double> out(c, 2);
   const int chunk = 4;
   for (;;) {
-    for (int k = 0; k < chunk; ++k) {
-      MM3D_LAUNCH(c, "icp_corr_reduce", ns * 12.0, k_nn_wave<0>, dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items, gv, (const float4 *)tgt->pts.get(),
-                  (const IcpState *)st.get(), (const float *)nullptr, max_d2, rmax, max_ring, partials.get());
-      MM3D_LAUNCH(c, "icp_finalize", nblocks * kAcc * 8.0, k_icp_finalize, dim3(1), dim3(256), 0, (const double *)partials.get(),
-                  (int)nblocks, st.get());
+    if (run_icp) {
+      const GridView gv = tg->view();
+      for (int k = 0; k < chunk; ++k) {
+        MM3D_LAUNCH(c, "icp_corr_reduce", ns * 12.0, k_nn_wave<0>, dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items, gv,
+                    (const float4 *)tgt->pts.get(), (const IcpState *)st.get(), (const float *)nullptr, max_d2, rmax, max_ring, partials.get());
+        MM3D_LAUNCH(c, "icp_finalize", nblocks * kAcc * 8.0, k_icp_finalize, dim3(1), dim3(256), 0, (const double *)partials.get(),
+                    (int)nblocks, st.get());
+      }
+    }
+    if (want_score) {
+      MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + sg->n * 12.0, k_nn_wave<1>, dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items,
+                  sg->view(), (const float4 *)tgt->pts.get(), (const IcpState *)nullptr, (const float *)st.get(), s_max_d2, s_rmax, s_ring,
+                  s_partials.get());
+      MM3D_LAUNCH(c, "score_finalize", 0, k_score_finalize, dim3(1), dim3(256), 0, (const double *)s_partials.get(), (int)nblocks, out.get());
+      MM3D_HIP(hipMemcpyAsync(ho, out.get(), 16, hipMemcpyDeviceToHost, c->stream));
     }
     MM3D_HIP(hipMemcpyAsync(hp, st.get(), sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
     c->sync();
@@ -408,8 +449,20 @@ IcpResult icp(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const fl
   memcpy(res.T, hp->T, sizeof(res.T));
   res.iterations = hp->iters;
   res.converged = hp->converged;
+  if (want_score) res.score = ho[1] > 0.0 ? ho[0] / ho[1] : DBL_MAX;
   c->last_icp_iterations = res.iterations;
   c->last_icp_converged = res.converged;
+  return res;
+}
+
+IcpResult icp(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float guess[16],
+              double max_corr_dist, int max_iterations, double eps)
+{
+  const PairTail t = icp_score(c, src, tgt, nullptr, guess, true, max_corr_dist, max_iterations, eps, false, 0.0);
+  IcpResult res;
+  memcpy(res.T, t.T, sizeof(res.T));
+  res.iterations = t.iterations;
+  res.converged = t.converged;
   return res;
 }
 

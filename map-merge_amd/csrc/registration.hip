@@ -147,12 +147,20 @@ __global__ void __launch_bounds__(256) k_seq_sum(const float *__restrict__ E, in
   const int rows = min(kSumRows, H - h0);
   const int ntiles = (ns + kSumTile - 1) / kSumTile;
   auto stage = [&](int t, int b) {
-    // kSumRows x kSumTile floats = 2048 float4, 8 per thread
-    for (int e = threadIdx.x; e < kSumRows * (kSumTile / 4); e += blockDim.x) {
+    // kSumRows x kSumTile floats = 2048 float4, staged by waves 1..3 only (after the first tile): wave 0
+    // carries the add chains and must not sit on a global-memory wait between tiles
+    const int first = t == 0 ? 0 : kWave;
+    for (int e = (int)threadIdx.x - first; e >= 0 && e < kSumRows * (kSumTile / 4); e += (int)blockDim.x - first) {
       const int r = e / (kSumTile / 4), c4 = e % (kSumTile / 4);
       const int i = t * kSumTile + c4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < rows && i < ns_pad) v = *reinterpret_cast<const float4 *>(E + (size_t)(h0 + r) * ns_pad + i);
+      // everything past the row's end becomes +0: e + 0 == e, so the chain below can run in whole
+      // groups of 16 without a tail
+      if (i + 1 >= ns) v.y = 0.f;
+      if (i + 2 >= ns) v.z = 0.f;
+      if (i + 3 >= ns) v.w = 0.f;
+      if (i >= ns) v.x = 0.f;
       *reinterpret_cast<float4 *>(&buf[b][r][c4 * 4]) = v;
     }
   };
@@ -163,13 +171,19 @@ __global__ void __launch_bounds__(256) k_seq_sum(const float *__restrict__ E, in
     if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
     if ((int)threadIdx.x < rows) {
       const int cnt = min(kSumTile, ns - t * kSumTile);
-      const float *row = buf[t & 1][threadIdx.x];
-      int i = 0;
-      for (; i + 4 <= cnt; i += 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(row + i);
-        e += v.x; e += v.y; e += v.z; e += v.w;
+      const float4 *row = reinterpret_cast<const float4 *>(buf[t & 1][threadIdx.x]);
+      const int groups = (cnt + 15) >> 4;
+      // the add chain is the critical path (one dependent v_add_f32 after another): keep the next 16
+      // values in registers so it never waits for LDS
+      float4 n0 = row[0], n1 = row[1], n2 = row[2], n3 = row[3];
+      for (int gi = 0; gi < groups; ++gi) {
+        const float4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
+        if (gi + 1 < groups) { n0 = row[gi * 4 + 4]; n1 = row[gi * 4 + 5]; n2 = row[gi * 4 + 6]; n3 = row[gi * 4 + 7]; }
+        e += v0.x; e += v0.y; e += v0.z; e += v0.w;
+        e += v1.x; e += v1.y; e += v1.z; e += v1.w;
+        e += v2.x; e += v2.y; e += v2.z; e += v2.w;
+        e += v3.x; e += v3.y; e += v3.z; e += v3.w;
       }
-      for (; i < cnt; ++i) e += row[i];
     }
     __syncthreads();
   }
@@ -193,7 +207,38 @@ void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp
               ns_pad, g.view(), T_all, H, corr_thresh, radius, E.get());
   MM3D_LAUNCH(c, "sacia_seq_sum", total * 4.0, k_seq_sum, dim3(div_up(H, kSumRows)), dim3(256), 0, (const float *)E.get(), ns,
               ns_pad, H, errors);
-  c->sync();
+}
+
+// "if (i == 0 || error < lowest_error) keep": the first minimum, by one wave.  A NaN never wins a
+// '<', and a NaN at i == 0 is never beaten.
+__global__ void __launch_bounds__(64) k_sacia_pick(const float *__restrict__ err, int H, const float *__restrict__ T_all,
+                                                   float *__restrict__ T_best)
+{
+  const int lane = threadIdx.x;
+  const float e0 = err[0];
+  unsigned long long best = ~0ull;
+  if (e0 == e0) {
+    for (int i = lane; i < H; i += kWave) {
+      const float e = err[i];
+      if (e == e) {
+        // e >= 0 (sums of non-negative terms) or -0: order the bits as values, ties to the lower index
+        const unsigned long long key = ((unsigned long long)f2ord(e) << 32) | (unsigned)i;
+        best = key < best ? key : best;
+      }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const unsigned long long other = __shfl_xor(best, s, kWave);
+      best = other < best ? other : best;
+    }
+  }
+  const int h = (e0 == e0) ? (int)(unsigned)(best & 0xffffffffull) : 0;
+  if (lane < 16) T_best[lane] = T_all[(size_t)h * 16 + lane];
+}
+
+void sacia_pick(Context *c, const float *errors, int H, const float *T_all, float *T_best)
+{
+  MM3D_LAUNCH(c, "sacia_pick", H * 4.0 + 128.0, k_sacia_pick, dim3(1), dim3(64), 0, errors, H, T_all, T_best);
 }
 
 }  // namespace mm3d

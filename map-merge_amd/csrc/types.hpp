@@ -128,6 +128,12 @@ void desc_knn_rows(Context *c, const mm3d_desc *A, const int *rows_dev, int n_ro
 
 // registration.hip
 struct IcpResult { float T[16]; int iterations; int converged; };
+struct PairTail { float T[16]; int iterations; int converged; double score; };
+// ICP (optional) from a guess on the device (guess_dev != null) or on the host, then transformScore
+// (optional) of the result, with one host synchronisation
+PairTail icp_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float *guess_dev, const float guess_host[16],
+                   bool run_icp, double max_corr_dist, int max_iterations, double eps, bool want_score,
+                   double score_max_distance);
 IcpResult icp(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float guess[16],
               double max_corr_dist, int max_iterations, double eps);
 double transform_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float T[16],
@@ -140,14 +146,24 @@ void sacia_models(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp
                   const int *corr_ref /* H*3 dev: index into nn */, const int *nn /* dev k-NN table */, int H,
                   float *T_all /* H*16 dev */);
 void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const float *T_all /* H*16 dev */,
-                  int H, float corr_thresh, float *errors /* device H */);
+                  int H, float corr_thresh, float *errors /* device H */);   // asynchronous
+// first minimum of errors[0..H) -> its model copied to T_best (16 floats, device)
+void sacia_pick(Context *c, const float *errors /* dev */, int H, const float *T_all /* dev */, float *T_best /* dev */);
 
 // host_pipeline.cpp
 size_t find_correspondences(Context *c, const mm3d_desc *s, const mm3d_desc *t, size_t k, std::vector<mm3d_corr> &out);
 size_t ransac_transform(Context *c, const mm3d_cloud *skp, const mm3d_cloud *tkp, const mm3d_corr *corr,
                         size_t n_corr, double inlier_threshold, float T[16], std::vector<mm3d_corr> &inliers);
-void sac_ia(Context *c, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tkp, const mm3d_desc *td,
-            double min_sample_distance, double max_corr_dist, int max_iterations, float T[16], bool execute);
+// T_dev == nullptr: the winning transform is returned in T (host).  Otherwise, when the device path
+// ran, *T_dev receives it (16 floats on the device), T is left at identity and true is returned.
+bool sac_ia(Context *c, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tkp, const mm3d_desc *td,
+            double min_sample_distance, double max_corr_dist, int max_iterations, float T[16], bool execute,
+            DevBuf<float> *T_dev = nullptr);
+// estimateTransform + (optionally) transformScore of the result; returns the ICP iteration count
+int estimate_pair(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tp,
+                  const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine, double inlier_threshold,
+                  double max_corr_dist, int max_iterations, size_t matching_k, double eps, float T[16], bool execute,
+                  bool want_score, double score_max_distance, double *score);
 int estimate_transform(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd,
                        const mm3d_cloud *tp, const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine,
                        double inlier_threshold, double max_corr_dist, int max_iterations, size_t matching_k,
