@@ -140,10 +140,15 @@ k_sacia_err(const float4 *__restrict__ skp, int ns, int ns_pad, GridView g, cons
 // 16-byte loads (double buffered), the first kSumRows lanes walk their row out of LDS sequentially.
 constexpr int kSumRows = 8;
 constexpr int kSumTile = 1024;
+constexpr int kSumPad = 36;
 __global__ void __launch_bounds__(256) k_seq_sum(const float *__restrict__ E, int ns, int ns_pad, int H, float *__restrict__ err)
 {
-  __shared__ __attribute__((aligned(16))) float buf[2][kSumRows][kSumTile + 4];
+  // row stride = tile + 36 floats: lane r's 16-byte reads land on banks 36 r mod 64 (all distinct), and
+  // the zeroed tail lets the chain prefetch two groups past the end without a branch
+  __shared__ __attribute__((aligned(16))) float buf[2][kSumRows][kSumTile + kSumPad];
   const int h0 = blockIdx.x * kSumRows;
+  for (int e = threadIdx.x; e < 2 * kSumRows * kSumPad; e += blockDim.x)
+    buf[e / (kSumRows * kSumPad)][(e / kSumPad) % kSumRows][kSumTile + e % kSumPad] = 0.0f;
   const int rows = min(kSumRows, H - h0);
   const int ntiles = (ns + kSumTile - 1) / kSumTile;
   auto stage = [&](int t, int b) {
@@ -173,16 +178,25 @@ __global__ void __launch_bounds__(256) k_seq_sum(const float *__restrict__ E, in
       const int cnt = min(kSumTile, ns - t * kSumTile);
       const float4 *row = reinterpret_cast<const float4 *>(buf[t & 1][threadIdx.x]);
       const int groups = (cnt + 15) >> 4;
-      // the add chain is the critical path (one dependent v_add_f32 after another): keep the next 16
-      // values in registers so it never waits for LDS
-      float4 n0 = row[0], n1 = row[1], n2 = row[2], n3 = row[3];
-      for (int gi = 0; gi < groups; ++gi) {
-        const float4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
-        if (gi + 1 < groups) { n0 = row[gi * 4 + 4]; n1 = row[gi * 4 + 5]; n2 = row[gi * 4 + 6]; n3 = row[gi * 4 + 7]; }
-        e += v0.x; e += v0.y; e += v0.z; e += v0.w;
-        e += v1.x; e += v1.y; e += v1.z; e += v1.w;
-        e += v2.x; e += v2.y; e += v2.z; e += v2.w;
-        e += v3.x; e += v3.y; e += v3.z; e += v3.w;
+      // The add chain is the critical path (one dependent v_add_f32 after another).  Two register
+      // sets of 16 values leapfrog: while one is being added the other is in flight from LDS.  Groups
+      // past the end are zeros (+0 leaves the sum unchanged).
+      float4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+      float4 b0 = row[4], b1 = row[5], b2 = row[6], b3 = row[7];
+#pragma unroll 1
+      for (int gi = 0; gi < groups; gi += 2) {
+        e += a0.x; e += a0.y; e += a0.z; e += a0.w;
+        e += a1.x; e += a1.y; e += a1.z; e += a1.w;
+        e += a2.x; e += a2.y; e += a2.z; e += a2.w;
+        e += a3.x; e += a3.y; e += a3.z; e += a3.w;
+        a0 = row[gi * 4 + 8]; a1 = row[gi * 4 + 9]; a2 = row[gi * 4 + 10]; a3 = row[gi * 4 + 11];
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch HERE: the scheduler otherwise sinks it to its first use
+        e += b0.x; e += b0.y; e += b0.z; e += b0.w;
+        e += b1.x; e += b1.y; e += b1.z; e += b1.w;
+        e += b2.x; e += b2.y; e += b2.z; e += b2.w;
+        e += b3.x; e += b3.y; e += b3.z; e += b3.w;
+        b0 = row[gi * 4 + 12]; b1 = row[gi * 4 + 13]; b2 = row[gi * 4 + 14]; b3 = row[gi * 4 + 15];
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
