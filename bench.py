@@ -26,6 +26,8 @@ import json
 import os
 import sys
 import time
+import zlib
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -57,12 +59,13 @@ def make_workload(n_maps, n_points, cache=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--maps", type=int, default=16)
     ap.add_argument("--points", type=int, default=500000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache", action="store_true")
+    ap.add_argument("--streams", type=int, default=6, help="contexts (HIP stream + host thread) per GPU")
     ap.add_argument("--kernel-table", default=None, help="write rank 0's full per-kernel HIP-event table (CSV) here")
     args = ap.parse_args()
 
@@ -127,32 +130,64 @@ def main():
 
     stats = {}
 
+    # Within a rank the same round-robin is applied once more over S contexts (one HIP stream, one
+    # host thread each): a pair is a chain of dependent launches with a few host round trips, so one
+    # stream leaves SIMDs idle that another stream's kernels can use.  Every context replays the
+    # whole rand() stream, exactly like the ranks do.
+    S = max(1, args.streams)
+    ctxs = [ctx] + [mm.Context(local_rank) for _ in range(S - 1)]
+    tpool = ThreadPoolExecutor(S) if S > 1 else None
+
+    def run_streams(fn):
+        if tpool is None:
+            fn(0)
+        else:
+            list(tpool.map(fn, range(S)))                  # re-raises a worker's exception
+
     def step():
-        ctx.srand(1)                                       # the reference's process starts at glibc seed 1
         t0 = time.perf_counter()
-        maps = []
-        for i in range(n_maps):
-            owner = i % world
-            m = None
-            if owner == rank:
-                raw = ctx.cloud_from_ptr(dev_raw[i].data_ptr(), len(host[i]))
-                m = ctx.mapFeatures(raw, params)
+        maps = [None] * n_maps
+        my_maps = [i for i in range(n_maps) if sharding.map_owner(i, world) == rank]
+
+        def features(s):
+            c = ctxs[s]
+            for k, i in enumerate(my_maps):
+                if k % S != s:
+                    continue
+                raw = c.cloud_from_ptr(dev_raw[i].data_ptr(), len(host[i]))
+                m = c.mapFeatures(raw, params)
                 raw.free()
-            maps.append(m)
-        ctx.synchronize()
+                c.mapPrepare(m, params)                    # from here on pair estimates only read the map
+                maps[i] = m
+            c.synchronize()
+
+        run_streams(features)
         t1 = time.perf_counter()
         for i in range(n_maps):
-            maps[i] = bcast_map(sharding.map_owner(i, world), maps[i])
+            owner = sharding.map_owner(i, world)
+            maps[i] = bcast_map(owner, maps[i])
+            if owner != rank:
+                ctx.mapPrepare(maps[i], params)
         kn = [len(m.keypoints) for m in maps]
         live = sharding.live_pairs(n_maps, kn)
         t2 = time.perf_counter()
         mine = np.zeros(len(live), dtype=mm.PAIR)
-        for p, (i, j) in enumerate(live):
-            # non-owners only replay the pair's rand() draws (mm3d_pair_estimate, execute = 0)
-            r = ctx.pairEstimate(maps[i], maps[j], params, execute=(sharding.pair_owner(p, world) == rank))
-            r["source_idx"], r["target_idx"] = i, j
-            mine[p] = r
-        ctx.synchronize()
+
+        def pairs(s):
+            c = ctxs[s]
+            c.srand(1)                                     # the reference's process starts at glibc seed 1
+            for p, (i, j) in enumerate(live):
+                # non-owners only replay the pair's rand() draws (mm3d_pair_estimate, execute = 0)
+                own = sharding.pair_owner(p, world) == rank and (p // world) % S == s
+                r = c.pairEstimate(maps[i], maps[j], params, execute=own)
+                if own:
+                    r["source_idx"], r["target_idx"] = i, j
+                    mine[p] = r
+            c.synchronize()
+
+        run_streams(pairs)
+        mine["source_idx"] = [i for i, _ in live]
+        mine["target_idx"] = [j for _, j in live]
         t3 = time.perf_counter()
         # C1: all-gather of the fixed-size pair records over RCCL
         mine = sharding.gather_pair_records(mine, world, rank, dist if world > 1 else None, dev)
@@ -161,7 +196,8 @@ def main():
         stats.update(dict(n_pairs=len(live), t_features=t1 - t0, t_exchange=t2 - t1, t_pairs=t3 - t2, t_gather_graph=t4 - t3,
                           pts_filtered=[len(m.points) for m in maps], keypoints=kn,
                           icp_iters=[int(x) for x in mine["icp_iterations"]],
-                          n_estimated=int(sum(1 for t in T if np.any(t)))))
+                          n_estimated=int(sum(1 for t in T if np.any(t))),
+                          crc=zlib.crc32(np.ascontiguousarray(mine["transform"]).tobytes()) & 0xffffffff))
         for m in maps:
             m.free()
         return T
@@ -170,25 +206,33 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    ctx.profile_reset()
-    ctx.profile(True)
+    for c in ctxs:
+        c.profile_reset()
+        c.profile(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    ctx.profile(False)
+    for c in ctxs:
+        c.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    prof = ctx.profile_entries()
+    prof = {}
+    for c in ctxs:                                         # per-kernel HIP-event times, summed over the rank's streams
+        for k, v in c.profile_entries().items():
+            e = prof.setdefault(k, {"ms": 0.0, "launches": 0, "bytes": 0.0})
+            for f in ("ms", "launches", "bytes"):
+                e[f] += v[f]
 
     if rank == 0:
         n_pairs = stats["n_pairs"]
@@ -230,7 +274,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n_maps} maps x {n_pts} raw pts, FPFH + SAC_IA + ICP refine, {n_pairs} pairs",
-                       "parallelism": f"maps and pairs round-robin over {world} GPU(s)",
+                       "parallelism": f"maps and pairs round-robin over {world} GPU(s) x {S} streams",
                        "points_after_filter_mean": int(np.mean(npts_f)), "keypoints_mean": int(np.mean(stats["keypoints"]))},
             "pair_stage_pairs_per_s": round(n_pairs / max(stats["t_pairs"], 1e-9), 3),
             "mpoints_per_s": {
@@ -242,12 +286,16 @@ def main():
             "stage_seconds_last_step": {k: round(stats[k], 4) for k in ("t_features", "t_exchange", "t_pairs", "t_gather_graph")},
             "top_kernels_ms_per_step": {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in top},
             "maps_estimated": stats["n_estimated"],
+            "pair_transforms_crc32": stats["crc"],          # same job, same bits: independent of --gpus / --streams
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, n_maps, n_pairs)
         print(json.dumps(out))
-    ctx.close()
+    if tpool is not None:
+        tpool.shutdown()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -210,6 +210,12 @@ const mm3d_cloud *mm3d_map_keypoints(const mm3d_map *m);
 const mm3d_desc *mm3d_map_descriptors(const mm3d_map *m);
 int mm3d_map_from_parts(mm3d_ctx *ctx, mm3d_cloud *points, mm3d_cloud *keypoints, mm3d_desc *desc,
                         mm3d_map **out);            /* takes ownership (feature exchange between ranks) */
+/* Builds every search structure that pair estimates with `params` read from this map (point and
+ * keypoint grids with their distance transforms, the Hilbert-ordered query copy, the host copy of
+ * the keypoints).  Optional -- they are otherwise built lazily by the first pair that needs them --
+ * but after it mm3d_pair_estimate only READS the map, so one map may serve pairs running on
+ * several contexts (streams) at once.  Call it on the context that created the map. */
+int mm3d_map_prepare(mm3d_ctx *ctx, mm3d_map *m, const mm3d_params *params);
 void mm3d_map_free(mm3d_ctx *ctx, mm3d_map *m);
 /* the per-pair loop body of map_merging.cpp:256-269.  execute == 0 only advances the context's
  * rand() replay exactly as the pair would (ranks that do not own the pair stay in lock-step with

@@ -332,6 +332,11 @@ class Context:
             o._owned = False                             # the map owns them now
         return Map(self, h)
 
+    def mapPrepare(self, m: "Map", params: MapMergingParams) -> None:
+        """mm3d_map_prepare: build the map's search structures now, so that pair estimates only read it
+        (and may then run on several contexts at once)."""
+        self._ck(lib().mm3d_map_prepare(self._h, m._h, C.byref(params)))
+
     def pairEstimate(self, source: "Map", target: "Map", params: MapMergingParams, execute: bool = True):
         r = np.zeros(1, dtype=PAIR)
         self._ck(lib().mm3d_pair_estimate(self._h, source._h, target._h, C.byref(params), int(execute),

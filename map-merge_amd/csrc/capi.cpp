@@ -471,6 +471,17 @@ int mm3d_map_from_parts(mm3d_ctx *ctx, mm3d_cloud *points, mm3d_cloud *keypoints
   return MM3D_OK;
 }
 
+int mm3d_map_prepare(mm3d_ctx *ctx, mm3d_map *m, const mm3d_params *p)
+{
+  if (!m || !p) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    prepare_pair_search(ctx, m->points, p->max_correspondence_distance, p->max_correspondence_distance);
+    if (p->estimation_method == MM3D_EST_SAC_IA) prepare_sacia_target(ctx, m->keypoints, (float)p->max_correspondence_distance);
+    (void)cloud_host(ctx, m->keypoints);
+    ctx->sync();
+  });
+}
+
 void mm3d_map_free(mm3d_ctx *ctx, mm3d_map *m)
 {
   if (!ctx || !m) return;

@@ -506,4 +506,20 @@ extern "C" void mm3d_debug_nn_stats(unsigned long long *out, int reset)
 }
 #endif
 
+// Everything icp_score() would build lazily on its first use of these clouds: afterwards pair
+// estimates only READ the clouds' caches, so one map can serve pairs on several contexts at once.
+void prepare_pair_search(Context *c, const mm3d_cloud *points, double max_corr_dist, double score_max_distance)
+{
+  if (points->n == 0) return;
+  int ns = 0;
+  (void)morton_source(c, points, ns);
+  const double radii[2] = {max_corr_dist, std::sqrt(score_max_distance > 0 ? score_max_distance : 0.0)};
+  for (double radius : radii) {
+    const Grid &g = cloud_grid(c, points, nn_cell_for(radius));
+    if (g.n == 0) continue;
+    const float rmax = (float)(radius * 1.0001 + 1e-5);
+    grid_ensure_dt(c, g, (int)std::ceil(rmax / g.cell) + 1);
+  }
+}
+
 }  // namespace mm3d

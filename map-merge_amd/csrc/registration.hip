@@ -204,17 +204,30 @@ __global__ void __launch_bounds__(256) k_seq_sum(const float *__restrict__ E, in
   if ((int)threadIdx.x < rows) err[h0 + threadIdx.x] = e;
 }
 
+// the target-side search structure of SAC-IA scoring (cached on the keypoint cloud)
+static const Grid &sacia_target_grid(Context *c, const mm3d_cloud *tgt_kp, float corr_thresh)
+{
+  const float radius = std::sqrt(corr_thresh > 0.f ? corr_thresh : 0.f);
+  // cell a hair larger than the search radius: anything two cells away is strictly out of range,
+  // which is what makes the distance-transform test in k_sacia_err exact
+  const float cell = radius * 1.001f > 0.25f ? radius * 1.001f : 0.25f;
+  const Grid &g = cloud_grid(c, tgt_kp, cell);
+  grid_ensure_dt(c, g, 1);
+  return g;
+}
+
+void prepare_sacia_target(Context *c, const mm3d_cloud *kp, float corr_thresh)
+{
+  if (kp->n) (void)sacia_target_grid(c, kp, corr_thresh);
+}
+
 void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const float *T_all, int H,
                   float corr_thresh, float *errors)
 {
   const int ns = (int)src_kp->n;
   const int ns_pad = (ns + 3) & ~3;
-  float radius = std::sqrt(corr_thresh > 0.f ? corr_thresh : 0.f);
-  // cell a hair larger than the search radius: anything two cells away is strictly out of range,
-  // which is what makes the distance-transform test in k_sacia_err exact
-  float cell = radius * 1.001f > 0.25f ? radius * 1.001f : 0.25f;
-  const Grid &g = cloud_grid(c, tgt_kp, cell);
-  grid_ensure_dt(c, g, 1);
+  const float radius = std::sqrt(corr_thresh > 0.f ? corr_thresh : 0.f);
+  const Grid &g = sacia_target_grid(c, tgt_kp, corr_thresh);
   DevBuf<float> E(c, (size_t)ns_pad * H);
   const size_t total = (size_t)ns * H;
   MM3D_LAUNCH(c, "sacia_err", total * 4.0 + ns * 16.0, k_sacia_err, dim3(div_up(total, 256)), dim3(256), 0, src_kp->pts.get(), ns,

@@ -147,6 +147,9 @@ void sacia_models(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp
                   float *T_all /* H*16 dev */);
 void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const float *T_all /* H*16 dev */,
                   int H, float corr_thresh, float *errors /* device H */);   // asynchronous
+// build (and cache on the clouds) every search structure pair estimates with these parameters read
+void prepare_pair_search(Context *c, const mm3d_cloud *points, double max_corr_dist, double score_max_distance);
+void prepare_sacia_target(Context *c, const mm3d_cloud *kp, float corr_thresh);
 // first minimum of errors[0..H) -> its model copied to T_best (16 floats, device)
 void sacia_pick(Context *c, const float *errors /* dev */, int H, const float *T_all /* dev */, float *T_best /* dev */);
 

@@ -339,3 +339,51 @@ def test_compose_maps(ctx, po, scene):
     ref = po.compose_maps([a["filt"], b["filt"]], T, 0.05)
     got = ctx.composeMaps([ctx.cloud(a["filt"]), ctx.cloud(b["filt"])], T, 0.05).numpy()
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_pairs_on_several_contexts_are_bit_identical(ctx, mm, scene):
+    """bench.py runs several contexts (stream + host thread) per GPU over shared, prepared maps:
+    every pair must come out with the same bits as on one context, whatever the interleaving."""
+    from concurrent.futures import ThreadPoolExecutor
+    params = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
+    raws = [m["raw"] for m in scene] + [scene[0]["raw"][::2].copy()]
+    order = [(0, 1), (0, 2), (1, 2), (1, 0), (2, 0), (2, 1)]
+
+    def features(c, i):
+        m = c.mapFeatures(c.cloud(raws[i]), params)
+        c.mapPrepare(m, params)
+        return m
+
+    # one context, sequential
+    ctx.srand(1)
+    maps = [features(ctx, i) for i in range(3)]
+    ref = [ctx.pairEstimate(maps[i], maps[j], params).copy() for i, j in order]
+    # three contexts: features in parallel, then every context replays all pairs and executes its own
+    S = 3
+    ctxs = [mm.Context(0) for _ in range(S)]
+    try:
+        with ThreadPoolExecutor(S) as tp:
+            maps2 = list(tp.map(lambda s: features(ctxs[s], s), range(S)))
+            got = [None] * len(order)
+
+            def work(s):
+                c = ctxs[s]
+                c.srand(1)
+                for p, (i, j) in enumerate(order):
+                    r = c.pairEstimate(maps2[i], maps2[j], params, execute=(p % S == s))
+                    if p % S == s:
+                        got[p] = r.copy()
+                c.synchronize()
+
+            for _ in range(3):      # a few rounds: different interleavings
+                list(tp.map(work, range(S)))
+                for r, g in zip(ref, got):
+                    assert np.array_equal(r["transform"].view(np.uint32), g["transform"].view(np.uint32))
+                    assert r["confidence"] == g["confidence"] and r["icp_iterations"] == g["icp_iterations"]
+        for m in maps2:
+            m.free()
+    finally:
+        for c in ctxs:
+            c.close()
+    for m in maps:
+        m.free()
