@@ -234,6 +234,31 @@ def main():
             for f in ("ms", "launches", "bytes"):
                 e[f] += v[f]
 
+    # untimed: the same kernels alone on the GPU (one stream, maps 0 and 1 and their pair).  In the
+    # timed region several streams share the CUs, so a kernel's HIP-event duration there includes the
+    # time it spent sharing; the isolated figure is what speaks about the kernel itself.
+    iso = {}
+    if rank == 0:
+        ctx.profile_reset()
+        ctx.profile(True)
+        ctx.srand(1)
+        two = []
+        for i in (0, 1):
+            raw = ctx.cloud_from_ptr(dev_raw[i].data_ptr(), len(host[i]))
+            two.append(ctx.mapFeatures(raw, params))
+            raw.free()
+        ctx.pairEstimate(two[0], two[1], params)
+        ctx.synchronize()
+        ctx.profile(False)
+        iso = ctx.profile_entries()
+        for m in two:
+            m.free()
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01c_traffic.json")) as f:
+            pmc_traffic = json.load(f)["bytes_per_launch"]
+    except Exception:
+        pmc_traffic = {}
+
     if rank == 0:
         n_pairs = stats["n_pairs"]
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
@@ -256,6 +281,19 @@ def main():
                             "unit": "GB/s", "frac": round(rate / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                             "avg_launch_us": round(avg_ms * 1e3, 3), "launches_per_step": k["launches"] / max(args.steps, 1),
                             "algorithmic_bytes_per_launch": round(work_per_launch, 1)}
+            # HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 per
+            # the gfx950 note + WRITE_SIZE); null when that kernel was not in the counted run
+            roofline["traffic"] = pmc_traffic.get(dom[0])
+            roofline["traffic_source"] = "profiles/r01c_pmc_hbm_traffic.csv" if dom[0] in pmc_traffic else None
+            if dom[0] in iso and iso[dom[0]]["launches"]:
+                iso_ms = iso[dom[0]]["ms"] / iso[dom[0]]["launches"]
+                iso_work = iso[dom[0]]["bytes"] / iso[dom[0]]["launches"]
+                peak = MFMA_F32_PEAK_TFLOPS * 1e12 if dom[0] in MFMA_KERNELS else HBM_PEAK_GBS * 1e9
+                roofline["isolated_avg_launch_us"] = round(iso_ms * 1e3, 3)
+                roofline["isolated_frac"] = round(iso_work / (iso_ms * 1e-3) / peak, 6) if iso_ms > 0 else None
+            roofline["note"] = ("timed region runs %d streams per GPU, so avg_launch_us includes time shared with other kernels; "
+                                "neighbourhood kernels (sift_dog, spfh, sacia_err, *_nn_reduce) are f32-VALU-bound on "
+                                "in-radius pair work, not HBM-bound: see DESIGN.md section 6" % S)
         ranked = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])
         top = ranked[:8]
         if args.kernel_table:
