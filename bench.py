@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--points", type=int, default=500000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache", action="store_true")
-    ap.add_argument("--streams", type=int, default=6, help="contexts (HIP stream + host thread) per GPU")
+    ap.add_argument("--streams", type=int, default=16, help="contexts (HIP stream + host thread) per GPU")
     ap.add_argument("--kernel-table", default=None, help="write rank 0's full per-kernel HIP-event table (CSV) here")
     args = ap.parse_args()
 

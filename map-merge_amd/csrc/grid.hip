@@ -438,6 +438,71 @@ void grid_ensure_dt(Context *c, const Grid &g_, int R)
   g.dt_cap = R;
 }
 
+// ---------------------------------------------------------------- merged neighbourhood lists
+// For a search whose radius is fixed and whose queries are many (SAC-IA scores 500 x K_s transformed
+// keypoints against K_t targets), the stencil walk is paid once per CELL instead of once per query:
+// every cell gets the concatenation of the points of its (2R+1)^3 block, in stencil order.  A query
+// then reads one contiguous span; an empty span means "nothing within R cells".
+__global__ void k_nb_count(const int *__restrict__ cell_start, int dx, int dy, int dz, int R, int *__restrict__ counts)
+{
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nc = (size_t)dx * dy * dz;
+  if (c > nc) return;
+  if (c == nc) { counts[c] = 0; return; }
+  const int x = (int)(c % dx), y = (int)((c / dx) % dy), z = (int)(c / ((size_t)dx * dy));
+  const int x0 = max(x - R, 0), x1 = min(x + R, dx - 1);
+  int total = 0;
+  for (int zz = max(z - R, 0); zz <= min(z + R, dz - 1); ++zz)
+    for (int yy = max(y - R, 0); yy <= min(y + R, dy - 1); ++yy) {
+      const int row = (zz * dy + yy) * dx;
+      total += cell_start[row + x1 + 1] - cell_start[row + x0];
+    }
+  counts[c] = total;
+}
+
+__global__ void k_nb_fill(const int *__restrict__ cell_start, const float4 *__restrict__ sorted, int dx, int dy, int dz, int R,
+                          const int *__restrict__ nb_start, float4 *__restrict__ nb_pts)
+{
+  // one wave per cell: lanes stride over each row span
+  const size_t c = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t nc = (size_t)dx * dy * dz;
+  if (c >= nc) return;
+  const int lane = threadIdx.x & 63;
+  int out = nb_start[c];
+  if (nb_start[c + 1] == out) return;
+  const int x = (int)(c % dx), y = (int)((c / dx) % dy), z = (int)(c / ((size_t)dx * dy));
+  const int x0 = max(x - R, 0), x1 = min(x + R, dx - 1);
+  for (int zz = max(z - R, 0); zz <= min(z + R, dz - 1); ++zz)
+    for (int yy = max(y - R, 0); yy <= min(y + R, dy - 1); ++yy) {
+      const int row = (zz * dy + yy) * dx;
+      const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
+      for (int j = b + lane; j < e; j += 64) nb_pts[out + (j - b)] = sorted[j];
+      out += e - b;
+    }
+}
+
+void grid_ensure_nblists(Context *c, const Grid &g_, int R)
+{
+  Grid &g = const_cast<Grid &>(g_);
+  if (g.nb_start.get() && g.nb_R == R) return;
+  const size_t nc = (size_t)g.dims[0] * g.dims[1] * g.dims[2];
+  DevBuf<int> counts(c, nc + 1);
+  MM3D_LAUNCH(c, "grid_nblists", nc * 8.0, k_nb_count, dim3(div_up(nc + 1, 256)), dim3(256), 0, (const int *)g.cell_start.get(),
+              g.dims[0], g.dims[1], g.dims[2], R, counts.get());
+  g.nb_start = DevBuf<int>(c, nc + 1);
+  exclusive_scan_int(c, counts.get(), g.nb_start.get(), nc + 1);
+  int *h = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(h, g.nb_start.get() + nc, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  const size_t total = (size_t)h[0];
+  g.nb_pts = DevBuf<float4>(c, total ? total : 1);
+  if (total)
+    MM3D_LAUNCH(c, "grid_nblists", total * 32.0, k_nb_fill, dim3(div_up(nc, 4)), dim3(256), 0, (const int *)g.cell_start.get(),
+                (const float4 *)g.sorted.get(), g.dims[0], g.dims[1], g.dims[2], R, (const int *)g.nb_start.get(), g.nb_pts.get());
+  g.nb_R = R;
+  c->sync();
+}
+
 // ---------------------------------------------------------------- Hilbert order + wave work items
 // Queries that run 64 to a wave should form a compact patch, so that the cells they can reach are a
 // small box (wave_stream_box).  Points are ordered by the Hilbert index of their (x, y) column with

@@ -87,9 +87,9 @@ __global__ void __launch_bounds__(256)
 k_sacia_err(const float4 *__restrict__ skp, int ns, int ns_pad, GridView g, const float *__restrict__ T_all, int H,
             float thresh, float radius, float *__restrict__ E)
 {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)ns * H) return;
-  const int h = (int)(t / ns), i = (int)(t % ns);   // row h of E is contiguous over the keypoints
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const int h = blockIdx.y;                           // uniform: the model sits in scalar registers
   const float *T = T_all + (size_t)h * 16;
   float Tl[16];
 #pragma unroll
@@ -97,36 +97,25 @@ k_sacia_err(const float4 *__restrict__ skp, int ns, int ns_pad, GridView g, cons
   const float4 s = skp[i];
   const float3 p = xform(Tl, s.x, s.y, s.z);
   float best = INFINITY;
-  // hypotheses that throw the keypoint far from every target keypoint cost one byte of the distance
-  // transform (cell a hair larger than the search radius, so "no occupied cell within 1" = out of range)
+  // The kernel is VALU-bound on candidate distance tests (measured; 500 x K_s queries per pair), so the
+  // stencil walk is taken out of it: the target grid carries, per cell, the merged list of its
+  // 5x5x5 block (cell = radius / 2, grid_ensure_nblists), and a query scans ONE contiguous span.  An
+  // empty span is the "nothing in range" answer most wrong hypotheses get.
   const int cx = cell_floor(p.x, g.minx, g.inv), cy = cell_floor(p.y, g.miny, g.inv), cz = cell_floor(p.z, g.minz, g.inv);
   const bool inside = cx >= 0 && cx < g.dx && cy >= 0 && cy < g.dy && cz >= 0 && cz < g.dz;
   if (inside) {
-    if (g.dt[((size_t)cz * g.dy + cy) * g.dx + cx] <= 1) {
-      // the 3x3x3 block holds every point in range: nine row spans, all eighteen headers fetched
-      // before the first candidate
-      int bb[9], ee[9];
-      const int lo = cx > 0 ? cx - 1 : 0, hi = cx + 1 < g.dx ? cx + 1 : g.dx - 1;
-#pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
-        const bool ok = z >= 0 && z < g.dz && y >= 0 && y < g.dy;
-        const int row = ok ? (z * g.dy + y) * g.dx : 0;
-        bb[r] = ok ? g.cell_start[row + lo] : 0;
-        ee[r] = ok ? g.cell_start[row + hi + 1] : 0;
-      }
-      // (measured: the kernel is VALU-bound on these short, ragged row loops -- ~26 wave instructions
-      // per query; compacting the survivors of the DT test through LDS and 4-wide packed candidate
-      // loads were both slower than this plain loop)
-#pragma unroll
-      for (int r = 0; r < 9; ++r)
-        for (int j = bb[r]; j < ee[r]; ++j) {
-          const float4 q = g.pts[j];
-          best = fminf(best, dist2(p.x, p.y, p.z, q.x, q.y, q.z));
-        }
+    const size_t c = ((size_t)cz * g.dy + cy) * g.dx + cx;
+    const int b = g.nb_start[c], e = g.nb_start[c + 1];
+    // four loads in flight per step; min is idempotent, so the tail just re-reads the last point
+    for (int j = b; j < e; j += 4) {
+      const int last = e - 1;
+      const float4 q0 = g.nb_pts[j], q1 = g.nb_pts[min(j + 1, last)], q2 = g.nb_pts[min(j + 2, last)], q3 = g.nb_pts[min(j + 3, last)];
+      const float d0 = dist2(p.x, p.y, p.z, q0.x, q0.y, q0.z), d1 = dist2(p.x, p.y, p.z, q1.x, q1.y, q1.z);
+      const float d2 = dist2(p.x, p.y, p.z, q2.x, q2.y, q2.z), d3 = dist2(p.x, p.y, p.z, q3.x, q3.y, q3.z);
+      best = fminf(best, fminf(fminf(d0, d1), fminf(d2, d3)));
     }
   } else {
-    // outside the grid the distance transform says nothing: clipped walk
+    // outside the grid: clipped stencil walk
     for_each_candidate(g, p.x, p.y, p.z, radius, [&](const float4 &q) {
       best = fminf(best, dist2(p.x, p.y, p.z, q.x, q.y, q.z));
       return true;
@@ -208,11 +197,11 @@ __global__ void __launch_bounds__(256) k_seq_sum(const float *__restrict__ E, in
 static const Grid &sacia_target_grid(Context *c, const mm3d_cloud *tgt_kp, float corr_thresh)
 {
   const float radius = std::sqrt(corr_thresh > 0.f ? corr_thresh : 0.f);
-  // cell a hair larger than the search radius: anything two cells away is strictly out of range,
-  // which is what makes the distance-transform test in k_sacia_err exact
-  const float cell = radius * 1.001f > 0.25f ? radius * 1.001f : 0.25f;
+  // cell a hair larger than half the search radius: everything within the radius of a point of cell c
+  // lies in c's 5x5x5 block (cloud_grid may only ever ENLARGE the cell, which keeps that true)
+  const float cell = radius * 0.5005f > 0.125f ? radius * 0.5005f : 0.125f;
   const Grid &g = cloud_grid(c, tgt_kp, cell);
-  grid_ensure_dt(c, g, 1);
+  grid_ensure_nblists(c, g, 2);
   return g;
 }
 
@@ -230,7 +219,7 @@ void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp
   const Grid &g = sacia_target_grid(c, tgt_kp, corr_thresh);
   DevBuf<float> E(c, (size_t)ns_pad * H);
   const size_t total = (size_t)ns * H;
-  MM3D_LAUNCH(c, "sacia_err", total * 4.0 + ns * 16.0, k_sacia_err, dim3(div_up(total, 256)), dim3(256), 0, src_kp->pts.get(), ns,
+  MM3D_LAUNCH(c, "sacia_err", total * 4.0 + ns * 16.0, k_sacia_err, dim3(div_up(ns, 256), H), dim3(256), 0, src_kp->pts.get(), ns,
               ns_pad, g.view(), T_all, H, corr_thresh, radius, E.get());
   MM3D_LAUNCH(c, "sacia_seq_sum", total * 4.0, k_seq_sum, dim3(div_up(H, kSumRows)), dim3(256), 0, (const float *)E.get(), ns,
               ns_pad, H, errors);

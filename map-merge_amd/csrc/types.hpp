@@ -27,6 +27,11 @@ struct GridView {
   int n;
   const unsigned char *dt;   // optional: Chebyshev distance (in cells, capped) to the nearest occupied cell
   int dt_cap;                // values > dt_cap are stored as 255
+  // optional merged neighbourhood lists: nb_pts[nb_start[c] .. nb_start[c+1]) = every point of the
+  // (2 nb_R + 1)^3 block of cells around cell c, so a fixed-radius query reads ONE contiguous span
+  const int *nb_start;
+  const float4 *nb_pts;
+  int nb_R;
 };
 
 struct Grid {
@@ -38,6 +43,9 @@ struct Grid {
   int n = 0;
   DevBuf<unsigned char> dt;   // built on demand by grid_ensure_dt
   int dt_cap = 0;
+  DevBuf<int> nb_start;       // built on demand by grid_ensure_nblists
+  DevBuf<float4> nb_pts;
+  int nb_R = 0;
   GridView view() const
   {
     GridView v;
@@ -46,6 +54,7 @@ struct Grid {
     v.dx = dims[0]; v.dy = dims[1]; v.dz = dims[2];
     v.cell_start = cell_start.get(); v.pts = sorted.get(); v.n = n;
     v.dt = dt.get(); v.dt_cap = dt_cap;
+    v.nb_start = nb_start.get(); v.nb_pts = nb_pts.get(); v.nb_R = nb_R;
     return v;
   }
 };
@@ -91,6 +100,8 @@ void cloud_bbox(Context *c, mm3d_cloud *cl);
 const Grid &cloud_grid(Context *c, const mm3d_cloud *cl, float cell);
 // per-cell Chebyshev distance transform (capped at R cells), cached on the grid
 void grid_ensure_dt(Context *c, const Grid &g, int R);
+// per-cell merged candidate lists over the (2R+1)^3 block of cells, cached on the grid
+void grid_ensure_nblists(Context *c, const Grid &g, int R);
 // Hilbert-ordered copy of the finite points (.w = original index) + wave work items, cached on the cloud
 void cloud_hilbert(Context *c, const mm3d_cloud *cl);
 mm3d_cloud *cloud_from_device(Context *c, DevBuf<float4> &&pts, size_t n);
