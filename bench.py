@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--streams", type=int, default=16, help="contexts (HIP stream + host thread) per GPU")
+    ap.add_argument("--descriptor", choices=["FPFH", "PFH"], default="FPFH")
+    ap.add_argument("--method", choices=["SAC_IA", "MATCHING"], default="SAC_IA")
     ap.add_argument("--kernel-table", default=None, help="write rank 0's full per-kernel HIP-event table (CSV) here")
     args = ap.parse_args()
 
@@ -87,7 +89,11 @@ def main():
     mm = ge.load()
     from map_merge_amd import sharding
     ctx = mm.Context(local_rank)
-    params = mm.MapMergingParams(descriptor_type=mm.Descriptor.FPFH, estimation_method=mm.EstimationMethod.SAC_IA,
+    # BASELINE.json's configuration is FPFH + SAC_IA; the other combinations (PFH is the reference's default
+    # descriptor, MATCHING its default method) can be timed with the flags
+    desc_type = mm.Descriptor[args.descriptor]
+    desc_dim = {"FPFH": 33, "PFH": 125}[args.descriptor]
+    params = mm.MapMergingParams(descriptor_type=desc_type, estimation_method=mm.EstimationMethod[args.method],
                                  refine_transform=1)
 
     # ---- synthetic workload, resident in HBM before timing ---------------------------------
@@ -109,7 +115,7 @@ def main():
         npts, nkp = int(sizes[0]), int(sizes[1])
         tp = torch.empty((max(npts, 1), 16), dtype=torch.uint8, device=dev)
         tk = torch.empty((max(nkp, 1), 16), dtype=torch.uint8, device=dev)
-        td = torch.empty((max(nkp, 1), 33), dtype=torch.float32, device=dev)
+        td = torch.empty((max(nkp, 1), desc_dim), dtype=torch.float32, device=dev)
         if rank == owner:
             L = mm.lib()
             ctx._ck(L.mm3d_cloud_download(ctx._h, pts._h, C.c_void_p(tp.data_ptr()), C.c_size_t(16), C.c_size_t(12)))
@@ -124,7 +130,7 @@ def main():
         cp = ctx.cloud_from_ptr(tp.data_ptr(), npts)
         ck = ctx.cloud_from_ptr(tk.data_ptr(), nkp)
         h = C.c_void_p()
-        ctx._ck(mm.lib().mm3d_desc_create(ctx._h, C.c_void_p(td.data_ptr()), C.c_size_t(nkp), 2, C.byref(h)))
+        ctx._ck(mm.lib().mm3d_desc_create(ctx._h, C.c_void_p(td.data_ptr()), C.c_size_t(nkp), int(desc_type), C.byref(h)))
         cd = mm.Descriptors(ctx, h)
         return ctx.mapFromParts(cp, ck, cd)
 
@@ -311,7 +317,7 @@ def main():
             "value": round(value, 4), "unit": "map-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n_maps} maps x {n_pts} raw pts, FPFH + SAC_IA + ICP refine, {n_pairs} pairs",
+            "config": {"workload": f"{n_maps} maps x {n_pts} raw pts, {args.descriptor} + {args.method} + ICP refine, {n_pairs} pairs",
                        "parallelism": f"maps and pairs round-robin over {world} GPU(s) x {S} streams",
                        "points_after_filter_mean": int(np.mean(npts_f)), "keypoints_mean": int(np.mean(stats["keypoints"]))},
             "pair_stage_pairs_per_s": round(n_pairs / max(stats["t_pairs"], 1e-9), 3),

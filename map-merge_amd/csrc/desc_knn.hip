@@ -23,9 +23,9 @@
 namespace mm3d {
 
 constexpr int kMaxK = 16;
-constexpr int kD = 33;
-constexpr int kKP = 36;          // padded contraction length
-constexpr int kSteps = kKP / 2;  // 32x32x2 MFMA steps
+// The kernels are templates on the descriptor dimension kD: 33 (FPFH) and 125 (PFH) are instantiated.
+// padded contraction length (dimension + the two augmentation columns, even): 36 / 128
+constexpr int knn_kp(int d) { return (d + 3) / 2 * 2; }
 constexpr int kSlices = 4;       // waves per query tile, each scanning a quarter of the targets
 constexpr int kLists = 2 * kSlices;
 constexpr int kListLen = 8;      // per-lane candidate list of the MFMA stage (8 lists x 8 = 64 candidates per query and part)
@@ -94,20 +94,21 @@ k_knn_exact(const float *__restrict__ A, int na, const float *__restrict__ B, in
     }
 }
 
-// Exact k-NN for the (few) rows that miss the certificate: one WAVE per row.  Lanes stride over the
-// targets (64-row tiles staged through LDS with coalesced loads), each keeps its own sorted top-16 in
-// registers, and the k winners are drawn by repeated wave-wide minimum over (distance, index) keys.
+// Exact k-NN for the (few) rows that miss the certificate: one BLOCK per row.  The four waves take
+// every fourth 64-target tile (staged through the wave's own LDS slab with coalesced loads), each lane
+// keeps a sorted top-16 in registers, every wave draws its k best by repeated wave-wide minimum over
+// (distance bits, index) keys, and wave 0 merges the four short lists the same way.
+template <int kD>
 __global__ void __launch_bounds__(256)
 k_knn_exact_wave(const float *__restrict__ A, const float *__restrict__ B, int nb, int k, const int *__restrict__ rows,
                  const int *__restrict__ nrows_dev, int *__restrict__ idx, float *__restrict__ d2out)
 {
-  __shared__ float tile[4][64][kD];
+  __shared__ float tile[4][64][kD];   // odd row stride (33, 125): lane-per-row reads are conflict free
+  __shared__ unsigned long long s_keys[4][kMaxK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrows = *nrows_dev;
-  const int t = blockIdx.x * 4 + wave;
-  if (blockIdx.x * 4 >= nrows) return;          // uniform per block
-  const bool live = t < nrows;                    // uniform per wave
-  const int row = live ? rows[t] : rows[0];
+  for (int t = blockIdx.x; t < nrows; t += gridDim.x) {   // uniform per block
+  const int row = rows[t];
   float a[kD];
 #pragma unroll
   for (int d = 0; d < kD; ++d) a[d] = A[(size_t)row * kD + d];
@@ -115,9 +116,9 @@ k_knn_exact_wave(const float *__restrict__ A, const float *__restrict__ B, int n
   int bi[kMaxK];
 #pragma unroll
   for (int s = 0; s < kMaxK; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
-  for (int j0 = 0; j0 < nb; j0 += 64) {
+  for (int j0 = wave * 64; j0 < nb; j0 += 256) {
     const int tn = min(64, nb - j0);
-    // coalesced copy of tn x 33 floats; a wave only ever touches its own LDS slab
+    // coalesced copy of tn x kD floats; a wave only ever touches its own LDS slab
     for (int e = lane; e < tn * kD; e += 64) (&tile[wave][0][0])[e] = B[(size_t)j0 * kD + e];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -149,7 +150,7 @@ k_knn_exact_wave(const float *__restrict__ A, const float *__restrict__ B, int n
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  // merge the 64 sorted lists: k rounds of "smallest head wins" on (distance bits, index) keys
+  // per wave: merge the 64 sorted lists, k rounds of "smallest head wins"
   for (int o = 0; o < k; ++o) {
     const unsigned long long key = ((unsigned long long)__float_as_uint(bd[0]) << 32) | (unsigned)bi[0];
     unsigned long long best = key;
@@ -158,17 +159,32 @@ k_knn_exact_wave(const float *__restrict__ A, const float *__restrict__ B, int n
       const unsigned long long other = __shfl_xor(best, s, kWave);
       best = other < best ? other : best;
     }
-    if (live && lane == 0) {
-      const float d = __uint_as_float((unsigned)(best >> 32));
-      const bool have = d < INFINITY;
-      idx[(size_t)row * k + o] = have ? (int)(unsigned)(best & 0xffffffffull) : -1;
-      d2out[(size_t)row * k + o] = d;
-    }
+    if (lane == 0) s_keys[wave][o] = best;
     if (key == best && bd[0] < INFINITY) {   // pop (indices are unique, so exactly one lane matches)
 #pragma unroll
       for (int s = 0; s + 1 < kMaxK; ++s) { bd[s] = bd[s + 1]; bi[s] = bi[s + 1]; }
       bd[kMaxK - 1] = INFINITY; bi[kMaxK - 1] = 0x7fffffff;
     }
+  }
+  __syncthreads();
+  // the four waves' lists partition the targets: wave 0 merges 4 x k keys (lane = wave * 16 + position)
+  unsigned long long key = ((lane & (kMaxK - 1)) < k) ? s_keys[lane >> 4][lane & (kMaxK - 1)] : ~0ull;
+  for (int o = 0; o < k && wave == 0; ++o) {
+    unsigned long long best = key;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const unsigned long long other = __shfl_xor(best, s, kWave);
+      best = other < best ? other : best;
+    }
+    if (lane == 0) {
+      const float d = __uint_as_float((unsigned)(best >> 32));
+      idx[(size_t)row * k + o] = d < INFINITY ? (int)(unsigned)(best & 0xffffffffull) : -1;
+      d2out[(size_t)row * k + o] = d;
+    }
+    // drop the winner; an "empty" key (+inf, 0x7fffffff) may sit in several lanes and stays
+    if (key == best && (unsigned)(key >> 32) < 0x7f800000u) key = ~0ull;
+  }
+  __syncthreads();                                    // s_keys is reused by the next row
   }
 }
 
@@ -179,19 +195,23 @@ k_knn_exact_wave(const float *__restrict__ A, const float *__restrict__ B, int n
 // column sums of the targets (33 floats) -> mu = sum / n.  Distances do not change when both sides
 // are shifted by the same vector, but the rounding error of the |a|^2 + |b|^2 - 2ab expansion does:
 // FPFH rows share a large common component, and centred rows make the certificate below tight.
+template <int kD>
 __global__ void k_knn_colsum(const float *__restrict__ X, int n, float *__restrict__ sum)
 {
-  const int d = threadIdx.x & 63;
-  const int part = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nparts = gridDim.x * (blockDim.x >> 6);
+  static_assert(kD <= 128, "one 128-lane group per partial sum");
+  const int d = threadIdx.x & 127;
+  const int part = blockIdx.x * (blockDim.x >> 7) + (threadIdx.x >> 7), nparts = gridDim.x * (blockDim.x >> 7);
   if (d >= kD) return;
   float acc = 0.0f;
   for (int r = part; r < n; r += nparts) acc += X[(size_t)r * kD + d];
   atomicAdd(&sum[d], acc);
 }
 
+template <int kD>
 __global__ void k_knn_prep(const float *__restrict__ X, int n, int ntiles, int is_target, const float *__restrict__ colsum,
                            float inv_nb, float *__restrict__ Xp)
 {
+  constexpr int kSteps = knn_kp(kD) / 2;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)ntiles * kSteps * 64) return;
   const int lane = (int)(e & 63);
@@ -224,10 +244,12 @@ __global__ void k_knn_prep(const float *__restrict__ X, int n, int ntiles, int i
 
 // ---------------------------------------------------------------- stage 2: MFMA distance tiles
 // block = one tile of 32 queries; its 4 waves scan disjoint quarters of the target tiles.
+template <int kD>
 __global__ void __launch_bounds__(256)
 k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, int nb, int nb_tiles,
            float *__restrict__ cand_d, int *__restrict__ cand_i)
 {
+  constexpr int kSteps = knn_kp(kD) / 2;   // 32x32x2 MFMA steps: 18 (FPFH) / 64 (PFH)
   const int lane = threadIdx.x & 63;
   const int slice = threadIdx.x >> 6;
   const int tile_a = blockIdx.x;
@@ -306,6 +328,7 @@ k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, i
 // full table, several hundred when the targets were split over parts), each re-ranks its share with
 // FLANN's accumulation order into a private sorted list, and the k winners are drawn by repeated
 // wave-wide minimum over (distance bits, index) keys -- i.e. ties go to the lower index.
+template <int kD>
 __global__ void __launch_bounds__(256)
 k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, int nb, int k, int n_lists,
              const float *__restrict__ cand_d, const int *__restrict__ cand_i, const float *__restrict__ colsum, float inv_nb,
@@ -387,24 +410,23 @@ k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, i
   // norms, the centring itself, and the 33-term exact sum).  2e-5 (|a-mu|^2 + rho^2) + 1e-5 kth
   // doubles that bound.
   const float rho = (sqrtf(na2) + sqrtf(kth)) * 1.001f + 1e-3f;
-  const float eps = 2e-5f * (na2 + rho * rho) + 1e-5f * kth;
+  // (stated for the 36-term chain of FPFH; the bound grows linearly with the chain length)
+  const float eps = (2e-5f * (na2 + rho * rho) + 1e-5f * kth) * ((float)knn_kp(kD) / 36.0f);
   const bool certified = !(tau < INFINITY) || (kth < tau - eps);
   if (!certified && lane == 0) fb_rows[atomicAdd(fb_count, 1)] = a;
 }
 
-void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2)
+template <int kD>
+static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2)
 {
-  MM3D_REQUIRE(A->dim == B->dim, "descriptor dimensions differ");
-  MM3D_REQUIRE(k >= 1, "k must be positive");
-  if (k > kMaxK) throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN supports k <= 16");
-  if (A->dim != kD) throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for FPFH (dim 33) only");
+  constexpr int kKP = knn_kp(kD), kSteps = kKP / 2;
   const int na = (int)A->n, nb = (int)B->n;
   idx = DevBuf<int>(c, (size_t)na * k);
   d2 = DevBuf<float>(c, (size_t)na * k);
   if (na == 0) return;
   const float *Ad = A->data.get(), *Bd = B->data.get();
   if ((double)na * nb < 65536.0 || nb < 64) {
-    MM3D_LAUNCH(c, "desc_knn_exact", ((double)na + nb) * 132.0, (k_knn_exact<kD>), dim3(div_up(na, 128)), dim3(128), 0, Ad, na,
+    MM3D_LAUNCH(c, "desc_knn_exact", ((double)na + nb) * kD * 4.0, (k_knn_exact<kD>), dim3(div_up(na, 128)), dim3(128), 0, Ad, na,
                 Bd, nb, k, (const int *)nullptr, (const int *)nullptr, na, idx.get(), d2.get());
     return;
   }
@@ -412,13 +434,13 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
   DevBuf<float> Ap(c, (size_t)na_tiles * kSteps * 64), Bp(c, (size_t)nb_tiles * kSteps * 64);
   DevBuf<unsigned> meta(c, 4);   // [1] fallback count
   MM3D_HIP(hipMemsetAsync(meta.get(), 0, 16, c->stream));
-  DevBuf<float> colsum(c, 64);
-  MM3D_HIP(hipMemsetAsync(colsum.get(), 0, 64 * sizeof(float), c->stream));
-  MM3D_LAUNCH(c, "desc_knn_prep", nb * 132.0, k_knn_colsum, dim3(64), dim3(256), 0, Bd, nb, colsum.get());
+  DevBuf<float> colsum(c, 128);
+  MM3D_HIP(hipMemsetAsync(colsum.get(), 0, 128 * sizeof(float), c->stream));
+  MM3D_LAUNCH(c, "desc_knn_prep", nb * kD * 4.0, (k_knn_colsum<kD>), dim3(64), dim3(256), 0, Bd, nb, colsum.get());
   const float inv_nb = 1.0f / (float)nb;
-  MM3D_LAUNCH(c, "desc_knn_prep", na * 276.0, k_knn_prep, dim3(div_up((size_t)na_tiles * kSteps * 64, 256)), dim3(256), 0, Ad, na,
+  MM3D_LAUNCH(c, "desc_knn_prep", na * (kD + kKP) * 4.0, (k_knn_prep<kD>), dim3(div_up((size_t)na_tiles * kSteps * 64, 256)), dim3(256), 0, Ad, na,
               na_tiles, 0, (const float *)colsum.get(), inv_nb, Ap.get());
-  MM3D_LAUNCH(c, "desc_knn_prep", nb * 276.0, k_knn_prep, dim3(div_up((size_t)nb_tiles * kSteps * 64, 256)), dim3(256), 0, Bd, nb,
+  MM3D_LAUNCH(c, "desc_knn_prep", nb * (kD + kKP) * 4.0, (k_knn_prep<kD>), dim3(div_up((size_t)nb_tiles * kSteps * 64, 256)), dim3(256), 0, Bd, nb,
               nb_tiles, 1, (const float *)colsum.get(), inv_nb, Bp.get());
   // few query tiles (SAC-IA's sampled rows): split the targets over `parts` blocks per query tile so
   // that the launch still has >= 2 blocks per CU; each part keeps its own 8 lists per query
@@ -427,16 +449,16 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
   const int n_lists = kLists * parts;
   DevBuf<float> cand_d(c, (size_t)na * n_lists * kListLen);
   DevBuf<int> cand_i(c, (size_t)na * n_lists * kListLen);
-  // roofline unit for this kernel is FLOPs (2 * na * nb * 36 per launch), reported as such by bench.py
-  MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, k_knn_mfma, dim3(na_tiles, parts),
+  // roofline unit for this kernel is FLOPs (2 * na * nb * kKP per launch), reported as such by bench.py
+  MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, (k_knn_mfma<kD>), dim3(na_tiles, parts),
               dim3(256), 0, (const float *)Ap.get(), na, (const float *)Bp.get(), nb, nb_tiles, cand_d.get(), cand_i.get());
   DevBuf<int> fb_rows(c, na);
-  MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * 140 + 132), k_knn_rerank, dim3(div_up(na, 4)), dim3(256), 0,
+  MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * (kD * 4 + 8) + kD * 4), (k_knn_rerank<kD>), dim3(div_up(na, 4)), dim3(256), 0,
               Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), (const float *)colsum.get(), inv_nb,
               idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
   // rows without a certificate: exact brute force (the grid is sized for the worst case; blocks
   // beyond the device-side count exit at once)
-  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, k_knn_exact_wave, dim3(div_up(na, 4)), dim3(256), 0, Ad, Bd, nb, k,
+  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, (k_knn_exact_wave<kD>), dim3(na < 1024 ? na : 1024), dim3(256), 0, Ad, Bd, nb, k,
               (const int *)fb_rows.get(), (const int *)(meta.get() + 1), idx.get(), d2.get());
   if (c->debug) {
     unsigned *h = (unsigned *)c->pin(64);
@@ -445,6 +467,16 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
     c->knn_fallback_rows += (long long)h[1];
     c->knn_rows += na;
   }
+}
+
+void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2)
+{
+  MM3D_REQUIRE(A->dim == B->dim, "descriptor dimensions differ");
+  MM3D_REQUIRE(k >= 1, "k must be positive");
+  if (k > kMaxK) throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN supports k <= 16");
+  if (A->dim == 33) desc_knn_impl<33>(c, A, B, k, idx, d2);          // FPFHSignature33
+  else if (A->dim == 125) desc_knn_impl<125>(c, A, B, k, idx, d2);   // PFHSignature125
+  else throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for FPFH (33) and PFH (125) rows");
 }
 
 __global__ void k_gather_desc_rows(const float *__restrict__ X, const int *__restrict__ rows, int n_rows, int dim,

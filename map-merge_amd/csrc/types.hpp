@@ -130,6 +130,10 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
 mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,
                         mm3d_cloud *keypoints, double radius);
 
+// pfh.hip
+mm3d_desc *compute_pfh(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,
+                       mm3d_cloud *keypoints, double radius);
+
 // desc_knn.hip
 // k nearest rows of B for every row of A (squared L2, FLANN accumulation order); idx -1 padded
 void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2);

@@ -89,6 +89,12 @@ int mo_keypoints_sift(const mo_point *in, int n, double min_scale,
 int mo_descriptors_fpfh(const mo_point *surface, const mo_normal *normals, int n,
                         mo_point *keypoints, int n_kp, double radius,
                         float *desc);
+/* computeLocalDescriptors(PFH) -- the reference's default descriptor, dispatch_descriptors.h:38:
+ * desc must hold n_kp*125 floats; keypoints pruned in place; returns the survivors. */
+int mo_descriptors_pfh(const mo_point *surface, const mo_normal *normals, int n,
+                       mo_point *keypoints, int n_kp, double radius, float *desc);
+int mo_pfh_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints,
+               int n_kp, double radius, float *desc /* n_kp x 125, NaN rows where no neighbour */);
 /* Raw (un-pruned) FPFH plus the SPFH support set, for stage-level parity. */
 int mo_fpfh_raw(const mo_point *surface, const mo_normal *normals, int n,
                 const mo_point *keypoints, int n_kp, double radius, float *desc,

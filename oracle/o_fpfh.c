@@ -152,6 +152,81 @@ int mo_fpfh_raw(const mo_point *surface, const mo_normal *normals, int n,
   return ns;
 }
 
+/*
+ * computeLocalDescriptors(PFH): the PFH row of R/src/dispatch_descriptors.h:38 -- the reference's
+ * DEFAULT descriptor (map_merging.h:33) -- pcl::PFHEstimation<PointXYZRGB, Normal, PFHSignature125>.
+ * PCL 1.8.1 features/impl/pfh.hpp: computeFeature (no cache: use_cache_ defaults to false) and
+ * computePointPFHSignature: every pair (i, j < i) of the keypoint's radius neighbours (sorted by
+ * distance, so p1 = the farther one), 5 x 5 x 5 bins over (f1, f2, f3), each hit adds
+ * 100 / (n (n-1) / 2) with the pair count taken in size_t arithmetic.  Like FPFH's, the class'
+ * computePairFeatures wrapper returns true unconditionally, so degenerate pairs are binned.
+ */
+#define PFH_SPLIT 5
+int mo_pfh_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints,
+               int n_kp, double radius, float *desc /* n_kp x 125 */)
+{
+  mo_grid *g = mo_grid_build(surface, n, (float)(radius * 0.5));
+  const float r2 = (float)(radius * radius);
+  const float d_pi = 1.0f / (2.0f * (float)M_PI);
+  int cap = 4096;
+  int *idx = (int *)malloc(sizeof(int) * (size_t)cap);
+  float *d2 = (float *)malloc(sizeof(float) * (size_t)cap);
+  for (int k = 0; k < n_kp; ++k) {
+    float *out = &desc[(size_t)k * 125];
+    int cnt = mo_radius_search(g, keypoints[k].x, keypoints[k].y, keypoints[k].z, r2, idx, d2, cap);
+    if (cnt > cap) {
+      cap = cnt * 2;
+      idx = (int *)realloc(idx, sizeof(int) * (size_t)cap);
+      d2 = (float *)realloc(d2, sizeof(float) * (size_t)cap);
+      cnt = mo_radius_search(g, keypoints[k].x, keypoints[k].y, keypoints[k].z, r2, idx, d2, cap);
+    }
+    if (cnt == 0) {
+      for (int b = 0; b < 125; ++b) out[b] = NAN;
+      continue;
+    }
+    for (int b = 0; b < 125; ++b) out[b] = 0.0f;
+    const float hist_incr = 100.0f / (float)((size_t)cnt * ((size_t)cnt - 1) / 2);
+    for (int i = 0; i < cnt; ++i)
+      for (int j = 0; j < i; ++j) {
+        float f1, f2, f3, f4;
+        pair_features(&surface[idx[i]], &normals[idx[i]], &surface[idx[j]], &normals[idx[j]], &f1, &f2, &f3, &f4);
+        int h1 = floor_to_int(PFH_SPLIT * ((f1 + M_PI) * d_pi));
+        if (h1 < 0) h1 = 0;
+        if (h1 >= PFH_SPLIT) h1 = PFH_SPLIT - 1;
+        int h2 = floor_to_int(PFH_SPLIT * ((f2 + 1.0) * 0.5));
+        if (h2 < 0) h2 = 0;
+        if (h2 >= PFH_SPLIT) h2 = PFH_SPLIT - 1;
+        int h3 = floor_to_int(PFH_SPLIT * ((f3 + 1.0) * 0.5));
+        if (h3 < 0) h3 = 0;
+        if (h3 >= PFH_SPLIT) h3 = PFH_SPLIT - 1;
+        out[h1 + PFH_SPLIT * h2 + PFH_SPLIT * PFH_SPLIT * h3] += hist_incr;
+      }
+  }
+  free(idx); free(d2);
+  mo_grid_free(g);
+  return n_kp;
+}
+
+int mo_descriptors_pfh(const mo_point *surface, const mo_normal *normals, int n,
+                       mo_point *keypoints, int n_kp, double radius, float *desc)
+{
+  if (n_kp <= 0) return 0;
+  mo_pfh_raw(surface, normals, n, keypoints, n_kp, radius, desc);
+  /* DefaultPointRepresentation<PFHSignature125>::isValid: all bins finite; prune both (features.cpp:118-143) */
+  int m = 0;
+  for (int k = 0; k < n_kp; ++k) {
+    int valid = 1;
+    for (int b = 0; b < 125; ++b) if (!isfinite(desc[(size_t)k * 125 + b])) { valid = 0; break; }
+    if (!valid) continue;
+    if (m != k) {
+      memmove(&desc[(size_t)m * 125], &desc[(size_t)k * 125], sizeof(float) * 125);
+      keypoints[m] = keypoints[k];
+    }
+    ++m;
+  }
+  return m;
+}
+
 int mo_descriptors_fpfh(const mo_point *surface, const mo_normal *normals, int n,
                         mo_point *keypoints, int n_kp, double radius, float *desc)
 {

@@ -5,7 +5,8 @@
  * estimateMapsTransforms     R/src/map_merging.cpp:188-275
  * composeMaps                R/src/map_merging.cpp:277-305
  *
- * Only descriptor_type = FPFH and keypoint_type = SIFT are restated (the north-star path);
+ * Only descriptor_type = FPFH | PFH and keypoint_type = SIFT are restated (the north-star path and
+ * the reference's default descriptor);
  * other enum values make mo_estimate_maps_transforms return -3.
  */
 #include "mm3d_oracle.h"
@@ -47,7 +48,8 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
   if (n_pairs_out) *n_pairs_out = 0;
   if (n_clouds == 0) return 0;
   if (n_clouds == 1) { identity16(out_T); return 1; }
-  if (params->descriptor_type != 2 || params->keypoint_type != 0) return -3;
+  if ((params->descriptor_type != 2 && params->descriptor_type != 0) || params->keypoint_type != 0) return -3;
+  const int dim = params->descriptor_type == 0 ? 125 : 33;
 
   mo_point **resized = (mo_point **)calloc((size_t)n_clouds, sizeof(mo_point *));
   int *rn = (int *)calloc((size_t)n_clouds, sizeof(int));
@@ -68,8 +70,9 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
     normals[i] = (mo_normal *)malloc(sizeof(mo_normal) * (size_t)(nb > 0 ? nb : 1));
     mo_normals(b, nb, params->normal_radius, normals[i]);
     kn[i] = mo_keypoints_sift(b, nb, params->resolution, 3, 3, params->keypoint_threshold, &kps[i], NULL);
-    desc[i] = (float *)malloc(sizeof(float) * 33 * (size_t)(kn[i] > 0 ? kn[i] : 1));
-    kn[i] = mo_descriptors_fpfh(b, normals[i], nb, kps[i], kn[i], params->descriptor_radius, desc[i]);
+    desc[i] = (float *)malloc(sizeof(float) * (size_t)dim * (size_t)(kn[i] > 0 ? kn[i] : 1));
+    kn[i] = dim == 125 ? mo_descriptors_pfh(b, normals[i], nb, kps[i], kn[i], params->descriptor_radius, desc[i])
+                       : mo_descriptors_fpfh(b, normals[i], nb, kps[i], kn[i], params->descriptor_radius, desc[i]);
   }
 
   int max_pairs = n_clouds * (n_clouds - 1) / 2;
@@ -85,7 +88,7 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
   for (int p = 0; p < np; ++p) {
     int i = (int)pairs[p].source_idx, j = (int)pairs[p].target_idx;
     mo_estimate_transform(resized[i], rn[i], kps[i], desc[i], kn[i], resized[j], rn[j], kps[j], desc[j],
-                          kn[j], 33, params->estimation_method, params->refine_transform,
+                          kn[j], dim, params->estimation_method, params->refine_transform,
                           params->inlier_threshold, params->max_correspondence_distance,
                           params->max_iterations, (size_t)params->matching_k,
                           params->transform_epsilon, pairs[p].transform);

@@ -114,6 +114,26 @@ def fpfh_raw(surface, nrm, keypoints, radius):
     return desc, support[:ns].copy(), spfh[:ns].copy()
 
 
+def descriptors_pfh(surface, nrm, keypoints, radius):
+    """computeLocalDescriptors(PFH): returns (pruned keypoints, desc[n, 125])."""
+    surface = _pts(surface)
+    nrm = np.ascontiguousarray(nrm, dtype=NORMAL)
+    kp = _pts(keypoints).copy()
+    desc = np.empty((max(len(kp), 1), 125), dtype=np.float32)
+    n = lib().mo_descriptors_pfh(_p(surface), _p(nrm), len(surface), _p(kp), len(kp), C.c_double(radius), _p(desc))
+    return kp[:n].copy(), desc[:n].copy()
+
+
+def pfh_raw(surface, nrm, keypoints, radius):
+    """Un-pruned PFH rows (NaN where a keypoint has no neighbour)."""
+    surface = _pts(surface)
+    nrm = np.ascontiguousarray(nrm, dtype=NORMAL)
+    keypoints = _pts(keypoints)
+    desc = np.empty((max(len(keypoints), 1), 125), dtype=np.float32)
+    lib().mo_pfh_raw(_p(surface), _p(nrm), len(surface), _p(keypoints), len(keypoints), C.c_double(radius), _p(desc))
+    return desc[:len(keypoints)].copy()
+
+
 def descriptors_fpfh(surface, nrm, keypoints, radius):
     """Returns (pruned keypoints, descriptors) like computeLocalDescriptors (which mutates keypoints)."""
     surface = _pts(surface)

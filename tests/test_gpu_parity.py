@@ -387,3 +387,68 @@ def test_pairs_on_several_contexts_are_bit_identical(ctx, mm, scene):
             c.close()
     for m in maps:
         m.free()
+
+
+def test_pfh(ctx, po, scene):
+    """The reference's default descriptor (PFHSignature125): every pair of a keypoint's neighbours."""
+    for m in scene:
+        kp_ref, ref = po.descriptors_pfh(m["filt"], m["nrm"], m["kp_raw"], R_DESC)
+        kp = ctx.cloud(m["kp_raw"])
+        desc = ctx.computeLocalDescriptors(ctx.cloud(m["filt"]), ctx.normals(m["nrm"]), kp, 0, R_DESC)
+        got = desc.numpy()
+        assert got.shape == ref.shape and got.shape[1] == 125
+        assert np.array_equal(kp.numpy().view(np.uint32), kp_ref.view(np.uint32))       # same pruning
+        assert np.allclose(got.sum(axis=1), 100.0, atol=2e-2)
+        # bins are counted in integers and the float chain is replayed, so a row differs from the oracle
+        # only when an atan2f ulp moves a pair across a bin edge: one pair = 100 / (m (m-1) / 2) ~ 5e-3.
+        err = np.abs(got - ref).max(axis=1)
+        assert np.mean(err <= 1e-3) >= 0.9, np.percentile(err, [50, 90, 99, 100])
+        assert err.max() <= 0.5
+    # isolated keypoints are pruned like the reference does
+    kp = scene[0]["kp_raw"][:40].copy()
+    kp["x"][3] += 400.0
+    kp_ref, ref = po.descriptors_pfh(scene[0]["filt"], scene[0]["nrm"], kp, R_DESC)
+    k = ctx.cloud(kp)
+    desc = ctx.computeLocalDescriptors(ctx.cloud(scene[0]["filt"]), ctx.normals(scene[0]["nrm"]), k, 0, R_DESC)
+    assert len(desc) == len(ref) == 39 and np.array_equal(k.numpy().view(np.uint32), kp_ref.view(np.uint32))
+
+
+def test_desc_knn_dim125_exact(ctx, po, mm, scene):
+    """k-NN over PFH rows (125 wide, 64 MFMA steps): exact FLANN-order results, few fallbacks."""
+    rng = np.random.default_rng(11)
+    _, base = po.descriptors_pfh(scene[0]["filt"], scene[0]["nrm"], scene[0]["kp_raw"], R_DESC)
+    A = base[rng.integers(0, len(base), 900)] + rng.normal(0, 0.2, (900, 125)).astype(np.float32)
+    B = base[rng.integers(0, len(base), 1300)] + rng.normal(0, 0.2, (1300, 125)).astype(np.float32)
+    B[50:70] = B[150:170]
+    A[:10] = B[300:310]
+    A, B = A.astype(np.float32), B.astype(np.float32)
+    L = mm.lib()
+    L.mm3d_debug_knn_fallback_rows.restype = L.mm3d_debug_knn_rows.restype = __import__("ctypes").c_longlong
+    L.mm3d_set_debug(ctx._h, 1)
+    r0, f0 = L.mm3d_debug_knn_rows(ctx._h), L.mm3d_debug_knn_fallback_rows(ctx._h)
+    da, db = ctx.descriptors(A, 0), ctx.descriptors(B, 0)
+    for k in (1, 5, 10):
+        got = ctx.findFeatureCorrespondences(da, db, k)
+        ref = po.find_correspondences(A, B, k)
+        assert np.array_equal(got["index_query"], ref["index_query"]), k
+        assert np.array_equal(got["index_match"], ref["index_match"]), k
+        assert np.array_equal(got["distance"].view(np.uint32), ref["distance"].view(np.uint32)), k
+    rows, fb = L.mm3d_debug_knn_rows(ctx._h) - r0, L.mm3d_debug_knn_fallback_rows(ctx._h) - f0
+    L.mm3d_set_debug(ctx._h, 0)
+    assert rows > 0 and fb <= 0.05 * rows, (rows, fb)
+
+
+def test_default_configuration_end_to_end(ctx, po, mm, scene):
+    """The reference's DEFAULT parameters: PFH descriptors + reciprocal matching + RANSAC + ICP."""
+    a, b = scene
+    params = mm.MapMergingParams()                      # descriptor PFH, estimation MATCHING
+    op = po.params_default()
+    assert params.descriptor_type == 0 and params.estimation_method == 0 and op.descriptor_type == 0
+    po.srand(1); ctx.srand(1)
+    ref_T, ref_pairs = po.estimate_maps_transforms([a["raw"], b["raw"]], op)
+    T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
+    assert len(T) == len(ref_T) == 2 and len(pairs) == len(ref_pairs) == 1
+    # same basin as the CPU path (the matcher is fed the device's own descriptors, see the MATCHING
+    # note in test_estimate_maps_transforms_end_to_end): Frobenius 0.15, confidence within 20 %
+    assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= 0.15
+    assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=0.2)
