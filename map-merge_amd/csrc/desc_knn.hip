@@ -94,97 +94,114 @@ k_knn_exact(const float *__restrict__ A, int na, const float *__restrict__ B, in
     }
 }
 
-// Exact k-NN for the (few) rows that miss the certificate: one BLOCK per row.  The four waves take
-// every fourth 64-target tile (staged through the wave's own LDS slab with coalesced loads), each lane
-// keeps a sorted top-16 in registers, every wave draws its k best by repeated wave-wide minimum over
-// (distance bits, index) keys, and wave 0 merges the four short lists the same way.
+// Exact k-NN for the rows that miss the certificate.  Brute force is the honest answer for them (the
+// usual cause is hundreds of near-identical targets, e.g. PFH rows of flat ground), so it has to
+// scale: a block owns 16 rows x one interleaved part of the target tiles.  The part's 64-target tiles
+// are staged through LDS ONCE for all 16 rows (16 threads per row take 4 targets each), every thread
+// keeps a sorted top-16 in registers, the 16 partial lists of a row are merged through LDS, and
+// k_knn_merge_parts merges the parts.  Keys are (distance bits, index): ties go to the lower index.
+constexpr int kFbRows = 16;
+constexpr int kFbParts = 16;
+constexpr unsigned long long kEmptyKey = 0x7f8000007fffffffull;   // (+inf, no index)
+
 template <int kD>
 __global__ void __launch_bounds__(256)
-k_knn_exact_wave(const float *__restrict__ A, const float *__restrict__ B, int nb, int k, const int *__restrict__ rows,
-                 const int *__restrict__ nrows_dev, int *__restrict__ idx, float *__restrict__ d2out)
+k_knn_exact_part(const float *__restrict__ A, const float *__restrict__ B, int nb, int k, const int *__restrict__ rows,
+                 const int *__restrict__ nrows_dev, unsigned long long *__restrict__ part_keys /* [row slot][part][kMaxK] */)
 {
-  __shared__ float tile[4][64][kD];   // odd row stride (33, 125): lane-per-row reads are conflict free
-  __shared__ unsigned long long s_keys[4][kMaxK];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float tile[64][kD];                                    // odd row stride: conflict free
+  __shared__ unsigned long long s_keys[kFbRows][16][kMaxK];
   const int nrows = *nrows_dev;
-  for (int t = blockIdx.x; t < nrows; t += gridDim.x) {   // uniform per block
-  const int row = rows[t];
-  float a[kD];
+  const int part = blockIdx.y;
+  const int t = threadIdx.x, r = t & (kFbRows - 1), ts = t >> 4;
+  const int ntiles = (nb + 63) / 64;
+  for (int g = blockIdx.x; g * kFbRows < nrows; g += gridDim.x) {   // uniform per block
+    const int slot = g * kFbRows + r;
+    const bool live = slot < nrows;
+    const int row = rows[live ? slot : g * kFbRows];
+    float a[kD];
 #pragma unroll
-  for (int d = 0; d < kD; ++d) a[d] = A[(size_t)row * kD + d];
-  float bd[kMaxK];
-  int bi[kMaxK];
+    for (int d = 0; d < kD; ++d) a[d] = A[(size_t)row * kD + d];
+    float bd[kMaxK];
+    int bi[kMaxK];
 #pragma unroll
-  for (int s = 0; s < kMaxK; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
-  for (int j0 = wave * 64; j0 < nb; j0 += 256) {
-    const int tn = min(64, nb - j0);
-    // coalesced copy of tn x kD floats; a wave only ever touches its own LDS slab
-    for (int e = lane; e < tn * kD; e += 64) (&tile[wave][0][0])[e] = B[(size_t)j0 * kD + e];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < tn) {
-      float r = 0.0f;
+    for (int s = 0; s < kMaxK; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
+    for (int tl = part; tl < ntiles; tl += kFbParts) {
+      const int j0 = tl * 64, tn = min(64, nb - j0);
+      __syncthreads();
+      for (int e = t; e < tn * kD; e += 256) (&tile[0][0])[e] = B[(size_t)j0 * kD + e];
+      __syncthreads();
 #pragma unroll
-      for (int d = 0; d < kD; ++d) {
-        const float df = a[d] - tile[wave][lane][d];
-        r = __fadd_rn(r, __fmul_rn(df, df));
-      }
-      const int j = j0 + lane;
-      if (r < bd[kMaxK - 1]) {     // a lane sees its targets in ascending index order: strict < keeps the lower index
-        float cd = r;
-        int ci = j;
-        bool carrying = false;
+      for (int u = 0; u < 4; ++u) {
+        const int jj = ts + 16 * u;
+        if (jj < tn) {
+          float rr = 0.0f;
 #pragma unroll
-        for (int s = 0; s < kMaxK; ++s) {
-          const bool sw = carrying || cd < bd[s];
-          carrying = sw;
-          const float td = bd[s];
-          const int ti = bi[s];
-          bd[s] = sw ? cd : td; bi[s] = sw ? ci : ti;
-          cd = sw ? td : cd; ci = sw ? ti : ci;
+          for (int d = 0; d < kD; ++d) {
+            const float df = a[d] - tile[jj][d];
+            rr = __fadd_rn(rr, __fmul_rn(df, df));
+          }
+          if (rr < bd[kMaxK - 1]) {     // a thread sees its targets in ascending index order: strict < keeps the lower index
+            float cd = rr;
+            int ci = j0 + jj;
+            bool carrying = false;
+#pragma unroll
+            for (int s = 0; s < kMaxK; ++s) {
+              const bool sw = carrying || cd < bd[s];
+              carrying = sw;
+              const float td = bd[s];
+              const int ti = bi[s];
+              bd[s] = sw ? cd : td; bi[s] = sw ? ci : ti;
+              cd = sw ? td : cd; ci = sw ? ti : ci;
+            }
+          }
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int s = 0; s < kMaxK; ++s) s_keys[r][ts][s] = ((unsigned long long)__float_as_uint(bd[s]) << 32) | (unsigned)bi[s];
+    __syncthreads();
+    // one thread per row: k rounds of "smallest key above the previous winner" over the 16 lists
+    if (t < kFbRows && g * kFbRows + t < nrows) {
+      unsigned long long prev = 0ull;
+      bool first = true;
+      for (int o = 0; o < k; ++o) {
+        unsigned long long best = kEmptyKey;
+        for (int l = 0; l < 16; ++l)
+          for (int s = 0; s < k; ++s) {
+            const unsigned long long key = s_keys[t][l][s];
+            if ((first || key > prev) && key < best) best = key;
+          }
+        part_keys[((size_t)(g * kFbRows + t) * kFbParts + part) * kMaxK + o] = best;
+        prev = best;
+        first = false;
+      }
+    }
+    __syncthreads();
   }
-  // per wave: merge the 64 sorted lists, k rounds of "smallest head wins"
+}
+
+__global__ void k_knn_merge_parts(const unsigned long long *__restrict__ part_keys, int k, const int *__restrict__ rows,
+                                  const int *__restrict__ nrows_dev, int *__restrict__ idx, float *__restrict__ d2out)
+{
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= *nrows_dev) return;
+  const int row = rows[slot];
+  const unsigned long long *pk = part_keys + (size_t)slot * kFbParts * kMaxK;
+  unsigned long long prev = 0ull;
+  bool first = true;
   for (int o = 0; o < k; ++o) {
-    const unsigned long long key = ((unsigned long long)__float_as_uint(bd[0]) << 32) | (unsigned)bi[0];
-    unsigned long long best = key;
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-      const unsigned long long other = __shfl_xor(best, s, kWave);
-      best = other < best ? other : best;
-    }
-    if (lane == 0) s_keys[wave][o] = best;
-    if (key == best && bd[0] < INFINITY) {   // pop (indices are unique, so exactly one lane matches)
-#pragma unroll
-      for (int s = 0; s + 1 < kMaxK; ++s) { bd[s] = bd[s + 1]; bi[s] = bi[s + 1]; }
-      bd[kMaxK - 1] = INFINITY; bi[kMaxK - 1] = 0x7fffffff;
-    }
-  }
-  __syncthreads();
-  // the four waves' lists partition the targets: wave 0 merges 4 x k keys (lane = wave * 16 + position)
-  unsigned long long key = ((lane & (kMaxK - 1)) < k) ? s_keys[lane >> 4][lane & (kMaxK - 1)] : ~0ull;
-  for (int o = 0; o < k && wave == 0; ++o) {
-    unsigned long long best = key;
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-      const unsigned long long other = __shfl_xor(best, s, kWave);
-      best = other < best ? other : best;
-    }
-    if (lane == 0) {
-      const float d = __uint_as_float((unsigned)(best >> 32));
-      idx[(size_t)row * k + o] = d < INFINITY ? (int)(unsigned)(best & 0xffffffffull) : -1;
-      d2out[(size_t)row * k + o] = d;
-    }
-    // drop the winner; an "empty" key (+inf, 0x7fffffff) may sit in several lanes and stays
-    if (key == best && (unsigned)(key >> 32) < 0x7f800000u) key = ~0ull;
-  }
-  __syncthreads();                                    // s_keys is reused by the next row
+    unsigned long long best = kEmptyKey;
+    for (int p = 0; p < kFbParts; ++p)
+      for (int s = 0; s < k; ++s) {
+        const unsigned long long key = pk[p * kMaxK + s];
+        if ((first || key > prev) && key < best) best = key;
+      }
+    const float d = __uint_as_float((unsigned)(best >> 32));
+    idx[(size_t)row * k + o] = d < INFINITY ? (int)(unsigned)(best & 0xffffffffull) : -1;
+    d2out[(size_t)row * k + o] = d;
+    prev = best;
+    first = false;
   }
 }
 
@@ -458,8 +475,13 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
               idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
   // rows without a certificate: exact brute force (the grid is sized for the worst case; blocks
   // beyond the device-side count exit at once)
-  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, (k_knn_exact_wave<kD>), dim3(na < 1024 ? na : 1024), dim3(256), 0, Ad, Bd, nb, k,
-              (const int *)fb_rows.get(), (const int *)(meta.get() + 1), idx.get(), d2.get());
+  DevBuf<unsigned long long> part_keys(c, (size_t)na * kFbParts * kMaxK);
+  const int fb_groups = div_up(na, kFbRows);
+  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, (k_knn_exact_part<kD>), dim3(fb_groups < 64 ? fb_groups : 64, kFbParts), dim3(256), 0, Ad, Bd,
+              nb, k, (const int *)fb_rows.get(), (const int *)(meta.get() + 1), part_keys.get());
+  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, k_knn_merge_parts, dim3(div_up(na, 64)), dim3(64), 0,
+              (const unsigned long long *)part_keys.get(), k, (const int *)fb_rows.get(), (const int *)(meta.get() + 1), idx.get(),
+              d2.get());
   if (c->debug) {
     unsigned *h = (unsigned *)c->pin(64);
     MM3D_HIP(hipMemcpyAsync(h, meta.get(), 16, hipMemcpyDeviceToHost, c->stream));

@@ -177,6 +177,37 @@ def test_fpfh_blocks_and_rigid_invariance(po):
     assert np.percentile(np.abs(desc - desc2).max(1), 90) < 2.0
 
 
+def test_pfh_known_answers(po):
+    """PFHSignature125 (the reference's default descriptor).  On an exact plane with exact normals every
+    pair has f1 = f2 = f3 = 0 -> bin (2, 2, 2) = 62 of the 5 x 5 x 5 histogram holds all 100 %."""
+    rng = np.random.default_rng(8)
+    uv = rng.uniform(-1, 1, (600, 2)).astype(np.float32)
+    pts = cloud(po, np.stack([uv[:, 0], uv[:, 1], np.full(600, 2.0, np.float32)], 1))
+    nrm = np.zeros(len(pts), dtype=po.NORMAL)
+    nrm["nz"] = 1.0
+    kp = pts[::60].copy()
+    desc = po.pfh_raw(pts, nrm, kp, 0.4)
+    assert desc.shape == (len(kp), 125)
+    assert np.allclose(desc[:, 62], 100.0, atol=1e-2) and np.allclose(np.delete(desc, 62, axis=1), 0.0)
+    # a keypoint without neighbours: NaN row, pruned together with the keypoint (features.cpp:118-143)
+    kp2 = kp.copy()
+    kp2["x"][1] += 50.0
+    raw = po.pfh_raw(pts, nrm, kp2, 0.4)
+    assert np.isnan(raw[1]).all() and np.isfinite(np.delete(raw, 1, axis=0)).all()
+    kept, d = po.descriptors_pfh(pts, nrm, kp2, 0.4)
+    assert len(kept) == len(kp2) - 1 and np.array_equal(kept, np.delete(kp2, 1))
+    # a single neighbour: no pair, the histogram stays zero (and is valid)
+    lone = cloud(po, np.array([[9.0, 9.0, 9.0]], np.float32))
+    ln = np.zeros(1, dtype=po.NORMAL); ln["nz"] = 1.0
+    assert not po.pfh_raw(lone, ln, lone.copy(), 0.4).any()
+    # curved surface with estimated normals: rows sum to 100, pair count n (n-1) / 2 in the increment
+    P = np.stack([uv[:, 0], uv[:, 1], 0.3 * np.sin(2 * uv[:, 0])], 1).astype(np.float32) + np.array([3, 1, 4], np.float32)
+    pts = cloud(po, P)
+    n2 = po.normals(pts, 0.25)
+    d = po.pfh_raw(pts, n2, pts[::40].copy(), 0.35)
+    assert np.allclose(d.sum(1), 100.0, atol=2e-2) and (d >= 0).all()
+
+
 def test_desc_knn_and_reciprocal_matching(po):
     rng = np.random.default_rng(5)
     A = rng.uniform(0, 30, (120, 33)).astype(np.float32)
