@@ -313,7 +313,8 @@ def main():
         npts_f = stats["pts_filtered"]
         icp_pts = sum(npts_f[i] * it for (i, j), it in zip([(i, j) for (i, j) in pairs_idx], stats["icp_iters"]))
         out = {
-            "metric": "map-pairs/sec (normals+FPFH+SAC-IA+ICP, end to end incl. per-map features)",
+            "metric": "map-pairs/sec (normals+%s+%s+ICP, end to end incl. per-map features)"
+                      % (args.descriptor, "SAC-IA" if args.method == "SAC_IA" else "matching+RANSAC"),
             "value": round(value, 4), "unit": "map-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
