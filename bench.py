@@ -25,6 +25,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 import zlib
 from concurrent.futures import ThreadPoolExecutor
@@ -76,10 +77,16 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("MM3D_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    backend = os.environ.get("MM3D_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # (test knobs: MM3D_BENCH_BACKEND=gloo MM3D_BENCH_DEVICE=0 run several ranks on ONE GPU to exercise
+        # the exchange / gather code where only a single-GPU box is available)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if args.gpus != world:
         if rank == 0:
             print(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
@@ -103,43 +110,63 @@ def main():
     torch.cuda.synchronize()
     pairs_idx = [(i, j) for i in range(n_maps - 1) for j in range(i + 1, n_maps)]
 
-    def bcast_map(owner, m):
-        """Exchange one map's feature bundle (filtered cloud, keypoints, descriptors) over RCCL."""
+    def exchange(maps, run_streams):
+        """C2: every map's feature bundle (filtered cloud, keypoints, descriptors) travels from its owner
+        to all ranks over RCCL -- one all-reduce for the sizes, one broadcast per map (the three arrays
+        packed into one byte buffer) -- and the receivers rebuild and prepare the maps on their streams
+        in parallel."""
         if world == 1:
-            return m
-        sizes = torch.zeros(2, dtype=torch.int64, device=dev)
-        if rank == owner:
-            pts, kp, ds = m.points, m.keypoints, m.descriptors
-            sizes[0], sizes[1] = len(pts), len(kp)
-        dist.broadcast(sizes, owner)
-        npts, nkp = int(sizes[0]), int(sizes[1])
-        tp = torch.empty((max(npts, 1), 16), dtype=torch.uint8, device=dev)
-        tk = torch.empty((max(nkp, 1), 16), dtype=torch.uint8, device=dev)
-        td = torch.empty((max(nkp, 1), desc_dim), dtype=torch.float32, device=dev)
-        if rank == owner:
-            L = mm.lib()
-            ctx._ck(L.mm3d_cloud_download(ctx._h, pts._h, C.c_void_p(tp.data_ptr()), C.c_size_t(16), C.c_size_t(12)))
-            ctx._ck(L.mm3d_cloud_download(ctx._h, kp._h, C.c_void_p(tk.data_ptr()), C.c_size_t(16), C.c_size_t(12)))
-            ctx._ck(L.mm3d_desc_download(ctx._h, ds._h, C.c_void_p(td.data_ptr())))
-        dist.broadcast(tp, owner)
-        dist.broadcast(tk, owner)
-        dist.broadcast(td, owner)
-        if rank == owner:
-            return m
+            return
+        sizes = torch.zeros((n_maps, 2), dtype=torch.int64, device=dev)
+        for i, m in enumerate(maps):
+            if m is not None:
+                sizes[i, 0], sizes[i, 1] = len(m.points), len(m.keypoints)
+        dist.all_reduce(sizes)                             # every row has exactly one non-zero contributor
+        sz = sizes.cpu().tolist()
+        L = mm.lib()
+        received = {}
+        for i in range(n_maps):
+            owner = sharding.map_owner(i, world)
+            npts, nkp = int(sz[i][0]), int(sz[i][1])
+            o_kp, o_ds = npts * 16, npts * 16 + nkp * 16
+            buf = torch.empty(max(o_ds + nkp * desc_dim * 4, 16), dtype=torch.uint8, device=dev)
+            if rank == owner:
+                m = maps[i]
+                ctx._ck(L.mm3d_cloud_download(ctx._h, m.points._h, C.c_void_p(buf.data_ptr()), C.c_size_t(16), C.c_size_t(12)))
+                ctx._ck(L.mm3d_cloud_download(ctx._h, m.keypoints._h, C.c_void_p(buf.data_ptr() + o_kp), C.c_size_t(16), C.c_size_t(12)))
+                ctx._ck(L.mm3d_desc_download(ctx._h, m.descriptors._h, C.c_void_p(buf.data_ptr() + o_ds)))
+            dist.broadcast(buf, owner)
+            if rank != owner:
+                received[i] = (buf, npts, nkp, o_kp, o_ds)
         torch.cuda.synchronize()
-        cp = ctx.cloud_from_ptr(tp.data_ptr(), npts)
-        ck = ctx.cloud_from_ptr(tk.data_ptr(), nkp)
-        h = C.c_void_p()
-        ctx._ck(mm.lib().mm3d_desc_create(ctx._h, C.c_void_p(td.data_ptr()), C.c_size_t(nkp), int(desc_type), C.byref(h)))
-        cd = mm.Descriptors(ctx, h)
-        return ctx.mapFromParts(cp, ck, cd)
+        todo, lock = iter(sorted(received)), threading.Lock()
+
+        def rebuild(s):
+            c = ctxs[s]
+            while True:
+                with lock:
+                    i = next(todo, None)
+                if i is None:
+                    break
+                buf, npts, nkp, o_kp, o_ds = received[i]
+                cp = c.cloud_from_ptr(buf.data_ptr(), npts)
+                ck = c.cloud_from_ptr(buf.data_ptr() + o_kp, nkp)
+                h = C.c_void_p()
+                c._ck(L.mm3d_desc_create(c._h, C.c_void_p(buf.data_ptr() + o_ds), C.c_size_t(nkp), int(desc_type), C.byref(h)))
+                m = c.mapFromParts(cp, ck, mm.Descriptors(c, h))
+                c.mapPrepare(m, params)
+                maps[i] = m
+            c.synchronize()
+
+        run_streams(rebuild)
 
     stats = {}
 
-    # Within a rank the same round-robin is applied once more over S contexts (one HIP stream, one
-    # host thread each): a pair is a chain of dependent launches with a few host round trips, so one
-    # stream leaves SIMDs idle that another stream's kernels can use.  Every context replays the
-    # whole rand() stream, exactly like the ranks do.
+    # Within a rank the maps and pairs are dealt once more over S contexts (one HIP stream, one host
+    # thread each): a pair is a chain of dependent launches with a few host round trips, so one
+    # stream leaves SIMDs idle that another stream's kernels can use.  Streams claim the next unit in
+    # order as they become free; every context replays the rand() draws of the pairs it skips,
+    # exactly like the ranks do, so the results do not depend on who ran what.
     S = max(1, args.streams)
     ctxs = [ctx] + [mm.Context(local_rank) for _ in range(S - 1)]
     tpool = ThreadPoolExecutor(S) if S > 1 else None
@@ -155,11 +182,16 @@ def main():
         maps = [None] * n_maps
         my_maps = [i for i in range(n_maps) if sharding.map_owner(i, world) == rank]
 
+        lock = threading.Lock()
+        next_map = iter(my_maps)
+
         def features(s):
             c = ctxs[s]
-            for k, i in enumerate(my_maps):
-                if k % S != s:
-                    continue
+            while True:
+                with lock:                                 # streams claim the rank's maps in order
+                    i = next(next_map, None)
+                if i is None:
+                    break
                 raw = c.cloud_from_ptr(dev_raw[i].data_ptr(), len(host[i]))
                 m = c.mapFeatures(raw, params)
                 raw.free()
@@ -169,26 +201,29 @@ def main():
 
         run_streams(features)
         t1 = time.perf_counter()
-        for i in range(n_maps):
-            owner = sharding.map_owner(i, world)
-            maps[i] = bcast_map(owner, maps[i])
-            if owner != rank:
-                ctx.mapPrepare(maps[i], params)
+        exchange(maps, run_streams)
         kn = [len(m.keypoints) for m in maps]
         live = sharding.live_pairs(n_maps, kn)
         t2 = time.perf_counter()
         mine = np.zeros(len(live), dtype=mm.PAIR)
 
+        next_pair = iter(p for p in range(len(live)) if sharding.pair_owner(p, world) == rank)
+
         def pairs(s):
             c = ctxs[s]
             c.srand(1)                                     # the reference's process starts at glibc seed 1
-            for p, (i, j) in enumerate(live):
-                # non-owners only replay the pair's rand() draws (mm3d_pair_estimate, execute = 0)
-                own = sharding.pair_owner(p, world) == rank and (p // world) % S == s
-                r = c.pairEstimate(maps[i], maps[j], params, execute=own)
-                if own:
-                    r["source_idx"], r["target_idx"] = i, j
-                    mine[p] = r
+            pos = 0                                        # pairs [0, pos) have had their rand() draws replayed here
+            while True:
+                with lock:                                 # streams claim the rank's pairs in order (dynamic balance)
+                    p = next(next_pair, None)
+                if p is None:
+                    break
+                # pairs this stream does not execute only have their rand() draws replayed
+                # (mm3d_pair_estimate, execute = 0: ~30 us of host work, no device work)
+                for q in range(pos, p):
+                    c.pairEstimate(maps[live[q][0]], maps[live[q][1]], params, execute=False)
+                mine[p] = c.pairEstimate(maps[live[p][0]], maps[live[p][1]], params, execute=True)
+                pos = p + 1
             c.synchronize()
 
         run_streams(pairs)
@@ -196,7 +231,7 @@ def main():
         mine["target_idx"] = [j for _, j in live]
         t3 = time.perf_counter()
         # C1: all-gather of the fixed-size pair records over RCCL
-        mine = sharding.gather_pair_records(mine, world, rank, dist if world > 1 else None, dev)
+        mine = sharding.gather_pair_records(mine, world, rank, dist if world > 1 else None, dev if backend == "nccl" else None)
         T = mm.globalTransforms(mine, params.confidence_threshold, n_maps)
         t4 = time.perf_counter()
         stats.update(dict(n_pairs=len(live), t_features=t1 - t0, t_exchange=t2 - t1, t_pairs=t3 - t2, t_gather_graph=t4 - t3,

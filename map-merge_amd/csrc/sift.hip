@@ -292,8 +292,9 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     gvr.pts = pv.get();
     MM3D_LAUNCH(c, "sift_dog", gr.n * 36.0, k_sift_dog, dim3(nblocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
                 (const int2 *)cur->wave_items.get(), n_items, gvr, max_radius, r2, sc, dog.get());
-    // extrema on a finer grid (25 neighbours lie within ~3 leaf sizes on a surface)
-    const Grid &gk = cloud_grid(c, cur.get(), 3.0f * scale);
+    // the extremum test walks the same grid (25 neighbours lie within ~3 leaf sizes on a surface, i.e.
+    // within one of these cells): one radix sort per octave instead of two
+    const Grid &gk = gr;
     DevBuf<float4> dogx(c, (size_t)gk.n * 2);
     MM3D_LAUNCH(c, "sift_pack", gk.n * 48.0, k_sift_dogx, dim3(div_up(gk.n, 256)), dim3(256), 0, (const float4 *)gk.sorted.get(),
                 (const float *)dog.get(), gk.n, dogx.get());

@@ -4,6 +4,9 @@ All calls go through the C ABI (libmm3d.so via map_merge_amd).  Integer/index re
 bit-exact; floating-point stages carry their tolerance in the test.  Run with `-m gpu` on the
 MI355X box.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -452,3 +455,29 @@ def test_default_configuration_end_to_end(ctx, po, mm, scene):
     # note in test_estimate_maps_transforms_end_to_end): Frobenius 0.15, confidence within 20 %
     assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= 0.15
     assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=0.2)
+
+
+def test_bench_ranks_and_streams_give_the_same_bits():
+    """bench.py end to end on a small job: 1 rank x 1 stream, 1 rank x 4 streams and 2 ranks x 2 streams
+    (the ranks share this box's single GPU through gloo: MM3D_BENCH_BACKEND / MM3D_BENCH_DEVICE) must
+    print the same pair-transform CRC -- the exchange, rebuild, replay and gather paths are exact."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--maps", "4", "--points", "40000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-cache"]
+
+    def run(cmd, env=None):
+        e = dict(os.environ)
+        e.update(env or {})
+        out = subprocess.run(cmd, cwd=root, env=e, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+    a = run([sys.executable, "bench.py", "--streams", "1"] + common)
+    b = run([sys.executable, "bench.py", "--streams", "4"] + common)
+    c = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", "29533", "bench.py", "--gpus", "2", "--streams", "2"] + common,
+            env={"MM3D_BENCH_BACKEND": "gloo", "MM3D_BENCH_DEVICE": "0"})
+    assert a["pair_transforms_crc32"] == b["pair_transforms_crc32"] == c["pair_transforms_crc32"]
+    assert a["maps_estimated"] == b["maps_estimated"] == c["maps_estimated"]
+    assert c["n_gpus"] == 2
