@@ -95,25 +95,36 @@ __device__ __forceinline__ int bin_of(double x)
 
 // 2. SPFH, wave-cooperative: a wave owns one compact patch of the surface (<= 64 points in Hilbert
 // order, the lanes that belong to the support set are live), streams the box of cells those lanes
-// can reach through LDS together with the candidates' normals, and every live lane bins the pairs
-// inside its own radius.  Every hit of one point adds the SAME float 100/(|N|-1), so a bin's value
-// depends only on its hit count: the scan counts in integers (LDS, bin-major so lane l owns bank
-// l) in whatever order the tiles arrive, and the float chain "0 + incr + incr + ..." of the CPU
-// loop is replayed once per bin at the end, bit for bit.
-constexpr int kSpfhTile = 128;
-__global__ void __launch_bounds__(256)
+// can reach through LDS together with the candidates' normals, and bins the pairs inside every live
+// lane's radius.  Every hit of one point adds the SAME float 100/(|N|-1), so a bin's value depends
+// only on its hit count: hits are counted in integers (LDS, bin-major so lane l owns bank l) in
+// whatever order they are processed, and the float chain "0 + incr + incr + ..." of the CPU loop is
+// replayed once per bin at the end, bit for bit.
+//
+// The expensive part is the pair feature (~300 VALU instructions: atan2f, two square roots, five
+// IEEE divisions, three double bin computations), so its lanes must be full.  Per tile the cheap
+// in-radius test leaves a per-lane bitset; the (owner lane, candidate) hits of the whole wave are
+// then numbered by a prefix sum, written to an LDS pool and dealt round-robin to the 64 lanes: a lane
+// works on ANY point's hit (the owner's position and normal come through the cross-lane network) and
+// bumps the owner's counters with LDS atomics.  Trip count = total hits / 64 instead of the largest
+// per-lane hit count.
+constexpr int kSpfhTile = 64;
+constexpr int kSpfhPool = 2048;
+constexpr int kSpfhWaves = 2;
+__global__ void __launch_bounds__(64 * kSpfhWaves)
 k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g,
        const float4 *__restrict__ nrm /* original order */, const float4 *__restrict__ nrm_sorted,
        const int *__restrict__ in_set, const int *__restrict__ pos, float radius, float r2, float *__restrict__ spfh /* [ns][33] */)
 {
-  __shared__ float4 s_pts[4][kSpfhTile];
-  __shared__ float4 s_nrm[4][kSpfhTile];
-  __shared__ int s_off[4][64];
-  __shared__ int s_beg[4][64];
-  __shared__ unsigned hist[4][kDim][64];
+  __shared__ float4 s_pts[kSpfhWaves][kSpfhTile];
+  __shared__ float4 s_nrm[kSpfhWaves][kSpfhTile];
+  __shared__ int s_off[kSpfhWaves][64];
+  __shared__ int s_beg[kSpfhWaves][64];
+  __shared__ unsigned hist[kSpfhWaves][kDim][64];
+  __shared__ unsigned short s_pool[kSpfhWaves][kSpfhPool];
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = bid * 4 + wave;
+  const int item = bid * kSpfhWaves + wave;
   const int2 it = item < n_items ? items[item] : make_int2(0, 0);
   const bool valid = lane < it.y;
   if (it.y == 0) return;                      // wave-uniform
@@ -136,26 +147,62 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
   const float4 *sp = s_pts[wave];
   const float4 *sn = s_nrm[wave];
   unsigned(*hw)[64] = hist[wave];
+  unsigned short *pool = s_pool[wave];
   wave_stream_box<kSpfhTile, 1>(
       g, x0, x1, y0, y1, z0, z1, s_pts[wave], s_nrm[wave], s_off[wave], s_beg[wave], lane,
       [&](int j, float4 (&out)[1]) { out[0] = nrm_sorted[j]; },
       [&](int n_tile) {
         unsigned hits[kSpfhTile / 32];
         tile_hit_mask<kSpfhTile>(sp, n_tile, q.x, q.y, q.z, r2, live, hits);
+        const int mine = __popc(hits[0]) + __popc(hits[1]);
+        cnt += mine;
+        // number the wave's hits: exclusive prefix of the per-lane counts
+        int incl = mine;
 #pragma unroll
-        for (int gq = 0; gq < kSpfhTile / 32; ++gq) cnt += __popc(hits[gq]);
-        for_each_hit(hits, [&](int k) {
-          const float4 p = sp[k];
-          if (__float_as_int(p.w) == self) return;           // p_idx == indices[idx]
-          float f1, f2, f3;
-          pair_features(q, nq, p, sn[k], f1, f2, f3);
-          const int h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
-          const int h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
-          const int h3 = bin_of(kBins * (((double)f3 + 1.0) * 0.5));
-          hw[h1][lane] += 1u;
-          hw[kBins + h2][lane] += 1u;
-          hw[2 * kBins + h3][lane] += 1u;
-        });
+        for (int o = 1; o < kWave; o <<= 1) {
+          const int t = __shfl_up(incl, o, kWave);
+          if (lane >= o) incl += t;
+        }
+        const int total = __shfl(incl, kWave - 1, kWave);
+        const int first = incl - mine;
+        for (int base = 0; base < total; base += kSpfhPool) {   // one chunk unless nearly every lane hits every candidate
+          {
+            unsigned m0 = hits[0], m1 = hits[1];
+            int r = first;
+            while (m0 | m1) {
+              int k;
+              if (m0) { k = __ffs((int)m0) - 1; m0 &= m0 - 1u; }
+              else { k = 32 + __ffs((int)m1) - 1; m1 &= m1 - 1u; }
+              if (r >= base && r < base + kSpfhPool) pool[r - base] = (unsigned short)((lane << 6) | k);
+              ++r;
+            }
+          }
+          wave_lds_fence();
+          const int n = min(kSpfhPool, total - base);
+          for (int e0 = 0; e0 < n; e0 += kWave) {                 // all 64 lanes take part in the cross-lane reads
+            const int e = e0 + lane;
+            const bool has = e < n;
+            const unsigned ent = has ? pool[e] : 0u;
+            const int o = (int)(ent >> 6), k = (int)(ent & 63u);
+            float4 qo, no;
+            qo.x = __shfl(q.x, o, kWave); qo.y = __shfl(q.y, o, kWave); qo.z = __shfl(q.z, o, kWave); qo.w = __shfl(q.w, o, kWave);
+            no.x = __shfl(nq.x, o, kWave); no.y = __shfl(nq.y, o, kWave); no.z = __shfl(nq.z, o, kWave); no.w = 0.f;
+            if (has) {
+              const float4 p = sp[k];
+              if (__float_as_int(p.w) != __float_as_int(qo.w)) {   // p_idx == indices[idx] is skipped
+                float f1, f2, f3;
+                pair_features(qo, no, p, sn[k], f1, f2, f3);
+                const int h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
+                const int h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
+                const int h3 = bin_of(kBins * (((double)f3 + 1.0) * 0.5));
+                atomicAdd(&hw[h1][o], 1u);
+                atomicAdd(&hw[kBins + h2][o], 1u);
+                atomicAdd(&hw[2 * kBins + h3][o], 1u);
+              }
+            }
+          }
+          wave_lds_fence();
+        }
       });
   if (!live) return;
   const float hist_incr = 100.0f / (float)(cnt - 1);
@@ -287,7 +334,7 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
   if (ns > 0) {
     cloud_hilbert(c, points);                            // query order + wave work items (shared with ICP / score)
     const int n_items = points->n_wave_items;
-    MM3D_LAUNCH(c, "spfh", ns * 156.0, k_spfh, dim3(div_up(n_items, 4)), dim3(256), 0, (const float4 *)points->hil_pts.get(),
+    MM3D_LAUNCH(c, "spfh", ns * 156.0, k_spfh, dim3(div_up(n_items, kSpfhWaves)), dim3(64 * kSpfhWaves), 0, (const float4 *)points->hil_pts.get(),
                 (const int2 *)points->wave_items.get(), n_items, g.view(), (const float4 *)normals->nrm.get(),
                 (const float4 *)nrm_sorted.get(), (const int *)in_set.get(), (const int *)pos.get(), (float)radius, r2, spfh.get());
   }
