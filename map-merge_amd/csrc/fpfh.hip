@@ -203,7 +203,9 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
           }
           wave_lds_fence();
         }
-      });
+      },
+      // only points inside the patch's bounding box grown by the radius can be in range
+      KeepInBox{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri});
   if (!live) return;
   const float hist_incr = 100.0f / (float)(cnt - 1);
   float *o = spfh + (size_t)pos[self] * kDim;

@@ -98,7 +98,9 @@ k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int
                                       den[s] += w;
                                     }
                                   }
-                                });
+                                },
+                                // only points inside the patch's bounding box grown by the radius can be in range
+                                KeepInBox{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri});
   if (!valid) return;
   float prev = num[0] / den[0];
   float *o = dog + (size_t)__float_as_int(q.w) * kDog;
