@@ -78,7 +78,10 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
 {
   __shared__ float Ts[16];
   __shared__ double red[4][kAcc];
-  __shared__ float4 s_pts[4][kTile];
+  // staged candidates, one array per component: four candidates' x (y, z, index) are ONE 16-byte
+  // broadcast read, and the distance arithmetic of candidate pairs packs into v_pk_* instructions
+  __shared__ __attribute__((aligned(16))) float s_cx[4][kTile], s_cy[4][kTile], s_cz[4][kTile];
+  __shared__ __attribute__((aligned(16))) unsigned s_cw[4][kTile];
   __shared__ int s_off[4][64];
   __shared__ int s_beg[4][64];
   if (MODE == 0 && st->done) return;
@@ -115,7 +118,7 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
   // (d2 bits, original index) as one 64-bit key: d2 >= 0 so its bits order like the value, and the
   // low word breaks ties towards the lower original index, like the CPU path
   unsigned long long bkey = ~0ull;
-  float best = INFINITY;
+  float best = INFINITY, bestd = INFINITY;
 
   for (int pass = 0; pass < 64; ++pass) {
     if (!__ballot(active)) break;
@@ -178,7 +181,15 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
 #pragma unroll
         for (int u = 0; u < kTile / kWave; ++u) {
           const int s = lane + u * kWave;
-          if (s < cnt) s_pts[wave][s] = stage[u];
+          if (s < cnt) {
+            s_cx[wave][s] = stage[u].x; s_cy[wave][s] = stage[u].y; s_cz[wave][s] = stage[u].z;
+            s_cw[wave][s] = __float_as_uint(stage[u].w);
+          }
+        }
+        // pad to a multiple of four with points at infinity (distance +inf never wins)
+        if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) {
+          s_cx[wave][cnt + lane] = INFINITY; s_cy[wave][cnt + lane] = INFINITY; s_cz[wave][cnt + lane] = INFINITY;
+          s_cw[wave][cnt + lane] = 0x7fffffffu;
         }
         wave_lds_sync();
 #if defined(MM3D_ABL) && MM3D_ABL == 1
@@ -186,19 +197,32 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
 #else
         if (active) {
 #endif
-#pragma unroll 4
-          for (int k = 0; k < cnt; ++k) {
-            const float4 q = s_pts[wave][k];
-            const float d = dist2(p.x, p.y, p.z, q.x, q.y, q.z);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_uint(q.w);
-            bkey = key < bkey ? key : bkey;
+          for (int k = 0; k < cnt; k += 4) {
+            const float4 X = *reinterpret_cast<const float4 *>(&s_cx[wave][k]);
+            const float4 Y = *reinterpret_cast<const float4 *>(&s_cy[wave][k]);
+            const float4 Z = *reinterpret_cast<const float4 *>(&s_cz[wave][k]);
+            const float d0 = dist2(p.x, p.y, p.z, X.x, Y.x, Z.x), d1 = dist2(p.x, p.y, p.z, X.y, Y.y, Z.y);
+            const float d2 = dist2(p.x, p.y, p.z, X.z, Y.z, Z.z), d3 = dist2(p.x, p.y, p.z, X.w, Y.w, Z.w);
+            if (MODE == 1) {
+              // transformScore only needs the distance
+              bestd = fminf(fminf(bestd, fminf(d0, d1)), fminf(d2, d3));
+            } else {
+              const uint4 W = *reinterpret_cast<const uint4 *>(&s_cw[wave][k]);
+              const unsigned long long k0 = ((unsigned long long)__float_as_uint(d0) << 32) | W.x;
+              const unsigned long long k1 = ((unsigned long long)__float_as_uint(d1) << 32) | W.y;
+              const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2) << 32) | W.z;
+              const unsigned long long k3 = ((unsigned long long)__float_as_uint(d3) << 32) | W.w;
+              const unsigned long long a = k0 < k1 ? k0 : k1, b2 = k2 < k3 ? k2 : k3;
+              const unsigned long long m = a < b2 ? a : b2;
+              bkey = m < bkey ? m : bkey;
+            }
           }
         }
         wave_lds_sync();
       }
     }
     // what the scanned box proves: every target point closer than `guard` to this lane has been seen
-    best = (bkey == ~0ull) ? INFINITY : __uint_as_float((unsigned)(bkey >> 32));
+    best = MODE == 1 ? bestd : ((bkey == ~0ull) ? INFINITY : __uint_as_float((unsigned)(bkey >> 32)));
     if (active) {
       const float gx0 = (lx - E > 0) ? p.x - (g.minx + (float)(lx - E) * g.cell) : INFINITY;
       const float gx1 = (hx + E < g.dx - 1) ? (g.minx + (float)(hx + E + 1) * g.cell) - p.x : INFINITY;
