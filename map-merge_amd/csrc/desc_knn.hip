@@ -477,7 +477,7 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
   // beyond the device-side count exit at once)
   DevBuf<unsigned long long> part_keys(c, (size_t)na * kFbParts * kMaxK);
   const int fb_groups = div_up(na, kFbRows);
-  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, (k_knn_exact_part<kD>), dim3(fb_groups < 64 ? fb_groups : 64, kFbParts), dim3(256), 0, Ad, Bd,
+  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, (k_knn_exact_part<kD>), dim3(fb_groups < 16 ? fb_groups : 16, kFbParts), dim3(256), 0, Ad, Bd,
               nb, k, (const int *)fb_rows.get(), (const int *)(meta.get() + 1), part_keys.get());
   MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, k_knn_merge_parts, dim3(div_up(na, 64)), dim3(64), 0,
               (const unsigned long long *)part_keys.get(), k, (const int *)fb_rows.get(), (const int *)(meta.get() + 1), idx.get(),
