@@ -482,6 +482,7 @@ int mm3d_map_prepare(mm3d_ctx *ctx, mm3d_map *m, const mm3d_params *p)
     prepare_pair_search(ctx, m->points, p->max_correspondence_distance, p->max_correspondence_distance);
     if (p->estimation_method == MM3D_EST_SAC_IA) prepare_sacia_target(ctx, m->keypoints, (float)p->max_correspondence_distance);
     (void)cloud_host(ctx, m->keypoints);
+    desc_knn_prepare_target(ctx, m->desc);
     ctx->sync();
   });
 }

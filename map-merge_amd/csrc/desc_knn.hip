@@ -433,6 +433,28 @@ k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, i
   if (!certified && lane == 0) fb_rows[atomicAdd(fb_count, 1)] = a;
 }
 
+// column sums and MFMA-ordered operands of a TARGET set
+template <int kD>
+static void knn_target_operands(Context *c, const mm3d_desc *B, DevBuf<float> &colsum, DevBuf<float> &Bp)
+{
+  constexpr int kKP = knn_kp(kD), kSteps = kKP / 2;
+  const int nb = (int)B->n, nb_tiles = (nb + 31) / 32;
+  colsum = DevBuf<float>(c, 128);
+  Bp = DevBuf<float>(c, (size_t)nb_tiles * kSteps * 64);
+  MM3D_HIP(hipMemsetAsync(colsum.get(), 0, 128 * sizeof(float), c->stream));
+  MM3D_LAUNCH(c, "desc_knn_prep", nb * kD * 4.0, (k_knn_colsum<kD>), dim3(64), dim3(256), 0, (const float *)B->data.get(), nb, colsum.get());
+  MM3D_LAUNCH(c, "desc_knn_prep", nb * (kD + kKP) * 4.0, (k_knn_prep<kD>), dim3(div_up((size_t)nb_tiles * kSteps * 64, 256)), dim3(256), 0,
+              (const float *)B->data.get(), nb, nb_tiles, 1, (const float *)colsum.get(), 1.0f / (float)nb, Bp.get());
+}
+
+void desc_knn_prepare_target(Context *c, const mm3d_desc *B_)
+{
+  auto *B = const_cast<mm3d_desc *>(B_);
+  if (B->n < 64 || B->knn_Bp.get()) return;
+  if (B->dim == 33) knn_target_operands<33>(c, B, B->knn_colsum, B->knn_Bp);
+  else if (B->dim == 125) knn_target_operands<125>(c, B, B->knn_colsum, B->knn_Bp);
+}
+
 template <int kD>
 static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2)
 {
@@ -448,17 +470,20 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
     return;
   }
   const int na_tiles = (na + 31) / 32, nb_tiles = (nb + 31) / 32;
-  DevBuf<float> Ap(c, (size_t)na_tiles * kSteps * 64), Bp(c, (size_t)nb_tiles * kSteps * 64);
+  DevBuf<float> Ap(c, (size_t)na_tiles * kSteps * 64);
   DevBuf<unsigned> meta(c, 4);   // [1] fallback count
   MM3D_HIP(hipMemsetAsync(meta.get(), 0, 16, c->stream));
-  DevBuf<float> colsum(c, 128);
-  MM3D_HIP(hipMemsetAsync(colsum.get(), 0, 128 * sizeof(float), c->stream));
-  MM3D_LAUNCH(c, "desc_knn_prep", nb * kD * 4.0, (k_knn_colsum<kD>), dim3(64), dim3(256), 0, Bd, nb, colsum.get());
+  // target-side operands: cached on the descriptor set when it was prepared, else built here
+  DevBuf<float> colsum_tmp, Bp_tmp;
+  const float *colsum = B->knn_colsum.get(), *Bp = B->knn_Bp.get();
+  if (!colsum || !Bp) {
+    knn_target_operands<kD>(c, B, colsum_tmp, Bp_tmp);
+    colsum = colsum_tmp.get();
+    Bp = Bp_tmp.get();
+  }
   const float inv_nb = 1.0f / (float)nb;
   MM3D_LAUNCH(c, "desc_knn_prep", na * (kD + kKP) * 4.0, (k_knn_prep<kD>), dim3(div_up((size_t)na_tiles * kSteps * 64, 256)), dim3(256), 0, Ad, na,
-              na_tiles, 0, (const float *)colsum.get(), inv_nb, Ap.get());
-  MM3D_LAUNCH(c, "desc_knn_prep", nb * (kD + kKP) * 4.0, (k_knn_prep<kD>), dim3(div_up((size_t)nb_tiles * kSteps * 64, 256)), dim3(256), 0, Bd, nb,
-              nb_tiles, 1, (const float *)colsum.get(), inv_nb, Bp.get());
+              na_tiles, 0, colsum, inv_nb, Ap.get());
   // few query tiles (SAC-IA's sampled rows): split the targets over `parts` blocks per query tile so
   // that the launch still has >= 2 blocks per CU; each part keeps its own 8 lists per query
   int parts = 1;
@@ -468,10 +493,10 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
   DevBuf<int> cand_i(c, (size_t)na * n_lists * kListLen);
   // roofline unit for this kernel is FLOPs (2 * na * nb * kKP per launch), reported as such by bench.py
   MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, (k_knn_mfma<kD>), dim3(na_tiles, parts),
-              dim3(256), 0, (const float *)Ap.get(), na, (const float *)Bp.get(), nb, nb_tiles, cand_d.get(), cand_i.get());
+              dim3(256), 0, (const float *)Ap.get(), na, Bp, nb, nb_tiles, cand_d.get(), cand_i.get());
   DevBuf<int> fb_rows(c, na);
   MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * (kD * 4 + 8) + kD * 4), (k_knn_rerank<kD>), dim3(div_up(na, 4)), dim3(256), 0,
-              Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), (const float *)colsum.get(), inv_nb,
+              Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
               idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
   // rows without a certificate: exact brute force (the grid is sized for the worst case; blocks
   // beyond the device-side count exit at once)

@@ -85,6 +85,10 @@ struct mm3d_desc {
   size_t n = 0;
   int dim = 0;
   int type = 0;
+  // target-side operands of the MFMA k-NN (column sums + centred, augmented, MFMA-ordered rows):
+  // they depend on this set alone, so a map that is the target of 15 pairs prepares them once
+  // (desc_knn_prepare_target, called from mm3d_map_prepare)
+  mm3d::DevBuf<float> knn_colsum, knn_Bp;
 };
 
 struct mm3d_map {
@@ -137,6 +141,8 @@ mm3d_desc *compute_pfh(Context *c, const mm3d_cloud *points, const mm3d_normals 
 // desc_knn.hip
 // k nearest rows of B for every row of A (squared L2, FLANN accumulation order); idx -1 padded
 void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2);
+// cache the target-side operands of B on the set itself (a no-op for small or already prepared sets)
+void desc_knn_prepare_target(Context *c, const mm3d_desc *B);
 // the same for a subset of A's rows given as a device index list; result row r belongs to rows[r]
 void desc_knn_rows(Context *c, const mm3d_desc *A, const int *rows_dev, int n_rows, const mm3d_desc *B, int k,
                    DevBuf<int> &idx, DevBuf<float> &d2);
