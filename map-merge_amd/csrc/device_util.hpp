@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "types.hpp"
 
 namespace mm3d {
@@ -226,7 +228,10 @@ __device__ __forceinline__ void wave_stream_box(const GridView &g, int x0, int x
         kept += __popcll(m);
       }
       wave_lds_fence();
-      scan(kept);
+      // a scan that also takes a bool is told whether this tile IS the whole box (one header round, one
+      // tile): a caller that needs a second look at the same candidates can then take it from LDS
+      if constexpr (std::is_invocable_v<Scan, int, bool>) scan(kept, nrows <= kWave && total <= TILE);
+      else scan(kept);
       wave_lds_fence();
     }
   }

@@ -112,14 +112,17 @@ k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int
   }
 }
 
-// DoG rows in the extrema grid's sorted order, two float4 per point: (d0,d1,d2,d3) and (d4,-,-,-)
+// per point, in the grid's sorted order, two float4: (mn1, mn2, mn3, mx1) and (mx2, mx3, -, -)
 __global__ void k_sift_dogx(const float4 *__restrict__ sorted, const float *__restrict__ dog, int n, float4 *__restrict__ dogx)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const float *d = dog + (size_t)__float_as_int(sorted[j].w) * kDog;
-  dogx[j] = make_float4(d[0], d[1], d[2], d[3]);
-  dogx[n + j] = make_float4(d[4], 0.f, 0.f, 0.f);
+  // what a neighbour contributes to the extremum tests of scale s = 1, 2, 3: the min and the max of its
+  // own DoG over s-1, s, s+1 (computed once per point instead of once per (query, neighbour))
+  dogx[j] = make_float4(fminf(fminf(d[0], d[1]), d[2]), fminf(fminf(d[1], d[2]), d[3]), fminf(fminf(d[2], d[3]), d[4]),
+                        fmaxf(fmaxf(d[0], d[1]), d[2]));
+  dogx[n + j] = make_float4(fmaxf(fmaxf(d[1], d[2]), d[3]), fmaxf(fmaxf(d[2], d[3]), d[4]), 0.f, 0.f);
 }
 
 // findScaleSpaceExtrema
@@ -177,46 +180,49 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
     unsigned long long vmin[3], vmax[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) { vmin[s] = ~0ull; vmax[s] = ~0ull; }
+    // scan 2 (below): how many points are closer than each nearest violator, and how many lie within guard
+    int cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0}, cg = 0;
+    auto count_closer = [&](int cnt) {
+      if (!active) return;
+      for (int k = 0; k < cnt; ++k) {
+        const float4 c = sp[k];
+        const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_uint(c.w);
+        cg += (d2 <= guard2) ? 1 : 0;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          cmin[s] += (key < vmin[s]) ? 1 : 0;
+          cmax[s] += (key < vmax[s]) ? 1 : 0;
+        }
+      }
+    };
+    bool counted = false;                       // wave-uniform
     wave_stream_box<kSiftTile, 2>(
         g, x0, x1, y0, y1, z0, z1, s_pts[wave], s_x[wave], s_off[wave], s_beg[wave], lane,
         [&](int j, float4 (&out)[2]) { out[0] = dogx[j]; out[1] = dogx[ngrid + j]; },
-        [&](int cnt) {
-          if (!active) return;
-          for (int k = 0; k < cnt; ++k) {
-            const float4 c = sp[k];
-            const float4 a = sx[k];
-            const float d4 = sx[kSiftTile + k].x;
-            const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_uint(c.w);
-            // min / max of the candidate's DoG over scales s-1, s, s+1 for s = 1, 2, 3
-            const float mn[3] = {fminf(fminf(a.x, a.y), a.z), fminf(fminf(a.y, a.z), a.w), fminf(fminf(a.z, a.w), d4)};
-            const float mx[3] = {fmaxf(fmaxf(a.x, a.y), a.z), fmaxf(fmaxf(a.y, a.z), a.w), fmaxf(fmaxf(a.z, a.w), d4)};
+        [&](int cnt, bool whole_box) {
+          if (active)
+            for (int k = 0; k < cnt; ++k) {
+              const float4 c = sp[k];
+              const float4 a = sx[k];
+              const float4 b = sx[kSiftTile + k];
+              const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
+              const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_uint(c.w);
+              // min / max of the candidate's DoG over scales s-1, s, s+1 for s = 1, 2, 3 (k_sift_dogx)
+              const float mn[3] = {a.x, a.y, a.z};
+              const float mx[3] = {a.w, b.x, b.y};
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-              if (mn[s] < v[s] && key < vmin[s]) vmin[s] = key;
-              if (mx[s] > v[s] && key < vmax[s]) vmax[s] = key;
+              for (int s = 0; s < 3; ++s) {
+                if (mn[s] < v[s] && key < vmin[s]) vmin[s] = key;
+                if (mx[s] > v[s] && key < vmax[s]) vmax[s] = key;
+              }
             }
-          }
+          // the usual case: the whole box was this one tile, so the counting scan reads it from LDS again
+          if (whole_box) { count_closer(cnt); counted = true; }
         });
-    // scan 2: how many points are closer than each nearest violator, and how many lie within guard
-    int cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0}, cg = 0;
-    wave_stream_box<kSiftTile, 0>(g, x0, x1, y0, y1, z0, z1, s_pts[wave], (float4 *)nullptr, s_off[wave], s_beg[wave], lane,
-                                  [](int, float4 (&)[1]) {},
-                                  [&](int cnt) {
-                                    if (!active) return;
-                                    for (int k = 0; k < cnt; ++k) {
-                                      const float4 c = sp[k];
-                                      const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
-                                      const unsigned long long key =
-                                          ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_uint(c.w);
-                                      cg += (d2 <= guard2) ? 1 : 0;
-#pragma unroll
-                                      for (int s = 0; s < 3; ++s) {
-                                        cmin[s] += (key < vmin[s]) ? 1 : 0;
-                                        cmax[s] += (key < vmax[s]) ? 1 : 0;
-                                      }
-                                    }
-                                  });
+    if (!counted)
+      wave_stream_box<kSiftTile, 0>(g, x0, x1, y0, y1, z0, z1, s_pts[wave], (float4 *)nullptr, s_off[wave], s_beg[wave], lane,
+                                    [](int, float4 (&)[1]) {}, count_closer);
     if (active) {
       const int kk = n_total < kKnn ? n_total : kKnn;
       const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dx - 1 && y1 == g.dy - 1 && z1 == g.dz - 1;
