@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -294,11 +295,15 @@ def main():
         iso = ctx.profile_entries()
         for m in two:
             m.free()
+    # HBM-side traffic per launch from the most recent committed PMC passes (scripts/profile_round.sh)
+    pmc_traffic, pmc_source = {}, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01c_traffic.json")) as f:
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+        with open(latest) as f:
             pmc_traffic = json.load(f)["bytes_per_launch"]
+        pmc_source = "profiles/" + os.path.basename(latest).replace("traffic.json", "pmc_hbm_traffic.csv")
     except Exception:
-        pmc_traffic = {}
+        pass
 
     if rank == 0:
         n_pairs = stats["n_pairs"]
@@ -325,7 +330,7 @@ def main():
             # HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 per
             # the gfx950 note + WRITE_SIZE); null when that kernel was not in the counted run
             roofline["traffic"] = pmc_traffic.get(dom[0])
-            roofline["traffic_source"] = "profiles/r01c_pmc_hbm_traffic.csv" if dom[0] in pmc_traffic else None
+            roofline["traffic_source"] = pmc_source if dom[0] in pmc_traffic else None
             if dom[0] in iso and iso[dom[0]]["launches"]:
                 iso_ms = iso[dom[0]]["ms"] / iso[dom[0]]["launches"]
                 iso_work = iso[dom[0]]["bytes"] / iso[dom[0]]["launches"]

@@ -305,14 +305,56 @@ __global__ void k_cell_keys(const float4 *__restrict__ pts, int n, float minx, f
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
-  vals[i] = (uint32_t)i;
-  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = invalid_key; return; }
+  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = invalid_key; vals[i] = 0u; return; }
   int cx = clampi(cell_floor(p.x, minx, inv), 0, dx - 1);
   int cy = clampi(cell_floor(p.y, miny, inv), 0, dy - 1);
   int cz = clampi(cell_floor(p.z, minz, inv), 0, dz - 1);
   uint32_t key = (uint32_t)((cz * dy + cy) * dx + cx);
   keys[i] = key;
-  atomicAdd(&counts[key], 1);
+  vals[i] = (uint32_t)atomicAdd(&counts[key], 1);   // arrival rank in the cell (k_cell_scatter)
+}
+
+// Cell sort without a radix sort.  The keys are dense cell numbers, so a counting sort needs only
+// the histogram the grid wants anyway: (1) k_cell_keys also keeps each point's arrival rank in its
+// cell (atomicAdd's return value: arbitrary order), (2) after the scan every point is dropped into an
+// arbitrary slot of its cell, (3) every point finds its STABLE place by counting the points of its
+// cell with a smaller index -- a handful of L2-resident reads -- and is written there.  The result
+// is exactly the stable sort by (cell, original index), with three small kernels and the scan.
+// Cells longer than kCellSortMax (degenerate clouds) leave that to the rocPRIM path.
+constexpr int kCellSortMax = 4096;
+
+__global__ void k_cell_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ranks, const int *__restrict__ cell_start,
+                               int n, uint32_t invalid_key, int *__restrict__ slots, int *__restrict__ too_long)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = keys[i];
+  if (key == invalid_key) return;
+  const int b = cell_start[key];
+  slots[b + (int)ranks[i]] = i;
+  if (cell_start[key + 1] - b > kCellSortMax) *too_long = 1;
+}
+
+__global__ void k_cell_place(const float4 *__restrict__ pts, const uint32_t *__restrict__ keys, const int *__restrict__ cell_start,
+                             const int *__restrict__ slots, int n, uint32_t invalid_key, const int *__restrict__ too_long,
+                             float4 *__restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || *too_long) return;
+  const uint32_t key = keys[i];
+  if (key == invalid_key) return;
+  const int b = cell_start[key], e = cell_start[key + 1];
+  int r = 0;
+  for (int j = b; j < e; ++j) r += slots[j] < i ? 1 : 0;
+  float4 p = pts[i];
+  p.w = __int_as_float(i);
+  out[b + r] = p;
+}
+
+__global__ void k_iota_u32(uint32_t *__restrict__ v, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (uint32_t)i;
 }
 
 __global__ void k_gather_sorted(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, int n,
@@ -357,19 +399,34 @@ const Grid &cloud_grid(Context *c, const mm3d_cloud *cl_, float cell)
     const int n = (int)cl->n;
     DevBuf<int> counts(c, ncell + 1);
     MM3D_HIP(hipMemsetAsync(counts.get(), 0, (ncell + 1) * sizeof(int), c->stream));
-    DevBuf<uint32_t> keys(c, n), vals(c, n), keys2(c, n), vals2(c, n);
+    DevBuf<uint32_t> keys(c, n), ranks(c, n);
     const uint32_t invalid = (uint32_t)ncell;   // sorts after every real cell
     MM3D_LAUNCH(c, "grid_cell_keys", n * 24.0, k_cell_keys, dim3(div_up(n, 256)), dim3(256), 0, cl->pts.get(), n,
                 g->mn[0], g->mn[1], g->mn[2], 1.0f / g->cell, g->dims[0], g->dims[1], g->dims[2], keys.get(),
-                vals.get(), counts.get(), invalid);
-    int bits = 1;
-    while (((size_t)1 << bits) <= ncell) ++bits;
-    sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), n, bits);
+                ranks.get(), counts.get(), invalid);
     g->cell_start = DevBuf<int>(c, ncell + 1);
     exclusive_scan_int(c, counts.get(), g->cell_start.get(), ncell + 1);
     g->sorted = DevBuf<float4>(c, nfin);
-    MM3D_LAUNCH(c, "grid_gather", nfin * 36.0, k_gather_sorted, dim3(div_up(nfin, 256)), dim3(256), 0, cl->pts.get(),
-                vals2.get(), (int)nfin, g->sorted.get());
+    DevBuf<int> slots(c, nfin), too_long(c, 1);
+    MM3D_HIP(hipMemsetAsync(too_long.get(), 0, sizeof(int), c->stream));
+    MM3D_LAUNCH(c, "grid_cell_sort", n * 16.0, k_cell_scatter, dim3(div_up(n, 256)), dim3(256), 0, (const uint32_t *)keys.get(),
+                (const uint32_t *)ranks.get(), (const int *)g->cell_start.get(), n, invalid, slots.get(), too_long.get());
+    MM3D_LAUNCH(c, "grid_cell_sort", n * 40.0, k_cell_place, dim3(div_up(n, 256)), dim3(256), 0, cl->pts.get(),
+                (const uint32_t *)keys.get(), (const int *)g->cell_start.get(), (const int *)slots.get(), n, invalid,
+                (const int *)too_long.get(), g->sorted.get());
+    int *h_long = (int *)c->pin(64);
+    MM3D_HIP(hipMemcpyAsync(h_long, too_long.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    if (*h_long) {
+      // a cell with thousands of points: stable radix sort of (cell, index) instead
+      DevBuf<uint32_t> vals(c, n), keys2(c, n), vals2(c, n);
+      MM3D_LAUNCH(c, "grid_cell_keys", n * 8.0, k_iota_u32, dim3(div_up(n, 256)), dim3(256), 0, vals.get(), n);
+      int bits = 1;
+      while (((size_t)1 << bits) <= ncell) ++bits;
+      sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), n, bits);
+      MM3D_LAUNCH(c, "grid_gather", nfin * 36.0, k_gather_sorted, dim3(div_up(nfin, 256)), dim3(256), 0, cl->pts.get(),
+                  vals2.get(), (int)nfin, g->sorted.get());
+    }
     g->n = (int)nfin;
     c->sync();   // temporaries return to the pool after the stream is done with them
   }

@@ -97,10 +97,12 @@ k_sacia_err(const float4 *__restrict__ skp, int ns, int ns_pad, GridView g, cons
   const float4 s = skp[i];
   const float3 p = xform(Tl, s.x, s.y, s.z);
   float best = INFINITY;
-  // The kernel is VALU-bound on candidate distance tests (measured; 500 x K_s queries per pair), so the
-  // stencil walk is taken out of it: the target grid carries, per cell, the merged list of its
-  // 5x5x5 block (cell = radius / 2, grid_ensure_nblists), and a query scans ONE contiguous span.  An
-  // empty span is the "nothing in range" answer most wrong hypotheses get.
+  // 500 x K_s queries per pair against the same K_t targets: the stencil walk is taken out of the
+  // query.  The target grid carries, per cell, the merged list of its 3x3x3 block (cell = radius,
+  // grid_ensure_nblists), and a query scans ONE contiguous span; an empty span is the "nothing in
+  // range" answer most wrong hypotheses get.  (5x5x5 blocks of half-size cells have 30 % fewer
+  // candidates per query but a 5x larger table that no longer stays in L2: measured equal, 35x the
+  // HBM-side traffic.)
   const int cx = cell_floor(p.x, g.minx, g.inv), cy = cell_floor(p.y, g.miny, g.inv), cz = cell_floor(p.z, g.minz, g.inv);
   const bool inside = cx >= 0 && cx < g.dx && cy >= 0 && cy < g.dy && cz >= 0 && cz < g.dz;
   if (inside) {
@@ -197,11 +199,11 @@ __global__ void __launch_bounds__(256) k_seq_sum(const float *__restrict__ E, in
 static const Grid &sacia_target_grid(Context *c, const mm3d_cloud *tgt_kp, float corr_thresh)
 {
   const float radius = std::sqrt(corr_thresh > 0.f ? corr_thresh : 0.f);
-  // cell a hair larger than half the search radius: everything within the radius of a point of cell c
-  // lies in c's 5x5x5 block (cloud_grid may only ever ENLARGE the cell, which keeps that true)
-  const float cell = radius * 0.5005f > 0.125f ? radius * 0.5005f : 0.125f;
+  // cell a hair larger than the search radius: everything within the radius of a point of cell c
+  // lies in c's 3x3x3 block (cloud_grid may only ever ENLARGE the cell, which keeps that true)
+  const float cell = radius * 1.001f > 0.25f ? radius * 1.001f : 0.25f;
   const Grid &g = cloud_grid(c, tgt_kp, cell);
-  grid_ensure_nblists(c, g, 2);
+  grid_ensure_nblists(c, g, 1);
   return g;
 }
 
