@@ -481,3 +481,17 @@ def test_bench_ranks_and_streams_give_the_same_bits():
     assert a["pair_transforms_crc32"] == b["pair_transforms_crc32"] == c["pair_transforms_crc32"]
     assert a["maps_estimated"] == b["maps_estimated"] == c["maps_estimated"]
     assert c["n_gpus"] == 2
+
+
+def test_pfh_neighbourhoods_beyond_lds(ctx, po, scene):
+    """More than 1024 neighbours per keypoint: the neighbour list no longer fits the block's LDS and the
+    keypoint goes through the global-scratch pass of the same kernel."""
+    m = scene[0]
+    kp = m["kp_raw"][:6].copy()
+    radius = 2.2                                          # ~1500-3000 neighbours on this scene
+    kp_ref, ref = po.descriptors_pfh(m["filt"], m["nrm"], kp, radius)
+    k = ctx.cloud(kp)
+    got = ctx.computeLocalDescriptors(ctx.cloud(m["filt"]), ctx.normals(m["nrm"]), k, 0, radius).numpy()
+    assert got.shape == ref.shape == (6, 125)
+    assert np.allclose(got.sum(axis=1), 100.0, atol=5e-2)
+    assert np.abs(got - ref).max() <= 2e-2, np.abs(got - ref).max()
