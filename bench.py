@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--streams", type=int, default=16, help="contexts (HIP stream + host thread) per GPU")
+    ap.add_argument("--feature-streams", type=int, default=6,
+                    help="one GPU only: pipeline the stages, this many streams extract features (0 = two barriered stages)")
     ap.add_argument("--descriptor", choices=["FPFH", "PFH"], default="FPFH")
     ap.add_argument("--method", choices=["SAC_IA", "MATCHING"], default="SAC_IA")
     ap.add_argument("--kernel-table", default=None, help="write rank 0's full per-kernel HIP-event table (CSV) here")
@@ -243,6 +245,82 @@ def main():
         for m in maps:
             m.free()
         return T
+
+    def step_pipelined():
+        """One GPU: no exchange separates the stages, so a pair starts as soon as its two maps exist.  Only
+        `--feature-streams` of the streams extract features (maps finish earlier that way), the others -- and
+        the feature streams once the maps are handed out -- claim pairs in order and wait for their maps."""
+        t0 = time.perf_counter()
+        maps, kn = [None] * n_maps, [0] * n_maps
+        ready = [threading.Event() for _ in range(n_maps)]
+        lock = threading.Lock()
+        next_map, next_pair = iter(range(n_maps)), iter(range(len(pairs_idx)))
+        recs = np.zeros(len(pairs_idx), dtype=mm.PAIR)
+        is_live = np.zeros(len(pairs_idx), dtype=bool)
+        t_last_map = [t0]
+        F = max(1, min(S, args.feature_streams))
+
+        def live(q):
+            i, j = pairs_idx[q]
+            for e in (ready[i], ready[j]):
+                if not e.wait(timeout=300):
+                    raise RuntimeError("a map never became ready")
+            return kn[i] > 0 and kn[j] > 0
+
+        def worker(s):
+            c = ctxs[s]
+            c.srand(1)                                     # the reference's process starts at glibc seed 1
+            try:
+                while s < F:
+                    with lock:
+                        i = next(next_map, None)
+                    if i is None:
+                        break
+                    raw = c.cloud_from_ptr(dev_raw[i].data_ptr(), len(host[i]))
+                    m = c.mapFeatures(raw, params)
+                    raw.free()
+                    c.mapPrepare(m, params)
+                    maps[i], kn[i] = m, len(m.keypoints)
+                    with lock:
+                        t_last_map[0] = max(t_last_map[0], time.perf_counter())
+                    ready[i].set()
+            except BaseException:
+                for e in ready:                            # do not leave the other streams waiting
+                    e.set()
+                raise
+            pos = 0
+            while True:
+                with lock:
+                    p = next(next_pair, None)
+                if p is None:
+                    break
+                for q in range(pos, p):                    # replay the draws of the pairs other streams execute
+                    if live(q):
+                        c.pairEstimate(maps[pairs_idx[q][0]], maps[pairs_idx[q][1]], params, execute=False)
+                if live(p):
+                    recs[p] = c.pairEstimate(maps[pairs_idx[p][0]], maps[pairs_idx[p][1]], params, execute=True)
+                    is_live[p] = True
+                pos = p + 1
+            c.synchronize()
+
+        run_streams(worker)
+        t3 = time.perf_counter()
+        recs["source_idx"] = [i for i, _ in pairs_idx]
+        recs["target_idx"] = [j for _, j in pairs_idx]
+        mine = recs[is_live]
+        T = mm.globalTransforms(mine, params.confidence_threshold, n_maps)
+        t4 = time.perf_counter()
+        stats.update(dict(n_pairs=len(mine), t_features=t_last_map[0] - t0, t_exchange=0.0, t_pairs=t3 - t_last_map[0],
+                          t_gather_graph=t4 - t3, pts_filtered=[len(m.points) for m in maps], keypoints=kn,
+                          icp_iters=[int(x) for x in mine["icp_iterations"]],
+                          n_estimated=int(sum(1 for t in T if np.any(t))),
+                          crc=zlib.crc32(np.ascontiguousarray(mine["transform"]).tobytes()) & 0xffffffff))
+        for m in maps:
+            m.free()
+        return T
+
+    if world == 1 and args.feature_streams > 0:
+        step = step_pipelined                              # noqa: F811
 
     def barrier():
         torch.cuda.synchronize()
