@@ -5,19 +5,22 @@
 //   SAC-IA findSimilarFeatures   R/src/matching.cpp:159-173 (k_correspondences_ = 10)
 // A kd-tree in 33+ dimensions degenerates to a linear scan; here it IS a linear scan, tiled.
 //
-// Three stages (desc_knn below):
-//   1. knn_prep: descriptors -> augmented, MFMA-ordered operands.  Query  a' = [a, |a|^2, 1, 0],
-//      target b' = [-2b, 1, |b|^2, 0]  (36 wide), so a'.b' = |a|^2 + |b|^2 - 2 a.b directly.
+// Three stages (desc_knn below), templates on the row width (33 floats = FPFH, 125 = PFH):
+//   1. knn_prep: descriptors -> centred, augmented, MFMA-ordered operands.  With mu = the targets'
+//      column mean, query a' = [a - mu, |a - mu|^2, 1, 0], target b' = [-2 (b - mu), 1, |b - mu|^2, 0]
+//      (36 / 128 wide), so a'.b' = |a - b|^2 directly.  The target side is cached on the descriptor
+//      set (desc_knn_prepare_target): a map is the target of 15 pairs.
 //   2. knn_mfma: the one genuine dense contraction of the pipeline on the matrix cores,
 //      v_mfma_f32_32x32x2_f32 (exact f32 FMA chains, 157 TF peak).  One wave owns 32 queries as the
 //      COLUMNS of the product, so each lane sees 16 target rows of one query per tile and keeps a
 //      register-resident sorted list of the 8 best approximate distances.
-//   3. knn_rerank: the candidates (2 lane halves x 4 target slices x 8) are re-ranked with FLANN's
-//      L2_Simple accumulation (diff*diff summed in dimension order, no FMA) -- the ONLY distances
-//      that leave this file -- and certified: the k-th exact distance must clear the smallest
-//      "worst kept approximate distance" of any full list by more than the expansion's rounding
-//      bound.  Rows that fail go through the exact brute-force kernel.  The result is therefore the
-//      exact k-NN with ties to the lower index, bit-identical to the CPU path.
+//   3. knn_rerank (one wave per query row): the candidates (2 lane halves x 4 target slices x parts
+//      x 8) are re-ranked with FLANN's L2_Simple accumulation (diff*diff summed in dimension order,
+//      no FMA) -- the ONLY distances that leave this file -- and certified: the k-th exact distance
+//      must clear the smallest "worst kept approximate distance" of any full list by more than the
+//      expansion's rounding bound.  Rows that fail go through the exact brute-force kernels
+//      (k_knn_exact_part / k_knn_merge_parts).  The result is therefore the exact k-NN with ties to
+//      the lower index, bit-identical to the CPU path.
 #include "device_util.hpp"
 
 namespace mm3d {

@@ -5,14 +5,15 @@
 //                       TransformationEstimationSVD/Umeyama, DefaultConvergenceCriteria)
 // transformScore        R/src/matching.cpp:259-268 -> TransformationValidationEuclidean
 //
-// Wave-cooperative search.  A wave owns 64 consecutive source points in Morton order (a compact
-// patch), so the cells its queries can touch form a small box of the target grid.  The wave
+// Wave-cooperative search.  A wave owns one work item of the source's Hilbert order (<= 64 points
+// forming a compact patch), so the cells its queries can touch form a small box of the target grid.  The wave
 //   1. reads one distance-transform byte per lane (how many cells to the nearest occupied cell;
 //      out of range -> that lane is done),
 //   2. takes the bounding box of its lanes' cells, grows it by the largest radius any lane needs,
 //   3. streams the box's rows (contiguous spans of the cell-sorted target) through LDS with
 //      coalesced 16-byte loads, 512 points per tile,
-//   4. every lane scans the tile out of LDS (same address for all lanes = broadcast reads),
+//   4. every lane scans the tile out of LDS (same address for all lanes = broadcast reads; the tile is
+//      kept per component, so four candidates are one 16-byte read and their distances pack),
 //   5. a lane is finished when its best distance is within what the box provably covers; otherwise
 //      the box grows once more to the radius that lane needs.
 // Candidate traffic is therefore LDS traffic; HBM sees the source once (16 B/point) and each target
