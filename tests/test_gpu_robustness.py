@@ -1,0 +1,56 @@
+"""Degenerate inputs through the whole path: nothing may crash or hang, and the outcome is the one the
+reference's semantics give (no keypoints -> the pair is skipped, map_merging.cpp:246-254)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(mm, xyz, grey=128):
+    a = np.zeros(len(xyz), dtype=mm.POINT)
+    a["x"], a["y"], a["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    a["rgba"] = 0xFF000000 | (grey << 16) | (grey << 8) | grey
+    return a
+
+
+@pytest.fixture(scope="module")
+def textured(mm):
+    rng = np.random.default_rng(3)
+    c = _cloud(mm, np.concatenate([rng.uniform(0, 8, (30000, 2)), 0.2 * rng.standard_normal((30000, 1))], 1).astype(np.float32))
+    c["rgba"] = 0xFF000000 | (rng.integers(0, 255, 30000).astype(np.uint32) * 0x010101)
+    return c
+
+
+def test_degenerate_clouds(ctx, mm, textured):
+    rng = np.random.default_rng(4)
+    cases = {
+        "empty": _cloud(mm, np.zeros((0, 3), np.float32)),
+        "all_nan": _cloud(mm, np.full((100, 3), np.nan, np.float32)),
+        "identical": _cloud(mm, np.tile(np.array([[1, 2, 3]], np.float32), (500, 1))),
+        "tiny": _cloud(mm, rng.uniform(0, 1, (10, 3)).astype(np.float32)),
+        "line": _cloud(mm, np.stack([np.linspace(0, 30, 3000), np.zeros(3000), np.zeros(3000)], 1).astype(np.float32)),
+        "flat_untextured": _cloud(mm, np.concatenate([rng.uniform(0, 10, (20000, 2)), np.zeros((20000, 1))], 1).astype(np.float32)),
+    }
+    P = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
+    for name, c in cases.items():
+        m = ctx.mapFeatures(ctx.cloud(c), P)
+        assert len(m.keypoints) == 0 and len(m.descriptors) == 0, name      # nothing SIFT could fire on
+        m.free()
+        T, pairs = ctx.estimateMapsTransforms([c, textured], P, return_pairs=True)
+        assert len(pairs) == 0, name                                        # pair skipped: a map without keypoints
+        assert len(T) == 2 and not np.any(T[0]) and not np.any(T[1]), name  # documented: zero matrices, not UB
+
+
+def test_non_finite_points_are_ignored(ctx, po, mm, textured):
+    dirty = textured.copy()
+    dirty["x"][::7] = np.nan
+    dirty["z"][::11] = np.inf
+    clean = dirty[np.isfinite(dirty["x"]) & np.isfinite(dirty["z"])]
+    P = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
+    a = ctx.mapFeatures(ctx.cloud(dirty), P)
+    b = ctx.mapFeatures(ctx.cloud(clean), P)
+    # the voxel grid skips non-finite points, so both clouds give the same filtered cloud and keypoints
+    assert np.array_equal(a.points.numpy().view(np.uint32), b.points.numpy().view(np.uint32))
+    assert np.array_equal(a.keypoints.numpy().view(np.uint32), b.keypoints.numpy().view(np.uint32))
+    assert len(a.keypoints) > 50
+    a.free(); b.free()
