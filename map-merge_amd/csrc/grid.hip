@@ -518,7 +518,7 @@ __global__ void k_nb_count(const int *__restrict__ cell_start, int dx, int dy, i
 }
 
 __global__ void k_nb_fill(const int *__restrict__ cell_start, const float4 *__restrict__ sorted, int dx, int dy, int dz, int R,
-                          const int *__restrict__ nb_start, float4 *__restrict__ nb_pts)
+                          const int *__restrict__ nb_start, float *__restrict__ nb_pts)
 {
   // one wave per cell: lanes stride over each row span
   const size_t c = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -533,7 +533,11 @@ __global__ void k_nb_fill(const int *__restrict__ cell_start, const float4 *__re
     for (int yy = max(y - R, 0); yy <= min(y + R, dy - 1); ++yy) {
       const int row = (zz * dy + yy) * dx;
       const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
-      for (int j = b + lane; j < e; j += 64) nb_pts[out + (j - b)] = sorted[j];
+      for (int j = b + lane; j < e; j += 64) {
+        const float4 p = sorted[j];
+        float *o = nb_pts + (size_t)(out + (j - b)) * 3;
+        o[0] = p.x; o[1] = p.y; o[2] = p.z;
+      }
       out += e - b;
     }
 }
@@ -552,7 +556,7 @@ void grid_ensure_nblists(Context *c, const Grid &g_, int R)
   MM3D_HIP(hipMemcpyAsync(h, g.nb_start.get() + nc, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   c->sync();
   const size_t total = (size_t)h[0];
-  g.nb_pts = DevBuf<float4>(c, total ? total : 1);
+  g.nb_pts = DevBuf<float>(c, total ? total * 3 : 1);
   if (total)
     MM3D_LAUNCH(c, "grid_nblists", total * 32.0, k_nb_fill, dim3(div_up(nc, 4)), dim3(256), 0, (const int *)g.cell_start.get(),
                 (const float4 *)g.sorted.get(), g.dims[0], g.dims[1], g.dims[2], R, (const int *)g.nb_start.get(), g.nb_pts.get());

@@ -111,7 +111,10 @@ k_sacia_err(const float4 *__restrict__ skp, int ns, int ns_pad, GridView g, cons
     // four loads in flight per step; min is idempotent, so the tail just re-reads the last point
     for (int j = b; j < e; j += 4) {
       const int last = e - 1;
-      const float4 q0 = g.nb_pts[j], q1 = g.nb_pts[min(j + 1, last)], q2 = g.nb_pts[min(j + 2, last)], q3 = g.nb_pts[min(j + 3, last)];
+      const float3 q0 = *reinterpret_cast<const float3 *>(g.nb_pts + (size_t)j * 3);
+      const float3 q1 = *reinterpret_cast<const float3 *>(g.nb_pts + (size_t)min(j + 1, last) * 3);
+      const float3 q2 = *reinterpret_cast<const float3 *>(g.nb_pts + (size_t)min(j + 2, last) * 3);
+      const float3 q3 = *reinterpret_cast<const float3 *>(g.nb_pts + (size_t)min(j + 3, last) * 3);
       const float d0 = dist2(p.x, p.y, p.z, q0.x, q0.y, q0.z), d1 = dist2(p.x, p.y, p.z, q1.x, q1.y, q1.z);
       const float d2 = dist2(p.x, p.y, p.z, q2.x, q2.y, q2.z), d3 = dist2(p.x, p.y, p.z, q3.x, q3.y, q3.z);
       best = fminf(best, fminf(fminf(d0, d1), fminf(d2, d3)));

@@ -30,7 +30,7 @@ struct GridView {
   // optional merged neighbourhood lists: nb_pts[nb_start[c] .. nb_start[c+1]) = every point of the
   // (2 nb_R + 1)^3 block of cells around cell c, so a fixed-radius query reads ONE contiguous span
   const int *nb_start;
-  const float4 *nb_pts;
+  const float *nb_pts;       // packed x, y, z triples (12 B per entry)
   int nb_R;
 };
 
@@ -44,7 +44,7 @@ struct Grid {
   DevBuf<unsigned char> dt;   // built on demand by grid_ensure_dt
   int dt_cap = 0;
   DevBuf<int> nb_start;       // built on demand by grid_ensure_nblists
-  DevBuf<float4> nb_pts;
+  DevBuf<float> nb_pts;       // packed x, y, z triples
   int nb_R = 0;
   GridView view() const
   {
