@@ -173,11 +173,7 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
 #pragma unroll
           for (int step = 32; step > 0; step >>= 1)
             if (s_off[wave][lo + step] <= slot) lo += step;   // offsets are non-decreasing; empty rows collapse
-#if defined(MM3D_ABL) && MM3D_ABL == 2
-          stage[u] = make_float4((float)lo, (float)slot, 0.f, 0.f);
-#else
           stage[u] = g.pts[s_beg[wave][lo] + (slot - s_off[wave][lo])];
-#endif
         }
 #pragma unroll
         for (int u = 0; u < kTile / kWave; ++u) {
@@ -193,11 +189,7 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
           s_cw[wave][cnt + lane] = 0x7fffffffu;
         }
         wave_lds_sync();
-#if defined(MM3D_ABL) && MM3D_ABL == 1
-        if (active && cnt < 0) {
-#else
         if (active) {
-#endif
           for (int k = 0; k < cnt; k += 4) {
             const float4 X = *reinterpret_cast<const float4 *>(&s_cx[wave][k]);
             const float4 Y = *reinterpret_cast<const float4 *>(&s_cy[wave][k]);
