@@ -105,6 +105,14 @@ long long mm3d_debug_knn_rows(mm3d_ctx *ctx);
 /* SAC-IA draws from libc rand() in the reference (process-global, glibc seed 1).  The context
  * carries its own replay of that generator; mm3d_srand re-seeds it (srand semantics). */
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed);
+/* Number of HIP streams (each with its own memory pool and, while a call runs, its own host thread)
+ * that mm3d_estimate_maps_transforms deals the per-cloud and per-pair loops of
+ * map_merging.cpp:212-242,256-269 to.  1 (the default) = the reference's sequential loops on one
+ * stream.  One pair is a chain of dependent kernels that cannot fill an MI355X by itself; 16 streams
+ * roughly double the throughput.  The results do not depend on the setting, bit for bit: every
+ * stream replays the rand() draws of the pairs it does not run.  1 <= n <= 64. */
+int mm3d_set_streams(mm3d_ctx *ctx, int n_streams);
+int mm3d_get_streams(const mm3d_ctx *ctx);
 
 /* ---- cloud objects -------------------------------------------------------------------- */
 int mm3d_cloud_create(mm3d_ctx *ctx, const void *points, size_t n, size_t stride, size_t rgba_offset,

@@ -157,6 +157,11 @@ class Context:
     def srand(self, seed: int):
         lib().mm3d_srand(self._h, C.c_uint(seed))
 
+    def setStreams(self, n: int):
+        """mm3d_set_streams: HIP streams estimateMapsTransforms deals its two loops to (results are
+        bit-identical for every setting)."""
+        self._ck(lib().mm3d_set_streams(self._h, int(n)))
+
     def synchronize(self):
         self._ck(lib().mm3d_synchronize(self._h))
 

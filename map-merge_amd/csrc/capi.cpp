@@ -1,8 +1,11 @@
 // capi.cpp -- the extern "C" boundary of libmm3d.so (include/mm3d.h).  Nothing throws across it.
 #include <algorithm>
 #include <cfloat>
+#include <condition_variable>
 #include <cstdlib>
+#include <exception>
 #include <functional>
+#include <thread>
 #include <sstream>
 #include <string>
 
@@ -177,9 +180,30 @@ int mm3d_create(int device, mm3d_ctx **out)
   return MM3D_OK;
 }
 
+int mm3d_set_streams(mm3d_ctx *ctx, int n_streams)
+{
+  if (n_streams < 1 || n_streams > 64) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    while ((int)ctx->helpers.size() + 1 > n_streams) {
+      mm3d_destroy(ctx->helpers.back());
+      ctx->helpers.pop_back();
+    }
+    while ((int)ctx->helpers.size() + 1 < n_streams) {
+      mm3d_ctx *h = nullptr;
+      const int st = mm3d_create(ctx->device, &h);
+      if (st != MM3D_OK) throw Error(st, "mm3d_set_streams: could not create a helper context");
+      ctx->helpers.push_back(h);
+    }
+  });
+}
+
+int mm3d_get_streams(const mm3d_ctx *ctx) { return ctx ? (int)ctx->helpers.size() + 1 : 0; }
+
 void mm3d_destroy(mm3d_ctx *ctx)
 {
   if (!ctx) return;
+  for (mm3d_ctx *h : ctx->helpers) mm3d_destroy(h);
+  ctx->helpers.clear();
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -475,16 +499,19 @@ int mm3d_map_from_parts(mm3d_ctx *ctx, mm3d_cloud *points, mm3d_cloud *keypoints
   return MM3D_OK;
 }
 
+static void map_prepare_impl(mm3d_ctx *ctx, mm3d_map *m, const mm3d_params *p)
+{
+  prepare_pair_search(ctx, m->points, p->max_correspondence_distance, p->max_correspondence_distance);
+  if (p->estimation_method == MM3D_EST_SAC_IA) prepare_sacia_target(ctx, m->keypoints, (float)p->max_correspondence_distance);
+  (void)cloud_host(ctx, m->keypoints);
+  desc_knn_prepare_target(ctx, m->desc);
+  ctx->sync();
+}
+
 int mm3d_map_prepare(mm3d_ctx *ctx, mm3d_map *m, const mm3d_params *p)
 {
   if (!m || !p) return MM3D_EINVAL;
-  return guarded(ctx, [&] {
-    prepare_pair_search(ctx, m->points, p->max_correspondence_distance, p->max_correspondence_distance);
-    if (p->estimation_method == MM3D_EST_SAC_IA) prepare_sacia_target(ctx, m->keypoints, (float)p->max_correspondence_distance);
-    (void)cloud_host(ctx, m->keypoints);
-    desc_knn_prepare_target(ctx, m->desc);
-    ctx->sync();
-  });
+  return guarded(ctx, [&] { map_prepare_impl(ctx, m, p); });
 }
 
 void mm3d_map_free(mm3d_ctx *ctx, mm3d_map *m)
@@ -533,6 +560,118 @@ int mm3d_global_transforms(const mm3d_pair_result *pairs, size_t n_pairs, double
   }
 }
 
+// estimateMapsTransforms over the context's streams (mm3d_set_streams).  The reference's two loops
+// (map_merging.cpp:212-242 per cloud, :256-269 per pair) are dealt to S workers, one context (HIP
+// stream + memory pool) and one host thread each: about 3/8 of them extract features, every worker
+// then claims pairs in the reference's order and waits until both maps of its pair exist.  A map is
+// prepared (map_prepare_impl) before it is published, so pairs only read it.  The reference's single
+// rand() stream is kept by replay: every worker starts from the caller's generator state and replays
+// the draws of the pairs it does not execute (execute = false, host only), so each pair sees exactly
+// the state the sequential loop would give it; worker 0 (the caller's own context) replays to the
+// end, which leaves the caller's generator where the sequential loop would.
+static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, const mm3d_params *params, float *out_T,
+                                  size_t *n_out, mm3d_pair_result *pairs_out, size_t *n_pairs_out)
+{
+  std::vector<mm3d_ctx *> cs{ctx};
+  cs.insert(cs.end(), ctx->helpers.begin(), ctx->helpers.end());
+  const size_t S = cs.size();
+  const size_t F = S <= 4 ? S : std::max<size_t>(4, S * 3 / 8);
+  std::vector<std::pair<size_t, size_t>> all;
+  for (size_t i = 0; i + 1 < n; ++i)
+    for (size_t j = i + 1; j < n; ++j) all.emplace_back(i, j);
+  std::vector<mm3d_map *> maps(n, nullptr);
+  std::vector<mm3d_pair_result> rec(all.size());
+  std::vector<char> ready(n, 0), done(all.size(), 0);
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t next_map = 0, next_pair = 0;
+  bool abort = false;
+  std::exception_ptr first_error;
+  const GlibcRand rnd0 = ctx->rnd;
+
+  auto pair_is_live = [&](size_t q) -> bool {          // false also when the run is being aborted
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return abort || (ready[all[q].first] && ready[all[q].second]); });
+    if (abort) throw Error(MM3D_EDEVICE, "aborted");
+    return maps[all[q].first]->keypoints->n > 0 && maps[all[q].second]->keypoints->n > 0;
+  };
+  auto worker = [&](size_t w) {
+    mm3d_ctx *c = cs[w];
+    try {
+      if (hipSetDevice(c->device) != hipSuccess) throw Error(MM3D_EDEVICE, "hipSetDevice failed");
+      c->rnd = rnd0;
+      while (w < F) {
+        size_t i;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          if (abort || next_map >= n) break;
+          i = next_map++;
+        }
+        // a null / empty map (robot subscribed but no message yet) counts as "no keypoints"
+        std::unique_ptr<mm3d_cloud> raw(cloud_from_memory(c, clouds[i].points, clouds[i].points ? clouds[i].n : 0,
+                                                          clouds[i].stride ? clouds[i].stride : 16,
+                                                          clouds[i].stride ? clouds[i].rgba_offset : 12));
+        mm3d_map *m = map_features_impl(c, raw.get(), params);
+        raw.reset();
+        map_prepare_impl(c, m, params);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          maps[i] = m;
+          ready[i] = 1;
+        }
+        cv.notify_all();
+      }
+      size_t pos = 0;                                   // pairs [0, pos) have had their draws replayed on c
+      auto replay_to = [&](size_t p) {
+        for (; pos < p; ++pos)
+          if (pair_is_live(pos)) {
+            mm3d_pair_result dummy;
+            pair_estimate_impl(c, maps[all[pos].first], maps[all[pos].second], params, false, &dummy);
+          }
+      };
+      for (;;) {
+        size_t p;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          if (abort || next_pair >= all.size()) break;
+          p = next_pair++;
+        }
+        replay_to(p);
+        if (pair_is_live(p)) {
+          pair_estimate_impl(c, maps[all[p].first], maps[all[p].second], params, true, &rec[p]);
+          rec[p].source_idx = all[p].first;
+          rec[p].target_idx = all[p].second;
+          done[p] = 1;
+        }
+        pos = p + 1;
+      }
+      if (w == 0) replay_to(all.size());                // the caller's generator ends where the sequential loop would
+      c->sync();
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!first_error) first_error = std::current_exception();
+      abort = true;
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> threads;
+  for (size_t w = 1; w < S; ++w) threads.emplace_back(worker, w);
+  worker(0);
+  for (auto &t : threads) t.join();
+  // every stream has been synchronised by its worker (or the run was aborted): the maps can go
+  for (size_t w = 0; w < S; ++w) (void)hipStreamSynchronize(cs[w]->stream);
+  for (mm3d_map *m : maps)
+    if (m) { delete m->points; delete m->keypoints; delete m->desc; delete m; }
+  if (first_error) std::rethrow_exception(first_error);
+  std::vector<mm3d_pair_result> pairs;
+  for (size_t p = 0; p < all.size(); ++p)
+    if (done[p]) pairs.push_back(rec[p]);
+  if (pairs_out) std::memcpy(pairs_out, pairs.data(), pairs.size() * sizeof(mm3d_pair_result));
+  if (n_pairs_out) *n_pairs_out = pairs.size();
+  const int st = global_transforms(pairs.data(), pairs.size(), params->confidence_threshold, n, out_T, n_out);
+  if (st != MM3D_OK) throw Error(st, "computeGlobalTransforms failed");
+}
+
 // ---------------------------------------------------------------- map_merging.h
 int mm3d_estimate_maps_transforms(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, const mm3d_params *params,
                                   float *out_T, size_t *n_out, mm3d_pair_result *pairs_out, size_t *n_pairs_out)
@@ -548,6 +687,10 @@ int mm3d_estimate_maps_transforms(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
     return MM3D_OK;
   }
   return guarded(ctx, [&] {
+    if (!ctx->helpers.empty()) {
+      estimate_maps_streams(ctx, clouds, n, params, out_T, n_out, pairs_out, n_pairs_out);
+      return;
+    }
     std::vector<std::unique_ptr<mm3d_map, std::function<void(mm3d_map *)>>> maps;
     auto del = [](mm3d_map *m) { if (m) { delete m->points; delete m->keypoints; delete m->desc; delete m; } };
     for (size_t i = 0; i < n; ++i) {

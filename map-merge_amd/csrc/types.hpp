@@ -13,7 +13,11 @@
 #include "common.hpp"
 
 // the opaque C handles are these structs
-struct mm3d_ctx : mm3d::Context {};
+struct mm3d_ctx : mm3d::Context {
+  // mm3d_set_streams: helper contexts (one HIP stream + one host thread each while a call is running)
+  // that mm3d_estimate_maps_transforms deals maps and pairs to; owned by this context
+  std::vector<mm3d_ctx *> helpers;
+};
 
 namespace mm3d {
 
