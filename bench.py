@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--streams", type=int, default=16, help="contexts (HIP stream + host thread) per GPU")
+    ap.add_argument("--engine", choices=["library", "python"], default="library",
+                    help="one GPU only: 'library' = one mm3d_estimate_maps_transforms call, streams inside libmm3d; "
+                         "'python' = the shardable pieces driven from Python threads (what N > 1 always uses)")
     ap.add_argument("--feature-streams", type=int, default=6,
                     help="one GPU only: pipeline the stages, this many streams extract features (0 = two barriered stages)")
     ap.add_argument("--descriptor", choices=["FPFH", "PFH"], default="FPFH")
@@ -319,7 +322,34 @@ def main():
             m.free()
         return T
 
-    if world == 1 and args.feature_streams > 0:
+    def step_library():
+        """One GPU, default: the whole job is ONE call of the reference's own entry point on HBM-resident
+        clouds; the library deals the two loops to its streams itself (mm3d_set_streams: C++ threads and
+        helper contexts inside libmm3d, the same pipelined scheme as step_pipelined without the Python
+        in between)."""
+        ctx.srand(1)                                       # the reference's process starts at glibc seed 1
+        views = [(dev_raw[i].data_ptr(), len(host[i])) for i in range(n_maps)]
+        T, mine = ctx.estimateMapsTransforms(views, params, return_pairs=True)
+        L = mm.lib()
+        f_s, tot_s = C.c_double(), C.c_double()
+        L.mm3d_last_run_stage_seconds(ctx._h, C.byref(f_s), C.byref(tot_s))
+        pts, kps = (C.c_size_t * n_maps)(), (C.c_size_t * n_maps)()
+        L.mm3d_last_run_map_sizes.restype = C.c_size_t
+        L.mm3d_last_run_map_sizes(ctx._h, pts, kps, C.c_size_t(n_maps))
+        stats.update(dict(n_pairs=len(mine), t_features=f_s.value, t_exchange=0.0, t_pairs=tot_s.value - f_s.value,
+                          t_gather_graph=0.0, pts_filtered=list(pts), keypoints=list(kps),
+                          icp_iters=[int(x) for x in mine["icp_iterations"]],
+                          n_estimated=int(sum(1 for t in T if np.any(t))),
+                          crc=zlib.crc32(np.ascontiguousarray(mine["transform"]).tobytes()) & 0xffffffff))
+        return T
+
+    if world == 1 and args.engine == "library":
+        for c in ctxs[1:]:
+            c.close()
+        ctxs = [ctx]
+        ctx.setStreams(S)
+        step = step_library                                # noqa: F811
+    elif world == 1 and args.feature_streams > 0:
         step = step_pipelined                              # noqa: F811
 
     def barrier():
@@ -437,7 +467,9 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n_maps} maps x {n_pts} raw pts, {args.descriptor} + {args.method} + ICP refine, {n_pairs} pairs",
-                       "parallelism": f"maps and pairs round-robin over {world} GPU(s) x {S} streams",
+                       "parallelism": (f"one mm3d_estimate_maps_transforms call, {S} streams inside the library"
+                                       if world == 1 and args.engine == "library" else
+                                       f"maps and pairs dealt over {world} GPU(s) x {S} streams (Python threads)"),
                        "points_after_filter_mean": int(np.mean(npts_f)), "keypoints_mean": int(np.mean(stats["keypoints"]))},
             "pair_stage_pairs_per_s": round(n_pairs / max(stats["t_pairs"], 1e-9), 3),
             "mpoints_per_s": {

@@ -113,6 +113,12 @@ void mm3d_srand(mm3d_ctx *ctx, unsigned seed);
  * stream replays the rand() draws of the pairs it does not run.  1 <= n <= 64. */
 int mm3d_set_streams(mm3d_ctx *ctx, int n_streams);
 int mm3d_get_streams(const mm3d_ctx *ctx);
+/* diagnostics of the most recent mm3d_estimate_maps_transforms on this context: seconds from entry
+ * until the last map's features existed and until the call returned; per input cloud, the number
+ * of points after downSample + removeOutliers and of keypoints after descriptor pruning (returns
+ * the number of clouds; at most `capacity` entries are written) */
+int mm3d_last_run_stage_seconds(const mm3d_ctx *ctx, double *features_s, double *total_s);
+size_t mm3d_last_run_map_sizes(const mm3d_ctx *ctx, size_t *points, size_t *keypoints, size_t capacity);
 
 /* ---- cloud objects -------------------------------------------------------------------- */
 int mm3d_cloud_create(mm3d_ctx *ctx, const void *points, size_t n, size_t stride, size_t rgba_offset,

@@ -1,6 +1,7 @@
 // capi.cpp -- the extern "C" boundary of libmm3d.so (include/mm3d.h).  Nothing throws across it.
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <exception>
@@ -217,6 +218,23 @@ void mm3d_destroy(mm3d_ctx *ctx)
 const char *mm3d_last_error(const mm3d_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int mm3d_last_icp_iterations(const mm3d_ctx *ctx) { return ctx ? ctx->last_icp_iterations : 0; }
 int mm3d_last_icp_converged(const mm3d_ctx *ctx) { return ctx ? ctx->last_icp_converged : 0; }
+int mm3d_last_run_stage_seconds(const mm3d_ctx *ctx, double *features_s, double *total_s)
+{
+  if (!ctx) return MM3D_EINVAL;
+  if (features_s) *features_s = ctx->last_features_s;
+  if (total_s) *total_s = ctx->last_total_s;
+  return MM3D_OK;
+}
+size_t mm3d_last_run_map_sizes(const mm3d_ctx *ctx, size_t *points, size_t *keypoints, size_t capacity)
+{
+  if (!ctx) return 0;
+  const size_t n = ctx->last_points.size();
+  for (size_t i = 0; i < n && i < capacity; ++i) {
+    if (points) points[i] = ctx->last_points[i];
+    if (keypoints) keypoints[i] = ctx->last_keypoints[i];
+  }
+  return n;
+}
 void mm3d_set_debug(mm3d_ctx *ctx, int on)
 {
   if (!ctx) return;
@@ -588,6 +606,11 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   bool abort = false;
   std::exception_ptr first_error;
   const GlibcRand rnd0 = ctx->rnd;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+  ctx->last_points.assign(n, 0);
+  ctx->last_keypoints.assign(n, 0);
+  ctx->last_features_s = ctx->last_total_s = 0.0;
 
   auto pair_is_live = [&](size_t q) -> bool {          // false also when the run is being aborted
     std::unique_lock<std::mutex> lk(mu);
@@ -618,6 +641,9 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
           std::lock_guard<std::mutex> lk(mu);
           maps[i] = m;
           ready[i] = 1;
+          ctx->last_points[i] = m->points->n;
+          ctx->last_keypoints[i] = m->keypoints->n;
+          ctx->last_features_s = std::max(ctx->last_features_s, since_start());
         }
         cv.notify_all();
       }
@@ -670,6 +696,7 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   if (n_pairs_out) *n_pairs_out = pairs.size();
   const int st = global_transforms(pairs.data(), pairs.size(), params->confidence_threshold, n, out_T, n_out);
   if (st != MM3D_OK) throw Error(st, "computeGlobalTransforms failed");
+  ctx->last_total_s = since_start();
 }
 
 // ---------------------------------------------------------------- map_merging.h
@@ -691,6 +718,10 @@ int mm3d_estimate_maps_transforms(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
       estimate_maps_streams(ctx, clouds, n, params, out_T, n_out, pairs_out, n_pairs_out);
       return;
     }
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+    ctx->last_points.assign(n, 0);
+    ctx->last_keypoints.assign(n, 0);
     std::vector<std::unique_ptr<mm3d_map, std::function<void(mm3d_map *)>>> maps;
     auto del = [](mm3d_map *m) { if (m) { delete m->points; delete m->keypoints; delete m->desc; delete m; } };
     for (size_t i = 0; i < n; ++i) {
@@ -699,7 +730,10 @@ int mm3d_estimate_maps_transforms(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
                                                         clouds[i].stride ? clouds[i].stride : 16,
                                                         clouds[i].stride ? clouds[i].rgba_offset : 12));
       maps.emplace_back(map_features_impl(ctx, raw.get(), params), del);
+      ctx->last_points[i] = maps.back()->points->n;
+      ctx->last_keypoints[i] = maps.back()->keypoints->n;
     }
+    ctx->last_features_s = since_start();
     std::vector<mm3d_pair_result> pairs;
     for (size_t i = 0; i + 1 < n; ++i)
       for (size_t j = i + 1; j < n; ++j)
@@ -714,6 +748,7 @@ int mm3d_estimate_maps_transforms(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
     if (n_pairs_out) *n_pairs_out = pairs.size();
     int st = global_transforms(pairs.data(), pairs.size(), params->confidence_threshold, n, out_T, n_out);
     if (st != MM3D_OK) throw Error(st, "computeGlobalTransforms failed");
+    ctx->last_total_s = since_start();
   });
 }
 
@@ -737,7 +772,11 @@ int mm3d_compose_maps(mm3d_ctx *ctx, const mm3d_cloud *const *clouds, size_t n, 
 // ---------------------------------------------------------------- measurement
 int mm3d_profile_enable(mm3d_ctx *ctx, int on)
 {
-  return guarded(ctx, [&] { ctx->prof_resolve(); ctx->prof_on = on != 0; });
+  return guarded(ctx, [&] {
+    ctx->prof_resolve();
+    ctx->prof_on = on != 0;
+    for (mm3d_ctx *h : ctx->helpers) { h->prof_resolve(); h->prof_on = on != 0; }   // mm3d_set_streams helpers
+  });
 }
 void mm3d_profile_reset(mm3d_ctx *ctx)
 {
@@ -745,12 +784,27 @@ void mm3d_profile_reset(mm3d_ctx *ctx)
   std::lock_guard<std::mutex> lock(ctx->mu);
   try { ctx->prof_resolve(); } catch (...) {}
   for (auto &e : ctx->prof) e = ProfEntry();
+  for (mm3d_ctx *h : ctx->helpers) {
+    try { h->prof_resolve(); } catch (...) {}
+    for (auto &e : h->prof) e = ProfEntry();
+  }
 }
 int mm3d_profile_count(mm3d_ctx *ctx)
 {
   if (!ctx) return 0;
   std::lock_guard<std::mutex> lock(ctx->mu);
   try { ctx->prof_resolve(); } catch (...) {}
+  // fold what the helper streams recorded into this context's table (summed over streams)
+  for (mm3d_ctx *h : ctx->helpers) {
+    try { h->prof_resolve(); } catch (...) {}
+    for (size_t i = 0; i < h->prof.size(); ++i) {
+      const int s = ctx->prof_slot(h->prof_names[i].c_str());
+      ctx->prof[s].ms += h->prof[i].ms;
+      ctx->prof[s].launches += h->prof[i].launches;
+      ctx->prof[s].bytes += h->prof[i].bytes;
+      h->prof[i] = ProfEntry();
+    }
+  }
   return (int)ctx->prof.size();
 }
 int mm3d_profile_entry(mm3d_ctx *ctx, int i, const char **name, double *total_ms, uint64_t *launches, double *bytes)

@@ -17,6 +17,9 @@ struct mm3d_ctx : mm3d::Context {
   // mm3d_set_streams: helper contexts (one HIP stream + one host thread each while a call is running)
   // that mm3d_estimate_maps_transforms deals maps and pairs to; owned by this context
   std::vector<mm3d_ctx *> helpers;
+  // diagnostics of the most recent mm3d_estimate_maps_transforms (mm3d_last_run_*)
+  double last_features_s = 0.0, last_total_s = 0.0;      // when the last map was ready / when the call returned
+  std::vector<size_t> last_points, last_keypoints;       // per input cloud, after filtering / after pruning
 };
 
 namespace mm3d {
