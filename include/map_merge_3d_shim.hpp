@@ -23,6 +23,7 @@
 #include <map_merge_3d/map_merging.h>
 #include <pcl/conversions.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -40,6 +41,11 @@ inline mm3d_ctx *ctx()
   static mm3d_ctx *c = [] {
     mm3d_ctx *p = nullptr;
     if (mm3d_create(0, &p) != MM3D_OK) throw std::runtime_error("mm3d: no MI355X device");
+    // estimateMapsTransforms deals its per-cloud and per-pair loops to 16 HIP streams inside the
+    // library (same bits as one stream, about twice the throughput); MM3D_STREAMS overrides
+    const char *s = std::getenv("MM3D_STREAMS");
+    const int n = s ? std::atoi(s) : 16;
+    (void)mm3d_set_streams(p, n >= 1 && n <= 64 ? n : 16);
     return p;
   }();
   return c;
