@@ -481,6 +481,7 @@ def main():
             "stage_seconds_last_step": {k: round(stats[k], 4) for k in ("t_features", "t_exchange", "t_pairs", "t_gather_graph")},
             "top_kernels_ms_per_step": {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in top},
             "maps_estimated": stats["n_estimated"],
+            "icp_iterations_histogram": {str(k): int(v) for k, v in zip(*np.unique(stats["icp_iters"], return_counts=True))},
             "pair_transforms_crc32": stats["crc"],          # same job, same bits: independent of --gpus / --streams
             "roofline": roofline,
         }

@@ -730,6 +730,7 @@ int mm3d_estimate_maps_transforms(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
                                                         clouds[i].stride ? clouds[i].stride : 16,
                                                         clouds[i].stride ? clouds[i].rgba_offset : 12));
       maps.emplace_back(map_features_impl(ctx, raw.get(), params), del);
+      map_prepare_impl(ctx, maps.back().get(), params);   // search structures and k-NN target operands, once per map
       ctx->last_points[i] = maps.back()->points->n;
       ctx->last_keypoints[i] = maps.back()->keypoints->n;
     }

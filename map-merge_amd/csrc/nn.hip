@@ -441,7 +441,9 @@ PairTail icp_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, con
   const unsigned nblocks = div_up(n_items, 4);
   DevBuf<double> partials(c, (size_t)nblocks * kAcc), s_partials(c, want_score ? (size_t)nblocks * kAcc : 1);
   DevBuf<double> out(c, 2);
-  const int chunk = 4;
+  // iterations launched between two looks at the `done` flag: with the reference's loose epsilon 90 % of
+  // the pairs converge in one iteration and 98 % in two (launches after `done` are no-ops)
+  const int chunk = 2;
   for (;;) {
     if (run_icp) {
       const GridView gv = tg->view();
