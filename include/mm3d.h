@@ -135,6 +135,9 @@ size_t mm3d_desc_size(const mm3d_desc *d);
 int mm3d_desc_dim(const mm3d_desc *d);
 int mm3d_desc_type(const mm3d_desc *d);
 int mm3d_desc_download(mm3d_ctx *ctx, const mm3d_desc *d, float *dst /* size*dim */);
+/* SHOT only: the local reference frames, 9 floats per row (x, y, z axes) = the "rf" field of
+ * pcl::SHOT1344; MM3D_EINVAL for other descriptor types. */
+int mm3d_desc_download_frames(mm3d_ctx *ctx, const mm3d_desc *d, float *dst /* size*9 */);
 int mm3d_desc_create(mm3d_ctx *ctx, const float *data, size_t n, int descriptor_type, mm3d_desc **out);
 void mm3d_desc_free(mm3d_ctx *ctx, mm3d_desc *d);
 

@@ -435,6 +435,12 @@ class Descriptors(_Obj):
         self.ctx._ck(lib().mm3d_desc_download(self.ctx._h, self._h, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def frames(self) -> np.ndarray:
+        """SHOT only: the local reference frames [n, 9] (x, y, z axes), the rf field of pcl::SHOT1344."""
+        out = np.empty((len(self), 9), dtype=np.float32)
+        self.ctx._ck(lib().mm3d_desc_download_frames(self.ctx._h, self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
 
 class Map(_Obj):
     _free = "mm3d_map_free"

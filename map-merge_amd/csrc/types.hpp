@@ -96,6 +96,9 @@ struct mm3d_desc {
   // they depend on this set alone, so a map that is the target of 15 pairs prepares them once
   // (desc_knn_prepare_target, called from mm3d_map_prepare)
   mm3d::DevBuf<float> knn_colsum, knn_Bp;
+  // SHOT only: the local reference frames (x, y, z axes, 9 floats per row) -- the "rf" field of
+  // pcl::SHOT1344; not part of the point representation that matching reads
+  mm3d::DevBuf<float> rf;
 };
 
 struct mm3d_map {
@@ -144,6 +147,10 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
 // pfh.hip
 mm3d_desc *compute_pfh(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,
                        mm3d_cloud *keypoints, double radius);
+
+// shot.hip
+mm3d_desc *compute_shot(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,
+                        mm3d_cloud *keypoints, double radius);
 
 // desc_knn.hip
 // k nearest rows of B for every row of A (squared L2, FLANN accumulation order); idx -1 padded

@@ -95,6 +95,15 @@ int mo_descriptors_pfh(const mo_point *surface, const mo_normal *normals, int n,
                        mo_point *keypoints, int n_kp, double radius, float *desc);
 int mo_pfh_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints,
                int n_kp, double radius, float *desc /* n_kp x 125, NaN rows where no neighbour */);
+/* computeLocalDescriptors(SHOT): dispatch_descriptors.h:46 = SHOTColorEstimation / SHOT1344 (o_shot.c).
+ * desc must hold n_kp*1344 floats; keypoints pruned in place; returns the survivors. */
+int mo_descriptors_shot(const mo_point *surface, const mo_normal *normals, int n,
+                        mo_point *keypoints, int n_kp, double radius, float *desc);
+/* un-pruned rows (NaN where PCL gives up) and the local reference frames (x, y, z axes; may be NULL) */
+int mo_shot_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints,
+                int n_kp, double radius, float *desc /* n_kp x 1344 */, float *rf /* n_kp x 9 */);
+/* RGB2CIELAB + the normalisation of computePointSHOT: lab = (L/100, a/120, b/120) */
+void mo_shot_rgb2lab(unsigned char R, unsigned char G, unsigned char B, float lab[3]);
 /* Raw (un-pruned) FPFH plus the SPFH support set, for stage-level parity. */
 int mo_fpfh_raw(const mo_point *surface, const mo_normal *normals, int n,
                 const mo_point *keypoints, int n_kp, double radius, float *desc,

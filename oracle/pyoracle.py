@@ -134,6 +134,34 @@ def pfh_raw(surface, nrm, keypoints, radius):
     return desc[:len(keypoints)].copy()
 
 
+def descriptors_shot(surface, nrm, keypoints, radius):
+    """computeLocalDescriptors(SHOT) = SHOTColorEstimation/SHOT1344: (pruned keypoints, desc[n, 1344])."""
+    surface = _pts(surface)
+    nrm = np.ascontiguousarray(nrm, dtype=NORMAL)
+    kp = _pts(keypoints).copy()
+    desc = np.empty((max(len(kp), 1), 1344), dtype=np.float32)
+    n = lib().mo_descriptors_shot(_p(surface), _p(nrm), len(surface), _p(kp), len(kp), C.c_double(radius), _p(desc))
+    return kp[:n].copy(), desc[:n].copy()
+
+
+def shot_raw(surface, nrm, keypoints, radius):
+    """Un-pruned SHOT1344 rows (NaN where PCL gives up) and the local reference frames [n, 9]."""
+    surface = _pts(surface)
+    nrm = np.ascontiguousarray(nrm, dtype=NORMAL)
+    keypoints = _pts(keypoints)
+    desc = np.empty((max(len(keypoints), 1), 1344), dtype=np.float32)
+    rf = np.empty((max(len(keypoints), 1), 9), dtype=np.float32)
+    lib().mo_shot_raw(_p(surface), _p(nrm), len(surface), _p(keypoints), len(keypoints), C.c_double(radius),
+                      _p(desc), _p(rf))
+    return desc[:len(keypoints)].copy(), rf[:len(keypoints)].copy()
+
+
+def shot_rgb2lab(r, g, b):
+    out = (C.c_float * 3)()
+    lib().mo_shot_rgb2lab(C.c_ubyte(r), C.c_ubyte(g), C.c_ubyte(b), out)
+    return np.array(out[:], dtype=np.float32)
+
+
 def descriptors_fpfh(surface, nrm, keypoints, radius):
     """Returns (pruned keypoints, descriptors) like computeLocalDescriptors (which mutates keypoints)."""
     surface = _pts(surface)

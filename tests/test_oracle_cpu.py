@@ -208,6 +208,75 @@ def test_pfh_known_answers(po):
     assert np.allclose(d.sum(1), 100.0, atol=2e-2) and (d >= 0).all()
 
 
+def test_shot_known_answers(po):
+    """SHOT1344 (SHOTColorEstimation, dispatch_descriptors.h:46): frame, interpolation mass, pruning."""
+    # RGB2CIELAB: black is the origin, mid grey has a = b = 0 and L ~ 53.6, clamps hold
+    assert np.array_equal(po.shot_rgb2lab(0, 0, 0), np.zeros(3, np.float32))
+    g = po.shot_rgb2lab(128, 128, 128)
+    assert abs(g[0] * 100 - 53.6) < 0.5 and abs(g[1]) < 2e-3 and abs(g[2]) < 2e-3
+    w = po.shot_rgb2lab(255, 255, 255)          # int(v * 4000) reaches the end of the table here
+    assert abs(w[0] - 1.0) < 5e-3 and np.isfinite(w).all()
+    r = po.shot_rgb2lab(255, 0, 0)
+    assert abs(r[0] * 100 - 53.2) < 0.6 and abs(r[1] * 120 - 80.1) < 1.5 and abs(r[2] * 120 - 67.2) < 1.5
+
+    # a cap z = -0.3 (x^2 + y^2) under its apex, stretched along x: z axis = -e_z (all neighbours lie below),
+    # x axis = +-e_x (largest spread), chosen so that most neighbours have a positive x coordinate
+    rng = np.random.default_rng(11)
+    uv = rng.uniform(-1, 1, (1500, 2))
+    uv[:, 0] = uv[:, 0] * 0.5 + 0.25                              # more points at x > 0
+    uv[:, 1] *= 0.25
+    P = np.stack([uv[:, 0], uv[:, 1], -0.3 * (uv[:, 0] ** 2 + uv[:, 1] ** 2)], 1)
+    P = np.vstack([[0.0, 0.0, 0.0], P, [[10, 10, 10], [10.1, 10, 10], [10, 10.1, 10]]]).astype(np.float32)
+    N = np.stack([0.6 * P[:, 0], 0.6 * P[:, 1], np.ones(len(P))], 1)
+    N /= np.linalg.norm(N, axis=1, keepdims=True)
+    col = (0xFF000000 | (rng.integers(0, 256, len(P)) << 16) | (rng.integers(0, 256, len(P)) << 8) |
+           rng.integers(0, 256, len(P))).astype(np.uint32)
+    pts = cloud(po, P, col)
+    nrm = np.zeros(len(P), dtype=po.NORMAL)
+    nrm["nx"], nrm["ny"], nrm["nz"] = N[:, 0], N[:, 1], N[:, 2]
+    kp = pts[:1].copy()
+    kp["rgba"] = 0                                                # features.cpp:57-60 copies x, y, z only
+    desc, rf = po.shot_raw(pts, nrm, kp, 0.4)
+    assert desc.shape == (1, 1344) and np.isfinite(desc).all()
+    assert np.allclose(rf[0, 6:9], [0, 0, -1], atol=6e-2)
+    assert np.allclose(rf[0, 0:3], [1, 0, 0], atol=8e-2)
+    assert np.allclose(rf[0, 3:6], np.cross(rf[0, 6:9], rf[0, 0:3]), atol=1e-6)
+    # unit L2 norm, no negative bin, and both channels carry the same mass: every neighbour adds
+    # 1 (cosine / colour) + 1 (shell) + 1 (inclination) + 1 (azimuth) to each of them
+    assert abs(np.linalg.norm(desc[0].astype(np.float64)) - 1.0) < 1e-5 and (desc >= 0).all()
+    assert abs(desc[0, :352].sum() - desc[0, 352:].sum()) < 1e-4 * desc[0, :352].sum()
+    # normals point along -z of the frame: cosine ~ -1 -> shape mass sits in the low cosine slots
+    shape = desc[0, :352].reshape(32, 11)
+    assert shape[:, :2].sum() > 0.95 * shape.sum()
+    # nothing above the tangent plane of the apex (z_ref > 0 <=> world z < 0 here: odd volumes only),
+    # apart from what the inclination interpolation hands to the partner volume
+    assert shape[1::2].sum() > 0.75 * shape.sum()
+
+    # rigid motion: frames rotate with the cloud, descriptors stay (float noise only)
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]]) @ \
+        np.array([[1, 0, 0], [0, np.cos(0.3), -np.sin(0.3)], [0, np.sin(0.3), np.cos(0.3)]])
+    P2 = (P.astype(np.float64) @ R.T + np.array([2.0, -1.0, 0.5])).astype(np.float32)
+    N2 = N @ R.T
+    pts2 = cloud(po, P2, col)
+    nrm2 = nrm.copy()
+    nrm2["nx"], nrm2["ny"], nrm2["nz"] = N2[:, 0], N2[:, 1], N2[:, 2]
+    kp2 = pts2[:1].copy()
+    kp2["rgba"] = 0
+    desc2, rf2 = po.shot_raw(pts2, nrm2, kp2, 0.4)
+    assert np.allclose(rf2[0].reshape(3, 3), rf[0].reshape(3, 3) @ R.T, atol=1e-4)
+    assert np.abs(desc2 - desc).max() < 5e-3
+
+    # fewer than 5 neighbours / none at all: NaN rows, pruned with their keypoints (features.cpp:118-143)
+    kp3 = np.concatenate([kp, kp, kp])
+    kp3["x"][1] += 50.0
+    kp3["x"][2] = kp3["y"][2] = kp3["z"][2] = 10.0                # three neighbours only
+    raw, rf3 = po.shot_raw(pts, nrm, kp3, 0.4)
+    assert np.isnan(raw[1:]).all() and np.isnan(rf3[1:]).all() and np.isfinite(raw[0]).all()
+    kept, d = po.descriptors_shot(pts, nrm, kp3, 0.4)
+    assert np.array_equal(d[0], desc[0]) and len(kept) == 1 and np.array_equal(kept, kp3[:1])
+
+
 def test_desc_knn_and_reciprocal_matching(po):
     rng = np.random.default_rng(5)
     A = rng.uniform(0, 30, (120, 33)).astype(np.float32)
