@@ -73,7 +73,7 @@ def main():
                          "'python' = the shardable pieces driven from Python threads (what N > 1 always uses)")
     ap.add_argument("--feature-streams", type=int, default=6,
                     help="one GPU only: pipeline the stages, this many streams extract features (0 = two barriered stages)")
-    ap.add_argument("--descriptor", choices=["FPFH", "PFH"], default="FPFH")
+    ap.add_argument("--descriptor", choices=["FPFH", "PFH", "SHOT"], default="FPFH")
     ap.add_argument("--method", choices=["SAC_IA", "MATCHING"], default="SAC_IA")
     ap.add_argument("--kernel-table", default=None, help="write rank 0's full per-kernel HIP-event table (CSV) here")
     args = ap.parse_args()
@@ -105,7 +105,7 @@ def main():
     # BASELINE.json's configuration is FPFH + SAC_IA; the other combinations (PFH is the reference's default
     # descriptor, MATCHING its default method) can be timed with the flags
     desc_type = mm.Descriptor[args.descriptor]
-    desc_dim = {"FPFH": 33, "PFH": 125}[args.descriptor]
+    desc_dim = {"FPFH": 33, "PFH": 125, "SHOT": 1344}[args.descriptor]
     params = mm.MapMergingParams(descriptor_type=desc_type, estimation_method=mm.EstimationMethod[args.method],
                                  refine_transform=1)
 

@@ -28,7 +28,8 @@ namespace mm3d {
 constexpr int kMaxK = 16;
 // The kernels are templates on the descriptor dimension kD: 33 (FPFH) and 125 (PFH) are instantiated.
 // padded contraction length (dimension + the two augmentation columns, even): 36 / 128
-constexpr int knn_kp(int d) { return (d + 3) / 2 * 2; }
+// (wide rows -- SHOT's 1344 floats -- pad to a multiple of 8 so the step loop unrolls by 4: 1352)
+constexpr int knn_kp(int d) { return d > 256 ? (d + 9) / 8 * 8 : (d + 3) / 2 * 2; }
 constexpr int kSlices = 4;       // waves per query tile, each scanning a quarter of the targets
 constexpr int kLists = 2 * kSlices;
 constexpr int kListLen = 8;      // per-lane candidate list of the MFMA stage (8 lists x 8 = 64 candidates per query and part)
@@ -182,6 +183,13 @@ k_knn_exact_part(const float *__restrict__ A, const float *__restrict__ B, int n
     }
     __syncthreads();
   }
+}
+
+__global__ void k_knn_iota(int *__restrict__ rows, int n, int *__restrict__ count)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rows[i] = i;
+  if (i == 0) *count = n;
 }
 
 __global__ void k_knn_merge_parts(const unsigned long long *__restrict__ part_keys, int k, const int *__restrict__ rows,
@@ -436,16 +444,380 @@ k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, i
   if (!certified && lane == 0) fb_rows[atomicAdd(fb_count, 1)] = a;
 }
 
+// ================================================================ wide rows (SHOT1344)
+// The narrow kernels above keep a whole row in registers; a 1344-float row does not fit, so the wide
+// path streams the contraction dimension instead.  Same three stages, same candidate format.
+
+__global__ void k_knn_colsum_wide(const float *__restrict__ X, int n, int dim, float *__restrict__ sum)
+{
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= dim) return;
+  float acc = 0.0f;
+  for (int r = blockIdx.y; r < n; r += gridDim.y) acc += X[(size_t)r * dim + d];
+  atomicAdd(&sum[d], acc);
+}
+
+// block = kWideQT tiles of 32 queries x (its share of) the target tiles; each of the 4 waves owns a
+// target tile at a time and keeps kWideQT accumulators, so one target operand load feeds kWideQT
+// MFMAs; the query operands are shared by the 4 waves through L1.  Operands stream from global
+// memory in MFMA order (one coalesced 256-byte wave load per step and tile), two groups of 4 steps
+// in flight.
+constexpr int kWideQT = 4;
+
+template <int kD>
+__global__ void __launch_bounds__(256)
+k_knn_mfma_wide(const float *__restrict__ Ap, int na, int na_tiles, const float *__restrict__ Bp, int nb, int nb_tiles,
+                float *__restrict__ cand_d, int *__restrict__ cand_i)
+{
+  constexpr int kSteps = knn_kp(kD) / 2;
+  static_assert(kSteps % 4 == 0, "step loop is unrolled by 4");
+  const int lane = threadIdx.x & 63;
+  const int slice = threadIdx.x >> 6;
+  const int tile_a0 = blockIdx.x * kWideQT;
+  const float *ap[kWideQT];
+#pragma unroll
+  for (int q = 0; q < kWideQT; ++q) ap[q] = Ap + (size_t)min(tile_a0 + q, na_tiles - 1) * kSteps * 64 + lane;
+  float ld[kWideQT][kListLen];
+  int li[kWideQT][kListLen];
+#pragma unroll
+  for (int q = 0; q < kWideQT; ++q)
+#pragma unroll
+    for (int s = 0; s < kListLen; ++s) { ld[q][s] = INFINITY; li[q][s] = -1; }
+  const int part = blockIdx.y, stride = kSlices * (int)gridDim.y;
+  for (int c = part * kSlices + slice; c < nb_tiles; c += stride) {
+    const float *bp = Bp + (size_t)c * kSteps * 64 + lane;
+    f32x16 acc[kWideQT];
+#pragma unroll
+    for (int q = 0; q < kWideQT; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    float bcur[4], acur[kWideQT][4], bnxt[4], anxt[kWideQT][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bcur[u] = bp[u * 64];
+#pragma unroll
+      for (int q = 0; q < kWideQT; ++q) acur[q][u] = ap[q][u * 64];
+    }
+    for (int s0 = 0; s0 < kSteps; s0 += 4) {
+      const int sn = s0 + 4 < kSteps ? s0 + 4 : s0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bnxt[u] = bp[(size_t)(sn + u) * 64];
+#pragma unroll
+        for (int q = 0; q < kWideQT; ++q) anxt[q][u] = ap[q][(size_t)(sn + u) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < kWideQT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(bcur[u], acur[q][u], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bcur[u] = bnxt[u];
+#pragma unroll
+        for (int q = 0; q < kWideQT; ++q) acur[q][u] = anxt[q][u];
+      }
+    }
+    const int rbase = c * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int q = 0; q < kWideQT; ++q) {
+      float tmin = acc[q][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tmin = fminf(tmin, acc[q][r]);
+      if (__any(tmin < ld[q][kListLen - 1]))
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[q][r];
+          if (v < ld[q][kListLen - 1]) {
+            float cd = v;
+            int ci = rbase + (r & 3) + 8 * (r >> 2);
+            bool carrying = false;
+#pragma unroll
+            for (int s = 0; s < kListLen; ++s) {
+              const bool sw = carrying || cd < ld[q][s];
+              carrying = sw;
+              const float td = ld[q][s];
+              const int ti = li[q][s];
+              ld[q][s] = sw ? cd : td; li[q][s] = sw ? ci : ti;
+              cd = sw ? td : cd; ci = sw ? ti : ci;
+            }
+          }
+        }
+    }
+  }
+  const int n_lists = kLists * (int)gridDim.y;
+  const int list = part * kLists + (lane >> 5) * kSlices + slice;
+#pragma unroll
+  for (int q = 0; q < kWideQT; ++q) {
+    const int a = (tile_a0 + q) * 32 + (lane & 31);
+    if (a >= na) continue;
+    float *od = cand_d + ((size_t)a * n_lists + list) * kListLen;
+    int *oi = cand_i + ((size_t)a * n_lists + list) * kListLen;
+#pragma unroll
+    for (int s = 0; s < kListLen; ++s) {
+      const bool real = li[q][s] >= 0 && li[q][s] < nb;
+      od[s] = real ? ld[q][s] : INFINITY;
+      oi[s] = real ? li[q][s] : -1;
+    }
+  }
+}
+
+// FLANN's L2_Simple between the row staged in LDS (broadcast reads) and target row b (this lane's)
+template <int kD>
+__device__ __forceinline__ float knn_wide_dist(const float *__restrict__ x /* LDS */, const float *__restrict__ b)
+{
+  static_assert(kD % 4 == 0, "rows are read as float4");
+  float r = 0.0f;
+  const float4 *b4 = (const float4 *)b;
+  const float4 *x4 = (const float4 *)x;
+#pragma unroll 4
+  for (int d = 0; d < kD / 4; ++d) {
+    const float4 bv = b4[d], xv = x4[d];
+    float df = xv.x - bv.x; r = __fadd_rn(r, __fmul_rn(df, df));
+    df = xv.y - bv.y; r = __fadd_rn(r, __fmul_rn(df, df));
+    df = xv.z - bv.z; r = __fadd_rn(r, __fmul_rn(df, df));
+    df = xv.w - bv.w; r = __fadd_rn(r, __fmul_rn(df, df));
+  }
+  return r;
+}
+
+// order-preserving map of a float's bits (approximate distances can come out slightly negative)
+__device__ __forceinline__ unsigned knn_ordered_bits(float v)
+{
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    const unsigned long long o = __shfl_xor(v, s, kWave);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// One wave per query row.  An exact distance costs a 1344-term chain per candidate, so only the
+// candidates that can still be among the k nearest are re-ranked:
+//   1. the k candidates with the smallest approximate distance are re-ranked first; the largest of
+//      their exact distances, U, bounds the k-th exact distance from above;
+//   2. a candidate b of the true k nearest has exact(b) <= U, hence |b - mu| <= rho(U) and
+//      approx(b) <= U + eps(rho(U)): every candidate under that threshold is re-ranked, nobody else;
+//   3. merge by (distance, index) and certify against the lists' worst kept entries as above.
+template <int kD>
+__global__ void __launch_bounds__(256)
+k_knn_rerank_wide(const float *__restrict__ A, int na, const float *__restrict__ B, int nb, int k, int n_lists,
+                  const float *__restrict__ cand_d, const int *__restrict__ cand_i, const float *__restrict__ colsum, float inv_nb,
+                  int *__restrict__ idx, float *__restrict__ d2out, int *__restrict__ fb_rows, int *__restrict__ fb_count)
+{
+  constexpr int kMaxCand = 64 * 32;                 // parts <= 32
+  __shared__ __attribute__((aligned(16))) float s_x[4][kD];
+  __shared__ int s_sel[4][kMaxCand];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int a_raw = blockIdx.x * 4 + w;
+  const bool live = a_raw < na;
+  const int a = live ? a_raw : na - 1;
+  float na2 = 0.0f;
+  for (int d = lane; d < kD; d += kWave) {
+    const float v = A[(size_t)a * kD + d];
+    s_x[w][d] = v;
+    const float xc = v - colsum[d] * inv_nb;
+    na2 = fmaf(xc, xc, na2);
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) na2 += __shfl_xor(na2, s, kWave);
+  __syncthreads();
+  const int n_cand = n_lists * kListLen;            // a multiple of 64
+  const float *cd_ = cand_d + (size_t)a * n_cand;
+  const int *ci_ = cand_i + (size_t)a * n_cand;
+  // 1. tau, and the k best approximate candidates (k rounds of wave-wide minimum over (approx, slot) keys)
+  float tau = INFINITY;
+  unsigned long long cur = ~0ull;
+  for (int e = lane; e < n_cand; e += kWave) {
+    if (ci_[e] < 0) continue;
+    const float ad = cd_[e];
+    if ((e & (kListLen - 1)) == kListLen - 1) tau = fminf(tau, ad);
+    const unsigned long long key = ((unsigned long long)knn_ordered_bits(ad) << 32) | (unsigned)e;
+    cur = key < cur ? key : cur;
+  }
+  tau = wave_min_f(tau);
+  int my_first = -1;                                // lane o < k: slot of the o-th best approximate candidate
+  for (int o = 0; o < k; ++o) {
+    const unsigned long long best = wave_min_u64(cur);
+    if (best == ~0ull) break;
+    if (lane == o) my_first = (int)(best & 0xffffffffull);
+    if (cur == best) {                              // the owner moves on to its next candidate
+      unsigned long long nxt = ~0ull;
+      for (int e = lane; e < n_cand; e += kWave) {
+        if (ci_[e] < 0) continue;
+        const unsigned long long key = ((unsigned long long)knn_ordered_bits(cd_[e]) << 32) | (unsigned)e;
+        if (key > best && key < nxt) nxt = key;
+      }
+      cur = nxt;
+    }
+  }
+  float first_d = -INFINITY;
+  if (my_first >= 0) first_d = knn_wide_dist<kD>(s_x[w], B + (size_t)ci_[my_first] * kD);
+  const int n_first = __popcll(__ballot(my_first >= 0));
+  const float U = n_first >= k ? wave_max_f(first_d) : INFINITY;
+  // 2. every candidate that can still be among the k nearest
+  const float rho_u = (sqrtf(na2) + sqrtf(U)) * 1.001f + 1e-3f;
+  const float eps_u = (2e-5f * (na2 + rho_u * rho_u) + 1e-5f * U) * ((float)knn_kp(kD) / 36.0f);
+  const float thr = U + eps_u;                      // +inf when fewer than k candidates exist
+  int n_sel = 0;
+  for (int e0 = 0; e0 < n_cand; e0 += kWave) {
+    const int e = e0 + lane;
+    const bool take = ci_[e] >= 0 && !(cd_[e] > thr);
+    const unsigned long long mask = __ballot(take);
+    if (take) s_sel[w][n_sel + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+    n_sel += __popcll(mask);
+  }
+  __syncthreads();
+  float bd[kMaxK];
+  int bi[kMaxK];
+#pragma unroll
+  for (int s = 0; s < kMaxK; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
+  for (int t = lane; t < n_sel; t += kWave) {
+    const int j = ci_[s_sel[w][t]];
+    const float r = knn_wide_dist<kD>(s_x[w], B + (size_t)j * kD);
+    if (r < bd[kMaxK - 1] || (r == bd[kMaxK - 1] && j < bi[kMaxK - 1])) {
+      float cd = r;
+      int ci = j;
+      bool carrying = false;
+#pragma unroll
+      for (int t2 = 0; t2 < kMaxK; ++t2) {
+        const bool sw = carrying || cd < bd[t2] || (cd == bd[t2] && ci < bi[t2]);
+        carrying = sw;
+        const float td = bd[t2];
+        const int ti = bi[t2];
+        bd[t2] = sw ? cd : td; bi[t2] = sw ? ci : ti;
+        cd = sw ? td : cd; ci = sw ? ti : ci;
+      }
+    }
+  }
+  // 3. merge the lanes' lists, certificate
+  float kth = INFINITY;
+  for (int o = 0; o < k; ++o) {
+    const unsigned long long key = ((unsigned long long)__float_as_uint(bd[0]) << 32) | (unsigned)bi[0];
+    const unsigned long long best = wave_min_u64(key);
+    const float d = __uint_as_float((unsigned)(best >> 32));
+    if (lane == 0 && live) {
+      idx[(size_t)a * k + o] = d < INFINITY ? (int)(unsigned)(best & 0xffffffffull) : -1;
+      d2out[(size_t)a * k + o] = d;
+    }
+    if (o == k - 1) kth = d;
+    if (key == best && bd[0] < INFINITY) {
+#pragma unroll
+      for (int s = 0; s + 1 < kMaxK; ++s) { bd[s] = bd[s + 1]; bi[s] = bi[s + 1]; }
+      bd[kMaxK - 1] = INFINITY; bi[kMaxK - 1] = 0x7fffffff;
+    }
+  }
+  const float rho = (sqrtf(na2) + sqrtf(kth)) * 1.001f + 1e-3f;
+  const float eps = (2e-5f * (na2 + rho * rho) + 1e-5f * kth) * ((float)knn_kp(kD) / 36.0f);
+  const bool certified = !(tau < INFINITY) || (kth < tau - eps);
+  if (!certified && lane == 0 && live) fb_rows[atomicAdd(fb_count, 1)] = a;
+}
+
+// Exact brute force for the rows without a certificate (and for small problems): one wave owns
+// kWideFbRows rows staged in LDS and one interleaved part of the target tiles; a lane takes one
+// target per tile and runs the full chains for all the rows (each target float is loaded once per
+// kWideFbRows rows), keeping a sorted top-16 per row in registers.  Output: the same per-part key
+// lists as k_knn_exact_part, merged by k_knn_merge_parts.
+constexpr int kWideFbRows = 4;
+
+template <int kD>
+__global__ void __launch_bounds__(64)
+k_knn_exact_wide(const float *__restrict__ A, const float *__restrict__ B, int nb, int k, const int *__restrict__ rows,
+                 const int *__restrict__ nrows_dev, int nrows_host, unsigned long long *__restrict__ part_keys)
+{
+  __shared__ __attribute__((aligned(16))) float s_x[kWideFbRows][kD];
+  const int nrows = nrows_dev ? *nrows_dev : nrows_host;
+  const int lane = threadIdx.x, part = blockIdx.y;
+  const int ntiles = (nb + 63) / 64;
+  for (int g = blockIdx.x; g * kWideFbRows < nrows; g += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kWideFbRows; ++r) {
+      const int slot = min(g * kWideFbRows + r, nrows - 1);
+      const int row = rows ? rows[slot] : slot;
+      for (int d = lane; d < kD; d += 64) s_x[r][d] = A[(size_t)row * kD + d];
+    }
+    __syncthreads();
+    float bd[kWideFbRows][kMaxK];
+    int bi[kWideFbRows][kMaxK];
+#pragma unroll
+    for (int r = 0; r < kWideFbRows; ++r)
+#pragma unroll
+      for (int s = 0; s < kMaxK; ++s) { bd[r][s] = INFINITY; bi[r][s] = 0x7fffffff; }
+    for (int tl = part; tl < ntiles; tl += kFbParts) {
+      const int j = tl * 64 + lane;
+      if (j >= nb) continue;
+      float acc[kWideFbRows];
+#pragma unroll
+      for (int r = 0; r < kWideFbRows; ++r) acc[r] = 0.0f;
+      const float4 *b4 = (const float4 *)(B + (size_t)j * kD);
+#pragma unroll 2
+      for (int d = 0; d < kD / 4; ++d) {
+        const float4 bv = b4[d];
+#pragma unroll
+        for (int r = 0; r < kWideFbRows; ++r) {
+          const float4 xv = ((const float4 *)s_x[r])[d];
+          float df = xv.x - bv.x; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+          df = xv.y - bv.y; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+          df = xv.z - bv.z; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+          df = xv.w - bv.w; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kWideFbRows; ++r) {
+        if (acc[r] < bd[r][kMaxK - 1]) {     // a lane sees its targets in ascending index order: strict < keeps the lower index
+          float cd = acc[r];
+          int ci = j;
+          bool carrying = false;
+#pragma unroll
+          for (int s = 0; s < kMaxK; ++s) {
+            const bool sw = carrying || cd < bd[r][s];
+            carrying = sw;
+            const float td = bd[r][s];
+            const int ti = bi[r][s];
+            bd[r][s] = sw ? cd : td; bi[r][s] = sw ? ci : ti;
+            cd = sw ? td : cd; ci = sw ? ti : ci;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kWideFbRows; ++r) {
+      const int slot = g * kWideFbRows + r;
+      for (int o = 0; o < k; ++o) {           // k rounds of wave-wide minimum over the lanes' list heads
+        const unsigned long long key = ((unsigned long long)__float_as_uint(bd[r][0]) << 32) | (unsigned)bi[r][0];
+        const unsigned long long best = wave_min_u64(key);
+        if (lane == 0 && slot < nrows) part_keys[((size_t)slot * kFbParts + part) * kMaxK + o] = best;
+        if (key == best && bd[r][0] < INFINITY) {
+#pragma unroll
+          for (int s = 0; s + 1 < kMaxK; ++s) { bd[r][s] = bd[r][s + 1]; bi[r][s] = bi[r][s + 1]; }
+          bd[r][kMaxK - 1] = INFINITY; bi[r][kMaxK - 1] = 0x7fffffff;
+        }
+      }
+    }
+  }
+}
+
 // column sums and MFMA-ordered operands of a TARGET set
 template <int kD>
 static void knn_target_operands(Context *c, const mm3d_desc *B, DevBuf<float> &colsum, DevBuf<float> &Bp)
 {
   constexpr int kKP = knn_kp(kD), kSteps = kKP / 2;
   const int nb = (int)B->n, nb_tiles = (nb + 31) / 32;
-  colsum = DevBuf<float>(c, 128);
+  constexpr int kCols = kD > 128 ? kD : 128;
+  colsum = DevBuf<float>(c, kCols);
   Bp = DevBuf<float>(c, (size_t)nb_tiles * kSteps * 64);
-  MM3D_HIP(hipMemsetAsync(colsum.get(), 0, 128 * sizeof(float), c->stream));
-  MM3D_LAUNCH(c, "desc_knn_prep", nb * kD * 4.0, (k_knn_colsum<kD>), dim3(64), dim3(256), 0, (const float *)B->data.get(), nb, colsum.get());
+  MM3D_HIP(hipMemsetAsync(colsum.get(), 0, kCols * sizeof(float), c->stream));
+  if constexpr (kD <= 128)
+    MM3D_LAUNCH(c, "desc_knn_prep", nb * kD * 4.0, (k_knn_colsum<kD>), dim3(64), dim3(256), 0, (const float *)B->data.get(), nb, colsum.get());
+  else
+    MM3D_LAUNCH(c, "desc_knn_prep", nb * kD * 4.0, k_knn_colsum_wide, dim3(div_up(kD, 256), 64), dim3(256), 0, (const float *)B->data.get(), nb,
+                kD, colsum.get());
   MM3D_LAUNCH(c, "desc_knn_prep", nb * (kD + kKP) * 4.0, (k_knn_prep<kD>), dim3(div_up((size_t)nb_tiles * kSteps * 64, 256)), dim3(256), 0,
               (const float *)B->data.get(), nb, nb_tiles, 1, (const float *)colsum.get(), 1.0f / (float)nb, Bp.get());
 }
@@ -456,6 +828,7 @@ void desc_knn_prepare_target(Context *c, const mm3d_desc *B_)
   if (B->n < 64 || B->knn_Bp.get()) return;
   if (B->dim == 33) knn_target_operands<33>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 125) knn_target_operands<125>(c, B, B->knn_colsum, B->knn_Bp);
+  else if (B->dim == 1344) knn_target_operands<1344>(c, B, B->knn_colsum, B->knn_Bp);
 }
 
 template <int kD>
@@ -519,6 +892,68 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
   }
 }
 
+// the wide path: same stages as desc_knn_impl with the streaming kernels
+template <int kD>
+static void desc_knn_wide_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2)
+{
+  constexpr int kKP = knn_kp(kD), kSteps = kKP / 2;
+  const int na = (int)A->n, nb = (int)B->n;
+  idx = DevBuf<int>(c, (size_t)na * k);
+  d2 = DevBuf<float>(c, (size_t)na * k);
+  if (na == 0) return;
+  const float *Ad = A->data.get(), *Bd = B->data.get();
+  DevBuf<unsigned long long> part_keys(c, (size_t)na * kFbParts * kMaxK);
+  DevBuf<unsigned> meta(c, 4);   // [1] fallback count
+  DevBuf<int> fb_rows(c, na);
+  const int fb_groups = div_up(na, kWideFbRows);
+  if ((double)na * nb < 65536.0 || nb < 64) {
+    // small problems: brute force for every row
+    MM3D_LAUNCH(c, "iota", na * 4.0, k_knn_iota, dim3(div_up(na, 256)), dim3(256), 0, fb_rows.get(), na, (int *)(meta.get() + 1));
+    MM3D_LAUNCH(c, "desc_knn_fallback", ((double)na + nb) * kD * 4.0, (k_knn_exact_wide<kD>), dim3(fb_groups < 64 ? fb_groups : 64, kFbParts),
+                dim3(64), 0, Ad, Bd, nb, k, (const int *)fb_rows.get(), (const int *)nullptr, na, part_keys.get());
+    MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, k_knn_merge_parts, dim3(div_up(na, 64)), dim3(64), 0,
+                (const unsigned long long *)part_keys.get(), k, (const int *)fb_rows.get(), (const int *)(meta.get() + 1), idx.get(),
+                d2.get());
+    return;
+  }
+  const int na_tiles = (na + 31) / 32, nb_tiles = (nb + 31) / 32;
+  DevBuf<float> Ap(c, (size_t)na_tiles * kSteps * 64);
+  MM3D_HIP(hipMemsetAsync(meta.get(), 0, 16, c->stream));
+  DevBuf<float> colsum_tmp, Bp_tmp;
+  const float *colsum = B->knn_colsum.get(), *Bp = B->knn_Bp.get();
+  if (!colsum || !Bp) {
+    knn_target_operands<kD>(c, B, colsum_tmp, Bp_tmp);
+    colsum = colsum_tmp.get();
+    Bp = Bp_tmp.get();
+  }
+  const float inv_nb = 1.0f / (float)nb;
+  MM3D_LAUNCH(c, "desc_knn_prep", na * (kD + kKP) * 4.0, (k_knn_prep<kD>), dim3(div_up((size_t)na_tiles * kSteps * 64, 256)), dim3(256), 0, Ad, na,
+              na_tiles, 0, colsum, inv_nb, Ap.get());
+  const int a_blocks = div_up(na_tiles, kWideQT);
+  int parts = 1;
+  while (parts < 32 && a_blocks * parts < 512 && nb_tiles / (kSlices * parts * 2) >= 2) parts *= 2;
+  const int n_lists = kLists * parts;
+  DevBuf<float> cand_d(c, (size_t)na * n_lists * kListLen);
+  DevBuf<int> cand_i(c, (size_t)na * n_lists * kListLen);
+  MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, (k_knn_mfma_wide<kD>), dim3(a_blocks, parts),
+              dim3(256), 0, (const float *)Ap.get(), na, na_tiles, Bp, nb, nb_tiles, cand_d.get(), cand_i.get());
+  MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * 8 + 32 * kD * 4), (k_knn_rerank_wide<kD>), dim3(div_up(na, 4)), dim3(256), 0,
+              Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb, idx.get(), d2.get(),
+              fb_rows.get(), (int *)(meta.get() + 1));
+  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, (k_knn_exact_wide<kD>), dim3(fb_groups < 64 ? fb_groups : 64, kFbParts), dim3(64), 0, Ad, Bd, nb, k,
+              (const int *)fb_rows.get(), (const int *)(meta.get() + 1), 0, part_keys.get());
+  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, k_knn_merge_parts, dim3(div_up(na, 64)), dim3(64), 0,
+              (const unsigned long long *)part_keys.get(), k, (const int *)fb_rows.get(), (const int *)(meta.get() + 1), idx.get(),
+              d2.get());
+  if (c->debug) {
+    unsigned *h = (unsigned *)c->pin(64);
+    MM3D_HIP(hipMemcpyAsync(h, meta.get(), 16, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    c->knn_fallback_rows += (long long)h[1];
+    c->knn_rows += na;
+  }
+}
+
 void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2)
 {
   MM3D_REQUIRE(A->dim == B->dim, "descriptor dimensions differ");
@@ -526,7 +961,8 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
   if (k > kMaxK) throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN supports k <= 16");
   if (A->dim == 33) desc_knn_impl<33>(c, A, B, k, idx, d2);          // FPFHSignature33
   else if (A->dim == 125) desc_knn_impl<125>(c, A, B, k, idx, d2);   // PFHSignature125
-  else throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for FPFH (33) and PFH (125) rows");
+  else if (A->dim == 1344) desc_knn_wide_impl<1344>(c, A, B, k, idx, d2);   // SHOT1344
+  else throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for FPFH (33), PFH (125) and SHOT (1344) rows");
 }
 
 __global__ void k_gather_desc_rows(const float *__restrict__ X, const int *__restrict__ rows, int n_rows, int dim,

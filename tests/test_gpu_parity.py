@@ -547,3 +547,62 @@ def test_shot_neighbourhoods_beyond_lds(ctx, po, scene):
     got = ctx.computeLocalDescriptors(ctx.cloud(m["filt"]), ctx.normals(m["nrm"]), k, 4, radius).numpy()
     assert got.shape == ref.shape == (6, 1344)
     assert np.abs(got - ref).max() <= 2e-6, np.abs(got - ref).max()
+
+
+def test_desc_knn_dim1344_exact(ctx, po, mm, scene):
+    """k-NN over SHOT rows (1344 wide: the contraction dimension is streamed, 676 MFMA steps): exact
+    FLANN-order results incl. duplicates, few fallbacks; and the small-problem brute-force path."""
+    rng = np.random.default_rng(12)
+    _, base = po.descriptors_shot(scene[0]["filt"], scene[0]["nrm"], scene[0]["kp_raw"], R_DESC)
+
+    def rows(n, noise):
+        X = base[rng.integers(0, len(base), n)] + np.abs(rng.normal(0, noise, (n, 1344))).astype(np.float32)
+        return (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+
+    A, B = rows(700, 0.004), rows(1500, 0.004)
+    B[50:70] = B[150:170]
+    A[:10] = B[300:310]
+    L = mm.lib()
+    L.mm3d_debug_knn_fallback_rows.restype = L.mm3d_debug_knn_rows.restype = __import__("ctypes").c_longlong
+    L.mm3d_set_debug(ctx._h, 1)
+    r0, f0 = L.mm3d_debug_knn_rows(ctx._h), L.mm3d_debug_knn_fallback_rows(ctx._h)
+    da, db = ctx.descriptors(A, 4), ctx.descriptors(B, 4)
+    for k in (1, 5, 10):
+        got = ctx.findFeatureCorrespondences(da, db, k)
+        ref = po.find_correspondences(A, B, k)
+        assert np.array_equal(got["index_query"], ref["index_query"]), k
+        assert np.array_equal(got["index_match"], ref["index_match"]), k
+        assert np.array_equal(got["distance"].view(np.uint32), ref["distance"].view(np.uint32)), k
+    rows_, fb = L.mm3d_debug_knn_rows(ctx._h) - r0, L.mm3d_debug_knn_fallback_rows(ctx._h) - f0
+    L.mm3d_set_debug(ctx._h, 0)
+    assert rows_ > 0 and fb <= 0.05 * rows_, (rows_, fb)
+    # small sets take the brute-force kernels for every row
+    sa, sb = ctx.descriptors(A[:37], 4), ctx.descriptors(B[:90], 4)
+    got = ctx.findFeatureCorrespondences(sa, sb, 5)
+    ref = po.find_correspondences(A[:37], B[:90], 5)
+    assert np.array_equal(got["index_query"], ref["index_query"]) and np.array_equal(got["index_match"], ref["index_match"])
+    assert np.array_equal(got["distance"].view(np.uint32), ref["distance"].view(np.uint32))
+
+
+def test_shot_configuration_end_to_end(ctx, po, mm, scene, synth):
+    """descriptor_type = SHOT through estimateMapsTransforms, both estimation methods (north_star:
+    "computeLocalDescriptors FPFH/SHOT").  The device rows are 1 ulp away from the oracle's on ~1 % of
+    the keypoints, so as on the MATCHING path above the comparison is "same basin" (Frobenius 0.15,
+    confidence within 20 %), plus the recovered relative pose against the ground truth."""
+    a, b = scene
+    for method in (1, 0):
+        params = mm.MapMergingParams(descriptor_type=4, estimation_method=method)
+        op = po.params_default(); op.descriptor_type = 4; op.estimation_method = method
+        po.srand(1); ctx.srand(1)
+        ref_T, ref_pairs = po.estimate_maps_transforms([a["raw"], b["raw"]], op)
+        T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
+        assert len(T) == len(ref_T) == 2 and len(pairs) == len(ref_pairs) == 1
+        assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= 0.15, method
+        assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=0.2)
+        # and the right basin: the generator's ground truth (ICP stops at transform_epsilon = 1e-2 on
+        # this sparse 12 k-point scene, a few decimetres short -- the CPU path stops at the same place)
+        gt = synth.relative_gt(a["T"], b["T"])
+        est = pairs[0]["transform"].reshape(4, 4).T
+        ref = ref_pairs[0]["transform"].reshape(4, 4).T
+        assert np.linalg.norm(est - gt) <= 0.75, (method, np.linalg.norm(est - gt))
+        assert abs(np.linalg.norm(est - gt) - np.linalg.norm(ref - gt)) <= 0.15
