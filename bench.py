@@ -73,6 +73,8 @@ def main():
                          "'python' = the shardable pieces driven from Python threads (what N > 1 always uses)")
     ap.add_argument("--feature-streams", type=int, default=6,
                     help="one GPU only: pipeline the stages, this many streams extract features (0 = two barriered stages)")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="diagnostic: do not bracket kernels with HIP events in the timed region (no roofline then)")
     ap.add_argument("--descriptor", choices=["FPFH", "PFH", "SHOT"], default="FPFH")
     ap.add_argument("--method", choices=["SAC_IA", "MATCHING"], default="SAC_IA")
     ap.add_argument("--kernel-table", default=None, help="write rank 0's full per-kernel HIP-event table (CSV) here")
@@ -364,7 +366,7 @@ def main():
         step()
     for c in ctxs:
         c.profile_reset()
-        c.profile(True)
+        c.profile(not args.no_kernel_events)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -6,6 +6,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -179,20 +180,27 @@ class DevBuf {
   size_t n_ = 0;
 };
 
-// RAII kernel timer: HIP events on the context stream around one launch (only when profiling)
+// RAII kernel timer (only when profiling).  attached = true: the two events ride on the kernel's own
+// dispatch packet (hipExtLaunchKernelGGL start / stop events, see MM3D_LAUNCH) -- no extra packets in
+// the queue; attached = false: events recorded on the stream around whatever the scope encloses
+// (library calls such as rocPRIM's that launch several kernels).
 struct KernelScope {
   Context *c;
   int slot = -1;
+  bool attached = false;
   hipEvent_t a = nullptr, b = nullptr;
-  KernelScope(Context *ctx, const char *name, double bytes);
+  KernelScope(Context *ctx, const char *name, double bytes, bool attached = false);
   ~KernelScope();
 };
 
-#define MM3D_LAUNCH(ctx, name, bytes, kernel, grid, block, shmem, ...)                      \
-  do {                                                                                      \
-    ::mm3d::KernelScope ks_((ctx), (name), (double)(bytes));                                \
-    hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (ctx)->stream, __VA_ARGS__);       \
-    MM3D_HIP(hipGetLastError());                                                            \
+#define MM3D_LAUNCH(ctx, name, bytes, kernel, grid, block, shmem, ...)                                            \
+  do {                                                                                                            \
+    ::mm3d::KernelScope ks_((ctx), (name), (double)(bytes), true);                                                \
+    if (ks_.a)                                                                                                    \
+      hipExtLaunchKernelGGL(kernel, (grid), (block), (shmem), (ctx)->stream, ks_.a, ks_.b, 0, __VA_ARGS__);       \
+    else                                                                                                          \
+      hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (ctx)->stream, __VA_ARGS__);                           \
+    MM3D_HIP(hipGetLastError());                                                                                  \
   } while (0)
 
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

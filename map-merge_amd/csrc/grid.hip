@@ -102,7 +102,7 @@ void Context::prof_resolve()
   pending.clear();
 }
 
-KernelScope::KernelScope(Context *ctx, const char *name, double bytes) : c(ctx)
+KernelScope::KernelScope(Context *ctx, const char *name, double bytes, bool attached_) : c(ctx), attached(attached_)
 {
   if (!c->prof_on) return;
   slot = c->prof_slot(name);
@@ -115,13 +115,13 @@ KernelScope::KernelScope(Context *ctx, const char *name, double bytes) : c(ctx)
     return e;
   };
   a = get(); b = get();
-  (void)hipEventRecord(a, c->stream);
+  if (!attached) (void)hipEventRecord(a, c->stream);
 }
 
 KernelScope::~KernelScope()
 {
   if (slot < 0) return;
-  (void)hipEventRecord(b, c->stream);
+  if (!attached) (void)hipEventRecord(b, c->stream);
   c->pending.push_back({slot, a, b});
   if (c->pending.size() > 8192) {
     try { c->prof_resolve(); } catch (...) {}

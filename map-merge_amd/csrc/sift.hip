@@ -144,19 +144,50 @@ __global__ void k_sift_dogx(const float4 *__restrict__ sorted, const float *__re
   dogx[n + j] = make_float4(fmaxf(fmaxf(d[1], d[2]), d[3]), fmaxf(fmaxf(d[2], d[3]), d[4]), 0.f, 0.f);
 }
 
-// findScaleSpaceExtrema
+// The extremum test only concerns points whose DoG passes the contrast test at some scale (about a
+// quarter of them): they are compacted, in Hilbert order, into dense runs of 64 so that a wave's
+// lanes all have work (k_sift_live + scan + k_sift_live_compact), instead of idling through the box
+// scans of their item's few live points.
+__global__ void k_sift_live(const float4 *__restrict__ hil, int n, const float *__restrict__ dog, float min_contrast,
+                            int *__restrict__ flag /* [n + 1] */)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n) return;
+  int f = 0;
+  if (j < n) {
+    const int self = __float_as_int(hil[j].w);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) f |= fabsf(dog[(size_t)self * kDog + s + 1]) >= min_contrast ? 1 : 0;
+  }
+  flag[j] = f;
+}
+
+__global__ void k_sift_live_compact(const float4 *__restrict__ hil, int n, const int *__restrict__ flag, const int *__restrict__ pos,
+                                    float4 *__restrict__ out)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n && flag[j]) out[pos[j]] = hil[j];
+}
+
+// findScaleSpaceExtrema.  q_pts = the live points (k_sift_live_compact), *n_live_dev of them; wave w
+// takes points [64 w, 64 w + 64).
+constexpr int kExtremaSpan = 8;   // a run that jumps farther than this many cells is worked in several groups
+
 __global__ void __launch_bounds__(256)
-k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* .w = original index */,
+k_sift_extrema(const float4 *__restrict__ q_pts, const int *__restrict__ n_live_dev, GridView g /* .w = original index */,
                const float4 *__restrict__ dogx, const float *__restrict__ dog, float min_contrast, int *__restrict__ flags /* [n*3] */)
 {
   __shared__ float4 s_pts[4][kSiftTile];
   __shared__ float4 s_x[4][2 * kSiftTile];
   __shared__ int s_off[4][64];
   __shared__ int s_beg[4][64];
-  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int n_live = *n_live_dev;
+  const int n_items = (n_live + 63) >> 6;
+  if ((int)(blockIdx.x * 4) >= n_items) return;            // the grid is sized for the worst case
+  const unsigned bid = xcd_remap(blockIdx.x, (unsigned)((n_items + 3) >> 2));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = bid * 4 + wave;
-  const int2 it = item < n_items ? items[item] : make_int2(0, 0);
+  const int2 it = item < n_items ? make_int2(item * 64, min(64, n_live - item * 64)) : make_int2(0, 0);
   const bool valid = lane < it.y;
   if (it.y == 0) return;                      // wave-uniform
   const float4 q = q_pts[it.x + (valid ? lane : 0)];
@@ -168,15 +199,24 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
     v[s] = valid ? dog[(size_t)self * kDog + s + 1] : 0.0f;
     if (valid && fabsf(v[s]) >= min_contrast) live |= 1u << s;
   }
-  bool active = live != 0;
+  bool todo = live != 0;
   bool is_min[3] = {false, false, false}, is_max[3] = {false, false, false};
   const int cx = cell_floor(q.x, g.minx, g.inv), cy = cell_floor(q.y, g.miny, g.inv), cz = cell_floor(q.z, g.minz, g.inv);
   const int n_total = g.n;
   const int max_e = max(max(g.dx, g.dy), g.dz) + 1;
-  int need = 1;
   const float4 *sp = s_pts[wave];
   const float4 *sx = s_x[wave];
   const int ngrid = g.n;
+  // a run of live points is normally one compact patch; where the Hilbert curve leaves the occupied
+  // area and re-enters far away it is worked group by group (lanes near the first open lane)
+  for (int grp = 0; grp < 64; ++grp) {
+  const unsigned long long open = __ballot(todo);
+  if (!open) break;
+  const int leader = __ffsll((long long)open) - 1;
+  const int ldx = cx - __shfl(cx, leader, 64), ldy = cy - __shfl(cy, leader, 64), ldz = cz - __shfl(cz, leader, 64);
+  bool active = todo && abs(ldx) <= kExtremaSpan && abs(ldy) <= kExtremaSpan && abs(ldz) <= kExtremaSpan;
+  todo = todo && !active;
+  int need = 1;
   for (int pass = 0; pass < 4096; ++pass) {
     if (!__ballot(active)) break;
     const int E = wave_max_int(active ? need : 0);
@@ -267,6 +307,7 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
       else need = min(E + 1, max_e);
     }
   }
+  }
   if (!valid) return;
 #pragma unroll
   for (int s = 0; s < 3; ++s)
@@ -327,8 +368,16 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
                 (const float *)dog.get(), gk.n, dogx.get());
     DevBuf<int> flags(c, (size_t)n * 3 + 1);
     MM3D_HIP(hipMemsetAsync(flags.get(), 0, ((size_t)n * 3 + 1) * sizeof(int), c->stream));
-    MM3D_LAUNCH(c, "sift_extrema", gk.n * 48.0, k_sift_extrema, dim3(nblocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
-                (const int2 *)cur->wave_items.get(), n_items, gk.view(), (const float4 *)dogx.get(), (const float *)dog.get(),
+    const int nh = (int)cur->n_finite;
+    DevBuf<int> lflag(c, (size_t)nh + 1), lpos(c, (size_t)nh + 1);
+    DevBuf<float4> lpts(c, (size_t)nh);
+    MM3D_LAUNCH(c, "sift_live", nh * 28.0, k_sift_live, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(), nh,
+                (const float *)dog.get(), (float)min_contrast, lflag.get());
+    exclusive_scan_int(c, lflag.get(), lpos.get(), (size_t)nh + 1);
+    MM3D_LAUNCH(c, "sift_live", nh * 24.0, k_sift_live_compact, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
+                nh, (const int *)lflag.get(), (const int *)lpos.get(), lpts.get());
+    MM3D_LAUNCH(c, "sift_extrema", gk.n * 48.0, k_sift_extrema, dim3(div_up(div_up((size_t)nh, 64), 4)), dim3(256), 0,
+                (const float4 *)lpts.get(), (const int *)(lpos.get() + nh), gk.view(), (const float4 *)dogx.get(), (const float *)dog.get(),
                 (float)min_contrast, flags.get());
     DevBuf<int> pos(c, (size_t)n * 3 + 1);
     exclusive_scan_int(c, flags.get(), pos.get(), (size_t)n * 3 + 1);
