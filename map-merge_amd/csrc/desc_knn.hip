@@ -28,8 +28,8 @@ namespace mm3d {
 constexpr int kMaxK = 16;
 // The kernels are templates on the descriptor dimension kD: 33 (FPFH) and 125 (PFH) are instantiated.
 // padded contraction length (dimension + the two augmentation columns, even): 36 / 128
-// (wide rows -- SHOT's 1344 floats -- pad to a multiple of 8 so the step loop unrolls by 4: 1352)
-constexpr int knn_kp(int d) { return d > 256 ? (d + 9) / 8 * 8 : (d + 3) / 2 * 2; }
+// (wide rows -- PFHRGB's 250 and SHOT's 1344 floats -- pad to a multiple of 8 so the step loop unrolls by 4: 256 / 1352)
+constexpr int knn_kp(int d) { return d > 128 ? (d + 9) / 8 * 8 : (d + 3) / 2 * 2; }
 constexpr int kSlices = 4;       // waves per query tile, each scanning a quarter of the targets
 constexpr int kLists = 2 * kSlices;
 constexpr int kListLen = 8;      // per-lane candidate list of the MFMA stage (8 lists x 8 = 64 candidates per query and part)
@@ -561,21 +561,33 @@ k_knn_mfma_wide(const float *__restrict__ Ap, int na, int na_tiles, const float 
   }
 }
 
-// FLANN's L2_Simple between the row staged in LDS (broadcast reads) and target row b (this lane's)
+// FLANN's L2_Simple between the row staged in LDS (broadcast reads) and target row b (this lane's);
+// rows are read 4 floats at a time when their length allows 16-byte alignment (1344), else 2 (250)
 template <int kD>
 __device__ __forceinline__ float knn_wide_dist(const float *__restrict__ x /* LDS */, const float *__restrict__ b)
 {
-  static_assert(kD % 4 == 0, "rows are read as float4");
   float r = 0.0f;
-  const float4 *b4 = (const float4 *)b;
-  const float4 *x4 = (const float4 *)x;
+  if constexpr (kD % 4 == 0) {
+    const float4 *b4 = (const float4 *)b;
+    const float4 *x4 = (const float4 *)x;
 #pragma unroll 4
-  for (int d = 0; d < kD / 4; ++d) {
-    const float4 bv = b4[d], xv = x4[d];
-    float df = xv.x - bv.x; r = __fadd_rn(r, __fmul_rn(df, df));
-    df = xv.y - bv.y; r = __fadd_rn(r, __fmul_rn(df, df));
-    df = xv.z - bv.z; r = __fadd_rn(r, __fmul_rn(df, df));
-    df = xv.w - bv.w; r = __fadd_rn(r, __fmul_rn(df, df));
+    for (int d = 0; d < kD / 4; ++d) {
+      const float4 bv = b4[d], xv = x4[d];
+      float df = xv.x - bv.x; r = __fadd_rn(r, __fmul_rn(df, df));
+      df = xv.y - bv.y; r = __fadd_rn(r, __fmul_rn(df, df));
+      df = xv.z - bv.z; r = __fadd_rn(r, __fmul_rn(df, df));
+      df = xv.w - bv.w; r = __fadd_rn(r, __fmul_rn(df, df));
+    }
+  } else {
+    static_assert(kD % 2 == 0, "rows are read as float2");
+    const float2 *b2 = (const float2 *)b;
+    const float2 *x2 = (const float2 *)x;
+#pragma unroll 4
+    for (int d = 0; d < kD / 2; ++d) {
+      const float2 bv = b2[d], xv = x2[d];
+      float df = xv.x - bv.x; r = __fadd_rn(r, __fmul_rn(df, df));
+      df = xv.y - bv.y; r = __fadd_rn(r, __fmul_rn(df, df));
+    }
   }
   return r;
 }
@@ -755,17 +767,31 @@ k_knn_exact_wide(const float *__restrict__ A, const float *__restrict__ B, int n
       float acc[kWideFbRows];
 #pragma unroll
       for (int r = 0; r < kWideFbRows; ++r) acc[r] = 0.0f;
-      const float4 *b4 = (const float4 *)(B + (size_t)j * kD);
+      if constexpr (kD % 4 == 0) {
+        const float4 *b4 = (const float4 *)(B + (size_t)j * kD);
 #pragma unroll 2
-      for (int d = 0; d < kD / 4; ++d) {
-        const float4 bv = b4[d];
+        for (int d = 0; d < kD / 4; ++d) {
+          const float4 bv = b4[d];
 #pragma unroll
-        for (int r = 0; r < kWideFbRows; ++r) {
-          const float4 xv = ((const float4 *)s_x[r])[d];
-          float df = xv.x - bv.x; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
-          df = xv.y - bv.y; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
-          df = xv.z - bv.z; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
-          df = xv.w - bv.w; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+          for (int r = 0; r < kWideFbRows; ++r) {
+            const float4 xv = ((const float4 *)s_x[r])[d];
+            float df = xv.x - bv.x; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+            df = xv.y - bv.y; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+            df = xv.z - bv.z; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+            df = xv.w - bv.w; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+          }
+        }
+      } else {
+        const float2 *b2 = (const float2 *)(B + (size_t)j * kD);
+#pragma unroll 2
+        for (int d = 0; d < kD / 2; ++d) {
+          const float2 bv = b2[d];
+#pragma unroll
+          for (int r = 0; r < kWideFbRows; ++r) {
+            const float2 xv = ((const float2 *)s_x[r])[d];
+            float df = xv.x - bv.x; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+            df = xv.y - bv.y; acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+          }
         }
       }
 #pragma unroll
@@ -828,6 +854,7 @@ void desc_knn_prepare_target(Context *c, const mm3d_desc *B_)
   if (B->n < 64 || B->knn_Bp.get()) return;
   if (B->dim == 33) knn_target_operands<33>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 125) knn_target_operands<125>(c, B, B->knn_colsum, B->knn_Bp);
+  else if (B->dim == 250) knn_target_operands<250>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 1344) knn_target_operands<1344>(c, B, B->knn_colsum, B->knn_Bp);
 }
 
@@ -961,8 +988,9 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
   if (k > kMaxK) throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN supports k <= 16");
   if (A->dim == 33) desc_knn_impl<33>(c, A, B, k, idx, d2);          // FPFHSignature33
   else if (A->dim == 125) desc_knn_impl<125>(c, A, B, k, idx, d2);   // PFHSignature125
+  else if (A->dim == 250) desc_knn_wide_impl<250>(c, A, B, k, idx, d2);     // PFHRGBSignature250
   else if (A->dim == 1344) desc_knn_wide_impl<1344>(c, A, B, k, idx, d2);   // SHOT1344
-  else throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for FPFH (33), PFH (125) and SHOT (1344) rows");
+  else throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for FPFH (33), PFH (125), PFHRGB (250) and SHOT (1344) rows");
 }
 
 __global__ void k_gather_desc_rows(const float *__restrict__ X, const int *__restrict__ rows, int n_rows, int dim,

@@ -57,6 +57,37 @@ __device__ __forceinline__ void pfh_pair_features(const PfhNb &p1, const PfhNb &
   f1 = atan2f(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);
 }
 
+// pcl::computeRGBPairFeatures (features/src/pfh.cpp), PFHRGB: the frame always sits on p1 (no swap),
+// f3 = angle1, and f5..f7 are colour ratios taken with INTEGER division (Eigen::Vector4i colours),
+// folded into [-1, 1] by f > 1 -> -1 / f.  The neighbour's rgba travels in PfhNb::d2.
+__device__ __forceinline__ void pfhrgb_pair_features(const PfhNb &p1, const PfhNb &p2, float &f1, float &f2, float &f3, float &f5,
+                                                     float &f6, float &f7)
+{
+  const float dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
+  const float f4 = sqrtf(dx * dx + dy * dy + dz * dz);
+  if (f4 == 0.0f) { f1 = f2 = f3 = f5 = f6 = f7 = 0.0f; return; }
+  const float ax = p1.nx, ay = p1.ny, az = p1.nz, bx = p2.nx, by = p2.ny, bz = p2.nz;
+  f3 = (ax * dx + ay * dy + az * dz) / f4;
+  float vx = dy * az - dz * ay, vy = dz * ax - dx * az, vz = dx * ay - dy * ax;
+  const float v_norm = sqrtf(vx * vx + vy * vy + vz * vz);
+  if (v_norm == 0.0f) { f1 = f2 = f3 = f5 = f6 = f7 = 0.0f; return; }
+  vx /= v_norm; vy /= v_norm; vz /= v_norm;
+  const float wx = ay * vz - az * vy, wy = az * vx - ax * vz, wz = ax * vy - ay * vx;
+  f2 = vx * bx + vy * by + vz * bz;
+  f1 = atan2f(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);
+  const unsigned c1 = __float_as_uint(p1.d2), c2 = __float_as_uint(p2.d2);
+  float r[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int sh = 16 - 8 * c;
+    const int a1 = (int)((c1 >> sh) & 0xffu), a2 = (int)((c2 >> sh) & 0xffu);
+    float q = (a2 != 0) ? (float)(a1 / a2) : 1.0f;
+    if (q > 1.0f) q = -1.0f / q;
+    r[c] = q;
+  }
+  f5 = r[0]; f6 = r[1]; f7 = r[2];
+}
+
 // static_cast<int>(floor(x)) with x86 semantics for NaN / out of range (INT_MIN -> clamped to 0)
 __device__ __forceinline__ int pfh_bin(double x)
 {
@@ -68,19 +99,24 @@ __device__ __forceinline__ int pfh_bin(double x)
 
 // rows: optional list of keypoints to process (the ones whose neighbourhood overflowed LDS), with
 // their neighbours then kept in `scratch` (cap_scratch entries per row)
+// kRgb: PFHRGBSignature250 (pfhrgb.hpp): every ORDERED pair (i, j != i), 125 geometry + 125 colour bins,
+// no "no neighbours" branch (the row stays zero and valid); pts = the cloud in original order (rgba)
+template <bool kRgb>
 __global__ void __launch_bounds__(256)
-k_pfh(const float4 *__restrict__ kp, int nk, GridView g, const float4 *__restrict__ nrm /* original order */, float radius,
+k_pfh(const float4 *__restrict__ kp, int nk, GridView g, const float4 *__restrict__ nrm /* original order */,
+      const float4 *__restrict__ pts, float radius,
       float r2, const int *__restrict__ rows, PfhNb *__restrict__ scratch, int cap, float *__restrict__ desc /* [nk][125] */,
       int *__restrict__ valid, int *__restrict__ overflow /* [0] count, [1..] keypoint ids, [nk + 1] max count */)
 {
   __shared__ PfhNb s_nb[kPfhCap];
-  __shared__ unsigned s_hist[kPfhDim];
+  constexpr int kBins = kRgb ? 2 * kPfhDim : kPfhDim;
+  __shared__ unsigned s_hist[kBins];
   __shared__ int s_m;
   const int k = rows ? rows[blockIdx.x] : (int)blockIdx.x;
   PfhNb *nb = rows ? scratch + (size_t)blockIdx.x * cap : s_nb;
   const int tid = threadIdx.x;
   if (tid == 0) s_m = 0;
-  if (tid < kPfhDim) s_hist[tid] = 0u;
+  if (tid < kBins) s_hist[tid] = 0u;
   __syncthreads();
   const float4 q = kp[k];
   // 1. gather the radius neighbours (any order; the sorted order is carried by the keys)
@@ -104,7 +140,7 @@ k_pfh(const float4 *__restrict__ kp, int nk, GridView g, const float4 *__restric
               const int oi = __float_as_int(p.w);
               const float4 n = nrm[oi];
               PfhNb v;
-              v.x = p.x; v.y = p.y; v.z = p.z; v.d2 = d2; v.nx = n.x; v.ny = n.y; v.nz = n.z; v.idx = oi;
+              v.x = p.x; v.y = p.y; v.z = p.z; v.d2 = kRgb ? pts[oi].w : d2; v.nx = n.x; v.ny = n.y; v.nz = n.z; v.idx = oi;
               nb[slot] = v;
             }
           }
@@ -122,10 +158,40 @@ k_pfh(const float4 *__restrict__ kp, int nk, GridView g, const float4 *__restric
     }
     return;
   }
-  float *out = desc + (size_t)k * kPfhDim;
-  if (m == 0) {
+  float *out = desc + (size_t)k * kBins;
+  if (m == 0 && !kRgb) {
     if (tid < kPfhDim) out[tid] = __uint_as_float(0x7fc00000u);   // searchForNeighbors == 0: NaN row, pruned below
     if (tid == 0) valid[k] = 0;
+    return;
+  }
+  if (kRgb) {
+    // all ordered pairs: m (m - 1) of them, row i pairs with every j != i
+    const float d_pi = 1.0f / (2.0f * 3.14159274f);
+    const long long total = (long long)m * (m - 1);
+    for (long long t = tid; t < total; t += 256) {
+      const int i = (int)(t / (m - 1)), c = (int)(t % (m - 1));
+      const int j = c < i ? c : c + 1;
+      float f1, f2, f3, f5, f6, f7;
+      pfhrgb_pair_features(nb[i], nb[j], f1, f2, f3, f5, f6, f7);
+      const int h1 = pfh_bin(kPfhSplit * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
+      const int h2 = pfh_bin(kPfhSplit * (((double)f2 + 1.0) * 0.5));
+      const int h3 = pfh_bin(kPfhSplit * (((double)f3 + 1.0) * 0.5));
+      atomicAdd(&s_hist[h1 + kPfhSplit * h2 + kPfhSplit * kPfhSplit * h3], 1u);
+      const int h5 = pfh_bin(kPfhSplit * (((double)f5 + 1.0) * 0.5));
+      const int h6 = pfh_bin(kPfhSplit * (((double)f6 + 1.0) * 0.5));
+      const int h7 = pfh_bin(kPfhSplit * (((double)f7 + 1.0) * 0.5));
+      atomicAdd(&s_hist[kPfhDim + h5 + kPfhSplit * h6 + kPfhSplit * kPfhSplit * h7], 1u);
+    }
+    __syncthreads();
+    if (tid < kBins) {
+      const unsigned long long pairs = (unsigned long long)m * (unsigned long long)(m - 1) / 2ull;
+      const float hist_incr = 100.0f / (float)pairs;
+      const unsigned hits = s_hist[tid];
+      float v = 0.0f;
+      for (unsigned i = 0; i < hits; ++i) v += hist_incr;
+      out[tid] = v;
+    }
+    if (tid == 0) valid[k] = 1;
     return;
   }
   // 2. all pairs (i, j < i).  Rows i and m-1-i together hold exactly m-1 pairs, so "super rows" of
@@ -174,12 +240,14 @@ __global__ void k_pfh_compact(const float *__restrict__ in, const int *__restric
   if (flags[r]) out[(size_t)pos[r] * dim + cidx] = in[e];
 }
 
-mm3d_desc *compute_pfh(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, mm3d_cloud *keypoints, double radius)
+template <bool kRgb>
+static mm3d_desc *compute_pfh_impl(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, mm3d_cloud *keypoints, double radius)
 {
   MM3D_REQUIRE(normals->n == points->n, "computeLocalDescriptors: normals and points differ in size");
+  constexpr int kDim = kRgb ? 2 * kPfhDim : kPfhDim;
   auto *res = new mm3d_desc();
-  res->dim = kPfhDim;
-  res->type = MM3D_DESC_PFH;
+  res->dim = kDim;
+  res->type = kRgb ? MM3D_DESC_PFHRGB : MM3D_DESC_PFH;
   const int nk = (int)keypoints->n;
   if (nk == 0) { res->n = 0; res->data = DevBuf<float>(c, 0); return res; }
   const float r2 = (float)(radius * radius);
@@ -189,14 +257,20 @@ mm3d_desc *compute_pfh(Context *c, const mm3d_cloud *points, const mm3d_normals 
     keypoints->pts = DevBuf<float4>(c, 0); keypoints->n = 0; keypoints->grids.clear(); keypoints->host.clear();
     keypoints->have_bbox = false;
   };
-  if (g.n == 0) { drop_all(); return res; }        // no surface: every descriptor is NaN and gets pruned
-  DevBuf<float> raw(c, (size_t)nk * kPfhDim);
+  if (g.n == 0 && !kRgb) { drop_all(); return res; }   // no surface: every PFH descriptor is NaN and gets pruned
+  DevBuf<float> raw(c, (size_t)nk * kDim);
+  if (g.n == 0) {                                       // PFHRGB keeps all-zero rows
+    MM3D_HIP(hipMemsetAsync(raw.get(), 0, (size_t)nk * kDim * sizeof(float), c->stream));
+    res->n = (size_t)nk; res->data = std::move(raw);
+    c->sync();
+    return res;
+  }
   DevBuf<int> valid(c, (size_t)nk + 1), overflow(c, (size_t)nk + 2);
   MM3D_HIP(hipMemsetAsync(valid.get(), 0, ((size_t)nk + 1) * sizeof(int), c->stream));
   MM3D_HIP(hipMemsetAsync(overflow.get(), 0, ((size_t)nk + 2) * sizeof(int), c->stream));
-  MM3D_LAUNCH(c, "pfh", nk * (200.0 * 32.0 + 500.0), k_pfh, dim3(nk), dim3(256), 0, (const float4 *)keypoints->pts.get(), nk, g.view(),
-              (const float4 *)normals->nrm.get(), (float)radius, r2, (const int *)nullptr, (PfhNb *)nullptr, kPfhCap, raw.get(),
-              valid.get(), overflow.get());
+  MM3D_LAUNCH(c, "pfh", nk * (200.0 * 32.0 + kDim * 4.0), (k_pfh<kRgb>), dim3(nk), dim3(256), 0, (const float4 *)keypoints->pts.get(), nk,
+              g.view(), (const float4 *)normals->nrm.get(), (const float4 *)points->pts.get(), (float)radius, r2, (const int *)nullptr,
+              (PfhNb *)nullptr, kPfhCap, raw.get(), valid.get(), overflow.get());
   int *h = (int *)c->pin(64);
   MM3D_HIP(hipMemcpyAsync(h, overflow.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MM3D_HIP(hipMemcpyAsync(h + 1, overflow.get() + nk + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -207,9 +281,9 @@ mm3d_desc *compute_pfh(Context *c, const mm3d_cloud *points, const mm3d_normals 
     const double bytes = (double)n_over * max_m * sizeof(PfhNb);
     if (bytes > 8e9) throw Error(MM3D_EUNSUPPORTED, "PFH: neighbourhoods too large for the scratch pass (reduce descriptor_radius)");
     DevBuf<PfhNb> scratch(c, (size_t)n_over * max_m);
-    MM3D_LAUNCH(c, "pfh", n_over * (max_m * 32.0 + 500.0), k_pfh, dim3(n_over), dim3(256), 0, (const float4 *)keypoints->pts.get(), nk,
-                g.view(), (const float4 *)normals->nrm.get(), (float)radius, r2, (const int *)(overflow.get() + 1), scratch.get(),
-                max_m, raw.get(), valid.get(), overflow.get());
+    MM3D_LAUNCH(c, "pfh", n_over * (max_m * 32.0 + kDim * 4.0), (k_pfh<kRgb>), dim3(n_over), dim3(256), 0,
+                (const float4 *)keypoints->pts.get(), nk, g.view(), (const float4 *)normals->nrm.get(), (const float4 *)points->pts.get(),
+                (float)radius, r2, (const int *)(overflow.get() + 1), scratch.get(), max_m, raw.get(), valid.get(), overflow.get());
     c->sync();
   }
   // prune invalid descriptors and the same keypoints (features.cpp:118-143)
@@ -222,11 +296,11 @@ mm3d_desc *compute_pfh(Context *c, const mm3d_cloud *points, const mm3d_normals 
   if (nv == nk) {
     res->data = std::move(raw);
   } else {
-    res->data = DevBuf<float>(c, (size_t)nv * kPfhDim);
+    res->data = DevBuf<float>(c, (size_t)nv * kDim);
     DevBuf<float4> kp2(c, nv);
     if (nv) {
-      MM3D_LAUNCH(c, "compact_rows", nk * 1000.0, k_pfh_compact, dim3(div_up((size_t)nk * kPfhDim, 256)), dim3(256), 0,
-                  (const float *)raw.get(), (const int *)valid.get(), (const int *)vpos.get(), nk, kPfhDim, res->data.get());
+      MM3D_LAUNCH(c, "compact_rows", nk * kDim * 8.0, k_pfh_compact, dim3(div_up((size_t)nk * kDim, 256)), dim3(256), 0,
+                  (const float *)raw.get(), (const int *)valid.get(), (const int *)vpos.get(), nk, kDim, res->data.get());
       MM3D_LAUNCH(c, "compact_rows", nk * 32.0, k_pfh_compact, dim3(div_up((size_t)nk * 4, 256)), dim3(256), 0,
                   (const float *)keypoints->pts.get(), (const int *)valid.get(), (const int *)vpos.get(), nk, 4, (float *)kp2.get());
     }
@@ -239,6 +313,16 @@ mm3d_desc *compute_pfh(Context *c, const mm3d_cloud *points, const mm3d_normals 
   }
   c->sync();
   return res;
+}
+
+mm3d_desc *compute_pfh(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, mm3d_cloud *keypoints, double radius)
+{
+  return compute_pfh_impl<false>(c, points, normals, keypoints, radius);
+}
+
+mm3d_desc *compute_pfhrgb(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, mm3d_cloud *keypoints, double radius)
+{
+  return compute_pfh_impl<true>(c, points, normals, keypoints, radius);
 }
 
 }  // namespace mm3d

@@ -95,6 +95,12 @@ int mo_descriptors_pfh(const mo_point *surface, const mo_normal *normals, int n,
                        mo_point *keypoints, int n_kp, double radius, float *desc);
 int mo_pfh_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints,
                int n_kp, double radius, float *desc /* n_kp x 125, NaN rows where no neighbour */);
+/* computeLocalDescriptors(PFHRGB): dispatch_descriptors.h:39 = PFHRGBEstimation / PFHRGBSignature250.
+ * desc must hold n_kp*250 floats; keypoints pruned in place; returns the survivors. */
+int mo_descriptors_pfhrgb(const mo_point *surface, const mo_normal *normals, int n,
+                          mo_point *keypoints, int n_kp, double radius, float *desc);
+int mo_pfhrgb_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints,
+                  int n_kp, double radius, float *desc /* n_kp x 250 */);
 /* computeLocalDescriptors(SHOT): dispatch_descriptors.h:46 = SHOTColorEstimation / SHOT1344 (o_shot.c).
  * desc must hold n_kp*1344 floats; keypoints pruned in place; returns the survivors. */
 int mo_descriptors_shot(const mo_point *surface, const mo_normal *normals, int n,

@@ -207,6 +207,108 @@ int mo_pfh_raw(const mo_point *surface, const mo_normal *normals, int n, const m
   return n_kp;
 }
 
+/*
+ * computeLocalDescriptors(PFHRGB): dispatch_descriptors.h:39 = pcl::PFHRGBEstimation<PointXYZRGB, Normal,
+ * PFHRGBSignature250>.  PCL 1.8.1 features/impl/pfhrgb.hpp (computeFeature, computePointPFHRGBSignature) and
+ * features/src/pfh.cpp pcl::computeRGBPairFeatures.  Unlike PFH:
+ *   - EVERY ordered pair (i, j != i) of the neighbours is binned (so each 125-bin half sums to 200);
+ *   - the Darboux frame is always built on the first point (no angle comparison / swap), f3 = angle1;
+ *   - f5..f7 are colour ratios computed with INTEGER division (Eigen::Vector4i colours:
+ *     static_cast<float>(c1 / c2), 1 when c2 == 0), folded into [-1, 1] by f > 1 -> -1 / f;
+ *   - computeFeature has no "no neighbours" branch: such a keypoint keeps an all-zero (valid) row.
+ * The class' computeRGBPairFeatures wrapper returns true unconditionally, so degenerate pairs are binned.
+ */
+static void rgb_pair_features(const mo_point *p1, const mo_normal *n1, const mo_point *p2, const mo_normal *n2, float f[7])
+{
+  float d[3] = {p2->x - p1->x, p2->y - p1->y, p2->z - p1->z};
+  f[3] = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (f[3] == 0.0f) { for (int i = 0; i < 7; ++i) f[i] = 0.0f; return; }
+  const float a[3] = {n1->nx, n1->ny, n1->nz}, b[3] = {n2->nx, n2->ny, n2->nz};
+  f[2] = (a[0] * d[0] + a[1] * d[1] + a[2] * d[2]) / f[3];
+  float v[3] = {d[1] * a[2] - d[2] * a[1], d[2] * a[0] - d[0] * a[2], d[0] * a[1] - d[1] * a[0]};
+  const float v_norm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  if (v_norm == 0.0f) { for (int i = 0; i < 7; ++i) f[i] = 0.0f; return; }
+  v[0] /= v_norm; v[1] /= v_norm; v[2] /= v_norm;
+  const float w[3] = {a[1] * v[2] - a[2] * v[1], a[2] * v[0] - a[0] * v[2], a[0] * v[1] - a[1] * v[0]};
+  f[1] = v[0] * b[0] + v[1] * b[1] + v[2] * b[2];
+  f[0] = atan2f(w[0] * b[0] + w[1] * b[1] + w[2] * b[2], a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
+  for (int c = 0; c < 3; ++c) {
+    const int sh = 16 - 8 * c;                                   /* r, g, b */
+    const int c1 = (int)((p1->rgba >> sh) & 0xff), c2 = (int)((p2->rgba >> sh) & 0xff);
+    float r = (c2 != 0) ? (float)(c1 / c2) : 1.0f;
+    if (r > 1.0f) r = -1.0f / r;
+    f[4 + c] = r;
+  }
+}
+
+static inline int split_bin(double x)
+{
+  int h = floor_to_int(x);
+  if (h < 0) h = 0;
+  if (h >= PFH_SPLIT) h = PFH_SPLIT - 1;
+  return h;
+}
+
+int mo_pfhrgb_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints,
+                  int n_kp, double radius, float *desc /* n_kp x 250 */)
+{
+  mo_grid *g = mo_grid_build(surface, n, (float)(radius * 0.5));
+  const float r2 = (float)(radius * radius);
+  const float d_pi = 1.0f / (2.0f * (float)M_PI);
+  int cap = 4096;
+  int *idx = (int *)malloc(sizeof(int) * (size_t)cap);
+  float *d2 = (float *)malloc(sizeof(float) * (size_t)cap);
+  for (int k = 0; k < n_kp; ++k) {
+    float *out = &desc[(size_t)k * 250];
+    int cnt = mo_radius_search(g, keypoints[k].x, keypoints[k].y, keypoints[k].z, r2, idx, d2, cap);
+    if (cnt > cap) {
+      cap = cnt * 2;
+      idx = (int *)realloc(idx, sizeof(int) * (size_t)cap);
+      d2 = (float *)realloc(d2, sizeof(float) * (size_t)cap);
+      cnt = mo_radius_search(g, keypoints[k].x, keypoints[k].y, keypoints[k].z, r2, idx, d2, cap);
+    }
+    for (int b = 0; b < 250; ++b) out[b] = 0.0f;
+    const float hist_incr = 100.0f / (float)((size_t)cnt * ((size_t)cnt - 1) / 2);
+    for (int i = 0; i < cnt; ++i)
+      for (int j = 0; j < cnt; ++j) {
+        if (i == j) continue;
+        float f[7];
+        rgb_pair_features(&surface[idx[i]], &normals[idx[i]], &surface[idx[j]], &normals[idx[j]], f);
+        const int h1 = split_bin(PFH_SPLIT * ((f[0] + M_PI) * d_pi));
+        const int h2 = split_bin(PFH_SPLIT * ((f[1] + 1.0) * 0.5));
+        const int h3 = split_bin(PFH_SPLIT * ((f[2] + 1.0) * 0.5));
+        out[h1 + PFH_SPLIT * h2 + PFH_SPLIT * PFH_SPLIT * h3] += hist_incr;
+        const int h5 = split_bin(PFH_SPLIT * ((f[4] + 1.0) * 0.5));
+        const int h6 = split_bin(PFH_SPLIT * ((f[5] + 1.0) * 0.5));
+        const int h7 = split_bin(PFH_SPLIT * ((f[6] + 1.0) * 0.5));
+        out[125 + h5 + PFH_SPLIT * h6 + PFH_SPLIT * PFH_SPLIT * h7] += hist_incr;
+      }
+  }
+  free(idx); free(d2);
+  mo_grid_free(g);
+  return n_kp;
+}
+
+int mo_descriptors_pfhrgb(const mo_point *surface, const mo_normal *normals, int n,
+                          mo_point *keypoints, int n_kp, double radius, float *desc)
+{
+  if (n_kp <= 0) return 0;
+  mo_pfhrgb_raw(surface, normals, n, keypoints, n_kp, radius, desc);
+  /* DefaultPointRepresentation<PFHRGBSignature250>::isValid: all bins finite; prune both (features.cpp:118-143) */
+  int m = 0;
+  for (int k = 0; k < n_kp; ++k) {
+    int valid = 1;
+    for (int b = 0; b < 250; ++b) if (!isfinite(desc[(size_t)k * 250 + b])) { valid = 0; break; }
+    if (!valid) continue;
+    if (m != k) {
+      memmove(&desc[(size_t)m * 250], &desc[(size_t)k * 250], sizeof(float) * 250);
+      keypoints[m] = keypoints[k];
+    }
+    ++m;
+  }
+  return m;
+}
+
 int mo_descriptors_pfh(const mo_point *surface, const mo_normal *normals, int n,
                        mo_point *keypoints, int n_kp, double radius, float *desc)
 {

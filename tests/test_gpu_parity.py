@@ -606,3 +606,42 @@ def test_shot_configuration_end_to_end(ctx, po, mm, scene, synth):
         ref = ref_pairs[0]["transform"].reshape(4, 4).T
         assert np.linalg.norm(est - gt) <= 0.75, (method, np.linalg.norm(est - gt))
         assert abs(np.linalg.norm(est - gt) - np.linalg.norm(ref - gt)) <= 0.15
+
+
+def test_pfhrgb(ctx, po, mm, scene):
+    """PFHRGBSignature250 (dispatch_descriptors.h:39): rows against the oracle, k-NN over 250-wide rows, and the
+    descriptor through estimateMapsTransforms."""
+    for m in scene:
+        kp_ref, ref = po.descriptors_pfhrgb(m["filt"], m["nrm"], m["kp_raw"], R_DESC)
+        kp = ctx.cloud(m["kp_raw"])
+        got = ctx.computeLocalDescriptors(ctx.cloud(m["filt"]), ctx.normals(m["nrm"]), kp, 1, R_DESC).numpy()
+        assert got.shape == ref.shape and got.shape[1] == 250
+        assert np.array_equal(kp.numpy().view(np.uint32), kp_ref.view(np.uint32))
+        assert np.allclose(got[:, :125].sum(axis=1), 200.0, atol=5e-2) and np.allclose(got[:, 125:].sum(axis=1), 200.0, atol=5e-2)
+        # colour bins are integer arithmetic: bit-equal; geometry bins move only by atan2f ulps at bin edges
+        assert np.array_equal(got[:, 125:].view(np.uint32), ref[:, 125:].view(np.uint32))
+        err = np.abs(got - ref).max(axis=1)
+        assert np.mean(err <= 1e-3) >= 0.9 and err.max() <= 0.5, np.percentile(err, [50, 90, 99, 100])
+    # k-NN on these rows (256-wide padded contraction on the streaming kernels)
+    rng = np.random.default_rng(13)
+    _, base = po.descriptors_pfhrgb(scene[0]["filt"], scene[0]["nrm"], scene[0]["kp_raw"], R_DESC)
+    A = (base[rng.integers(0, len(base), 800)] + rng.normal(0, 0.3, (800, 250))).astype(np.float32)
+    B = (base[rng.integers(0, len(base), 1200)] + rng.normal(0, 0.3, (1200, 250))).astype(np.float32)
+    B[50:70] = B[150:170]
+    A[:10] = B[300:310]
+    da, db = ctx.descriptors(A, 1), ctx.descriptors(B, 1)
+    for k in (1, 5):
+        got = ctx.findFeatureCorrespondences(da, db, k)
+        ref = po.find_correspondences(A, B, k)
+        assert np.array_equal(got["index_query"], ref["index_query"]) and np.array_equal(got["index_match"], ref["index_match"])
+        assert np.array_equal(got["distance"].view(np.uint32), ref["distance"].view(np.uint32))
+    # end to end, same-basin comparison as for the other float descriptors
+    a, b = scene
+    params = mm.MapMergingParams(descriptor_type=1, estimation_method=1)
+    op = po.params_default(); op.descriptor_type = 1; op.estimation_method = 1
+    po.srand(1); ctx.srand(1)
+    ref_T, ref_pairs = po.estimate_maps_transforms([a["raw"], b["raw"]], op)
+    T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
+    assert len(pairs) == len(ref_pairs) == 1
+    assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= 0.15
+    assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=0.2)

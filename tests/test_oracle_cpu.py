@@ -208,6 +208,35 @@ def test_pfh_known_answers(po):
     assert np.allclose(d.sum(1), 100.0, atol=2e-2) and (d >= 0).all()
 
 
+def test_pfhrgb_known_answers(po):
+    """PFHRGBSignature250: ordered pairs (each half sums to 200), integer colour ratios."""
+    rng = np.random.default_rng(9)
+    uv = rng.uniform(-1, 1, (500, 2)).astype(np.float32)
+    pts = cloud(po, np.stack([uv[:, 0], uv[:, 1], np.full(500, 2.0, np.float32)], 1))      # one colour: 0x808080
+    nrm = np.zeros(len(pts), dtype=po.NORMAL)
+    nrm["nz"] = 1.0
+    kp = pts[::50].copy()
+    _, d = po.descriptors_pfhrgb(pts, nrm, kp, 0.4)
+    assert d.shape == (len(kp), 250)
+    # exact plane, exact normals: f1 = f2 = f3 = 0 -> bin (2, 2, 2) = 62; equal colours: c1 / c2 = 1 -> f = 1 ->
+    # bin (4, 4, 4) = 124 of the colour half; every ordered pair counts -> 200 per half
+    assert np.allclose(d[:, 62], 200.0, atol=5e-2) and np.allclose(d[:, 125 + 124], 200.0, atol=5e-2)
+    assert np.allclose(np.delete(d, [62, 249], axis=1), 0.0)
+    # integer division: a darker first point gives 0 (bin 2), a more than twice brighter one n >= 2 -> -1/n (bins 1, 2)
+    two = cloud(po, np.array([[0, 0, 0], [0.1, 0, 0]], np.float32), np.array([0xFF102030, 0xFF804010], np.uint32))
+    n2 = np.zeros(2, dtype=po.NORMAL); n2["nz"] = 1.0
+    _, d2 = po.descriptors_pfhrgb(two, n2, two[:1].copy(), 0.5)
+    # pair (0 -> 1): r 0x10/0x80 = 0 -> bin 2, g 0x20/0x40 = 0 -> 2, b 0x30/0x10 = 3 -> -1/3 -> floor(5 * 0.333) = 1
+    # pair (1 -> 0): r 8 -> -1/8 -> floor(5 * 0.4375) = 2, g 2 -> -0.5 -> floor(1.25) = 1, b 0 -> 2
+    col = d2[0, 125:]
+    assert col[2 + 5 * 2 + 25 * 1] == pytest.approx(100.0) and col[2 + 5 * 1 + 25 * 2] == pytest.approx(100.0)
+    assert np.count_nonzero(col) == 2 and d2[0, :125].sum() == pytest.approx(200.0)
+    # a keypoint without neighbours keeps an all-zero, valid row (computeFeature has no such branch)
+    far = kp[:2].copy(); far["x"][1] += 50.0
+    kept, d3 = po.descriptors_pfhrgb(pts, nrm, far, 0.4)
+    assert len(kept) == 2 and not d3[1].any()
+
+
 def test_shot_known_answers(po):
     """SHOT1344 (SHOTColorEstimation, dispatch_descriptors.h:46): frame, interpolation mass, pruning."""
     # RGB2CIELAB: black is the origin, mid grey has a = b = 0 and L ~ 53.6, clamps hold
