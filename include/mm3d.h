@@ -149,11 +149,17 @@ int mm3d_remove_outliers(mm3d_ctx *ctx, const mm3d_cloud *in, double radius, int
                          mm3d_cloud **out);
 /* computeSurfaceNormals (features.h:97, features.cpp:168-179) */
 int mm3d_compute_normals(mm3d_ctx *ctx, const mm3d_cloud *in, double radius, mm3d_normals **out);
-/* detectKeypoints (features.h:65, features.cpp:85-96).  SIFT only; HARRIS -> MM3D_EUNSUPPORTED.
- * An invalid enum is UB in the reference (falls off the switch); here MM3D_EINVAL. */
+/* detectKeypoints (features.h:65, features.cpp:85-96): SIFT (features.cpp:45-62; normals and radius are
+ * not used) or HARRIS (features.cpp:64-83: HarrisKeypoint3D on the given normals, non-maximum suppression
+ * and refinement on, threshold, radius).  An invalid enum is UB in the reference (falls off the
+ * switch); here MM3D_EINVAL. */
 int mm3d_detect_keypoints(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_normals *normals,
                           int type, double threshold, double radius, double resolution,
                           mm3d_cloud **keypoints);
+/* The Harris response of every point (HarrisKeypoint3D::responseHarris, what detectKeypoints(HARRIS)
+ * thresholds and suppresses); dst receives mm3d_cloud_size(points) floats. */
+int mm3d_harris_response(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_normals *normals, double radius,
+                         float *dst);
 /* computeLocalDescriptors (features.h:83, features.cpp:99-166).  Like the reference it prunes
  * keypoints whose descriptor is not finite: *keypoints is replaced IN PLACE by the pruned cloud.
  * FPFH (dispatch_descriptors.h:40), PFH (:38, the reference's default), PFHRGB (:39) and SHOT

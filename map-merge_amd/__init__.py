@@ -219,6 +219,12 @@ class Context:
                                              C.c_double(resolution), C.byref(h)))
         return Cloud(self, h)
 
+    def harrisResponse(self, points: "Cloud", normals: "Normals", radius: float) -> np.ndarray:
+        """HarrisKeypoint3D::responseHarris of every point (what detectKeypoints(HARRIS) thresholds)."""
+        out = np.zeros(max(len(points), 1), dtype=np.float32)
+        self._ck(lib().mm3d_harris_response(self._h, points._h, normals._h, C.c_double(radius), out.ctypes.data_as(C.c_void_p)))
+        return out[:len(points)]
+
     def computeLocalDescriptors(self, points: "Cloud", normals: "Normals", keypoints: "Cloud", descriptor,
                                 feature_radius: float) -> "Descriptors":
         """Prunes `keypoints` in place like the reference (features.h:72-74)."""

@@ -380,10 +380,23 @@ int mm3d_detect_keypoints(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_no
       // detectKeypointsSIFT(points, resolution, 3, 3, threshold)  (features.cpp:92)
       *keypoints = detect_keypoints_sift(ctx, points, resolution, 3, 3, threshold);
     } else if (type == MM3D_KP_HARRIS) {
-      throw Error(MM3D_EUNSUPPORTED, "HARRIS keypoints are not built (outside the north-star path)");
+      // detectKeypointsHarris(points, normals, threshold, radius)  (features.cpp:94)
+      if (!normals) throw Error(MM3D_EINVAL, "HARRIS keypoints need the surface normals");
+      *keypoints = detect_keypoints_harris(ctx, points, normals, threshold, radius);
     } else {
       throw Error(MM3D_EINVAL, "invalid keypoint type");
     }
+  });
+}
+
+int mm3d_harris_response(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_normals *normals, double radius, float *dst)
+{
+  if (!points || !normals || (!dst && points->n)) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    DevBuf<float> r;
+    harris_response(ctx, points, normals, radius, r);
+    if (points->n) MM3D_HIP(hipMemcpyAsync(dst, r.get(), points->n * sizeof(float), hipMemcpyDefault, ctx->stream));
+    ctx->sync();
   });
 }
 
@@ -488,8 +501,7 @@ int mm3d_transform_score(mm3d_ctx *ctx, const mm3d_cloud *source, const mm3d_clo
 // ---------------------------------------------------------------- map bundles
 static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const mm3d_params *p)
 {
-  if (p->keypoint_type != MM3D_KP_SIFT) throw Error(p->keypoint_type == MM3D_KP_HARRIS ? MM3D_EUNSUPPORTED : MM3D_EINVAL,
-                                                   "only SIFT keypoints are built");
+  if (p->keypoint_type != MM3D_KP_SIFT && p->keypoint_type != MM3D_KP_HARRIS) throw Error(MM3D_EINVAL, "invalid keypoint type");
   if (p->descriptor_type != MM3D_DESC_FPFH && p->descriptor_type != MM3D_DESC_PFH && p->descriptor_type != MM3D_DESC_SHOT &&
       p->descriptor_type != MM3D_DESC_PFHRGB)
     throw Error((p->descriptor_type >= 0 && p->descriptor_type < 6) ? MM3D_EUNSUPPORTED : MM3D_EINVAL,
@@ -499,7 +511,10 @@ static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const m
   std::unique_ptr<mm3d_cloud> filt(remove_outliers(ctx, down.get(), p->descriptor_radius, p->outliers_min_neighbours));
   down.reset();
   std::unique_ptr<mm3d_normals> nrm(compute_normals(ctx, filt.get(), p->normal_radius));
-  std::unique_ptr<mm3d_cloud> kp(detect_keypoints_sift(ctx, filt.get(), p->resolution, 3, 3, p->keypoint_threshold));
+  // detectKeypoints(points, normals, type, keypoint_threshold, normal_radius, resolution)  (map_merging.cpp:231-233)
+  std::unique_ptr<mm3d_cloud> kp(p->keypoint_type == MM3D_KP_HARRIS
+                                     ? detect_keypoints_harris(ctx, filt.get(), nrm.get(), p->keypoint_threshold, p->normal_radius)
+                                     : detect_keypoints_sift(ctx, filt.get(), p->resolution, 3, 3, p->keypoint_threshold));
   std::unique_ptr<mm3d_desc> desc(p->descriptor_type == MM3D_DESC_PFH    ? compute_pfh(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                   : p->descriptor_type == MM3D_DESC_PFHRGB ? compute_pfhrgb(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                   : p->descriptor_type == MM3D_DESC_SHOT ? compute_shot(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)

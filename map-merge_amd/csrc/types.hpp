@@ -140,6 +140,11 @@ mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius);
 mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double min_scale, int nr_octaves,
                                   int nr_scales, double min_contrast);
 
+// harris.hip
+mm3d_cloud *detect_keypoints_harris(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, double threshold,
+                                    double radius);
+void harris_response(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, double radius, DevBuf<float> &out);
+
 // fpfh.hip
 mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,
                         mm3d_cloud *keypoints, double radius);

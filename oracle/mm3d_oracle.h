@@ -83,6 +83,12 @@ void mo_normals(const mo_point *in, int n, double radius, mo_normal *out);
 int mo_keypoints_sift(const mo_point *in, int n, double min_scale,
                       int nr_octaves, int nr_scales_per_octave,
                       double min_contrast, mo_point **out, float **scales_out);
+/* detectKeypoints(HARRIS): R/src/features.cpp:64-83 (o_harris.c).  Returns the count; keypoints (refined xyz,
+ * rgba = 0) malloc'ed into *out; kept_idx (optional, malloc'ed) = the source indices; response_out
+ * (optional, n floats) = the Harris response of every point. */
+int mo_keypoints_harris(const mo_point *in, const mo_normal *normals, int n, double threshold, double radius,
+                        mo_point **out, int **kept_idx, float *response_out);
+void mo_harris_response(const mo_point *in, const mo_normal *normals, int n, double radius, float *response);
 /* computeLocalDescriptors(FPFH): R/src/features.cpp:99-150 +
  * dispatch_descriptors.h:40.  keypoints are pruned IN PLACE (n_kp updated);
  * desc must hold n_kp*33 floats; returns the number of surviving keypoints. */

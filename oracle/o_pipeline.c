@@ -50,7 +50,7 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
   if (n_clouds == 1) { identity16(out_T); return 1; }
   if ((params->descriptor_type != 2 && params->descriptor_type != 0 && params->descriptor_type != 4 &&
        params->descriptor_type != 1) ||
-      params->keypoint_type != 0)
+      (params->keypoint_type != 0 && params->keypoint_type != 1))
     return -3;
   const int dim = params->descriptor_type == 0 ? 125 : params->descriptor_type == 4 ? 1344 : params->descriptor_type == 1 ? 250 : 33;
 
@@ -72,7 +72,10 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
     resized[i] = b; rn[i] = nb;
     normals[i] = (mo_normal *)malloc(sizeof(mo_normal) * (size_t)(nb > 0 ? nb : 1));
     mo_normals(b, nb, params->normal_radius, normals[i]);
-    kn[i] = mo_keypoints_sift(b, nb, params->resolution, 3, 3, params->keypoint_threshold, &kps[i], NULL);
+    /* detectKeypoints(points, normals, type, keypoint_threshold, normal_radius, resolution): map_merging.cpp:231-233 */
+    kn[i] = params->keypoint_type == 1
+                ? mo_keypoints_harris(b, normals[i], nb, params->keypoint_threshold, params->normal_radius, &kps[i], NULL, NULL)
+                : mo_keypoints_sift(b, nb, params->resolution, 3, 3, params->keypoint_threshold, &kps[i], NULL);
     desc[i] = (float *)malloc(sizeof(float) * (size_t)dim * (size_t)(kn[i] > 0 ? kn[i] : 1));
     kn[i] = dim == 125    ? mo_descriptors_pfh(b, normals[i], nb, kps[i], kn[i], params->descriptor_radius, desc[i])
             : dim == 250  ? mo_descriptors_pfhrgb(b, normals[i], nb, kps[i], kn[i], params->descriptor_radius, desc[i])

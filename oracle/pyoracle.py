@@ -102,6 +102,24 @@ def keypoints_sift(pts, min_scale, nr_octaves=3, nr_scales=3, min_contrast=5.0):
     return kp, sc
 
 
+def keypoints_harris(pts, nrm, threshold, radius):
+    """detectKeypoints(HARRIS): (keypoints, source indices, response of every point)."""
+    pts = _pts(pts)
+    nrm = np.ascontiguousarray(nrm, dtype=NORMAL)
+    outp, outi = C.c_void_p(), C.c_void_p()
+    resp = np.empty(max(len(pts), 1), dtype=np.float32)
+    n = lib().mo_keypoints_harris(_p(pts), _p(nrm), len(pts), C.c_double(threshold), C.c_double(radius),
+                                  C.byref(outp), C.byref(outi), _p(resp))
+    if n > 0:
+        kp = np.frombuffer((C.c_char * (16 * n)).from_address(outp.value), dtype=POINT).copy()
+        idx = np.frombuffer((C.c_char * (4 * n)).from_address(outi.value), dtype=np.int32).copy()
+    else:
+        kp, idx = np.empty(0, dtype=POINT), np.empty(0, dtype=np.int32)
+    lib().mo_free(outp)
+    lib().mo_free(outi)
+    return kp, idx, resp[:len(pts)].copy()
+
+
 def fpfh_raw(surface, nrm, keypoints, radius):
     surface = _pts(surface)
     nrm = np.ascontiguousarray(nrm, dtype=NORMAL)

@@ -645,3 +645,34 @@ def test_pfhrgb(ctx, po, mm, scene):
     assert len(pairs) == len(ref_pairs) == 1
     assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= 0.15
     assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=0.2)
+
+
+def test_harris_keypoints(ctx, po, mm, scene):
+    """detectKeypoints(HARRIS) (features.cpp:64-83): response within float rounding of the oracle (the sums
+    run in grid order instead of the oracle's neighbour order), the same corners, refined positions
+    bit-equal (the refinement keeps the oracle's order)."""
+    for m in scene:
+        pts, nrm = ctx.cloud(m["filt"]), ctx.normals(m["nrm"])
+        kp_ref, idx_ref, resp_ref = po.keypoints_harris(m["filt"], m["nrm"], 0.002, R_NRM)
+        resp = ctx.harrisResponse(pts, nrm, R_NRM)
+        assert np.abs(resp - resp_ref).max() <= 2e-6, np.abs(resp - resp_ref).max()
+        kp = ctx.detectKeypoints(pts, nrm, 1, 0.002, R_NRM, RES).numpy()
+        assert len(kp_ref) >= 10
+        # a response 1e-7 away from the oracle's can flip a comparison against the threshold or a neighbour:
+        # allow one corner of difference, the common ones must agree bit for bit
+        a = {tuple(r) for r in xyz(kp).view(np.uint32).tolist()}
+        b = {tuple(r) for r in xyz(kp_ref).view(np.uint32).tolist()}
+        assert len(a ^ b) <= 1 and len(a & b) >= len(b) - 1, (len(a), len(b), len(a & b))
+        assert (kp["rgba"] == 0).all()
+    # through the pipeline: keypoint_type = HARRIS with FPFH + SAC-IA on the two maps
+    a, b = scene
+    params = mm.MapMergingParams(keypoint_type=1, keypoint_threshold=0.0005, descriptor_type=2, estimation_method=1)
+    op = po.params_default(); op.keypoint_type = 1; op.keypoint_threshold = 0.0005; op.descriptor_type = 2; op.estimation_method = 1
+    po.srand(1); ctx.srand(1)
+    ref_T, ref_pairs = po.estimate_maps_transforms([a["raw"], b["raw"]], op)
+    T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
+    assert len(pairs) == len(ref_pairs) == 1 and np.isfinite(pairs[0]["transform"]).all()
+    f = ctx.mapFeatures(ctx.cloud(a["raw"]), params)
+    nk = len(f.keypoints)
+    f.free()
+    assert 5 <= nk <= 200

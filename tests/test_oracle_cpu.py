@@ -208,6 +208,36 @@ def test_pfh_known_answers(po):
     assert np.allclose(d.sum(1), 100.0, atol=2e-2) and (d >= 0).all()
 
 
+def test_harris_known_answers(po):
+    """HarrisKeypoint3D on exact normals: a plane answers 0.04 + 0 - 0.04 = 0; where three orthogonal faces
+    meet in equal shares C = I / 3 -> 0.04 + 1/27 - 0.04/1; refineCorners solves the least-squares
+    intersection of the neighbours' tangent planes, i.e. lands on the corner itself."""
+    g = np.arange(0.05, 1.0, 0.1, dtype=np.float32)
+    u, v = [a.ravel() for a in np.meshgrid(g, g)]
+    o = np.zeros_like(u)
+    c = np.array([1.0, 2.0, 3.0], np.float32)
+    P = np.concatenate([np.stack([u, v, o], 1), np.stack([u, o, v], 1), np.stack([o, u, v], 1)]) + c
+    N = np.concatenate([np.tile([0, 0, 1.0], (len(u), 1)), np.tile([0, 1.0, 0], (len(u), 1)), np.tile([1.0, 0, 0], (len(u), 1))])
+    pts = cloud(po, P.astype(np.float32))
+    nrm = np.zeros(len(P), dtype=po.NORMAL)
+    nrm["nx"], nrm["ny"], nrm["nz"] = N[:, 0], N[:, 1], N[:, 2]
+    kp, idx, resp = po.keypoints_harris(pts, nrm, 0.02, 0.3)
+    # far from the edges only one face is in reach: response 0
+    d_edge = np.sort(np.abs(P - c), axis=1)[:, 1]              # distance to the nearest edge of the own face
+    assert np.allclose(resp[d_edge > 0.31], 0.0, atol=1e-6)
+    # the strongest response sits next to the corner and is close to 1/27
+    assert 0.03 < resp.max() <= 1.0 / 27 + 1e-6 and np.linalg.norm(P[resp.argmax()] - c) < 0.15
+    # exactly one keypoint survives the suppression within the radius of the corner, and it is refined ONTO the corner
+    near = np.linalg.norm(xyz(kp) - c, axis=1) < 0.3
+    assert near.sum() >= 1 and np.abs(xyz(kp)[near] - c).max() < 1e-4
+    assert (kp["rgba"] == 0).all() and len(idx) == len(kp)
+    # a plane alone: nothing passes a positive threshold; with threshold 0 every point is its own maximum (ties)
+    plane = cloud(po, np.stack([u, v, o], 1) + c)
+    pn = np.zeros(len(plane), dtype=po.NORMAL); pn["nz"] = 1.0
+    assert len(po.keypoints_harris(plane, pn, 0.001, 0.3)[0]) == 0
+    assert len(po.keypoints_harris(plane, pn, 0.0, 0.3)[0]) == len(plane)
+
+
 def test_pfhrgb_known_answers(po):
     """PFHRGBSignature250: ordered pairs (each half sums to 200), integer colour ratios."""
     rng = np.random.default_rng(9)
