@@ -18,6 +18,12 @@
 #include <cfloat>
 
 #include "device_util.hpp"
+#ifndef MM3D_EXTREMA_NEED0
+#define MM3D_EXTREMA_NEED0 1
+#endif
+#ifndef MM3D_EXTREMA_RUN
+#define MM3D_EXTREMA_RUN 64
+#endif
 
 namespace mm3d {
 
@@ -171,6 +177,7 @@ __global__ void k_sift_live_compact(const float4 *__restrict__ hil, int n, const
 
 // findScaleSpaceExtrema.  q_pts = the live points (k_sift_live_compact), *n_live_dev of them; wave w
 // takes points [64 w, 64 w + 64).
+constexpr int kExtremaRun = MM3D_EXTREMA_RUN;   // live points per wave
 constexpr int kExtremaSpan = 8;   // a run that jumps farther than this many cells is worked in several groups
 
 __global__ void __launch_bounds__(256)
@@ -182,12 +189,12 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int *__restrict__ n_live_
   __shared__ int s_off[4][64];
   __shared__ int s_beg[4][64];
   const int n_live = *n_live_dev;
-  const int n_items = (n_live + 63) >> 6;
+  const int n_items = (n_live + kExtremaRun - 1) / kExtremaRun;
   if ((int)(blockIdx.x * 4) >= n_items) return;            // the grid is sized for the worst case
   const unsigned bid = xcd_remap(blockIdx.x, (unsigned)((n_items + 3) >> 2));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = bid * 4 + wave;
-  const int2 it = item < n_items ? make_int2(item * 64, min(64, n_live - item * 64)) : make_int2(0, 0);
+  const int2 it = item < n_items ? make_int2(item * kExtremaRun, min(kExtremaRun, n_live - item * kExtremaRun)) : make_int2(0, 0);
   const bool valid = lane < it.y;
   if (it.y == 0) return;                      // wave-uniform
   const float4 q = q_pts[it.x + (valid ? lane : 0)];
@@ -216,7 +223,7 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int *__restrict__ n_live_
   const int ldx = cx - __shfl(cx, leader, 64), ldy = cy - __shfl(cy, leader, 64), ldz = cz - __shfl(cz, leader, 64);
   bool active = todo && abs(ldx) <= kExtremaSpan && abs(ldy) <= kExtremaSpan && abs(ldz) <= kExtremaSpan;
   todo = todo && !active;
-  int need = 1;
+  int need = MM3D_EXTREMA_NEED0;
   for (int pass = 0; pass < 4096; ++pass) {
     if (!__ballot(active)) break;
     const int E = wave_max_int(active ? need : 0);
@@ -376,7 +383,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     exclusive_scan_int(c, lflag.get(), lpos.get(), (size_t)nh + 1);
     MM3D_LAUNCH(c, "sift_live", nh * 24.0, k_sift_live_compact, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
                 nh, (const int *)lflag.get(), (const int *)lpos.get(), lpts.get());
-    MM3D_LAUNCH(c, "sift_extrema", gk.n * 48.0, k_sift_extrema, dim3(div_up(div_up((size_t)nh, 64), 4)), dim3(256), 0,
+    MM3D_LAUNCH(c, "sift_extrema", gk.n * 48.0, k_sift_extrema, dim3(div_up(div_up((size_t)nh, kExtremaRun), 4)), dim3(256), 0,
                 (const float4 *)lpts.get(), (const int *)(lpos.get() + nh), gk.view(), (const float4 *)dogx.get(), (const float *)dog.get(),
                 (float)min_contrast, flags.get());
     DevBuf<int> pos(c, (size_t)n * 3 + 1);

@@ -37,4 +37,6 @@ with open(dst("pmc_hbm_traffic.csv"), "w") as fo:
         fo.write("%s,%d,%.1f,%.1f,%.0f\n" % r)
 for n in ("kernel_stats.csv", "hip_event_table.csv", "pmc_sq_counters.csv", "concurrency.txt", "bench_line.json"):
     shutil.copy(src(n), dst(n))
+if os.path.exists(src("hip_event_table_1stream.csv")):
+    shutil.copy(src("hip_event_table_1stream.csv"), dst("hip_event_table_1stream.csv"))
 print("profiles/%s_* written" % tag)

@@ -30,6 +30,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_V
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM \
     --output-format csv -d /tmp/prof_sqB -- python3 scripts/pmc_driver.py pair > /tmp/prof_sqB.log 2>&1
 python3 scripts/pmc_summary.py /tmp/prof_sqA/*/*counter_collection.csv /tmp/prof_sqB/*/*counter_collection.csv > "gpurun_out/${TAG}_pmc_sq_counters.csv"
+python3 bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --kernel-table "$R/gpurun_out/${TAG}_hip_event_table_1stream.csv" > /tmp/one_stream.log 2>&1
 python3 bench.py 2>&1 | tail -1 > "gpurun_out/${TAG}_bench_line.json"
 cut -c1-260 "gpurun_out/${TAG}_bench_line.json"
 cat "gpurun_out/${TAG}_concurrency.txt"
