@@ -18,12 +18,7 @@
 #include <cfloat>
 
 #include "device_util.hpp"
-#ifndef MM3D_EXTREMA_NEED0
-#define MM3D_EXTREMA_NEED0 1
-#endif
-#ifndef MM3D_EXTREMA_RUN
-#define MM3D_EXTREMA_RUN 64
-#endif
+
 
 namespace mm3d {
 
@@ -177,7 +172,7 @@ __global__ void k_sift_live_compact(const float4 *__restrict__ hil, int n, const
 
 // findScaleSpaceExtrema.  q_pts = the live points (k_sift_live_compact), *n_live_dev of them; wave w
 // takes points [64 w, 64 w + 64).
-constexpr int kExtremaRun = MM3D_EXTREMA_RUN;   // live points per wave
+constexpr int kExtremaRun = 64;   // live points per wave (32 and 16 measured slower: more, smaller boxes to stage)
 constexpr int kExtremaSpan = 8;   // a run that jumps farther than this many cells is worked in several groups
 
 __global__ void __launch_bounds__(256)
@@ -223,7 +218,7 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int *__restrict__ n_live_
   const int ldx = cx - __shfl(cx, leader, 64), ldy = cy - __shfl(cy, leader, 64), ldz = cz - __shfl(cz, leader, 64);
   bool active = todo && abs(ldx) <= kExtremaSpan && abs(ldy) <= kExtremaSpan && abs(ldz) <= kExtremaSpan;
   todo = todo && !active;
-  int need = MM3D_EXTREMA_NEED0;
+  int need = 1;                 // most lanes are decided by the first ring; starting wider measured slower
   for (int pass = 0; pass < 4096; ++pass) {
     if (!__ballot(active)) break;
     const int E = wave_max_int(active ? need : 0);

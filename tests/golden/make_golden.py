@@ -44,3 +44,27 @@ out["pair_transform"] = pairs["transform"]
 out["pair_confidence"] = pairs["confidence"]
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pair_6k.npz"), **out)
 print("wrote pair_6k.npz:", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+# features_6k.npz: the other keypoint / descriptor types on map 0 of the same pair (first 48 keypoints)
+filt = po.remove_outliers(po.downsample(raws[0], 0.1), 0.8, 50)
+nrm = po.normals(filt, 0.6)
+kp_sift, _ = po.keypoints_sift(filt, 0.1, 3, 3, 5.0)
+kp48 = kp_sift[:48].copy()
+feat = {"n_raw": N_RAW, "overlap_step": STEP}
+hk, hidx, hresp = po.keypoints_harris(filt, nrm, 0.002, 0.6)
+feat["harris_kp"] = np.stack([hk["x"], hk["y"], hk["z"]], 1)
+feat["harris_idx"] = hidx
+feat["harris_response"] = hresp
+for name, fn in (("pfh", po.descriptors_pfh), ("pfhrgb", po.descriptors_pfhrgb), ("shot", po.descriptors_shot)):
+    k, d = fn(filt, nrm, kp48, 0.8)
+    feat[name + "_kp"] = np.stack([k["x"], k["y"], k["z"]], 1)
+    feat[name] = d
+_, feat["shot_rf"] = po.shot_raw(filt, nrm, kp48, 0.8)
+for m, dt in ((1, 4), (0, 1)):   # SHOT + SAC_IA, PFHRGB + MATCHING through the whole pipeline
+    p = po.params_default()
+    p.descriptor_type, p.estimation_method = dt, m
+    po.srand(1)
+    T, pairs = po.estimate_maps_transforms(raws, p)
+    feat[f"pair_transform_d{dt}_m{m}"] = pairs["transform"]
+np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "features_6k.npz"), **feat)
+print("wrote features_6k.npz:", {k: getattr(v, "shape", v) for k, v in feat.items()})

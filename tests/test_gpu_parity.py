@@ -676,3 +676,28 @@ def test_harris_keypoints(ctx, po, mm, scene):
     nk = len(f.keypoints)
     f.free()
     assert 5 <= nk <= 200
+
+
+def test_golden_features_fixture_on_device(ctx, po, mm, synth):
+    """The device against the committed vectors of tests/golden/features_6k.npz (made by make_golden.py from
+    the oracle): Harris corners, PFH / PFHRGB / SHOT rows, frames."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "features_6k.npz"))
+    world, maps = synth.synth_maps(2, int(g["n_raw"]), overlap_step=float(g["overlap_step"]))
+    raw = synth.pack_points(maps[0][0], maps[0][1])
+    filt = ctx.removeOutliers(ctx.downSample(ctx.cloud(raw), 0.1), 0.8, 50)
+    nrm_host = po.normals(filt.numpy(), 0.6)            # descriptors are compared on identical normals
+    nrm = ctx.normals(nrm_host)
+    kp48 = po.keypoints_sift(filt.numpy(), 0.1, 3, 3, 5.0)[0][:48].copy()
+    hk = ctx.detectKeypoints(filt, nrm, 1, 0.002, 0.6, 0.1).numpy()
+    a = {tuple(r) for r in xyz(hk).view(np.uint32).tolist()}
+    b = {tuple(r) for r in g["harris_kp"].view(np.uint32).tolist()}
+    assert len(a ^ b) <= 1
+    assert np.abs(ctx.harrisResponse(filt, nrm, 0.6) - g["harris_response"]).max() <= 2e-6
+    for name, dt, tol in (("pfh", 0, 0.5), ("pfhrgb", 1, 0.5), ("shot", 4, 2e-6)):
+        k = ctx.cloud(kp48)
+        d = ctx.computeLocalDescriptors(filt, nrm, k, dt, 0.8)
+        assert np.array_equal(xyz(k.numpy()).view(np.uint32), g[name + "_kp"].view(np.uint32)), name
+        assert np.abs(d.numpy() - g[name]).max() <= tol, (name, np.abs(d.numpy() - g[name]).max())
+        if name == "shot":
+            assert np.array_equal(d.frames().view(np.uint32), g["shot_rf"].view(np.uint32))
+            assert (d.numpy().view(np.uint32) == g[name].view(np.uint32)).all(axis=1).mean() >= 0.95

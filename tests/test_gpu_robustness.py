@@ -54,3 +54,39 @@ def test_non_finite_points_are_ignored(ctx, po, mm, textured):
     assert np.array_equal(a.keypoints.numpy().view(np.uint32), b.keypoints.numpy().view(np.uint32))
     assert len(a.keypoints) > 50
     a.free(); b.free()
+
+
+def test_degenerate_inputs_for_the_other_feature_types(ctx, mm, textured):
+    """HARRIS keypoints and the PFH / PFHRGB / SHOT descriptors on inputs that leave them nothing to do."""
+    rng = np.random.default_rng(5)
+    flat = _cloud(mm, np.concatenate([rng.uniform(0, 10, (20000, 2)), np.zeros((20000, 1))], 1).astype(np.float32))
+    nan = _cloud(mm, np.full((100, 3), np.nan, np.float32))
+    empty = _cloud(mm, np.zeros((0, 3), np.float32))
+    for kt, thr in ((1, 0.001), (0, 5.0)):
+        for dt in (0, 1, 4):
+            P = mm.MapMergingParams(keypoint_type=kt, keypoint_threshold=thr, descriptor_type=dt, estimation_method=1)
+            for name, c in (("flat", flat), ("nan", nan), ("empty", empty)):
+                m = ctx.mapFeatures(ctx.cloud(c), P)
+                assert len(m.keypoints) == len(m.descriptors), (kt, dt, name)
+                if name != "flat" or kt == 0:
+                    assert len(m.keypoints) == 0, (kt, dt, name)
+                m.free()
+            T, pairs = ctx.estimateMapsTransforms([nan, textured], P, return_pairs=True)
+            assert len(pairs) == 0 and len(T) == 2
+    # descriptors for keypoints far away from the surface: pruned (PFH, SHOT: NaN rows) or all-zero rows (PFHRGB)
+    pts = ctx.cloud(textured)
+    nrm = ctx.computeSurfaceNormals(pts, 0.6)
+    far = _cloud(mm, np.array([[100, 100, 100], [200, 0, 0]], np.float32))
+    for dt, n_left in ((0, 0), (4, 0), (1, 2)):
+        k = ctx.cloud(far)
+        d = ctx.computeLocalDescriptors(pts, nrm, k, dt, 0.8)
+        assert len(d) == len(k) == n_left, dt
+        if n_left:
+            assert not d.numpy().any()
+    # no keypoints at all
+    k = ctx.cloud(far[:0])
+    for dt in (0, 1, 4):
+        assert len(ctx.computeLocalDescriptors(pts, nrm, k, dt, 0.8)) == 0
+    # SC3D / RSD are answered, not crashed on
+    with pytest.raises(Exception):
+        ctx.computeLocalDescriptors(pts, nrm, ctx.cloud(far), 5, 0.8)

@@ -507,3 +507,26 @@ def test_golden_fixture(po, synth):
     T, pairs = po.estimate_maps_transforms([g["raw0"].view(po.POINT).reshape(-1), g["raw1"].view(po.POINT).reshape(-1)], p)
     assert np.array_equal(np.stack(T).view(np.uint32), g["T_global"].view(np.uint32))
     assert np.array_equal(pairs["transform"].view(np.uint32), g["pair_transform"].view(np.uint32))
+
+
+def test_golden_features_fixture(po, synth):
+    """tests/golden/features_6k.npz: Harris keypoints, PFH / PFHRGB / SHOT rows and two more pipeline configurations."""
+    g = np.load(os.path.join(HERE, "golden", "features_6k.npz"))
+    world, maps = synth.synth_maps(2, int(g["n_raw"]), overlap_step=float(g["overlap_step"]))
+    raws = [synth.pack_points(x, c) for x, c, T in maps]
+    filt = po.remove_outliers(po.downsample(raws[0], 0.1), 0.8, 50)
+    nrm = po.normals(filt, 0.6)
+    kp48 = po.keypoints_sift(filt, 0.1, 3, 3, 5.0)[0][:48].copy()
+    hk, hidx, hresp = po.keypoints_harris(filt, nrm, 0.002, 0.6)
+    assert np.array_equal(xyz(hk).view(np.uint32), g["harris_kp"].view(np.uint32)) and np.array_equal(hidx, g["harris_idx"])
+    assert np.array_equal(hresp.view(np.uint32), g["harris_response"].view(np.uint32))
+    for name, fn in (("pfh", po.descriptors_pfh), ("pfhrgb", po.descriptors_pfhrgb), ("shot", po.descriptors_shot)):
+        k, d = fn(filt, nrm, kp48, 0.8)
+        assert np.array_equal(xyz(k).view(np.uint32), g[name + "_kp"].view(np.uint32)), name
+        assert np.array_equal(d.view(np.uint32), g[name].view(np.uint32)), name
+    assert np.array_equal(po.shot_raw(filt, nrm, kp48, 0.8)[1].view(np.uint32), g["shot_rf"].view(np.uint32))
+    for m, dt in ((1, 4), (0, 1)):
+        p = po.params_default(); p.descriptor_type = dt; p.estimation_method = m
+        po.srand(1)
+        T, pairs = po.estimate_maps_transforms(raws, p)
+        assert np.array_equal(pairs["transform"].view(np.uint32), g[f"pair_transform_d{dt}_m{m}"].view(np.uint32)), (m, dt)
