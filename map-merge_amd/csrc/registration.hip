@@ -84,8 +84,8 @@ void sacia_models(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp
 // E[h][i] = TruncatedError(d2 of (T_h * src_i) to its nearest target keypoint); rows padded to a
 // multiple of 4 floats so the summation kernel can stream them with 16-byte loads.
 __global__ void __launch_bounds__(256)
-k_sacia_err(const float4 *__restrict__ skp, int ns, int ns_pad, GridView g, const float *__restrict__ T_all, int H,
-            float thresh, float radius, float *__restrict__ E)
+k_sacia_err(const float4 *__restrict__ skp /* any order; .w = the keypoint's index when `permuted` */, int permuted, int ns, int ns_pad,
+            GridView g, const float *__restrict__ T_all, int H, float thresh, float radius, float *__restrict__ E)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ns) return;
@@ -126,7 +126,10 @@ k_sacia_err(const float4 *__restrict__ skp, int ns, int ns_pad, GridView g, cons
       return true;
     });
   }
-  E[(size_t)h * ns_pad + i] = (best <= thresh) ? best / thresh : 1.0f;
+  // the queries run in the source keypoints' Hilbert order (neighbouring lanes land in neighbouring target
+  // cells: similar span lengths, shared cache lines); the summation order is the keypoint index order
+  const int slot = permuted ? __float_as_int(s.w) : i;
+  E[(size_t)h * ns_pad + slot] = (best <= thresh) ? best / thresh : 1.0f;
 }
 
 // error += e in source-keypoint order, float: the same chain the CPU path evaluates, bit for bit.
@@ -212,7 +215,10 @@ static const Grid &sacia_target_grid(Context *c, const mm3d_cloud *tgt_kp, float
 
 void prepare_sacia_target(Context *c, const mm3d_cloud *kp, float corr_thresh)
 {
-  if (kp->n) (void)sacia_target_grid(c, kp, corr_thresh);
+  if (kp->n) {
+    (void)sacia_target_grid(c, kp, corr_thresh);
+    cloud_hilbert(c, kp);                      // source role: query order of sacia_errors
+  }
 }
 
 void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const float *T_all, int H,
@@ -224,8 +230,11 @@ void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp
   const Grid &g = sacia_target_grid(c, tgt_kp, corr_thresh);
   DevBuf<float> E(c, (size_t)ns_pad * H);
   const size_t total = (size_t)ns * H;
-  MM3D_LAUNCH(c, "sacia_err", total * 4.0 + ns * 16.0, k_sacia_err, dim3(div_up(ns, 256), H), dim3(256), 0, src_kp->pts.get(), ns,
-              ns_pad, g.view(), T_all, H, corr_thresh, radius, E.get());
+  cloud_hilbert(c, src_kp);                    // cached on the cloud (prepare_sacia_target)
+  const bool permuted = src_kp->hil_pts.get() && src_kp->n_finite == src_kp->n;
+  MM3D_LAUNCH(c, "sacia_err", total * 4.0 + ns * 16.0, k_sacia_err, dim3(div_up(ns, 256), H), dim3(256), 0,
+              permuted ? (const float4 *)src_kp->hil_pts.get() : (const float4 *)src_kp->pts.get(), permuted ? 1 : 0, ns, ns_pad, g.view(), T_all,
+              H, corr_thresh, radius, E.get());
   MM3D_LAUNCH(c, "sacia_seq_sum", total * 4.0, k_seq_sum, dim3(div_up(H, kSumRows)), dim3(256), 0, (const float *)E.get(), ns,
               ns_pad, H, errors);
 }
