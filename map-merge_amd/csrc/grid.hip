@@ -645,6 +645,7 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl_)
   MM3D_HIP(hipMemcpyAsync(h, blk.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   c->sync();
   cl->n_wave_items = h[0];
+  cl->hil_keys = std::move(keys2);
   cl->wave_items = DevBuf<int2>(c, (size_t)h[0]);
   MM3D_LAUNCH(c, "hilbert_items", n * 12.0, k_item_fill, dim3(div_up(n, 256)), dim3(256), 0, (const int *)heads.get(),
               (const int *)blk.get(), n, cl->wave_items.get());

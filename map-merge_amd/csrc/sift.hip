@@ -163,33 +163,54 @@ __global__ void k_sift_live(const float4 *__restrict__ hil, int n, const float *
   flag[j] = f;
 }
 
-__global__ void k_sift_live_compact(const float4 *__restrict__ hil, int n, const int *__restrict__ flag, const int *__restrict__ pos,
-                                    float4 *__restrict__ out)
+__global__ void k_sift_live_compact(const float4 *__restrict__ hil, const uint32_t *__restrict__ keys, int n, const int *__restrict__ flag,
+                                    const int *__restrict__ pos, float4 *__restrict__ out, uint32_t *__restrict__ out_keys)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n && flag[j]) out[pos[j]] = hil[j];
+  if (j < n && flag[j]) { out[pos[j]] = hil[j]; out_keys[pos[j]] = keys[j]; }
 }
 
-// findScaleSpaceExtrema.  q_pts = the live points (k_sift_live_compact), *n_live_dev of them; wave w
-// takes points [64 w, 64 w + 64).
-constexpr int kExtremaRun = 64;   // live points per wave (32 and 16 measured slower: more, smaller boxes to stage)
-constexpr int kExtremaSpan = 8;   // a run that jumps farther than this many cells is worked in several groups
+// work items over the live points: runs of at most 64 that stay inside one 2 m x 2 m column block of the
+// Hilbert order (key >> 16), like the items of the full cloud (grid.hip): where few points are live a
+// run of 64 would otherwise wander over many blocks and its wave would work them one after the other
+__global__ void k_sift_live_heads(const uint32_t *__restrict__ keys, const int *__restrict__ n_live_dev, int n_max, int *__restrict__ heads)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n_max) return;
+  const int n = *n_live_dev;
+  heads[j] = (j < n && (j == 0 || (keys[j] >> 16) != (keys[j - 1] >> 16) || (j & 63) == 0)) ? 1 : 0;
+}
+
+__global__ void k_sift_live_items(const int *__restrict__ heads, const int *__restrict__ pos, const int *__restrict__ n_live_dev,
+                                  int2 *__restrict__ items)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = *n_live_dev;
+  if (j >= n || !heads[j]) return;
+  int cnt = 1;
+  while (cnt < 64 && j + cnt < n && !heads[j + cnt]) ++cnt;
+  items[pos[j]] = make_int2(j, cnt);
+}
+
+// findScaleSpaceExtrema.  q_pts = the live points (k_sift_live_compact); items = their runs
+// (k_sift_live_items), *n_items_dev of them, one per wave.
+constexpr int kExtremaSpan = 8;   // a run that still jumps farther than this many cells is worked in several groups
 
 __global__ void __launch_bounds__(256)
-k_sift_extrema(const float4 *__restrict__ q_pts, const int *__restrict__ n_live_dev, GridView g /* .w = original index */,
+k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, const int *__restrict__ n_items_dev,
+               GridView g /* .w = original index */,
                const float4 *__restrict__ dogx, const float *__restrict__ dog, float min_contrast, int *__restrict__ flags /* [n*3] */)
 {
   __shared__ float4 s_pts[4][kSiftTile];
   __shared__ float4 s_x[4][2 * kSiftTile];
   __shared__ int s_off[4][64];
   __shared__ int s_beg[4][64];
-  const int n_live = *n_live_dev;
-  const int n_items = (n_live + kExtremaRun - 1) / kExtremaRun;
+  const int n_items = *n_items_dev;
   if ((int)(blockIdx.x * 4) >= n_items) return;            // the grid is sized for the worst case
   const unsigned bid = xcd_remap(blockIdx.x, (unsigned)((n_items + 3) >> 2));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = bid * 4 + wave;
-  const int2 it = item < n_items ? make_int2(item * kExtremaRun, min(kExtremaRun, n_live - item * kExtremaRun)) : make_int2(0, 0);
+  const int2 it = item < n_items ? items[item] : make_int2(0, 0);
   const bool valid = lane < it.y;
   if (it.y == 0) return;                      // wave-uniform
   const float4 q = q_pts[it.x + (valid ? lane : 0)];
@@ -306,7 +327,7 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int *__restrict__ n_live_
         }
       }
       if (all_done) active = false;
-      else need = min(E + 1, max_e);
+      else need = min(E + 1 + (E >> 1), max_e);   // sparse places: grow the ring by half each time (stragglers set the kernel time)
     }
   }
   }
@@ -373,14 +394,23 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     const int nh = (int)cur->n_finite;
     DevBuf<int> lflag(c, (size_t)nh + 1), lpos(c, (size_t)nh + 1);
     DevBuf<float4> lpts(c, (size_t)nh);
+    DevBuf<uint32_t> lkeys(c, (size_t)nh);
+    DevBuf<int> lheads(c, (size_t)nh + 1), lipos(c, (size_t)nh + 1);
+    const int max_items = 2 * n_items + 4;                // a block's live run splits at most once more than its full run
+    DevBuf<int2> litems(c, (size_t)max_items);
     MM3D_LAUNCH(c, "sift_live", nh * 28.0, k_sift_live, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(), nh,
                 (const float *)dog.get(), (float)min_contrast, lflag.get());
     exclusive_scan_int(c, lflag.get(), lpos.get(), (size_t)nh + 1);
-    MM3D_LAUNCH(c, "sift_live", nh * 24.0, k_sift_live_compact, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
-                nh, (const int *)lflag.get(), (const int *)lpos.get(), lpts.get());
-    MM3D_LAUNCH(c, "sift_extrema", gk.n * 48.0, k_sift_extrema, dim3(div_up(div_up((size_t)nh, kExtremaRun), 4)), dim3(256), 0,
-                (const float4 *)lpts.get(), (const int *)(lpos.get() + nh), gk.view(), (const float4 *)dogx.get(), (const float *)dog.get(),
-                (float)min_contrast, flags.get());
+    MM3D_LAUNCH(c, "sift_live", nh * 32.0, k_sift_live_compact, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
+                (const uint32_t *)cur->hil_keys.get(), nh, (const int *)lflag.get(), (const int *)lpos.get(), lpts.get(), lkeys.get());
+    MM3D_LAUNCH(c, "sift_live", nh * 8.0, k_sift_live_heads, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const uint32_t *)lkeys.get(),
+                (const int *)(lpos.get() + nh), nh, lheads.get());
+    exclusive_scan_int(c, lheads.get(), lipos.get(), (size_t)nh + 1);
+    MM3D_LAUNCH(c, "sift_live", nh * 12.0, k_sift_live_items, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const int *)lheads.get(),
+                (const int *)lipos.get(), (const int *)(lpos.get() + nh), litems.get());
+    MM3D_LAUNCH(c, "sift_extrema", gk.n * 48.0, k_sift_extrema, dim3(div_up((size_t)max_items, 4)), dim3(256), 0,
+                (const float4 *)lpts.get(), (const int2 *)litems.get(), (const int *)(lipos.get() + nh), gk.view(), (const float4 *)dogx.get(),
+                (const float *)dog.get(), (float)min_contrast, flags.get());
     DevBuf<int> pos(c, (size_t)n * 3 + 1);
     exclusive_scan_int(c, flags.get(), pos.get(), (size_t)n * 3 + 1);
     int *h = (int *)c->pin(64);

@@ -78,6 +78,7 @@ struct mm3d_cloud {
   std::map<int, std::unique_ptr<mm3d::Grid>> grids;   // key: cell size in units of 1e-4 m
   std::vector<float4> host;                            // host copy (keypoint clouds only)
   mm3d::DevBuf<float4> hil_pts;                        // finite points in Hilbert order, .w = original index
+  mm3d::DevBuf<uint32_t> hil_keys;                     // their sort keys: (Hilbert index of the 0.25 m column << 10) | z cell
   mm3d::DevBuf<int2> wave_items;                       // {first point, count <= 64}: one compact patch per wave
   int n_wave_items = 0;
 };
