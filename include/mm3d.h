@@ -162,9 +162,9 @@ int mm3d_harris_response(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_nor
                          float *dst);
 /* computeLocalDescriptors (features.h:83, features.cpp:99-166).  Like the reference it prunes
  * keypoints whose descriptor is not finite: *keypoints is replaced IN PLACE by the pruned cloud.
- * FPFH (dispatch_descriptors.h:40), PFH (:38, the reference's default), PFHRGB (:39) and SHOT
- * (:46, i.e. SHOTColorEstimation / SHOT1344: 352 shape + 992 colour bins) are built;
- * RSD / SC3D -> MM3D_EUNSUPPORTED. */
+ * FPFH (dispatch_descriptors.h:40), PFH (:38, the reference's default), PFHRGB (:39), RSD (:43) and
+ * SHOT (:46, i.e. SHOTColorEstimation / SHOT1344: 352 shape + 992 colour bins) are built;
+ * SC3D -> MM3D_EUNSUPPORTED. */
 int mm3d_compute_descriptors(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_normals *normals,
                              mm3d_cloud *keypoints, int descriptor, double feature_radius,
                              mm3d_desc **out);

@@ -412,10 +412,12 @@ int mm3d_compute_descriptors(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d
       *out = compute_pfh(ctx, points, normals, keypoints, feature_radius);
     } else if (descriptor == MM3D_DESC_PFHRGB) {
       *out = compute_pfhrgb(ctx, points, normals, keypoints, feature_radius);
+    } else if (descriptor == MM3D_DESC_RSD) {
+      *out = compute_rsd(ctx, points, normals, keypoints, feature_radius);
     } else if (descriptor == MM3D_DESC_SHOT) {
       *out = compute_shot(ctx, points, normals, keypoints, feature_radius);
     } else if (descriptor >= 0 && descriptor < 6) {
-      throw Error(MM3D_EUNSUPPORTED, std::string("descriptor ") + kDescNames[descriptor] + " is not built (FPFH, PFH, PFHRGB and SHOT are)");
+      throw Error(MM3D_EUNSUPPORTED, std::string("descriptor ") + kDescNames[descriptor] + " is not built (FPFH, PFH, PFHRGB, RSD and SHOT are)");
     } else {
       throw Error(MM3D_EINVAL, "unknown descriptor type");   // dispatch_descriptors.h:63
     }
@@ -503,9 +505,9 @@ static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const m
 {
   if (p->keypoint_type != MM3D_KP_SIFT && p->keypoint_type != MM3D_KP_HARRIS) throw Error(MM3D_EINVAL, "invalid keypoint type");
   if (p->descriptor_type != MM3D_DESC_FPFH && p->descriptor_type != MM3D_DESC_PFH && p->descriptor_type != MM3D_DESC_SHOT &&
-      p->descriptor_type != MM3D_DESC_PFHRGB)
+      p->descriptor_type != MM3D_DESC_PFHRGB && p->descriptor_type != MM3D_DESC_RSD)
     throw Error((p->descriptor_type >= 0 && p->descriptor_type < 6) ? MM3D_EUNSUPPORTED : MM3D_EINVAL,
-                "only FPFH, PFH, PFHRGB and SHOT descriptors are built");
+                "only FPFH, PFH, PFHRGB, RSD and SHOT descriptors are built");
   std::unique_ptr<mm3d_cloud> down(downsample(ctx, raw, p->resolution));
   // NB: the outlier radius is the DESCRIPTOR radius (map_merging.cpp:219-220)
   std::unique_ptr<mm3d_cloud> filt(remove_outliers(ctx, down.get(), p->descriptor_radius, p->outliers_min_neighbours));
@@ -516,6 +518,7 @@ static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const m
                                      ? detect_keypoints_harris(ctx, filt.get(), nrm.get(), p->keypoint_threshold, p->normal_radius)
                                      : detect_keypoints_sift(ctx, filt.get(), p->resolution, 3, 3, p->keypoint_threshold));
   std::unique_ptr<mm3d_desc> desc(p->descriptor_type == MM3D_DESC_PFH    ? compute_pfh(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
+                                  : p->descriptor_type == MM3D_DESC_RSD ? compute_rsd(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                   : p->descriptor_type == MM3D_DESC_PFHRGB ? compute_pfhrgb(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                   : p->descriptor_type == MM3D_DESC_SHOT ? compute_shot(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                                                          : compute_fpfh(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius));

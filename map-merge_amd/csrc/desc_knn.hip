@@ -853,6 +853,7 @@ void desc_knn_prepare_target(Context *c, const mm3d_desc *B_)
   auto *B = const_cast<mm3d_desc *>(B_);
   if (B->n < 64 || B->knn_Bp.get()) return;
   if (B->dim == 33) knn_target_operands<33>(c, B, B->knn_colsum, B->knn_Bp);
+  else if (B->dim == 2) knn_target_operands<2>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 125) knn_target_operands<125>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 250) knn_target_operands<250>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 1344) knn_target_operands<1344>(c, B, B->knn_colsum, B->knn_Bp);
@@ -987,10 +988,11 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
   MM3D_REQUIRE(k >= 1, "k must be positive");
   if (k > kMaxK) throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN supports k <= 16");
   if (A->dim == 33) desc_knn_impl<33>(c, A, B, k, idx, d2);          // FPFHSignature33
+  else if (A->dim == 2) desc_knn_impl<2>(c, A, B, k, idx, d2);       // PrincipalRadiiRSD (r_min, r_max)
   else if (A->dim == 125) desc_knn_impl<125>(c, A, B, k, idx, d2);   // PFHSignature125
   else if (A->dim == 250) desc_knn_wide_impl<250>(c, A, B, k, idx, d2);     // PFHRGBSignature250
   else if (A->dim == 1344) desc_knn_wide_impl<1344>(c, A, B, k, idx, d2);   // SHOT1344
-  else throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for FPFH (33), PFH (125), PFHRGB (250) and SHOT (1344) rows");
+  else throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for RSD (2), FPFH (33), PFH (125), PFHRGB (250) and SHOT (1344) rows");
 }
 
 __global__ void k_gather_desc_rows(const float *__restrict__ X, const int *__restrict__ rows, int n_rows, int dim,

@@ -107,6 +107,11 @@ int mo_descriptors_pfhrgb(const mo_point *surface, const mo_normal *normals, int
                           mo_point *keypoints, int n_kp, double radius, float *desc);
 int mo_pfhrgb_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints,
                   int n_kp, double radius, float *desc /* n_kp x 250 */);
+/* computeLocalDescriptors(RSD): dispatch_descriptors.h:43 = RSDEstimation / PrincipalRadiiRSD (r_min, r_max). */
+int mo_descriptors_rsd(const mo_point *surface, const mo_normal *normals, int n,
+                       mo_point *keypoints, int n_kp, double radius, float *desc /* n_kp x 2 */);
+int mo_rsd_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints,
+               int n_kp, double radius, float *desc /* n_kp x 2 */);
 /* computeLocalDescriptors(SHOT): dispatch_descriptors.h:46 = SHOTColorEstimation / SHOT1344 (o_shot.c).
  * desc must hold n_kp*1344 floats; keypoints pruned in place; returns the survivors. */
 int mo_descriptors_shot(const mo_point *surface, const mo_normal *normals, int n,

@@ -309,6 +309,97 @@ int mo_descriptors_pfhrgb(const mo_point *surface, const mo_normal *normals, int
   return m;
 }
 
+/*
+ * computeLocalDescriptors(RSD): dispatch_descriptors.h:43 = pcl::RSDEstimation<PointXYZRGB, Normal,
+ * PrincipalRadiiRSD> (field "r_min"; the point representation reads its 2 floats r_min, r_max).
+ * PCL 1.8.1 features/impl/rsd.hpp: computeFeature -> pcl::computeRSD (surface, normals, nn_indices,
+ * search_radius, nr_subdiv = 5, plane_radius = 0.2, out, false): the FIRST neighbour is the reference
+ * point; for every other neighbour the angle between the two normal LINES (acos, folded to [0, pi/2])
+ * and the distance go into 5 distance bins that keep the minimum and maximum angle; the radii are the
+ * least-squares slopes d ~ r * angle of the two envelopes, capped at plane_radius, scaled by 1.1 / 0.9
+ * and ordered.  Fewer than 2 neighbours: (0, 0).  Restatement choices: the neighbours come sorted by
+ * (distance, index), so the reference point is the NEAREST surface point (PCL's unsorted tree hands
+ * over whatever FLANN visits first); sqrt of the float sum of squares is the float overload
+ * (pcl_macros.h includes <math.h>); a distance that lands in bin 5 (dist == max_dist after rounding:
+ * out of bounds in PCL) is skipped.
+ */
+int mo_rsd_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints, int n_kp,
+               double radius, float *desc /* n_kp x 2: r_min, r_max */)
+{
+  const int nr_subdiv = 5;
+  const double plane_radius = 0.2, max_dist = radius;
+  mo_grid *g = mo_grid_build(surface, n, (float)(radius * 0.5));
+  const float r2 = (float)(radius * radius);
+  int cap = 4096;
+  int *idx = (int *)malloc(sizeof(int) * (size_t)cap);
+  float *d2 = (float *)malloc(sizeof(float) * (size_t)cap);
+  for (int k = 0; k < n_kp; ++k) {
+    float *out = &desc[(size_t)k * 2];
+    int cnt = mo_radius_search(g, keypoints[k].x, keypoints[k].y, keypoints[k].z, r2, idx, d2, cap);
+    if (cnt > cap) {
+      cap = cnt * 2;
+      idx = (int *)realloc(idx, sizeof(int) * (size_t)cap);
+      d2 = (float *)realloc(d2, sizeof(float) * (size_t)cap);
+      cnt = mo_radius_search(g, keypoints[k].x, keypoints[k].y, keypoints[k].z, r2, idx, d2, cap);
+    }
+    if (cnt < 2) { out[0] = out[1] = 0.0f; continue; }
+    double lo[5], hi[5];
+    lo[0] = hi[0] = 0.0;
+    for (int di = 1; di < nr_subdiv; ++di) { lo[di] = +1.7976931348623157e308; hi[di] = -1.7976931348623157e308; }
+    const mo_point *p0 = &surface[idx[0]];
+    const mo_normal *n0 = &normals[idx[0]];
+    for (int i = 1; i < cnt; ++i) {
+      const mo_point *p = &surface[idx[i]];
+      const mo_normal *nv = &normals[idx[i]];
+      double cosine = (double)(nv->nx * n0->nx + nv->ny * n0->ny + nv->nz * n0->nz);
+      if (cosine > 1) cosine = 1;
+      if (cosine < -1) cosine = -1;
+      double angle = acos(cosine);
+      if (angle > M_PI / 2) angle = M_PI - angle;
+      const double dist = (double)sqrtf((p->x - p0->x) * (p->x - p0->x) + (p->y - p0->y) * (p->y - p0->y) + (p->z - p0->z) * (p->z - p0->z));
+      if (dist > max_dist) continue;
+      const int bin_d = floor_to_int(nr_subdiv * dist / max_dist);
+      if (bin_d < 0 || bin_d >= nr_subdiv) continue;
+      if (lo[bin_d] > angle) lo[bin_d] = angle;
+      if (hi[bin_d] < angle) hi[bin_d] = angle;
+    }
+    double Amint_Amin = 0, Amint_d = 0, Amaxt_Amax = 0, Amaxt_d = 0;
+    for (int di = 0; di < nr_subdiv; ++di)
+      if (hi[di] >= 0) {
+        const double p_min = lo[di], p_max = hi[di];
+        const double f = (di + 0.5) * max_dist / nr_subdiv;
+        Amint_Amin += p_min * p_min;
+        Amint_d += p_min * f;
+        Amaxt_Amax += p_max * p_max;
+        Amaxt_d += p_max * f;
+      }
+    float min_radius = Amint_Amin == 0.0f ? (float)plane_radius : (float)fmin(Amint_d / Amint_Amin, plane_radius);
+    float max_radius = Amaxt_Amax == 0.0f ? (float)plane_radius : (float)fmin(Amaxt_d / Amaxt_Amax, plane_radius);
+    min_radius *= 1.1f;
+    max_radius *= 0.9f;
+    if (min_radius < max_radius) { out[0] = min_radius; out[1] = max_radius; }
+    else { out[1] = min_radius; out[0] = max_radius; }
+  }
+  free(idx); free(d2);
+  mo_grid_free(g);
+  return n_kp;
+}
+
+int mo_descriptors_rsd(const mo_point *surface, const mo_normal *normals, int n, mo_point *keypoints, int n_kp,
+                       double radius, float *desc)
+{
+  if (n_kp <= 0) return 0;
+  mo_rsd_raw(surface, normals, n, keypoints, n_kp, radius, desc);
+  /* DefaultPointRepresentation<PrincipalRadiiRSD>: 2 floats, both finite */
+  int m = 0;
+  for (int k = 0; k < n_kp; ++k) {
+    if (!isfinite(desc[(size_t)k * 2]) || !isfinite(desc[(size_t)k * 2 + 1])) continue;
+    if (m != k) { desc[(size_t)m * 2] = desc[(size_t)k * 2]; desc[(size_t)m * 2 + 1] = desc[(size_t)k * 2 + 1]; keypoints[m] = keypoints[k]; }
+    ++m;
+  }
+  return m;
+}
+
 int mo_descriptors_pfh(const mo_point *surface, const mo_normal *normals, int n,
                        mo_point *keypoints, int n_kp, double radius, float *desc)
 {

@@ -152,6 +152,16 @@ def pfh_raw(surface, nrm, keypoints, radius):
     return desc[:len(keypoints)].copy()
 
 
+def descriptors_rsd(surface, nrm, keypoints, radius):
+    """computeLocalDescriptors(RSD): returns (pruned keypoints, desc[n, 2] = r_min, r_max)."""
+    surface = _pts(surface)
+    nrm = np.ascontiguousarray(nrm, dtype=NORMAL)
+    kp = _pts(keypoints).copy()
+    desc = np.empty((max(len(kp), 1), 2), dtype=np.float32)
+    n = lib().mo_descriptors_rsd(_p(surface), _p(nrm), len(surface), _p(kp), len(kp), C.c_double(radius), _p(desc))
+    return kp[:n].copy(), desc[:n].copy()
+
+
 def descriptors_pfhrgb(surface, nrm, keypoints, radius):
     """computeLocalDescriptors(PFHRGB): returns (pruned keypoints, desc[n, 250])."""
     surface = _pts(surface)

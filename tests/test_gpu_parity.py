@@ -701,3 +701,27 @@ def test_golden_features_fixture_on_device(ctx, po, mm, synth):
         if name == "shot":
             assert np.array_equal(d.frames().view(np.uint32), g["shot_rf"].view(np.uint32))
             assert (d.numpy().view(np.uint32) == g[name].view(np.uint32)).all(axis=1).mean() >= 0.95
+
+
+def test_rsd(ctx, po, mm, scene):
+    """PrincipalRadiiRSD (dispatch_descriptors.h:43): rows against the oracle (minima / maxima of double angles:
+    bit-equal unless the two libms' acos differ in the last bit and that moves a float rounding), 2-wide k-NN
+    with its heavy ties, and the descriptor through estimateMapsTransforms."""
+    for m in scene:
+        kp_ref, ref = po.descriptors_rsd(m["filt"], m["nrm"], m["kp_raw"], R_DESC)
+        kp = ctx.cloud(m["kp_raw"])
+        d = ctx.computeLocalDescriptors(ctx.cloud(m["filt"]), ctx.normals(m["nrm"]), kp, 3, R_DESC)
+        got = d.numpy()
+        assert got.shape == ref.shape and got.shape[1] == 2 and len(kp) == len(kp_ref)
+        assert (got.view(np.uint32) == ref.view(np.uint32)).all(axis=1).mean() >= 0.98
+        assert np.abs(got - ref).max() <= 1e-6
+        # k-NN on identical inputs: exact, ties to the lower index
+        for k in (1, 5):
+            a = ctx.findFeatureCorrespondences(d, d, k)
+            b = po.find_correspondences(got, got, k)
+            assert np.array_equal(a["index_match"], b["index_match"]) and np.array_equal(a["distance"].view(np.uint32), b["distance"].view(np.uint32))
+    a, b = scene
+    params = mm.MapMergingParams(descriptor_type=3, estimation_method=1)
+    ctx.srand(1)
+    T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
+    assert len(pairs) == 1 and np.isfinite(pairs[0]["transform"]).all()

@@ -238,6 +238,29 @@ def test_harris_known_answers(po):
     assert len(po.keypoints_harris(plane, pn, 0.0, 0.3)[0]) == len(plane)
 
 
+def test_rsd_known_answers(po):
+    """PrincipalRadiiRSD: a plane answers the cap (plane_radius 0.2 -> 0.9 * 0.2, 1.1 * 0.2); on a sphere of radius R
+    the angle grows like d / R; the minimum of a densely sampled distance bin sits at its lower edge and the maximum
+    at its upper edge while both are fitted against the bin CENTRE, which gives slopes of 35/30 R and 47.5/55 R, then
+    x 1.1 and x 0.9: (r_min, r_max) ~ (0.777 R, 1.283 R)."""
+    rng = np.random.default_rng(10)
+    uv = rng.uniform(-1, 1, (3000, 2)).astype(np.float32)
+    plane = cloud(po, np.stack([uv[:, 0], uv[:, 1], np.full(3000, 2.0, np.float32)], 1))
+    pn = np.zeros(len(plane), dtype=po.NORMAL); pn["nz"] = 1.0
+    kept, d = po.descriptors_rsd(plane, pn, plane[::300].copy(), 0.3)
+    assert len(kept) == 10 and np.allclose(d, [0.18, 0.22], atol=1e-6)
+    R = 0.15
+    v = rng.standard_normal((6000, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    sph = cloud(po, (v * R + np.array([1, 2, 3])).astype(np.float32))
+    sn = np.zeros(len(sph), dtype=po.NORMAL); sn["nx"], sn["ny"], sn["nz"] = v[:, 0], v[:, 1], v[:, 2]
+    _, d = po.descriptors_rsd(sph, sn, sph[::600].copy(), 0.12)
+    assert np.allclose(d[:, 0], 0.777 * R, rtol=0.05) and np.allclose(d[:, 1], 1.283 * R, rtol=0.05), d
+    # fewer than two neighbours: (0, 0), a valid row
+    far = sph[:1].copy(); far["x"] += 50
+    kept, d = po.descriptors_rsd(sph, sn, far, 0.12)
+    assert len(kept) == 1 and not d.any()
+
+
 def test_pfhrgb_known_answers(po):
     """PFHRGBSignature250: ordered pairs (each half sums to 200), integer colour ratios."""
     rng = np.random.default_rng(9)
