@@ -34,7 +34,7 @@ typedef enum {
   MM3D_EINVAL = -1,        /* bad argument (also: unknown enum string, like enums::from_string) */
   MM3D_EDEVICE = -2,       /* HIP runtime / device failure */
   MM3D_ENOMEM = -3,
-  MM3D_EUNSUPPORTED = -4,  /* descriptor / keypoint type outside the implemented path */
+  MM3D_EUNSUPPORTED = -4,  /* a size outside what the kernels are built for (k > 16, neighbourhoods beyond the scratch pass, nr_scales != 3) */
   MM3D_ECAPACITY = -5      /* caller buffer too small; required size is reported */
 } mm3d_status;
 
@@ -162,9 +162,9 @@ int mm3d_harris_response(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_nor
                          float *dst);
 /* computeLocalDescriptors (features.h:83, features.cpp:99-166).  Like the reference it prunes
  * keypoints whose descriptor is not finite: *keypoints is replaced IN PLACE by the pruned cloud.
- * FPFH (dispatch_descriptors.h:40), PFH (:38, the reference's default), PFHRGB (:39), RSD (:43) and
- * SHOT (:46, i.e. SHOTColorEstimation / SHOT1344: 352 shape + 992 colour bins) are built;
- * SC3D -> MM3D_EUNSUPPORTED. */
+ * All six rows of the dispatch table are built: PFH (dispatch_descriptors.h:38, the reference's
+ * default), PFHRGB (:39), FPFH (:40), RSD (:43), SHOT (:46, i.e. SHOTColorEstimation / SHOT1344:
+ * 352 shape + 992 colour bins) and SC3D (:47); other values -> MM3D_EINVAL. */
 int mm3d_compute_descriptors(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d_normals *normals,
                              mm3d_cloud *keypoints, int descriptor, double feature_radius,
                              mm3d_desc **out);

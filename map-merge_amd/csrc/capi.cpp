@@ -416,8 +416,8 @@ int mm3d_compute_descriptors(mm3d_ctx *ctx, const mm3d_cloud *points, const mm3d
       *out = compute_rsd(ctx, points, normals, keypoints, feature_radius);
     } else if (descriptor == MM3D_DESC_SHOT) {
       *out = compute_shot(ctx, points, normals, keypoints, feature_radius);
-    } else if (descriptor >= 0 && descriptor < 6) {
-      throw Error(MM3D_EUNSUPPORTED, std::string("descriptor ") + kDescNames[descriptor] + " is not built (FPFH, PFH, PFHRGB, RSD and SHOT are)");
+    } else if (descriptor == MM3D_DESC_SC3D) {
+      *out = compute_sc3d(ctx, points, normals, keypoints, feature_radius);
     } else {
       throw Error(MM3D_EINVAL, "unknown descriptor type");   // dispatch_descriptors.h:63
     }
@@ -504,10 +504,7 @@ int mm3d_transform_score(mm3d_ctx *ctx, const mm3d_cloud *source, const mm3d_clo
 static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const mm3d_params *p)
 {
   if (p->keypoint_type != MM3D_KP_SIFT && p->keypoint_type != MM3D_KP_HARRIS) throw Error(MM3D_EINVAL, "invalid keypoint type");
-  if (p->descriptor_type != MM3D_DESC_FPFH && p->descriptor_type != MM3D_DESC_PFH && p->descriptor_type != MM3D_DESC_SHOT &&
-      p->descriptor_type != MM3D_DESC_PFHRGB && p->descriptor_type != MM3D_DESC_RSD)
-    throw Error((p->descriptor_type >= 0 && p->descriptor_type < 6) ? MM3D_EUNSUPPORTED : MM3D_EINVAL,
-                "only FPFH, PFH, PFHRGB, RSD and SHOT descriptors are built");
+  if (p->descriptor_type < 0 || p->descriptor_type >= 6) throw Error(MM3D_EINVAL, "unknown descriptor type");   // dispatch_descriptors.h:63
   std::unique_ptr<mm3d_cloud> down(downsample(ctx, raw, p->resolution));
   // NB: the outlier radius is the DESCRIPTOR radius (map_merging.cpp:219-220)
   std::unique_ptr<mm3d_cloud> filt(remove_outliers(ctx, down.get(), p->descriptor_radius, p->outliers_min_neighbours));
@@ -518,6 +515,7 @@ static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const m
                                      ? detect_keypoints_harris(ctx, filt.get(), nrm.get(), p->keypoint_threshold, p->normal_radius)
                                      : detect_keypoints_sift(ctx, filt.get(), p->resolution, 3, 3, p->keypoint_threshold));
   std::unique_ptr<mm3d_desc> desc(p->descriptor_type == MM3D_DESC_PFH    ? compute_pfh(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
+                                  : p->descriptor_type == MM3D_DESC_SC3D ? compute_sc3d(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                   : p->descriptor_type == MM3D_DESC_RSD ? compute_rsd(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                   : p->descriptor_type == MM3D_DESC_PFHRGB ? compute_pfhrgb(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                   : p->descriptor_type == MM3D_DESC_SHOT ? compute_shot(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)

@@ -857,6 +857,7 @@ void desc_knn_prepare_target(Context *c, const mm3d_desc *B_)
   else if (B->dim == 125) knn_target_operands<125>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 250) knn_target_operands<250>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 1344) knn_target_operands<1344>(c, B, B->knn_colsum, B->knn_Bp);
+  else if (B->dim == 1980) knn_target_operands<1980>(c, B, B->knn_colsum, B->knn_Bp);
 }
 
 template <int kD>
@@ -992,7 +993,8 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
   else if (A->dim == 125) desc_knn_impl<125>(c, A, B, k, idx, d2);   // PFHSignature125
   else if (A->dim == 250) desc_knn_wide_impl<250>(c, A, B, k, idx, d2);     // PFHRGBSignature250
   else if (A->dim == 1344) desc_knn_wide_impl<1344>(c, A, B, k, idx, d2);   // SHOT1344
-  else throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for RSD (2), FPFH (33), PFH (125), PFHRGB (250) and SHOT (1344) rows");
+  else if (A->dim == 1980) desc_knn_wide_impl<1980>(c, A, B, k, idx, d2);   // ShapeContext1980
+  else throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for RSD (2), FPFH (33), PFH (125), PFHRGB (250), SHOT (1344) and SC3D (1980) rows");
 }
 
 __global__ void k_gather_desc_rows(const float *__restrict__ X, const int *__restrict__ rows, int n_rows, int dim,

@@ -161,6 +161,10 @@ mm3d_desc *compute_pfhrgb(Context *c, const mm3d_cloud *points, const mm3d_norma
 mm3d_desc *compute_rsd(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,
                        mm3d_cloud *keypoints, double radius);
 
+// sc3d.hip
+mm3d_desc *compute_sc3d(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,
+                        mm3d_cloud *keypoints, double radius);
+
 // shot.hip
 mm3d_desc *compute_shot(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,
                         mm3d_cloud *keypoints, double radius);

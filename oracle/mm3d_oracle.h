@@ -112,6 +112,13 @@ int mo_descriptors_rsd(const mo_point *surface, const mo_normal *normals, int n,
                        mo_point *keypoints, int n_kp, double radius, float *desc /* n_kp x 2 */);
 int mo_rsd_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints,
                int n_kp, double radius, float *desc /* n_kp x 2 */);
+/* computeLocalDescriptors(SC3D): dispatch_descriptors.h:47 = ShapeContext3DEstimation / ShapeContext1980
+ * (o_sc3d.c); consumes 3 draws of a boost::mt19937 seeded with 12345 per keypoint that has a neighbour. */
+int mo_descriptors_sc3d(const mo_point *surface, const mo_normal *normals, int n,
+                        mo_point *keypoints, int n_kp, double radius, float *desc /* n_kp x 1980 */);
+int mo_sc3d_raw(const mo_point *surface, const mo_normal *normals, int n, const mo_point *keypoints,
+                int n_kp, double radius, float *desc /* n_kp x 1980 */);
+void mo_sc3d_tables(double search_radius, float radii[16], float theta_div[12], float phi_div[13], float volume_lut[1980]);
 /* computeLocalDescriptors(SHOT): dispatch_descriptors.h:46 = SHOTColorEstimation / SHOT1344 (o_shot.c).
  * desc must hold n_kp*1344 floats; keypoints pruned in place; returns the survivors. */
 int mo_descriptors_shot(const mo_point *surface, const mo_normal *normals, int n,

@@ -49,10 +49,10 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
   if (n_clouds == 0) return 0;
   if (n_clouds == 1) { identity16(out_T); return 1; }
   if ((params->descriptor_type != 2 && params->descriptor_type != 0 && params->descriptor_type != 4 &&
-       params->descriptor_type != 1 && params->descriptor_type != 3) ||
+       params->descriptor_type != 1 && params->descriptor_type != 3 && params->descriptor_type != 5) ||
       (params->keypoint_type != 0 && params->keypoint_type != 1))
     return -3;
-  const int dim = params->descriptor_type == 0 ? 125 : params->descriptor_type == 4 ? 1344 : params->descriptor_type == 1 ? 250 : params->descriptor_type == 3 ? 2 : 33;
+  const int dim = params->descriptor_type == 0 ? 125 : params->descriptor_type == 4 ? 1344 : params->descriptor_type == 1 ? 250 : params->descriptor_type == 3 ? 2 : params->descriptor_type == 5 ? 1980 : 33;
 
   mo_point **resized = (mo_point **)calloc((size_t)n_clouds, sizeof(mo_point *));
   int *rn = (int *)calloc((size_t)n_clouds, sizeof(int));
@@ -78,6 +78,7 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
                 : mo_keypoints_sift(b, nb, params->resolution, 3, 3, params->keypoint_threshold, &kps[i], NULL);
     desc[i] = (float *)malloc(sizeof(float) * (size_t)dim * (size_t)(kn[i] > 0 ? kn[i] : 1));
     kn[i] = dim == 125    ? mo_descriptors_pfh(b, normals[i], nb, kps[i], kn[i], params->descriptor_radius, desc[i])
+            : dim == 1980 ? mo_descriptors_sc3d(b, normals[i], nb, kps[i], kn[i], params->descriptor_radius, desc[i])
             : dim == 2    ? mo_descriptors_rsd(b, normals[i], nb, kps[i], kn[i], params->descriptor_radius, desc[i])
             : dim == 250  ? mo_descriptors_pfhrgb(b, normals[i], nb, kps[i], kn[i], params->descriptor_radius, desc[i])
             : dim == 1344 ? mo_descriptors_shot(b, normals[i], nb, kps[i], kn[i], params->descriptor_radius, desc[i])

@@ -152,6 +152,23 @@ def pfh_raw(surface, nrm, keypoints, radius):
     return desc[:len(keypoints)].copy()
 
 
+def sc3d_tables(radius):
+    """ShapeContext3DEstimation::initCompute: (radii[16], theta_div[12], phi_div[13], volume_lut[1980])."""
+    r, t, ph, lut = (np.empty(n, dtype=np.float32) for n in (16, 12, 13, 1980))
+    lib().mo_sc3d_tables(C.c_double(radius), _p(r), _p(t), _p(ph), _p(lut))
+    return r, t, ph, lut
+
+
+def descriptors_sc3d(surface, nrm, keypoints, radius):
+    """computeLocalDescriptors(SC3D): returns (pruned keypoints, desc[n, 1980])."""
+    surface = _pts(surface)
+    nrm = np.ascontiguousarray(nrm, dtype=NORMAL)
+    kp = _pts(keypoints).copy()
+    desc = np.empty((max(len(kp), 1), 1980), dtype=np.float32)
+    n = lib().mo_descriptors_sc3d(_p(surface), _p(nrm), len(surface), _p(kp), len(kp), C.c_double(radius), _p(desc))
+    return kp[:n].copy(), desc[:n].copy()
+
+
 def descriptors_rsd(surface, nrm, keypoints, radius):
     """computeLocalDescriptors(RSD): returns (pruned keypoints, desc[n, 2] = r_min, r_max)."""
     surface = _pts(surface)

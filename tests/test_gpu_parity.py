@@ -725,3 +725,38 @@ def test_rsd(ctx, po, mm, scene):
     ctx.srand(1)
     T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
     assert len(pairs) == 1 and np.isfinite(pairs[0]["transform"]).all()
+
+
+def test_sc3d(ctx, po, mm, scene):
+    """ShapeContext1980 (dispatch_descriptors.h:47): the random frame directions replay boost::mt19937(12345) in
+    keypoint order, bins take their votes in the oracle's neighbour order: rows are bit-equal unless an atan2f /
+    acosf ulp moves a neighbour across a bin edge (one vote of that row moves)."""
+    for m in scene:
+        kp_ref, ref = po.descriptors_sc3d(m["filt"], m["nrm"], m["kp_raw"], R_DESC)
+        kp = ctx.cloud(m["kp_raw"])
+        got = ctx.computeLocalDescriptors(ctx.cloud(m["filt"]), ctx.normals(m["nrm"]), kp, 5, R_DESC).numpy()
+        assert got.shape == ref.shape and got.shape[1] == 1980 and len(ref) > 100
+        assert np.array_equal(kp.numpy().view(np.uint32), kp_ref.view(np.uint32))
+        same = (got.view(np.uint32) == ref.view(np.uint32)).all(axis=1)
+        assert same.mean() >= 0.9, same.mean()
+        # a moved vote changes two bins of the row by that vote; the row's mass moves by at most the volume-factor ratio
+        assert np.abs(got.sum(1) - ref.sum(1)).max() <= 0.05 * ref.sum(1).max()
+        assert (np.abs(got - ref) > 1e-5).sum(axis=1).max() <= 8
+    # pruning: a keypoint without neighbours takes no random draws and goes
+    kp = scene[0]["kp_raw"][:40].copy()
+    kp["x"][3] += 400.0
+    kp_ref, ref = po.descriptors_sc3d(scene[0]["filt"], scene[0]["nrm"], kp, R_DESC)
+    k = ctx.cloud(kp)
+    d = ctx.computeLocalDescriptors(ctx.cloud(scene[0]["filt"]), ctx.normals(scene[0]["nrm"]), k, 5, R_DESC)
+    assert len(d) == len(ref) == 39 and np.array_equal(k.numpy().view(np.uint32), kp_ref.view(np.uint32))
+    assert (d.numpy().view(np.uint32) == ref.view(np.uint32)).all(axis=1).mean() >= 0.9
+    # k-NN over 1980-wide rows and the whole pipeline
+    got = d.numpy()
+    a = ctx.findFeatureCorrespondences(d, d, 3)
+    b = po.find_correspondences(got, got, 3)
+    assert np.array_equal(a["index_match"], b["index_match"]) and np.array_equal(a["distance"].view(np.uint32), b["distance"].view(np.uint32))
+    a, b = scene
+    params = mm.MapMergingParams(descriptor_type=5, estimation_method=1)
+    ctx.srand(1)
+    T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
+    assert len(pairs) == 1 and np.isfinite(pairs[0]["transform"]).all()

@@ -63,7 +63,7 @@ def test_degenerate_inputs_for_the_other_feature_types(ctx, mm, textured):
     nan = _cloud(mm, np.full((100, 3), np.nan, np.float32))
     empty = _cloud(mm, np.zeros((0, 3), np.float32))
     for kt, thr in ((1, 0.001), (0, 5.0)):
-        for dt in (0, 1, 4):
+        for dt in (0, 1, 3, 4, 5):
             P = mm.MapMergingParams(keypoint_type=kt, keypoint_threshold=thr, descriptor_type=dt, estimation_method=1)
             for name, c in (("flat", flat), ("nan", nan), ("empty", empty)):
                 m = ctx.mapFeatures(ctx.cloud(c), P)
@@ -87,6 +87,10 @@ def test_degenerate_inputs_for_the_other_feature_types(ctx, mm, textured):
     k = ctx.cloud(far[:0])
     for dt in (0, 1, 4):
         assert len(ctx.computeLocalDescriptors(pts, nrm, k, dt, 0.8)) == 0
-    # SC3D / RSD are answered, not crashed on
+    # RSD keeps (0, 0) rows for them, SC3D prunes them; a value outside the enum is answered, not crashed on
+    k = ctx.cloud(far)
+    assert len(ctx.computeLocalDescriptors(pts, nrm, k, 3, 0.8)) == 2
+    k = ctx.cloud(far)
+    assert len(ctx.computeLocalDescriptors(pts, nrm, k, 5, 0.8)) == 0 and len(k) == 0
     with pytest.raises(Exception):
-        ctx.computeLocalDescriptors(pts, nrm, ctx.cloud(far), 5, 0.8)
+        ctx.computeLocalDescriptors(pts, nrm, ctx.cloud(far), 9, 0.8)

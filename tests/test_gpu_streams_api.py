@@ -51,8 +51,8 @@ def test_streams_with_degenerate_maps(mm, clouds):
             one.close()
         assert np.array_equal(np.stack(T).view(np.uint32), np.stack(T1).view(np.uint32))
         assert np.array_equal(pairs.view(np.uint8), pairs1.view(np.uint8))
-        # an unsupported configuration fails on every worker: the status comes back, nothing hangs
-        bad = mm.MapMergingParams(descriptor_type=5, estimation_method=1)      # SC3D is not built
+        # an invalid configuration fails on every worker: the status comes back, nothing hangs
+        bad = mm.MapMergingParams(descriptor_type=9, estimation_method=1)      # not a Descriptor value
         with pytest.raises(Exception):
             c.estimateMapsTransforms([clouds[0], clouds[1]], bad)
         # and the context is still usable afterwards

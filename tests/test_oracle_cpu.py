@@ -261,6 +261,36 @@ def test_rsd_known_answers(po):
     assert len(kept) == 1 and not d.any()
 
 
+def test_sc3d_known_answers(po):
+    """ShapeContext1980 on a regular planar grid with exact normals: every neighbour sits at elevation 90 degrees
+    (division 5 of 11), the interior points share one local density D, so bin / volume factor * D is the integer
+    number of neighbours of that bin, and they add up to all neighbours but the keypoint itself."""
+    r, th, ph, lut = po.sc3d_tables(0.5)
+    assert r[0] == np.float32(0.1) and abs(r[15] - 0.5) < 1e-6 and (np.diff(r) > 0).all()
+    assert np.allclose(th, np.arange(12) * 180 / 11, atol=1e-4) and np.allclose(ph, np.arange(13) * 30.0)
+    assert (lut > 0).all() and (np.diff(lut.reshape(12, 11, 15), axis=2) < 0).all()       # bigger shells, smaller factors
+    g = (np.arange(-21, 22) * 0.07).astype(np.float32)            # no grid distance equals 0.2 or 0.5
+    x, y = [a.ravel() for a in np.meshgrid(g, g)]
+    pts = cloud(po, np.stack([x, y, np.zeros_like(x)], 1))
+    nrm = np.zeros(len(pts), dtype=po.NORMAL); nrm["nz"] = 1.0
+    centre = int(np.argmin(x * x + y * y))
+    kept, d = po.descriptors_sc3d(pts, nrm, pts[centre:centre + 1].copy(), 0.5)
+    assert d.shape == (1, 1980) and len(kept) == 1
+    row = d[0].reshape(12, 11, 15)
+    assert not np.delete(row, 5, axis=1).any() and (row[:, 5, :].sum(1) > 0).all()        # one elevation ring, all 12 sectors
+    m = int(((x - x[centre]) ** 2 + (y - y[centre]) ** 2 < np.float32(0.25)).sum())
+    D = int((x * x + y * y < np.float32(0.04)).sum())                                       # interior density (radius 0.2)
+    counts = d[0] / lut * D
+    assert np.allclose(counts, np.round(counts), atol=1e-3) and int(np.round(counts).sum()) == m - 1
+    # three draws per keypoint with a neighbour, none for one without: the second keypoint's frame does not
+    # depend on whether an isolated keypoint precedes it
+    two = pts[[centre, centre + 7]].copy()
+    far = two[:1].copy(); far["x"] += 50
+    _, d_a = po.descriptors_sc3d(pts, nrm, np.concatenate([two[:1], far, two[1:]]), 0.5)
+    _, d_b = po.descriptors_sc3d(pts, nrm, two, 0.5)
+    assert len(d_a) == 2 and np.array_equal(d_a, d_b)
+
+
 def test_pfhrgb_known_answers(po):
     """PFHRGBSignature250: ordered pairs (each half sums to 200), integer colour ratios."""
     rng = np.random.default_rng(9)
