@@ -33,10 +33,14 @@ constexpr int kAcc = 17;     // sum p(3) | sum q(3) | sum q p^T (9, row = q) | s
 constexpr int kTile = 512;   // staged target points per wave and tile (8 KiB of LDS)
 
 #ifdef MM3D_NN_STATS
-__device__ unsigned long long g_nn_stats[8];   // 0 waves, 1 passes, 2 row chunks, 3 staged points, 4 active lanes at pass, 5 rows
-#define MM3D_STAT(i_, v_) do { if (lane == 0) atomicAdd(&g_nn_stats[i_], (unsigned long long)(v_)); } while (0)
+__device__ unsigned long long g_nn_stats[40];   // 0 waves, 1 passes, 2 row chunks, 3 staged points, 4 active lanes at pass, 5 rows, 6 max wave cycles, 7 sum wave cycles, 8.. log2 histogram of wave cycles
+#define MM3D_STAT(i_, v_) do { if (MM3D_NN_STATS == 1 && lane == 0) atomicAdd(&g_nn_stats[i_], (unsigned long long)(v_)); } while (0)
+#define MM3D_TICK(var_) const long long var_ = wall_clock64()
+#define MM3D_TOCK(i_, from_) do { if (lane == 0) atomicAdd(&g_nn_stats[i_], (unsigned long long)(wall_clock64() - (from_))); } while (0)
 #else
 #define MM3D_STAT(i_, v_)
+#define MM3D_TICK(var_)
+#define MM3D_TOCK(i_, from_)
 #endif
 
 struct IcpState {
@@ -121,6 +125,9 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
   unsigned long long bkey = ~0ull;
   float best = INFINITY, bestd = INFINITY;
 
+#ifdef MM3D_NN_STATS
+  const long long t_begin = wall_clock64();
+#endif
   for (int pass = 0; pass < 64; ++pass) {
     if (!__ballot(active)) break;
     MM3D_STAT(1, 1);
@@ -137,6 +144,7 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
     const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
     const int nrows = (x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
     for (int r0 = 0; r0 < nrows; r0 += kWave) {
+      MM3D_TICK(t_hdr);
       // one row header per lane, exclusive scan of the span lengths
       const int r = r0 + lane;
       int b = 0, len = 0;
@@ -160,7 +168,9 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
       s_off[wave][lane] = incl - len;
       s_beg[wave][lane] = b;
       wave_lds_sync();
+      MM3D_TOCK(32, t_hdr);
       for (int t0 = 0; t0 < total; t0 += kTile) {
+        MM3D_TICK(t_stage);
         const int cnt = min(kTile, total - t0);
         // stage: slot -> (row by binary search over the 64 offsets) -> sorted target index
         // (all of a lane's gathers are issued before the first LDS store: one memory round trip per tile)
@@ -189,6 +199,8 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
           s_cw[wave][cnt + lane] = 0x7fffffffu;
         }
         wave_lds_sync();
+        MM3D_TOCK(33, t_stage);
+        MM3D_TICK(t_scan);
         if (active) {
           for (int k = 0; k < cnt; k += 4) {
             const float4 X = *reinterpret_cast<const float4 *>(&s_cx[wave][k]);
@@ -212,6 +224,7 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
           }
         }
         wave_lds_sync();
+        MM3D_TOCK(34, t_scan);
       }
     }
     // what the scanned box proves: every target point closer than `guard` to this lane has been seen
@@ -234,6 +247,16 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
     }
   }
 
+#ifdef MM3D_NN_STATS
+  if (it.y > 0 && lane == 0) {
+    const unsigned long long dt = (unsigned long long)(wall_clock64() - t_begin);   // 100 MHz ticks
+    atomicMax(&g_nn_stats[6], dt);
+    atomicAdd(&g_nn_stats[7], dt);
+    int b = 0;
+    while ((dt >> b) > 1 && b < 30) ++b;
+    atomicAdd(&g_nn_stats[8 + b], 1ull);
+  }
+#endif
   double acc[kAcc];
 #pragma unroll
   for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
@@ -520,8 +543,8 @@ double transform_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt,
 extern "C" void mm3d_debug_nn_stats(unsigned long long *out, int reset)
 {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stats), sizeof(unsigned long long) * 8);
-  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof(z)); }
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stats), sizeof(unsigned long long) * 40);
+  if (reset) { unsigned long long z[40] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof(z)); }
 }
 #endif
 

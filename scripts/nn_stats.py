@@ -1,0 +1,26 @@
+"""Per-wave timing of the ICP / score search kernel (k_nn_wave).  Needs a library built with the kernel's
+counters on:  hipcc ... -c csrc/nn.hip -DMM3D_NN_STATS=2  (=1 also counts passes / rows / staged points, which
+perturbs the timing), linked in place of build/nn.o.  Prints the histogram of wave durations and the share of the
+three phases (row headers, staging, candidate scan)."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import __graft_entry__ as ge
+mm = ge.load()
+import bench, numpy as np
+host = bench.make_workload(16, 500000)
+ctx = mm.Context(0)
+P = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
+maps = [ctx.mapFeatures(ctx.cloud(host[i]), P) for i in (0, 1)]
+L = mm.lib()
+out = (C.c_ulonglong * 40)()
+ctx.srand(1)
+L.mm3d_debug_nn_stats(out, 1)
+r = ctx.pairEstimate(maps[0], maps[1], P)
+ctx.synchronize()
+L.mm3d_debug_nn_stats(out, 1)
+v = list(out)
+print("waves", v[0], "passes", v[1], "row chunks", v[2], "staged", v[3], "active lanes@pass", v[4], "rows", v[5])
+print("max wave ticks(100MHz)", v[6], "= us", v[6] / 100.0, " mean us", v[7] / max(v[0], 1) / 100.0)
+print("hist log2(ticks):", {b: v[8 + b] for b in range(24) if v[8 + b]})
+print("phase ticks: headers", v[32], "staging", v[33], "scan", v[34], " total wave ticks", v[7])
+print("icp iters", r["icp_iterations"])
