@@ -625,7 +625,11 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   std::vector<mm3d_ctx *> cs{ctx};
   cs.insert(cs.end(), ctx->helpers.begin(), ctx->helpers.end());
   const size_t S = cs.size();
-  const size_t F = S <= 4 ? S : std::max<size_t>(4, S * 3 / 8);
+  size_t F = S <= 4 ? S : std::max<size_t>(4, S * 3 / 8);
+  if (const char *e = std::getenv("MM3D_FEATURE_WORKERS")) {     // tuning knob: how many workers start on features
+    const long v = std::atol(e);
+    if (v >= 1) F = std::min<size_t>(S, (size_t)v);
+  }
   std::vector<std::pair<size_t, size_t>> all;
   for (size_t i = 0; i + 1 < n; ++i)
     for (size_t j = i + 1; j < n; ++j) all.emplace_back(i, j);
