@@ -23,6 +23,7 @@
 // Algorithmic traffic: 12 B per source point per iteration.
 #include <cfloat>
 #include <cstddef>
+#include <type_traits>
 
 #include "device_util.hpp"
 #include "linalg_shared.hpp"
@@ -174,25 +175,33 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
         const int cnt = min(kTile, total - t0);
         // stage: slot -> (row by binary search over the 64 offsets) -> sorted target index
         // (all of a lane's gathers are issued before the first LDS store: one memory round trip per tile)
-        float4 stage[kTile / kWave];
+        // two fully unrolled variants (4 or 8 slots per lane): most chunks stage < 256 points, and the short
+        // variant neither searches nor loads the slots it does not have; inside a variant nothing branches,
+        // so the gathers still go out back to back
+        auto stage_tile = [&](auto per_tag) {
+          constexpr int kPer = decltype(per_tag)::value;
+          float4 stage[kPer];
 #pragma unroll
-        for (int u = 0; u < kTile / kWave; ++u) {
-          const int s = lane + u * kWave;
-          const int slot = t0 + (s < cnt ? s : 0);
-          int lo = 0;
+          for (int u = 0; u < kPer; ++u) {
+            const int s = lane + u * kWave;
+            const int slot = t0 + (s < cnt ? s : 0);
+            int lo = 0;
 #pragma unroll
-          for (int step = 32; step > 0; step >>= 1)
-            if (s_off[wave][lo + step] <= slot) lo += step;   // offsets are non-decreasing; empty rows collapse
-          stage[u] = g.pts[s_beg[wave][lo] + (slot - s_off[wave][lo])];
-        }
-#pragma unroll
-        for (int u = 0; u < kTile / kWave; ++u) {
-          const int s = lane + u * kWave;
-          if (s < cnt) {
-            s_cx[wave][s] = stage[u].x; s_cy[wave][s] = stage[u].y; s_cz[wave][s] = stage[u].z;
-            s_cw[wave][s] = __float_as_uint(stage[u].w);
+            for (int step = 32; step > 0; step >>= 1)
+              if (s_off[wave][lo + step] <= slot) lo += step;   // offsets are non-decreasing; empty rows collapse
+            stage[u] = g.pts[s_beg[wave][lo] + (slot - s_off[wave][lo])];
           }
-        }
+#pragma unroll
+          for (int u = 0; u < kPer; ++u) {
+            const int s = lane + u * kWave;
+            if (s < cnt) {
+              s_cx[wave][s] = stage[u].x; s_cy[wave][s] = stage[u].y; s_cz[wave][s] = stage[u].z;
+              s_cw[wave][s] = __float_as_uint(stage[u].w);
+            }
+          }
+        };
+        if (cnt <= kTile / 2) stage_tile(std::integral_constant<int, kTile / kWave / 2>());
+        else stage_tile(std::integral_constant<int, kTile / kWave>());
         // pad to a multiple of four with points at infinity (distance +inf never wins)
         if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) {
           s_cx[wave][cnt + lane] = INFINITY; s_cy[wave][cnt + lane] = INFINITY; s_cz[wave][cnt + lane] = INFINITY;
