@@ -462,7 +462,7 @@ __global__ void k_dt_axis(const unsigned char *__restrict__ in, int dx, int dy, 
   const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nc = (size_t)dx * dy * dz;
   if (c >= nc) return;
-  const int x = (int)(c % dx), y = (int)((c / dx) % dy), z = (int)(c / ((size_t)dx * dy));
+  const int y = (int)((c / dx) % dy), z = (int)(c / ((size_t)dx * dy));
   const int pos = axis == 1 ? y : z, lim = axis == 1 ? dy : dz;
   const size_t stride = axis == 1 ? (size_t)dx : (size_t)dx * dy;
   int best = 255;
