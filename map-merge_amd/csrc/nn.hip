@@ -34,7 +34,7 @@ constexpr int kAcc = 17;     // sum p(3) | sum q(3) | sum q p^T (9, row = q) | s
 constexpr int kTile = 512;   // staged target points per wave and tile (8 KiB of LDS)
 
 #ifdef MM3D_NN_STATS
-__device__ unsigned long long g_nn_stats[40];   // 0 waves, 1 passes, 2 row chunks, 3 staged points, 4 active lanes at pass, 5 rows, 6 max wave cycles, 7 sum wave cycles, 8.. log2 histogram of wave cycles
+__device__ unsigned long long g_nn_stats[64];   // 0 waves, 1 passes, 2 row chunks, 3 staged points, 4 active lanes at pass, 5 rows, 6 max wave cycles, 7 sum wave cycles, 8.. log2 histogram of wave cycles
 #define MM3D_STAT(i_, v_) do { if (MM3D_NN_STATS == 1 && lane == 0) atomicAdd(&g_nn_stats[i_], (unsigned long long)(v_)); } while (0)
 #define MM3D_TICK(var_) const long long var_ = wall_clock64()
 #define MM3D_TOCK(i_, from_) do { if (lane == 0) atomicAdd(&g_nn_stats[i_], (unsigned long long)(wall_clock64() - (from_))); } while (0)
@@ -136,6 +136,7 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
     if (pass == 0) MM3D_STAT(0, 1);
     // box = bounding box of the active lanes' cells, grown by the largest radius any of them needs
     const int E = wave_max_i(active ? need : 0);
+    MM3D_TICK(t_pass);
     const int lx = wave_min_i(active ? cx : 0x7fffffff), hx = wave_max_i(active ? cx : -0x7fffffff);
     const int ly = wave_min_i(active ? cy : 0x7fffffff), hy = wave_max_i(active ? cy : -0x7fffffff);
     const int lz = wave_min_i(active ? cz : 0x7fffffff), hz = wave_max_i(active ? cz : -0x7fffffff);
@@ -254,6 +255,13 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
         need = min(max(want, E + 1), max_ring + pass + 1);
       }
     }
+#ifdef MM3D_NN_STATS
+    if (lane == 0) {     // per ring size: passes, their ticks, active lanes
+      const int e = E < 7 ? E : 7;
+      atomicAdd(&g_nn_stats[40 + e], 1ull);
+      atomicAdd(&g_nn_stats[48 + e], (unsigned long long)(wall_clock64() - t_pass));
+    }
+#endif
   }
 
 #ifdef MM3D_NN_STATS
@@ -552,8 +560,8 @@ double transform_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt,
 extern "C" void mm3d_debug_nn_stats(unsigned long long *out, int reset)
 {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stats), sizeof(unsigned long long) * 40);
-  if (reset) { unsigned long long z[40] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof(z)); }
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stats), sizeof(unsigned long long) * 64);
+  if (reset) { unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof(z)); }
 }
 #endif
 

@@ -12,7 +12,7 @@ ctx = mm.Context(0)
 P = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
 maps = [ctx.mapFeatures(ctx.cloud(host[i]), P) for i in (0, 1)]
 L = mm.lib()
-out = (C.c_ulonglong * 40)()
+out = (C.c_ulonglong * 64)()
 ctx.srand(1)
 L.mm3d_debug_nn_stats(out, 1)
 r = ctx.pairEstimate(maps[0], maps[1], P)
@@ -23,4 +23,5 @@ print("waves", v[0], "passes", v[1], "row chunks", v[2], "staged", v[3], "active
 print("max wave ticks(100MHz)", v[6], "= us", v[6] / 100.0, " mean us", v[7] / max(v[0], 1) / 100.0)
 print("hist log2(ticks):", {b: v[8 + b] for b in range(24) if v[8 + b]})
 print("phase ticks: headers", v[32], "staging", v[33], "scan", v[34], " total wave ticks", v[7])
+print("per ring size E: passes", v[40:48], " ticks", v[48:56])
 print("icp iters", r["icp_iterations"])
