@@ -634,6 +634,14 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   for (size_t i = 0; i + 1 < n; ++i)
     for (size_t j = i + 1; j < n; ++j) all.emplace_back(i, j);
   std::vector<mm3d_map *> maps(n, nullptr);
+  struct MapsGuard {                                    // the maps go when the call ends, whichever way
+    std::vector<mm3d_map *> &m;
+    ~MapsGuard()
+    {
+      for (mm3d_map *x : m)
+        if (x) { delete x->points; delete x->keypoints; delete x->desc; delete x; }
+    }
+  } maps_guard{maps};
   std::vector<mm3d_pair_result> rec(all.size());
   std::vector<char> ready(n, 0), done(all.size(), 0);
   std::mutex mu;
@@ -648,17 +656,64 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   ctx->last_keypoints.assign(n, 0);
   ctx->last_features_s = ctx->last_total_s = 0.0;
 
-  auto pair_is_live = [&](size_t q) -> bool {          // false also when the run is being aborted
+  // The reference's single rand() stream, without serialising the pairs on it: the draws a pair consumes
+  // depend on its SOURCE keypoints only (pair_rand_replay), given that its target has a keypoint at all.
+  // state_at[q] = the generator before pair q; it is advanced pair by pair (once, under rng_mu) as far as
+  // a worker needs it, taking "is pair q live" from the maps that exist and ASSUMING a target that is
+  // still being computed will have keypoints.  A pair can therefore start as soon as its own two maps
+  // and the sources of the rows before it exist -- not only after the last map.  Every assumption is
+  // checked once all maps exist; a wrong one (a map without keypoints, e.g. an untextured cloud) makes
+  // the call redo the pair loop sequentially, which is the reference's loop.
+  const size_t P = all.size();
+  std::vector<GlibcRand> state_at(P + 1, rnd0);
+  std::vector<char> assumed_live(P, 0), claimed(P, 0);
+  size_t known_upto = 0;                                // state_at[0 .. known_upto] are final
+  std::mutex rng_mu;
+  auto wait_ready = [&](size_t i) {
     std::unique_lock<std::mutex> lk(mu);
-    cv.wait(lk, [&] { return abort || (ready[all[q].first] && ready[all[q].second]); });
+    cv.wait(lk, [&] { return abort || ready[i]; });
     if (abort) throw Error(MM3D_EDEVICE, "aborted");
-    return maps[all[q].first]->keypoints->n > 0 && maps[all[q].second]->keypoints->n > 0;
+  };
+  auto is_ready = [&](size_t i) { std::lock_guard<std::mutex> lk(mu); return ready[i] != 0; };
+  auto advance_states = [&](size_t p) {                 // make state_at[p] final
+    std::lock_guard<std::mutex> rl(rng_mu);
+    while (known_upto < p) {
+      const size_t q = known_upto, a = all[q].first, b = all[q].second;
+      wait_ready(a);
+      bool live = maps[a]->keypoints->n > 0;
+      if (live) {
+        if (is_ready(b)) live = maps[b]->keypoints->n > 0;
+        else assumed_live[q] = 1;
+      }
+      GlibcRand r = state_at[q];
+      if (live) pair_rand_replay(r, params->estimation_method, cloud_host(cs[0], maps[a]->keypoints), params->inlier_threshold,
+                                 params->max_iterations);
+      state_at[q + 1] = r;
+      known_upto = q + 1;
+    }
+  };
+  // the next pair to work on: the first unclaimed one, in the reference's order, whose two maps and all
+  // earlier sources exist (maps finish roughly in index order, so that is rarely a restriction)
+  auto claim_pair = [&](size_t &p) -> bool {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      if (abort) return false;
+      bool any_left = false;
+      size_t prefix = 0;
+      while (prefix < n && ready[prefix]) ++prefix;      // maps [0, prefix) exist
+      for (size_t q = 0; q < P; ++q) {
+        if (claimed[q]) continue;
+        any_left = true;
+        if (all[q].first < prefix && ready[all[q].second]) { claimed[q] = 1; p = q; return true; }
+      }
+      if (!any_left) return false;
+      cv.wait(lk);
+    }
   };
   auto worker = [&](size_t w) {
     mm3d_ctx *c = cs[w];
     try {
       if (hipSetDevice(c->device) != hipSuccess) throw Error(MM3D_EDEVICE, "hipSetDevice failed");
-      c->rnd = rnd0;
       while (w < F) {
         size_t i;
         {
@@ -683,31 +738,18 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
         }
         cv.notify_all();
       }
-      size_t pos = 0;                                   // pairs [0, pos) have had their draws replayed on c
-      auto replay_to = [&](size_t p) {
-        for (; pos < p; ++pos)
-          if (pair_is_live(pos)) {
-            mm3d_pair_result dummy;
-            pair_estimate_impl(c, maps[all[pos].first], maps[all[pos].second], params, false, &dummy);
-          }
-      };
-      for (;;) {
-        size_t p;
-        {
-          std::lock_guard<std::mutex> lk(mu);
-          if (abort || next_pair >= all.size()) break;
-          p = next_pair++;
-        }
-        replay_to(p);
-        if (pair_is_live(p)) {
-          pair_estimate_impl(c, maps[all[p].first], maps[all[p].second], params, true, &rec[p]);
+      size_t p;
+      while (claim_pair(p)) {
+        const mm3d_map *ms = maps[all[p].first], *mt = maps[all[p].second];
+        if (ms->keypoints->n > 0 && mt->keypoints->n > 0) {
+          advance_states(p);
+          c->rnd = state_at[p];
+          pair_estimate_impl(c, ms, mt, params, true, &rec[p]);
           rec[p].source_idx = all[p].first;
           rec[p].target_idx = all[p].second;
           done[p] = 1;
         }
-        pos = p + 1;
       }
-      if (w == 0) replay_to(all.size());                // the caller's generator ends where the sequential loop would
       c->sync();
     } catch (...) {
       std::lock_guard<std::mutex> lk(mu);
@@ -722,9 +764,29 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   for (auto &t : threads) t.join();
   // every stream has been synchronised by its worker (or the run was aborted): the maps can go
   for (size_t w = 0; w < S; ++w) (void)hipStreamSynchronize(cs[w]->stream);
-  for (mm3d_map *m : maps)
-    if (m) { delete m->points; delete m->keypoints; delete m->desc; delete m; }
   if (first_error) std::rethrow_exception(first_error);
+  // all maps exist now: finish the generator states and check what was assumed about late targets
+  advance_states(P);
+  bool assumptions_hold = true;
+  for (size_t q = 0; q < P; ++q)
+    if (assumed_live[q] && maps[all[q].second]->keypoints->n == 0) assumptions_hold = false;
+  if (assumptions_hold) {
+    ctx->rnd = state_at[P];                             // where the sequential loop leaves the generator
+  } else {
+    // a target turned out to have no keypoints: the states after that pair were positioned wrongly.
+    // Redo the pair loop the reference's way, on the caller's stream.
+    ctx->rnd = rnd0;
+    std::fill(done.begin(), done.end(), 0);
+    for (size_t q = 0; q < P; ++q) {
+      const mm3d_map *ms = maps[all[q].first], *mt = maps[all[q].second];
+      if (ms->keypoints->n == 0 || mt->keypoints->n == 0) continue;
+      pair_estimate_impl(ctx, ms, mt, params, true, &rec[q]);
+      rec[q].source_idx = all[q].first;
+      rec[q].target_idx = all[q].second;
+      done[q] = 1;
+    }
+    ctx->sync();
+  }
   std::vector<mm3d_pair_result> pairs;
   for (size_t p = 0; p < all.size(); ++p)
     if (done[p]) pairs.push_back(rec[p]);

@@ -231,34 +231,19 @@ size_t ransac_transform(Context *c, const mm3d_cloud *skp_, const mm3d_cloud *tk
   return inliers.size();
 }
 
-// ---------------------------------------------------------------- SAC-IA
-// R/src/matching.cpp:142-194 -> pcl::SampleConsensusInitialAlignment (nr_samples 3,
-// k_correspondences 10, TruncatedError(max_correspondence_distance)).
-bool sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_cloud *tkp_, const mm3d_desc *td,
-            double min_sample_distance_d, double max_corr_dist, int max_iterations, float T[16], bool execute,
-            DevBuf<float> *T_dev)
+// The rand() stream of one SampleConsensusInitialAlignment::computeTransformation: H iterations of
+// selectSamples (3 draws + rejections by the minimum sample distance, which halves after 3 * ns
+// failures) and findSimilarFeatures (one draw per sample).  It depends on the SOURCE keypoints only
+// (a target with at least one descriptor is assumed), which is what lets the stream scheduler of
+// mm3d_estimate_maps_transforms position the generator for a pair before that pair's target exists.
+void sac_ia_draws(GlibcRand &rnd, const std::vector<float4> &skp, int ns, float min_sample_distance, int H, int kk, int *samp,
+                  int *pick)
 {
-  std::memset(T, 0, sizeof(float) * 16);
-  T[0] = T[5] = T[10] = T[15] = 1.0f;   // final_transformation_ = guess = Identity
-  const int ns = (int)skp_->n, nt = (int)tkp_->n;
   const int nr_samples = 3, k_corr = 10;
-  if (ns < nr_samples || nt < 1) return false;
-  MM3D_REQUIRE(sd->n == (size_t)ns && td->n == (size_t)nt, "SAC-IA: keypoints and descriptors differ in size");
-  float min_sample_distance = (float)min_sample_distance_d;
-  const float corr_thresh = (float)max_corr_dist;
-  const std::vector<float4> &skp = cloud_host(c, skp_);
-  auto get_random_index = [&](int n) { return (int)(n * (c->rnd.next() / (2147483647 + 1.0))); };
-
-  const int kk = std::min(k_corr, nt);
-  const int H = max_iterations > 0 ? max_iterations : 0;
-  // The host only replays the sample stream: the rand() draws and the distance tests on source
-  // keypoints.  Nothing in that stream depends on the descriptor search (findSimilarFeatures draws
-  // one rand() per sample whatever the neighbours are), so the whole stream is replayed FIRST, the
-  // k-NN is then computed for the sampled rows only (<= 3 * 500 of ~16k), and the device looks the
-  // replayed picks up in its own table and builds the 500 three-point Umeyama models.
-  std::vector<int> samp((size_t)H * 3), pick((size_t)H * 3);
+  auto get_random_index = [&](int n) { return (int)(n * (rnd.next() / (2147483647 + 1.0))); };
+  int scratch[3];
   for (int it = 0; it < H; ++it) {
-    int *sample = &samp[(size_t)it * 3];
+    int *sample = samp ? &samp[(size_t)it * 3] : scratch;
     // selectSamples
     {
       int cnt = 0, without = 0;
@@ -281,9 +266,45 @@ bool sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
     for (int i = 0; i < nr_samples; ++i) {
       int rc = get_random_index(k_corr);
       if (rc >= kk) rc = kk - 1;     // the reference indexes past the resized result when nt < 10 (UB)
-      pick[(size_t)it * 3 + i] = rc;
+      if (pick) pick[(size_t)it * 3 + i] = rc;
     }
   }
+}
+
+// the draws estimate_pair(method, source, non-empty target) consumes, without touching the device or the target
+void pair_rand_replay(GlibcRand &rnd, int method, const std::vector<float4> &skp_host, double inlier_threshold, int max_iterations)
+{
+  if (method != MM3D_EST_SAC_IA) return;            // RANSAC seeds its own mt19937 per call
+  const int ns = (int)skp_host.size();
+  if (ns < 3) return;
+  sac_ia_draws(rnd, skp_host, ns, (float)inlier_threshold, max_iterations > 0 ? max_iterations : 0, 10, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------- SAC-IA
+// R/src/matching.cpp:142-194 -> pcl::SampleConsensusInitialAlignment (nr_samples 3,
+// k_correspondences 10, TruncatedError(max_correspondence_distance)).
+bool sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_cloud *tkp_, const mm3d_desc *td,
+            double min_sample_distance_d, double max_corr_dist, int max_iterations, float T[16], bool execute,
+            DevBuf<float> *T_dev)
+{
+  std::memset(T, 0, sizeof(float) * 16);
+  T[0] = T[5] = T[10] = T[15] = 1.0f;   // final_transformation_ = guess = Identity
+  const int ns = (int)skp_->n, nt = (int)tkp_->n;
+  const int nr_samples = 3, k_corr = 10;
+  if (ns < nr_samples || nt < 1) return false;
+  MM3D_REQUIRE(sd->n == (size_t)ns && td->n == (size_t)nt, "SAC-IA: keypoints and descriptors differ in size");
+  float min_sample_distance = (float)min_sample_distance_d;
+  const float corr_thresh = (float)max_corr_dist;
+  const std::vector<float4> &skp = cloud_host(c, skp_);
+  const int kk = std::min(k_corr, nt);
+  const int H = max_iterations > 0 ? max_iterations : 0;
+  // The host only replays the sample stream: the rand() draws and the distance tests on source
+  // keypoints.  Nothing in that stream depends on the descriptor search (findSimilarFeatures draws
+  // one rand() per sample whatever the neighbours are), so the whole stream is replayed FIRST, the
+  // k-NN is then computed for the sampled rows only (<= 3 * 500 of ~16k), and the device looks the
+  // replayed picks up in its own table and builds the 500 three-point Umeyama models.
+  std::vector<int> samp((size_t)H * 3), pick((size_t)H * 3);
+  sac_ia_draws(c->rnd, skp, ns, min_sample_distance, H, kk, samp.data(), pick.data());
   if (!execute || H == 0) return false;
   // distinct sampled rows -> position in the subset table
   std::vector<int> rows, row_pos((size_t)ns, -1), corr_ref((size_t)H * 3);

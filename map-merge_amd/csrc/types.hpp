@@ -214,6 +214,10 @@ size_t ransac_transform(Context *c, const mm3d_cloud *skp, const mm3d_cloud *tkp
 bool sac_ia(Context *c, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tkp, const mm3d_desc *td,
             double min_sample_distance, double max_corr_dist, int max_iterations, float T[16], bool execute,
             DevBuf<float> *T_dev = nullptr);
+void sac_ia_draws(GlibcRand &rnd, const std::vector<float4> &skp, int ns, float min_sample_distance, int H, int kk, int *samp,
+                  int *pick);
+// advances rnd by the rand() draws one estimateTransform(source -> any non-empty target) consumes (host only)
+void pair_rand_replay(GlibcRand &rnd, int method, const std::vector<float4> &skp_host, double inlier_threshold, int max_iterations);
 // estimateTransform + (optionally) transformScore of the result; returns the ICP iteration count
 int estimate_pair(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tp,
                   const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine, double inlier_threshold,

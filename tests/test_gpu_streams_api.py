@@ -60,3 +60,32 @@ def test_streams_with_degenerate_maps(mm, clouds):
         assert len(pairs) == 1
     finally:
         c.close()
+
+
+def test_late_map_without_keypoints(mm, clouds):
+    """The scheduler positions the rand() stream for a pair before the targets of earlier pairs exist, assuming they will
+    have keypoints.  A big untextured cloud (slow to process, no SIFT keypoint) in the middle of the list breaks that
+    assumption for whoever got ahead of it; the call must then still return the sequential loop's result, and leave
+    the generator where that loop leaves it."""
+    rng = np.random.default_rng(7)
+    flat = np.zeros(400000, dtype=mm.POINT)
+    flat["x"], flat["y"] = rng.uniform(0, 40, 400000), rng.uniform(0, 40, 400000)
+    flat["rgba"] = 0xFF808080
+    order = [clouds[0], flat, clouds[1], clouds[2], clouds[3]]
+    params = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
+    results = []
+    for n_streams in (1, 8, 8, 8):
+        c = mm.Context(0)
+        try:
+            c.setStreams(n_streams)
+            c.srand(1)
+            T, pairs = c.estimateMapsTransforms(order, params, return_pairs=True)
+            T2, pairs2 = c.estimateMapsTransforms(clouds[:2], params, return_pairs=True)
+            results.append((np.stack(T), pairs.copy(), pairs2.copy()))
+        finally:
+            c.close()
+    assert len(results[0][1]) == 6 and not (results[0][1]["source_idx"] == 1).any() and not (results[0][1]["target_idx"] == 1).any()
+    for T, pairs, pairs2 in results[1:]:
+        assert np.array_equal(T.view(np.uint32), results[0][0].view(np.uint32))
+        assert np.array_equal(pairs.view(np.uint8), results[0][1].view(np.uint8))
+        assert np.array_equal(pairs2.view(np.uint8), results[0][2].view(np.uint8))
