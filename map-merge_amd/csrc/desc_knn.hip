@@ -19,7 +19,7 @@
 //      no FMA) -- the ONLY distances that leave this file -- and certified: the k-th exact distance
 //      must clear the smallest "worst kept approximate distance" of any full list by more than the
 //      expansion's rounding bound.  Rows that fail go through the exact brute-force kernels
-//      (k_knn_exact_part / k_knn_merge_parts).  The result is therefore the exact k-NN with ties to
+//      (k_knn_exact_range; wide rows: k_knn_exact_wide / k_knn_merge_parts).  The result is therefore the exact k-NN with ties to
 //      the lower index, bit-identical to the CPU path.
 #include "device_util.hpp"
 
@@ -98,92 +98,9 @@ k_knn_exact(const float *__restrict__ A, int na, const float *__restrict__ B, in
     }
 }
 
-// Exact k-NN for the rows that miss the certificate.  Brute force is the honest answer for them (the
-// usual cause is hundreds of near-identical targets, e.g. PFH rows of flat ground), so it has to
-// scale: a block owns 16 rows x one interleaved part of the target tiles.  The part's 64-target tiles
-// are staged through LDS ONCE for all 16 rows (16 threads per row take 4 targets each), every thread
-// keeps a sorted top-16 in registers, the 16 partial lists of a row are merged through LDS, and
-// k_knn_merge_parts merges the parts.  Keys are (distance bits, index): ties go to the lower index.
-constexpr int kFbRows = 16;
+// per-part key lists of the wide brute-force kernel (k_knn_exact_wide), merged by k_knn_merge_parts
 constexpr int kFbParts = 16;
 constexpr unsigned long long kEmptyKey = 0x7f8000007fffffffull;   // (+inf, no index)
-
-template <int kD>
-__global__ void __launch_bounds__(256)
-k_knn_exact_part(const float *__restrict__ A, const float *__restrict__ B, int nb, int k, const int *__restrict__ rows,
-                 const int *__restrict__ nrows_dev, unsigned long long *__restrict__ part_keys /* [row slot][part][kMaxK] */)
-{
-  __shared__ float tile[64][kD];                                    // odd row stride: conflict free
-  __shared__ unsigned long long s_keys[kFbRows][16][kMaxK];
-  const int nrows = *nrows_dev;
-  const int part = blockIdx.y;
-  const int t = threadIdx.x, r = t & (kFbRows - 1), ts = t >> 4;
-  const int ntiles = (nb + 63) / 64;
-  for (int g = blockIdx.x; g * kFbRows < nrows; g += gridDim.x) {   // uniform per block
-    const int slot = g * kFbRows + r;
-    const bool live = slot < nrows;
-    const int row = rows[live ? slot : g * kFbRows];
-    float a[kD];
-#pragma unroll
-    for (int d = 0; d < kD; ++d) a[d] = A[(size_t)row * kD + d];
-    float bd[kMaxK];
-    int bi[kMaxK];
-#pragma unroll
-    for (int s = 0; s < kMaxK; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
-    for (int tl = part; tl < ntiles; tl += kFbParts) {
-      const int j0 = tl * 64, tn = min(64, nb - j0);
-      __syncthreads();
-      for (int e = t; e < tn * kD; e += 256) (&tile[0][0])[e] = B[(size_t)j0 * kD + e];
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int jj = ts + 16 * u;
-        if (jj < tn) {
-          float rr = 0.0f;
-#pragma unroll
-          for (int d = 0; d < kD; ++d) {
-            const float df = a[d] - tile[jj][d];
-            rr = __fadd_rn(rr, __fmul_rn(df, df));
-          }
-          if (rr < bd[kMaxK - 1]) {     // a thread sees its targets in ascending index order: strict < keeps the lower index
-            float cd = rr;
-            int ci = j0 + jj;
-            bool carrying = false;
-#pragma unroll
-            for (int s = 0; s < kMaxK; ++s) {
-              const bool sw = carrying || cd < bd[s];
-              carrying = sw;
-              const float td = bd[s];
-              const int ti = bi[s];
-              bd[s] = sw ? cd : td; bi[s] = sw ? ci : ti;
-              cd = sw ? td : cd; ci = sw ? ti : ci;
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < kMaxK; ++s) s_keys[r][ts][s] = ((unsigned long long)__float_as_uint(bd[s]) << 32) | (unsigned)bi[s];
-    __syncthreads();
-    // one thread per row: k rounds of "smallest key above the previous winner" over the 16 lists
-    if (t < kFbRows && g * kFbRows + t < nrows) {
-      unsigned long long prev = 0ull;
-      bool first = true;
-      for (int o = 0; o < k; ++o) {
-        unsigned long long best = kEmptyKey;
-        for (int l = 0; l < 16; ++l)
-          for (int s = 0; s < k; ++s) {
-            const unsigned long long key = s_keys[t][l][s];
-            if ((first || key > prev) && key < best) best = key;
-          }
-        part_keys[((size_t)(g * kFbRows + t) * kFbParts + part) * kMaxK + o] = best;
-        prev = best;
-        first = false;
-      }
-    }
-    __syncthreads();
-  }
-}
 
 __global__ void k_knn_iota(int *__restrict__ rows, int n, int *__restrict__ count)
 {
@@ -442,6 +359,104 @@ k_knn_rerank(const float *__restrict__ A, int na, const float *__restrict__ B, i
   const float eps = (2e-5f * (na2 + rho * rho) + 1e-5f * kth) * ((float)knn_kp(kD) / 36.0f);
   const bool certified = !(tau < INFINITY) || (kth < tau - eps);
   if (!certified && lane == 0) fb_rows[atomicAdd(fb_count, 1)] = a;
+}
+
+// ---------------------------------------------------------------- exact fallback on a norm range
+// |a - b| >= | |a| - |b| |: a target can only be among the k nearest of a if its norm lies within sqrt(U) of
+// |a|, U = the k-th exact distance the re-rank already found (an upper bound of the true k-th distance).
+// The target set keeps its norms sorted (knn_norm_order), so the candidates of a row are ONE contiguous
+// range of that order: for rows that fail the certificate because hundreds of near-identical targets
+// crowd their lists (PFH rows of flat ground) the range is those near-duplicates, not all targets.
+// Norms are float fmaf chains (relative error <= (D + 2) 2^-24); the range is widened by 1e-4 (|a| + reach).
+template <int kD>
+__global__ void k_knn_norms(const float *__restrict__ X, int n, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.0f;
+  for (int d = 0; d < kD; ++d) { const float v = X[(size_t)i * kD + d]; s = fmaf(v, v, s); }
+  keys[i] = __float_as_uint(sqrtf(s));      // >= 0 (or NaN: sorts last, never in a range): the bits order like the value
+  vals[i] = (uint32_t)i;
+}
+
+template <int kD>
+__global__ void __launch_bounds__(256)
+k_knn_exact_range(const float *__restrict__ A, const float *__restrict__ B, int nb, int k, const int *__restrict__ rows,
+                  const int *__restrict__ nrows_dev, const uint32_t *__restrict__ nsort, const uint32_t *__restrict__ nperm,
+                  int *__restrict__ idx, float *__restrict__ d2out)
+{
+  const int nrows = *nrows_dev;
+  const int lane = threadIdx.x & 63;
+  const int wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+  for (int slot = wave0; slot < nrows; slot += nwaves) {          // wave-uniform
+    const int row = rows[slot];
+    float x[kD];
+    float s = 0.0f;
+#pragma unroll
+    for (int d = 0; d < kD; ++d) { x[d] = A[(size_t)row * kD + d]; s = fmaf(x[d], x[d], s); }
+    const float na = sqrtf(s);
+    const float U = d2out[(size_t)row * k + k - 1];
+    int lo = 0, hi = nb;
+    if (U < INFINITY && na == na) {
+      const float reach = sqrtf(U);
+      const float slack = 1e-4f * (na + reach) + 1e-6f;
+      const float lo_v = na - reach - slack, hi_v = na + reach + slack;
+      // first index with norm >= lo_v / first index with norm > hi_v (NaN norms sit at the end and compare false)
+      int a = 0, b = nb;
+      while (a < b) { const int m = (a + b) >> 1; if (__uint_as_float(nsort[m]) >= lo_v) b = m; else a = m + 1; }
+      lo = a;
+      a = lo; b = nb;
+      while (a < b) { const int m = (a + b) >> 1; if (__uint_as_float(nsort[m]) > hi_v) b = m; else a = m + 1; }
+      hi = a;
+    }
+    float bd[kMaxK];
+    int bi[kMaxK];
+#pragma unroll
+    for (int t = 0; t < kMaxK; ++t) { bd[t] = INFINITY; bi[t] = 0x7fffffff; }
+    for (int t = lo + lane; t < hi; t += kWave) {
+      const int j = (int)nperm[t];
+      const float *bp = B + (size_t)j * kD;
+      float r = 0.0f;
+#pragma unroll
+      for (int d = 0; d < kD; ++d) {
+        const float df = x[d] - bp[d];
+        r = __fadd_rn(r, __fmul_rn(df, df));
+      }
+      if (r < bd[kMaxK - 1] || (r == bd[kMaxK - 1] && j < bi[kMaxK - 1])) {
+        float cd = r;
+        int ci = j;
+        bool carrying = false;
+#pragma unroll
+        for (int t2 = 0; t2 < kMaxK; ++t2) {
+          const bool sw = carrying || cd < bd[t2] || (cd == bd[t2] && ci < bi[t2]);
+          carrying = sw;
+          const float td = bd[t2];
+          const int ti = bi[t2];
+          bd[t2] = sw ? cd : td; bi[t2] = sw ? ci : ti;
+          cd = sw ? td : cd; ci = sw ? ti : ci;
+        }
+      }
+    }
+    for (int o = 0; o < k; ++o) {
+      const unsigned long long key = ((unsigned long long)__float_as_uint(bd[0]) << 32) | (unsigned)bi[0];
+      unsigned long long best = key;
+#pragma unroll
+      for (int sft = 32; sft > 0; sft >>= 1) {
+        const unsigned long long other = __shfl_xor(best, sft, kWave);
+        best = other < best ? other : best;
+      }
+      const float d = __uint_as_float((unsigned)(best >> 32));
+      if (lane == 0) {
+        idx[(size_t)row * k + o] = d < INFINITY ? (int)(unsigned)(best & 0xffffffffull) : -1;
+        d2out[(size_t)row * k + o] = d;
+      }
+      if (key == best && bd[0] < INFINITY) {
+#pragma unroll
+        for (int t = 0; t + 1 < kMaxK; ++t) { bd[t] = bd[t + 1]; bi[t] = bi[t + 1]; }
+        bd[kMaxK - 1] = INFINITY; bi[kMaxK - 1] = 0x7fffffff;
+      }
+    }
+  }
 }
 
 // ================================================================ wide rows (SHOT1344)
@@ -734,7 +749,7 @@ k_knn_rerank_wide(const float *__restrict__ A, int na, const float *__restrict__
 // kWideFbRows rows staged in LDS and one interleaved part of the target tiles; a lane takes one
 // target per tile and runs the full chains for all the rows (each target float is loaded once per
 // kWideFbRows rows), keeping a sorted top-16 per row in registers.  Output: the same per-part key
-// lists as k_knn_exact_part, merged by k_knn_merge_parts.
+// lists that k_knn_merge_parts merges.
 constexpr int kWideFbRows = 4;
 
 template <int kD>
@@ -848,13 +863,27 @@ static void knn_target_operands(Context *c, const mm3d_desc *B, DevBuf<float> &c
               (const float *)B->data.get(), nb, nb_tiles, 1, (const float *)colsum.get(), 1.0f / (float)nb, Bp.get());
 }
 
+// the target rows' norms, sorted, with their row indices (k_knn_exact_range)
+template <int kD>
+static void knn_norm_order(Context *c, const mm3d_desc *B, DevBuf<uint32_t> &nsort, DevBuf<uint32_t> &nperm)
+{
+  const int nb = (int)B->n;
+  DevBuf<uint32_t> keys(c, nb), vals(c, nb);
+  nsort = DevBuf<uint32_t>(c, nb);
+  nperm = DevBuf<uint32_t>(c, nb);
+  MM3D_LAUNCH(c, "desc_knn_prep", nb * kD * 4.0, (k_knn_norms<kD>), dim3(div_up(nb, 256)), dim3(256), 0, (const float *)B->data.get(), nb,
+              keys.get(), vals.get());
+  sort_pairs_u32(c, keys.get(), nsort.get(), vals.get(), nperm.get(), (size_t)nb, 32);
+  c->sync();                                   // keys / vals go out of scope
+}
+
 void desc_knn_prepare_target(Context *c, const mm3d_desc *B_)
 {
   auto *B = const_cast<mm3d_desc *>(B_);
   if (B->n < 64 || B->knn_Bp.get()) return;
-  if (B->dim == 33) knn_target_operands<33>(c, B, B->knn_colsum, B->knn_Bp);
-  else if (B->dim == 2) knn_target_operands<2>(c, B, B->knn_colsum, B->knn_Bp);
-  else if (B->dim == 125) knn_target_operands<125>(c, B, B->knn_colsum, B->knn_Bp);
+  if (B->dim == 33) { knn_target_operands<33>(c, B, B->knn_colsum, B->knn_Bp); knn_norm_order<33>(c, B, B->knn_nsort, B->knn_nperm); }
+  else if (B->dim == 2) { knn_target_operands<2>(c, B, B->knn_colsum, B->knn_Bp); knn_norm_order<2>(c, B, B->knn_nsort, B->knn_nperm); }
+  else if (B->dim == 125) { knn_target_operands<125>(c, B, B->knn_colsum, B->knn_Bp); knn_norm_order<125>(c, B, B->knn_nsort, B->knn_nperm); }
   else if (B->dim == 250) knn_target_operands<250>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 1344) knn_target_operands<1344>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 1980) knn_target_operands<1980>(c, B, B->knn_colsum, B->knn_Bp);
@@ -903,15 +932,18 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
   MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * (kD * 4 + 8) + kD * 4), (k_knn_rerank<kD>), dim3(div_up(na, 4)), dim3(256), 0,
               Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
               idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
-  // rows without a certificate: exact brute force (the grid is sized for the worst case; blocks
-  // beyond the device-side count exit at once)
-  DevBuf<unsigned long long> part_keys(c, (size_t)na * kFbParts * kMaxK);
-  const int fb_groups = div_up(na, kFbRows);
-  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, (k_knn_exact_part<kD>), dim3(fb_groups < 16 ? fb_groups : 16, kFbParts), dim3(256), 0, Ad, Bd,
-              nb, k, (const int *)fb_rows.get(), (const int *)(meta.get() + 1), part_keys.get());
-  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, k_knn_merge_parts, dim3(div_up(na, 64)), dim3(64), 0,
-              (const unsigned long long *)part_keys.get(), k, (const int *)fb_rows.get(), (const int *)(meta.get() + 1), idx.get(),
-              d2.get());
+  // rows without a certificate: exact search over the targets whose norm is within the row's current k-th
+  // distance of its own (the grid is sized for the worst case; waves beyond the device-side count exit at once)
+  DevBuf<uint32_t> nsort_tmp, nperm_tmp;
+  const uint32_t *nsort = B->knn_nsort.get(), *nperm = B->knn_nperm.get();
+  if (!nsort || !nperm) {
+    knn_norm_order<kD>(c, B, nsort_tmp, nperm_tmp);
+    nsort = nsort_tmp.get();
+    nperm = nperm_tmp.get();
+  }
+  const int fb_blocks = div_up(na, 4) < 1024 ? div_up(na, 4) : 1024;
+  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, (k_knn_exact_range<kD>), dim3(fb_blocks), dim3(256), 0, Ad, Bd, nb, k,
+              (const int *)fb_rows.get(), (const int *)(meta.get() + 1), nsort, nperm, idx.get(), d2.get());
   if (c->debug) {
     unsigned *h = (unsigned *)c->pin(64);
     MM3D_HIP(hipMemcpyAsync(h, meta.get(), 16, hipMemcpyDeviceToHost, c->stream));

@@ -97,6 +97,9 @@ struct mm3d_desc {
   // they depend on this set alone, so a map that is the target of 15 pairs prepares them once
   // (desc_knn_prepare_target, called from mm3d_map_prepare)
   mm3d::DevBuf<float> knn_colsum, knn_Bp;
+  // the rows' Euclidean norms in ascending order and the row index of each (the exact fallback of the k-NN only
+  // visits targets whose norm is within the current k-th distance of the query's: | |a| - |b| | <= |a - b|)
+  mm3d::DevBuf<uint32_t> knn_nsort, knn_nperm;
   // SHOT only: the local reference frames (x, y, z axes, 9 floats per row) -- the "rf" field of
   // pcl::SHOT1344; not part of the point representation that matching reads
   mm3d::DevBuf<float> rf;
