@@ -593,8 +593,7 @@ __device__ __forceinline__ float knn_wide_dist(const float *__restrict__ x /* LD
       df = xv.z - bv.z; r = __fadd_rn(r, __fmul_rn(df, df));
       df = xv.w - bv.w; r = __fadd_rn(r, __fmul_rn(df, df));
     }
-  } else {
-    static_assert(kD % 2 == 0, "rows are read as float2");
+  } else if constexpr (kD % 2 == 0) {
     const float2 *b2 = (const float2 *)b;
     const float2 *x2 = (const float2 *)x;
 #pragma unroll 4
@@ -602,6 +601,12 @@ __device__ __forceinline__ float knn_wide_dist(const float *__restrict__ x /* LD
       const float2 bv = b2[d], xv = x2[d];
       float df = xv.x - bv.x; r = __fadd_rn(r, __fmul_rn(df, df));
       df = xv.y - bv.y; r = __fadd_rn(r, __fmul_rn(df, df));
+    }
+  } else {
+#pragma unroll 5
+    for (int d = 0; d < kD; ++d) {
+      const float df = x[d] - b[d];
+      r = __fadd_rn(r, __fmul_rn(df, df));
     }
   }
   return r;
@@ -929,9 +934,16 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
   MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, (k_knn_mfma<kD>), dim3(na_tiles, parts),
               dim3(256), 0, (const float *)Ap.get(), na, Bp, nb, nb_tiles, cand_d.get(), cand_i.get());
   DevBuf<int> fb_rows(c, na);
-  MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * (kD * 4 + 8) + kD * 4), (k_knn_rerank<kD>), dim3(div_up(na, 4)), dim3(256), 0,
-              Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
-              idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
+  // short rows (RSD, FPFH): every candidate is re-ranked, a 33-term chain is cheaper than choosing; long rows (PFH):
+  // the pruned re-rank of the wide path (k best approximate candidates first, then only what can still matter)
+  if constexpr (kD >= 64)
+    MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * 8 + 32 * kD * 4), (k_knn_rerank_wide<kD>), dim3(div_up(na, 4)), dim3(256), 0,
+                Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
+                idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
+  else
+    MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * (kD * 4 + 8) + kD * 4), (k_knn_rerank<kD>), dim3(div_up(na, 4)), dim3(256), 0,
+                Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
+                idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
   // rows without a certificate: exact search over the targets whose norm is within the row's current k-th
   // distance of its own (the grid is sized for the worst case; waves beyond the device-side count exit at once)
   DevBuf<uint32_t> nsort_tmp, nperm_tmp;
