@@ -89,3 +89,23 @@ def test_late_map_without_keypoints(mm, clouds):
         assert np.array_equal(T.view(np.uint32), results[0][0].view(np.uint32))
         assert np.array_equal(pairs.view(np.uint8), results[0][1].view(np.uint8))
         assert np.array_equal(pairs2.view(np.uint8), results[0][2].view(np.uint8))
+
+
+@pytest.mark.parametrize("kp_type,thr,desc,method", [(0, 5.0, 0, 0), (0, 5.0, 1, 1), (0, 5.0, 3, 1), (0, 5.0, 4, 1), (0, 5.0, 4, 0),
+                                                     (0, 5.0, 5, 1), (1, 0.0005, 2, 1)])
+def test_every_feature_type_under_the_stream_scheduler(mm, clouds, kp_type, thr, desc, method):
+    """Keypoint / descriptor / method combinations through the multi-stream entry point: same bits as one stream."""
+    params = mm.MapMergingParams(keypoint_type=kp_type, keypoint_threshold=thr, descriptor_type=desc, estimation_method=method)
+    out = []
+    for n_streams in (1, 6):
+        c = mm.Context(0)
+        try:
+            c.setStreams(n_streams)
+            c.srand(1)
+            T, pairs = c.estimateMapsTransforms(clouds[:4], params, return_pairs=True)
+            out.append((np.stack(T), pairs.copy()))
+        finally:
+            c.close()
+    assert len(out[0][1]) == 6
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1].view(np.uint8), out[1][1].view(np.uint8))
