@@ -92,6 +92,42 @@ __device__ __forceinline__ void for_each_candidate(const GridView &g, float qx, 
     }
 }
 
+// "v = 0; repeat hits times: v += incr" in float, bit for bit, without walking the whole chain.  Inside one
+// binade of v every addition but possibly the first moves v by the same multiple of its ulp (round-to-nearest
+// of v + incr = v + q ulp + r: r </> ulp/2 always rounds the same way, and a tie r = ulp/2 alternates at most
+// once before the parity of v / ulp settles).  So after two equal consecutive steps inside one binade the
+// remaining steps of that binade are taken at once (exactly: everything is a small multiple of the ulp, done
+// in double), and only the few additions around each power of two are really executed.
+__device__ __forceinline__ float float_chain_sum(float incr, unsigned hits)
+{
+  float v = 0.0f;
+  unsigned h = hits;
+  if (!(incr > 0.0f) || !(incr < INFINITY)) {           // not a regular chain: just run it
+    for (; h > 0; --h) v += incr;
+    return v;
+  }
+  while (h > 0) {
+    if (h < 8) { v += incr; --h; continue; }
+    const float v1 = v + incr, v2 = v1 + incr, v3 = v2 + incr;
+    h -= 3;
+    v = v3;
+    const unsigned e1 = __float_as_uint(v1) >> 23, e3 = __float_as_uint(v3) >> 23;
+    const float s = v3 - v2;
+    if (s == 0.0f && v2 == v1) return v3;                // incr has fallen below half an ulp of v: the sum has saturated
+    if (e1 != e3 || (v2 - v1) != s || !(s > 0.0f)) continue;
+    // v1, v2, v3 share a binade and two equal steps s: all further steps below the next power of two equal s
+    const float top = __uint_as_float((e3 + 1u) << 23);
+    const double room = ((double)top - (double)v3) / (double)s;
+    if (room > 2.0) {
+      double n = floor(room) - 1.0;                      // stay strictly inside the binade
+      if (n > (double)h) n = (double)h;
+      v = (float)((double)v3 + n * (double)s);
+      h -= (unsigned)n;
+    }
+  }
+  return v;
+}
+
 // ---- wave / block reductions -------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v)
 {

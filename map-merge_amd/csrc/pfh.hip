@@ -187,9 +187,7 @@ k_pfh(const float4 *__restrict__ kp, int nk, GridView g, const float4 *__restric
       const unsigned long long pairs = (unsigned long long)m * (unsigned long long)(m - 1) / 2ull;
       const float hist_incr = 100.0f / (float)pairs;
       const unsigned hits = s_hist[tid];
-      float v = 0.0f;
-      for (unsigned i = 0; i < hits; ++i) v += hist_incr;
-      out[tid] = v;
+      out[tid] = float_chain_sum(hist_incr, hits);
     }
     if (tid == 0) valid[k] = 1;
     return;
@@ -224,9 +222,7 @@ k_pfh(const float4 *__restrict__ kp, int nk, GridView g, const float4 *__restric
     const unsigned long long pairs = (unsigned long long)m * (unsigned long long)(m - 1) / 2ull;
     const float hist_incr = 100.0f / (float)pairs;
     const unsigned hits = s_hist[tid];
-    float v = 0.0f;
-    for (unsigned i = 0; i < hits; ++i) v += hist_incr;
-    out[tid] = v;
+    out[tid] = float_chain_sum(hist_incr, hits);
   }
   if (tid == 0) valid[k] = 1;
 }
