@@ -102,6 +102,9 @@ int mm3d_last_icp_converged(const mm3d_ctx *ctx);
 void mm3d_set_debug(mm3d_ctx *ctx, int on);
 long long mm3d_debug_knn_fallback_rows(mm3d_ctx *ctx);
 long long mm3d_debug_knn_rows(mm3d_ctx *ctx);
+/* test hook: out[i] = the float sum "0 + incr[i] + incr[i] + ..." (hits[i] additions) as the PFH kernels
+ * replay it for a histogram bin (PFHEstimation: "histogram[h] += hist_incr" once per pair) */
+int mm3d_debug_float_chain(mm3d_ctx *ctx, const float *incr, const unsigned *hits, int n, float *out);
 /* SAC-IA draws from libc rand() in the reference (process-global, glibc seed 1).  The context
  * carries its own replay of that generator; mm3d_srand re-seeds it (srand semantics). */
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed);

@@ -243,6 +243,11 @@ void mm3d_set_debug(mm3d_ctx *ctx, int on)
 }
 long long mm3d_debug_knn_fallback_rows(mm3d_ctx *ctx) { return ctx ? ctx->knn_fallback_rows : 0; }
 long long mm3d_debug_knn_rows(mm3d_ctx *ctx) { return ctx ? ctx->knn_rows : 0; }
+int mm3d_debug_float_chain(mm3d_ctx *ctx, const float *incr, const unsigned *hits, int n, float *out)
+{
+  if (n < 0 || (n && (!incr || !hits || !out))) return MM3D_EINVAL;
+  return guarded(ctx, [&] { debug_float_chain(ctx, incr, hits, n, out); });
+}
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed) { if (ctx) ctx->rnd.seed(seed); }
 int mm3d_synchronize(mm3d_ctx *ctx) { return guarded(ctx, [&] { ctx->sync(); }); }
 

@@ -311,6 +311,26 @@ static mm3d_desc *compute_pfh_impl(Context *c, const mm3d_cloud *points, const m
   return res;
 }
 
+// test hook for float_chain_sum (device_util.hpp): out[i] = the float chain 0 + incr[i] + ... (hits[i] times)
+__global__ void k_float_chain(const float *__restrict__ incr, const unsigned *__restrict__ hits, int n, float *__restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = float_chain_sum(incr[i], hits[i]);
+}
+
+void debug_float_chain(Context *c, const float *incr_host, const unsigned *hits_host, int n, float *out_host)
+{
+  if (n <= 0) return;
+  DevBuf<float> di(c, n), dout(c, n);
+  DevBuf<unsigned> dh(c, n);
+  MM3D_HIP(hipMemcpyAsync(di.get(), incr_host, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  MM3D_HIP(hipMemcpyAsync(dh.get(), hits_host, n * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+  MM3D_LAUNCH(c, "debug", n * 12.0, k_float_chain, dim3(div_up(n, 64)), dim3(64), 0, (const float *)di.get(), (const unsigned *)dh.get(), n,
+              dout.get());
+  MM3D_HIP(hipMemcpyAsync(out_host, dout.get(), n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+}
+
 mm3d_desc *compute_pfh(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, mm3d_cloud *keypoints, double radius)
 {
   return compute_pfh_impl<false>(c, points, normals, keypoints, radius);

@@ -760,3 +760,26 @@ def test_sc3d(ctx, po, mm, scene):
     ctx.srand(1)
     T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
     assert len(pairs) == 1 and np.isfinite(pairs[0]["transform"]).all()
+
+
+def test_float_chain_replay_is_exact(ctx, mm):
+    """PFH bins are counted in integers and the float chain "0 + incr + incr + ..." is replayed once per bin, binade by
+    binade (device_util.hpp::float_chain_sum); the skip must give the bits of the plain loop."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    pairs = rng.integers(1, 60000, 1500)
+    incr = (np.float32(100.0) / pairs.astype(np.float32)).astype(np.float32)
+    hits = (rng.random(1500) * pairs).astype(np.uint32)
+    extra_i = np.array([1.5, 0.75, 3.0, 0.1, 1.0, 2.5, 1e-3, 7.0, 0.3333333, 1e-8, 0.0, 5e-3], np.float32)
+    extra_h = np.array([70000, 65536, 9, 100000, 1 << 20, 12345, 200000, 8, 7, 300000, 50, 16777216 // 64], np.uint32)
+    incr, hits = np.concatenate([incr, extra_i]), np.concatenate([hits, extra_h])
+    out = np.empty(len(incr), np.float32)
+    ctx._ck(mm.lib().mm3d_debug_float_chain(ctx._h, incr.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p), len(incr),
+                                            out.ctypes.data_as(C.c_void_p)))
+    ref = np.zeros(len(incr), np.float32)
+    left = hits.astype(np.int64).copy()
+    while (left > 0).any():                      # the plain loop, vectorised over the cases
+        m = left > 0
+        ref[m] = (ref[m] + incr[m]).astype(np.float32)
+        left[m] -= 1
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
