@@ -233,9 +233,8 @@ def main():
                 if p is None:
                     break
                 # pairs this stream does not execute only have their rand() draws replayed
-                # (mm3d_pair_estimate, execute = 0: ~30 us of host work, no device work)
-                for q in range(pos, p):
-                    c.pairEstimate(maps[live[q][0]], maps[live[q][1]], params, execute=False)
+                # (mm3d_pairs_skip: ~30 us of host work per pair in ONE call, no device work)
+                c.pairsSkip([maps[live[q][0]] for q in range(pos, p)], [maps[live[q][1]] for q in range(pos, p)], params)
                 mine[p] = c.pairEstimate(maps[live[p][0]], maps[live[p][1]], params, execute=True)
                 pos = p + 1
             c.synchronize()

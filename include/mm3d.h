@@ -250,6 +250,11 @@ void mm3d_map_free(mm3d_ctx *ctx, mm3d_map *m);
  * the reference's single global stream). */
 int mm3d_pair_estimate(mm3d_ctx *ctx, const mm3d_map *source, const mm3d_map *target,
                        const mm3d_params *params, int execute, mm3d_pair_result *out);
+/* The rand() draws of n consecutive pairs of that loop that this context does NOT execute (what
+ * mm3d_pair_estimate(execute = 0) does for one pair, in one call and without touching the device): keeps the
+ * context's generator where the reference's sequential loop would have it. */
+int mm3d_pairs_skip(mm3d_ctx *ctx, const mm3d_map *const *sources, const mm3d_map *const *targets, size_t n,
+                    const mm3d_params *params);
 /* computeGlobalTransforms (map_merging.cpp:153-186 + graph.cpp); host only, needs no device. */
 int mm3d_global_transforms(const mm3d_pair_result *pairs, size_t n_pairs, double confidence_threshold,
                            size_t n_clouds, float *out_T, size_t *n_out);

@@ -354,6 +354,15 @@ class Context:
                                           r.ctypes.data_as(C.c_void_p)))
         return r[0]
 
+    def pairsSkip(self, sources, targets, params: MapMergingParams):
+        """Replays the rand() draws of pairs this context does not execute (one call for the whole run)."""
+        n = len(sources)
+        if n == 0:
+            return
+        a = (C.c_void_p * n)(*[m._h for m in sources])
+        b = (C.c_void_p * n)(*[m._h for m in targets])
+        self._ck(lib().mm3d_pairs_skip(self._h, a, b, C.c_size_t(n), C.byref(params)))
+
     # ---- measurement -----------------------------------------------------------------------
     def profile(self, on: bool):
         self._ck(lib().mm3d_profile_enable(self._h, int(on)))

@@ -604,6 +604,20 @@ int mm3d_pair_estimate(mm3d_ctx *ctx, const mm3d_map *source, const mm3d_map *ta
   return guarded(ctx, [&] { pair_estimate_impl(ctx, source, target, params, execute != 0, out); });
 }
 
+int mm3d_pairs_skip(mm3d_ctx *ctx, const mm3d_map *const *sources, const mm3d_map *const *targets, size_t n, const mm3d_params *params)
+{
+  if (!params || (n && (!sources || !targets))) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    for (size_t i = 0; i < n; ++i) {
+      const mm3d_map *s = sources[i], *t = targets[i];
+      if (!s || !t) throw Error(MM3D_EINVAL, "null map");
+      if (s->keypoints->n == 0 || t->keypoints->n == 0) continue;      // not a pair (map_merging.cpp:250)
+      pair_rand_replay(ctx->rnd, params->estimation_method, cloud_host(ctx, s->keypoints), params->inlier_threshold,
+                       params->max_iterations);
+    }
+  });
+}
+
 int mm3d_global_transforms(const mm3d_pair_result *pairs, size_t n_pairs, double confidence_threshold, size_t n_clouds,
                            float *out_T, size_t *n_out)
 {
