@@ -207,13 +207,18 @@ int mm3d_transform_score(mm3d_ctx *ctx, const mm3d_cloud *source, const mm3d_clo
 
 /* ---- map_merging.h -------------------------------------------------------------------- */
 typedef struct { const void *points; size_t n; size_t stride; size_t rgba_offset; } mm3d_cloud_view;
-/* TransformEstimate (R/src/graph.h:24-36) plus diagnostics */
+/* TransformEstimate (R/src/graph.h:24-36) plus the integer observables of the pair: what
+ * registration_visualisation prints as "cross-matches count" / "inliers count"
+ * (R/src/registration_visualisation.cpp:129-130; both 0 for SAC_IA, which has neither) and the ICP trace
+ * (pcl::Registration::nr_iterations_ and the number of correspondences of its last iteration). */
 typedef struct {
   uint64_t source_idx, target_idx;
   float transform[16];
   double confidence;
   int32_t icp_iterations;
-  int32_t reserved;
+  int32_t n_correspondences;   /* findFeatureCorrespondences(...)->size()          (MATCHING) */
+  int32_t n_inliers;           /* inliers->size() of estimateTransformFromCorrespondences (MATCHING) */
+  int32_t icp_correspondences; /* correspondences within max_correspondence_distance in the last ICP iteration */
 } mm3d_pair_result;
 
 /* estimateMapsTransforms (map_merging.h:85, map_merging.cpp:188-275).

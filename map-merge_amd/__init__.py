@@ -25,7 +25,8 @@ POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
 NORMAL = np.dtype([("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4"), ("curvature", "<f4")])
 CORR = np.dtype([("index_query", "<i4"), ("index_match", "<i4"), ("distance", "<f4")])
 PAIR = np.dtype([("source_idx", "<u8"), ("target_idx", "<u8"), ("transform", "<f4", (16,)),
-                 ("confidence", "<f8"), ("icp_iterations", "<i4"), ("reserved", "<i4")])
+                 ("confidence", "<f8"), ("icp_iterations", "<i4"), ("n_correspondences", "<i4"),
+                 ("n_inliers", "<i4"), ("icp_correspondences", "<i4")])
 
 
 class Mm3dError(RuntimeError):

@@ -584,16 +584,20 @@ static void pair_estimate_impl(mm3d_ctx *ctx, const mm3d_map *s, const mm3d_map 
   std::memset(out->transform, 0, sizeof(out->transform));
   out->confidence = 0.0;
   out->icp_iterations = 0;
-  out->reserved = 0;
+  out->n_correspondences = out->n_inliers = out->icp_correspondences = 0;
   // estimateTransform and transformScore of its result (R/src/map_merging.cpp:91-107) as one device
   // pipeline: the transform never visits the host in between
   double score = DBL_MAX;
+  PairCounts counts;
   const int iters = estimate_pair(ctx, s->points, s->keypoints, s->desc, t->points, t->keypoints, t->desc,
                                   p->estimation_method, p->refine_transform, p->inlier_threshold,
                                   p->max_correspondence_distance, p->max_iterations, (size_t)p->matching_k,
-                                  p->transform_epsilon, out->transform, execute, true, p->max_correspondence_distance, &score);
+                                  p->transform_epsilon, out->transform, execute, true, p->max_correspondence_distance, &score, &counts);
   if (!execute) return;
   out->icp_iterations = iters;
+  out->n_correspondences = counts.n_correspondences;
+  out->n_inliers = counts.n_inliers;
+  out->icp_correspondences = counts.icp_correspondences;
   out->confidence = 1.0 / score;
 }
 
@@ -665,7 +669,7 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   std::vector<char> ready(n, 0), done(all.size(), 0);
   std::mutex mu;
   std::condition_variable cv;
-  size_t next_map = 0, next_pair = 0;
+  size_t next_map = 0;
   bool abort = false;
   std::exception_ptr first_error;
   const GlibcRand rnd0 = ctx->rnd;

@@ -344,7 +344,7 @@ bool sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
 int estimate_pair(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tp,
                   const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine, double inlier_threshold,
                   double max_corr_dist, int max_iterations, size_t matching_k, double eps, float T[16], bool execute,
-                  bool want_score, double score_max_distance, double *score)
+                  bool want_score, double score_max_distance, double *score, PairCounts *counts)
 {
   float T0[16];
   std::memset(T0, 0, sizeof(T0));
@@ -355,6 +355,7 @@ int estimate_pair(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const
       std::vector<mm3d_corr> corr, inl;
       find_correspondences(c, sd, td, matching_k, corr);
       ransac_transform(c, skp, tkp, corr.data(), corr.size(), inlier_threshold, T0, inl);
+      if (counts) { counts->n_correspondences = (int)corr.size(); counts->n_inliers = (int)inl.size(); }
     }
   } else if (method == MM3D_EST_SAC_IA) {
     // argument mapping of matching.cpp:243-246: min_sample_distance := inlier_threshold
@@ -368,6 +369,7 @@ int estimate_pair(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const
                                want_score, score_max_distance);
   std::memcpy(T, r.T, sizeof(r.T));
   if (score) *score = r.score;
+  if (counts) counts->icp_correspondences = r.n_corr;
   return r.iterations;
 }
 

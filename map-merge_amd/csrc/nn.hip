@@ -426,6 +426,7 @@ PairTail icp_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, con
   PairTail res;
   res.iterations = 0;
   res.converged = 0;
+  res.n_corr = 0;
   res.score = DBL_MAX;
   c->last_icp_iterations = 0;
   c->last_icp_converged = 0;
@@ -508,6 +509,7 @@ PairTail icp_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, con
   memcpy(res.T, hp->T, sizeof(res.T));
   res.iterations = hp->iters;
   res.converged = hp->converged;
+  res.n_corr = hp->n_corr;
   if (want_score) res.score = ho[1] > 0.0 ? ho[0] / ho[1] : DBL_MAX;
   c->last_icp_iterations = res.iterations;
   c->last_icp_converged = res.converged;

@@ -185,7 +185,8 @@ void desc_knn_rows(Context *c, const mm3d_desc *A, const int *rows_dev, int n_ro
 
 // registration.hip
 struct IcpResult { float T[16]; int iterations; int converged; };
-struct PairTail { float T[16]; int iterations; int converged; double score; };
+struct PairTail { float T[16]; int iterations; int converged; int n_corr; double score; };
+struct PairCounts { int n_correspondences = 0, n_inliers = 0, icp_correspondences = 0; };
 // ICP (optional) from a guess on the device (guess_dev != null) or on the host, then transformScore
 // (optional) of the result, with one host synchronisation
 PairTail icp_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float *guess_dev, const float guess_host[16],
@@ -227,7 +228,7 @@ void pair_rand_replay(GlibcRand &rnd, int method, const std::vector<float4> &skp
 int estimate_pair(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tp,
                   const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine, double inlier_threshold,
                   double max_corr_dist, int max_iterations, size_t matching_k, double eps, float T[16], bool execute,
-                  bool want_score, double score_max_distance, double *score);
+                  bool want_score, double score_max_distance, double *score, PairCounts *counts = nullptr);
 int estimate_transform(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd,
                        const mm3d_cloud *tp, const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine,
                        double inlier_threshold, double max_corr_dist, int max_iterations, size_t matching_k,

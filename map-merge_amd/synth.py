@@ -12,8 +12,8 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["World", "synth_world", "synth_map", "synth_maps", "pack_points", "relative_gt",
-           "POINT_DTYPE"]
+__all__ = ["World", "synth_world", "synth_map", "synth_maps", "cached_maps", "window_overlap", "pack_points",
+           "relative_gt", "POINT_DTYPE"]
 
 POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
 
@@ -209,6 +209,43 @@ def synth_maps(n_maps: int, n_points: int, world_seed: int = 1234, **kw):
     world = synth_world(world_seed, extent=extent)
     maps = [synth_map(world, i, n_points, n_maps=n_maps, **kw) for i in range(n_maps)]
     return world, maps
+
+
+def cached_maps(n_maps: int, n_points: int, cache_dir: str | None = "/tmp", **kw):
+    """synth_maps as packed records plus the ground-truth poses, kept in `cache_dir` between runs (generating
+    16 x 500 000 points takes ~20 s of CPU).  Returns (list of POINT_DTYPE arrays, list of 4x4 T_gt, window)."""
+    import os
+    w = kw.get("window") or window_for(n_points)
+    tag = "_".join(f"{k}{v}" for k, v in sorted(kw.items()))
+    path = os.path.join(cache_dir, f"mm3d_synth_{n_maps}x{n_points}{('_' + tag) if tag else ''}.npz") if cache_dir else None
+    if path and os.path.exists(path):
+        try:
+            z = np.load(path)
+            if z["pts"].shape[0] == n_maps:
+                return [z["pts"][i] for i in range(n_maps)], [z["T"][i] for i in range(n_maps)], float(w)
+        except Exception:
+            pass                                           # unreadable cache: regenerate
+    _, maps = synth_maps(n_maps, n_points, **kw)
+    packed = [pack_points(x, c) for x, c, _ in maps]
+    Ts = [T for _, _, T in maps]
+    if path:
+        try:                                               # several ranks may get here at once: write aside, rename atomically
+            tmp = f"{path}.{os.getpid()}.tmp.npz"
+            np.savez(tmp, pts=np.stack(packed), T=np.stack(Ts))
+            os.replace(tmp, path)
+        except Exception:
+            pass
+    return packed, Ts, float(w)
+
+
+def window_overlap(n_maps: int, n_points: int, i: int, j: int, overlap_step: float = 0.5, window: float | None = None) -> float:
+    """Fraction of map i's window that map j's window covers (both are axis-aligned squares of the same side
+    whose centres walk the loop of synth_map); 0 = disjoint."""
+    w = window_for(n_points) if window is None else float(window)
+    loop_r = overlap_step * w * max(n_maps, 2) / (2.0 * np.pi)
+    a = [2.0 * np.pi * k / max(n_maps, 1) for k in (i, j)]
+    d = np.abs(np.array([loop_r * (np.cos(a[0]) - np.cos(a[1])), loop_r * (np.sin(a[0]) - np.sin(a[1]))]))
+    return float(max(0.0, w - d[0]) * max(0.0, w - d[1]) / (w * w))
 
 
 def pack_points(xyz: np.ndarray, rgb: np.ndarray) -> np.ndarray:

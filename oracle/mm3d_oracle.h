@@ -171,6 +171,10 @@ void mo_estimate_transform(const mo_point *src, int ns, const mo_point *src_kp,
                            double max_correspondence_distance, int max_iterations,
                            size_t matching_k, double transform_epsilon,
                            float T[16]);
+/* the integer observables of the most recent mo_estimate_transform: cross-match and inlier counts
+ * (R/src/registration_visualisation.cpp:129-130; MATCHING only) and the ICP trace */
+typedef struct { int n_correspondences, n_inliers, icp_iterations, icp_correspondences; } mo_pair_trace;
+void mo_last_pair_trace(mo_pair_trace *out);
 /* transformScore: R/src/matching.cpp:259-268. */
 double mo_transform_score(const mo_point *src, int ns, const mo_point *tgt,
                           int nt, const float T[16], double max_distance);
@@ -207,6 +211,7 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
                                 int n_clouds, const mo_params *params,
                                 float *out_T, mo_estimate *pair_out,
                                 int *n_pairs_out);
+int mo_last_run_traces(mo_pair_trace *out, int cap);
 /* composeMaps: R/src/map_merging.cpp:277-305. returns -1 for empty input
  * (nullptr in the reference), -2 for size mismatch (the reference throws). */
 int mo_compose_maps(const mo_point *const *clouds, const int *sizes, int n_clouds,

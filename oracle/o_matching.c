@@ -336,6 +336,11 @@ void mo_sac_ia(const mo_point *src_kp, const float *src_desc, int ns, const mo_p
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* integer observables of the most recent mo_estimate_transform (what registration_visualisation.cpp:129-130
+ * prints for MATCHING, plus the ICP trace); process-global like the rand() state */
+static mo_pair_trace g_trace;
+void mo_last_pair_trace(mo_pair_trace *out) { *out = g_trace; }
+
 /* ICP */
 void mo_icp(const mo_point *src, int ns, const mo_point *tgt, int nt, const float guess[16],
             double max_correspondence_distance, double outlier_rejection_threshold,
@@ -373,6 +378,7 @@ void mo_icp(const mo_point *src, int ns, const mo_point *tgt, int nt, const floa
         cdist[cnt] = d2;
         ++cnt;
       }
+      g_trace.icp_correspondences = cnt;
       if (cnt < 3) { converged = 0; break; }   /* min_number_correspondences_ */
       float Tinc[16];
       mo_umeyama_f32(cs, cd, cnt, Tinc);
@@ -400,6 +406,7 @@ void mo_icp(const mo_point *src, int ns, const mo_point *tgt, int nt, const floa
     mo_grid_free(g);
   }
   if (iters_out) *iters_out = iters;
+  g_trace.icp_iterations = iters;
   mo_mat4_mul(final_T, guess, T);   /* icp.getFinalTransformation() * initial_guess */
 }
 
@@ -436,11 +443,14 @@ void mo_estimate_transform(const mo_point *src, int ns, const mo_point *src_kp, 
                            int max_iterations, size_t matching_k, double transform_epsilon, float T[16])
 {
   float T0[16];
+  memset(&g_trace, 0, sizeof(g_trace));
   if (method == 0) {
     mo_corr *corr = (mo_corr *)malloc(sizeof(mo_corr) * (size_t)(nsk > 0 ? nsk : 1));
     mo_corr *inl = (mo_corr *)malloc(sizeof(mo_corr) * (size_t)(nsk > 0 ? nsk : 1));
     int nc = mo_find_correspondences(src_desc, nsk, tgt_desc, ntk, dim, matching_k, corr);
-    mo_ransac(src_kp, nsk, tgt_kp, ntk, corr, nc, inlier_threshold, T0, inl, NULL, NULL);
+    int ni = mo_ransac(src_kp, nsk, tgt_kp, ntk, corr, nc, inlier_threshold, T0, inl, NULL, NULL);
+    g_trace.n_correspondences = nc;
+    g_trace.n_inliers = ni;
     free(corr); free(inl);
   } else {
     /* note the argument mapping at R/src/matching.cpp:243-246: min_sample_distance := inlier_threshold */

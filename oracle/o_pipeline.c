@@ -5,9 +5,8 @@
  * estimateMapsTransforms     R/src/map_merging.cpp:188-275
  * composeMaps                R/src/map_merging.cpp:277-305
  *
- * Only descriptor_type = FPFH | PFH and keypoint_type = SIFT are restated (the north-star path and
- * the reference's default descriptor);
- * other enum values make mo_estimate_maps_transforms return -3.
+ * Every row of the descriptor dispatch table and both keypoint detectors are restated; values outside the
+ * enums make mo_estimate_maps_transforms return -3.
  */
 #include "mm3d_oracle.h"
 
@@ -33,6 +32,15 @@ void mo_params_default(mo_params *p)
   p->transform_epsilon = 1e-2;
   p->confidence_threshold = 0.0;
   p->output_resolution = 0.05;
+}
+
+static mo_pair_trace *g_traces = NULL;
+static int g_n_traces = 0;
+/* per-pair traces of the most recent mo_estimate_maps_transforms, in pair order; returns how many exist */
+int mo_last_run_traces(mo_pair_trace *out, int cap)
+{
+  for (int i = 0; i < g_n_traces && i < cap; ++i) out[i] = g_traces[i];
+  return g_n_traces;
 }
 
 static void identity16(float *T)
@@ -95,6 +103,9 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
         memset(pairs[np].transform, 0, sizeof(float) * 16);
         ++np;
       }
+  free(g_traces);
+  g_traces = (mo_pair_trace *)calloc((size_t)(np > 0 ? np : 1), sizeof(mo_pair_trace));
+  g_n_traces = np;
   for (int p = 0; p < np; ++p) {
     int i = (int)pairs[p].source_idx, j = (int)pairs[p].target_idx;
     mo_estimate_transform(resized[i], rn[i], kps[i], desc[i], kn[i], resized[j], rn[j], kps[j], desc[j],
@@ -102,6 +113,7 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
                           params->inlier_threshold, params->max_correspondence_distance,
                           params->max_iterations, (size_t)params->matching_k,
                           params->transform_epsilon, pairs[p].transform);
+    mo_last_pair_trace(&g_traces[p]);
     pairs[p].confidence = 1.0 / mo_transform_score(resized[i], rn[i], resized[j], rn[j], pairs[p].transform,
                                                    params->max_correspondence_distance);
   }

@@ -354,6 +354,24 @@ def estimate_maps_transforms(clouds, params: Params):
     return [out[i].reshape(4, 4).T.copy() for i in range(m)], pairs[:npairs.value].copy()
 
 
+TRACE = np.dtype([("n_correspondences", "<i4"), ("n_inliers", "<i4"), ("icp_iterations", "<i4"), ("icp_correspondences", "<i4")])
+
+
+def last_run_traces():
+    """Per-pair integer observables of the most recent estimate_maps_transforms (cross-match / inlier counts of
+    R/src/registration_visualisation.cpp:129-130, ICP iterations and last-iteration correspondences), in pair order."""
+    n = lib().mo_last_run_traces(None, 0)
+    out = np.zeros(max(n, 1), dtype=TRACE)
+    lib().mo_last_run_traces(_p(out), n)
+    return out[:n].copy()
+
+
+def last_pair_trace():
+    out = np.zeros(1, dtype=TRACE)
+    lib().mo_last_pair_trace(_p(out))
+    return out[0]
+
+
 def compose_maps(clouds, transforms, resolution):
     clouds = [_pts(c) for c in clouds]
     n = len(clouds)

@@ -1,0 +1,158 @@
+"""The BASELINE.json configurations at their full sizes through the reference's entry point
+(estimateMapsTransforms, R/src/map_merging.cpp:188-275) on the MI355X.
+
+What is checked at these sizes, where the CPU oracle cannot run a whole job in test time:
+  * the library's stream scheduler never changes a bit: 1 stream == 16 streams for every pair record
+    (transform, confidence, ICP trace, match / inlier counts), every configuration;
+  * 16 x 500 000 (the headline configuration): the oracle runs maps 0 and 1 and pair (0, 1) (about a
+    minute of CPU) and every stage is compared with the device's;
+  * ground truth: the generator knows every map's pose.  Where the reference's algorithm itself finds
+    the basin on this data (colour-aware descriptors + reciprocal matching + RANSAC) the recovered
+    pair transforms are held against the ground truth with a stated bound.  FPFH + SAC_IA -- the
+    configuration BASELINE.json quotes -- does NOT find it at these sizes, on the device or on the
+    CPU path alike: FPFH sees geometry only and most SIFT keypoints of these scenes lie on the
+    textured, geometrically bland ground, and SAC-IA tries 500 hypotheses, each from 3 random picks among
+    10 nearest descriptors out of ~16 000.  That is the reference's behaviour, so the test there is
+    parity with the oracle, not registration success.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FPFH, PFHRGB, SHOT = 2, 1, 4
+MATCHING, SAC_IA = 0, 1
+
+# name -> (maps, raw points per map, descriptor, method): BASELINE.json configs[1..4]
+CONFIGS = {
+    "4x200k_FPFH": (4, 200000, FPFH, SAC_IA),
+    "16x500k_FPFH_ICP": (16, 500000, FPFH, SAC_IA),
+    "8x2M_SIFT_SHOT": (8, 2000000, SHOT, SAC_IA),
+    "64x50k_swarm": (64, 50000, FPFH, SAC_IA),
+}
+
+
+@pytest.fixture(scope="module")
+def workload(synth):
+    cache = {}
+
+    def get(n_maps, n_points):
+        key = (n_maps, n_points)
+        if key not in cache:
+            cache.clear()                                   # one configuration resident at a time (8 x 2M = 256 MB)
+            cache[key] = synth.cached_maps(n_maps, n_points)
+        return cache[key]
+
+    return get
+
+
+def xyz(a):
+    return np.stack([a["x"], a["y"], a["z"]], axis=1)
+
+
+def records_equal(a, b):
+    return (len(a) == len(b)
+            and np.array_equal(a["transform"].view(np.uint32), b["transform"].view(np.uint32))
+            and np.array_equal(a["confidence"].view(np.uint64), b["confidence"].view(np.uint64))
+            and all(np.array_equal(a[f], b[f]) for f in ("source_idx", "target_idx", "icp_iterations", "n_correspondences",
+                                                          "n_inliers", "icp_correspondences")))
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_full_size_configuration_runs_and_streams_do_not_change_a_bit(ctx, mm, workload, name):
+    n_maps, n_points, desc, method = CONFIGS[name]
+    raws, _, _ = workload(n_maps, n_points)
+    params = mm.MapMergingParams(descriptor_type=desc, estimation_method=method, refine_transform=1)
+    runs = []
+    for streams in (16, 1):
+        ctx.setStreams(streams)
+        ctx.srand(1)                                        # the reference's process starts at glibc seed 1
+        runs.append(ctx.estimateMapsTransforms(raws, params, return_pairs=True))
+    ctx.setStreams(1)
+    (T16, p16), (T1, p1) = runs
+    assert len(p16) == n_maps * (n_maps - 1) // 2           # every map has keypoints: every pair is estimated
+    assert records_equal(p16, p1)
+    assert len(T16) == len(T1) == n_maps and all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(T16, T1))
+    assert all(np.isfinite(t).all() and np.any(t) for t in T16)      # every map reached through the spanning tree
+    it = p16["icp_iterations"]
+    assert (it >= 1).all() and (it <= params.max_iterations).all()
+    assert (p16["icp_correspondences"] >= 3).all()          # ICP stops below 3 correspondences (then iterations = 0)
+    assert (p16["confidence"] > 0).all() and np.isfinite(p16["confidence"]).all()
+    if method == SAC_IA:
+        assert not p16["n_correspondences"].any() and not p16["n_inliers"].any()
+
+
+def test_16x500k_stage_by_stage_against_the_oracle(ctx, po, mm, workload):
+    """The headline configuration: maps 0 and 1 and pair (0, 1) on the CPU oracle, stage by stage."""
+    raws, _, _ = workload(16, 500000)
+    params = mm.MapMergingParams(descriptor_type=FPFH, estimation_method=SAC_IA, refine_transform=1)
+    ctx.setStreams(16)
+    ctx.srand(1)
+    _, pairs = ctx.estimateMapsTransforms(raws, params, return_pairs=True)
+    ctx.setStreams(1)
+    assert pairs[0]["source_idx"] == 0 and pairs[0]["target_idx"] == 1
+    ref, dev = [], []
+    for i in (0, 1):
+        d = po.downsample(raws[i], params.resolution)
+        f = po.remove_outliers(d, params.descriptor_radius, params.outliers_min_neighbours)
+        n = po.normals(f, params.normal_radius)
+        kp_raw, _ = po.keypoints_sift(f, params.resolution, 3, 3, params.keypoint_threshold)
+        kp, desc = po.descriptors_fpfh(f, n, kp_raw, params.descriptor_radius)
+        ref.append(dict(filt=f, nrm=n, kp=kp, desc=desc))
+        m = ctx.mapFeatures(ctx.cloud(raws[i]), params)
+        dev.append(dict(filt=m.points.numpy(), kp=m.keypoints.numpy(), desc=m.descriptors.numpy()))
+        m.free()
+    for r, g in zip(ref, dev):
+        # voxel grid + outlier filter: bit-exact
+        assert np.array_equal(g["filt"].view(np.uint32), r["filt"].view(np.uint32))
+        # keypoints and descriptors: the same arrays (sums run in the CPU path's neighbour order, libm restated)
+        assert np.array_equal(xyz(g["kp"]).view(np.uint32), xyz(r["kp"]).view(np.uint32)), (len(g["kp"]), len(r["kp"]))
+        assert np.array_equal(g["desc"].view(np.uint32), r["desc"].view(np.uint32))
+    # pair (0, 1) is the first pair: the generator is in its initial state on both sides
+    po.srand(1)
+    T0, _, _ = po.sac_ia(ref[0]["kp"], ref[0]["desc"], ref[1]["kp"], ref[1]["desc"], params.inlier_threshold,
+                         params.max_correspondence_distance, params.max_iterations)
+    T_ref, it_ref = po.icp(ref[0]["filt"], ref[1]["filt"], T0, params.max_correspondence_distance, params.inlier_threshold,
+                           params.max_iterations, params.transform_epsilon)
+    score = po.transform_score(ref[0]["filt"], ref[1]["filt"], T_ref, params.max_correspondence_distance)
+    got = pairs[0]["transform"].reshape(4, 4).T
+    # ICP reduces in double on the device and in float on the CPU path: Frobenius 1e-3, confidence 1e-4 relative
+    assert int(pairs[0]["icp_iterations"]) == it_ref
+    assert np.linalg.norm(got - T_ref) <= 1e-3, np.linalg.norm(got - T_ref)
+    assert pairs[0]["confidence"] == pytest.approx(1.0 / score, rel=1e-4)
+    # the reference's default method on the same maps: cross-match and inlier counts exact
+    # (R/src/registration_visualisation.cpp:129-130), transform bit-equal
+    corr = po.find_correspondences(ref[0]["desc"], ref[1]["desc"], int(params.matching_k))
+    T_r, inl_r, _, _ = po.ransac(ref[0]["kp"], ref[1]["kp"], corr, params.inlier_threshold)
+    d0, d1 = ctx.descriptors(dev[0]["desc"]), ctx.descriptors(dev[1]["desc"])
+    got_corr = ctx.findFeatureCorrespondences(d0, d1, int(params.matching_k))
+    assert len(got_corr) == len(corr) and np.array_equal(got_corr["index_match"], corr["index_match"])
+    T_g, inl_g = ctx.estimateTransformFromCorrespondences(ctx.cloud(dev[0]["kp"]), ctx.cloud(dev[1]["kp"]), got_corr,
+                                                          params.inlier_threshold)
+    assert len(inl_g) == len(inl_r) and np.array_equal(T_g.view(np.uint32), T_r.view(np.uint32))
+
+
+def test_ground_truth_is_recovered_where_the_reference_algorithm_finds_it(ctx, mm, synth, workload):
+    """4 x 200 000 with PFHRGB + MATCHING (+ RANSAC + ICP): every pair overlaps (>= 36 % of a window) and the
+    algorithm finds the basin, so the device's answers are held against the generator's poses.
+    Bounds: pair transform within 0.5 (Frobenius) of the ground truth -- ICP stops at the reference's loose
+    transform_epsilon = 1e-2, a few centimetres to decimetres short -- median <= 0.1, global poses <= 0.2."""
+    n_maps, n_points = 4, 200000
+    raws, Tg, _ = workload(n_maps, n_points)
+    params = mm.MapMergingParams(descriptor_type=PFHRGB, estimation_method=MATCHING, refine_transform=1)
+    ctx.setStreams(16)
+    ctx.srand(1)
+    T, pairs = ctx.estimateMapsTransforms(raws, params, return_pairs=True)
+    ctx.setStreams(1)
+    errs = []
+    for p in pairs:
+        i, j = int(p["source_idx"]), int(p["target_idx"])
+        assert synth.window_overlap(n_maps, n_points, i, j) >= 0.3
+        errs.append(np.linalg.norm(p["transform"].reshape(4, 4).T - synth.relative_gt(Tg[i], Tg[j])))
+        assert p["n_inliers"] >= 3 and p["n_correspondences"] >= p["n_inliers"]
+    assert max(errs) <= 0.5 and np.median(errs) <= 0.1, errs
+    ref = [k for k, t in enumerate(T) if np.array_equal(t, np.eye(4, dtype=np.float32))]
+    assert len(ref) == 1
+    for k in range(n_maps):
+        # T[k] takes map k into the reference map's frame
+        assert np.linalg.norm(T[k] - synth.relative_gt(Tg[k], Tg[ref[0]])) <= 0.2, k
