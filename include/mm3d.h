@@ -105,6 +105,9 @@ long long mm3d_debug_knn_rows(mm3d_ctx *ctx);
 /* test hook: out[i] = the float sum "0 + incr[i] + incr[i] + ..." (hits[i] additions) as the PFH kernels
  * replay it for a histogram bin (PFHEstimation: "histogram[h] += hist_incr" once per pair) */
 int mm3d_debug_float_chain(mm3d_ctx *ctx, const float *incr, const unsigned *hits, int n, float *out);
+/* test hook: out[i] = the device's restatement of glibc's expf (fn 0), atanf (1), sinf (2), cosf (3) of x[i] or
+ * atan2f(y[i], x[i]) (4) -- csrc/libm_exact.hpp, the functions the CPU path's PCL calls through libm */
+int mm3d_debug_libm(mm3d_ctx *ctx, int fn, const float *x, const float *y, int n, float *out);
 /* SAC-IA draws from libc rand() in the reference (process-global, glibc seed 1).  The context
  * carries its own replay of that generator; mm3d_srand re-seeds it (srand semantics). */
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed);

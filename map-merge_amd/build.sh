@@ -7,7 +7,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-parameter"
 mkdir -p build
-SRCS="grid.hip filters.hip normals.hip sift.hip harris.hip fpfh.hip pfh.hip rsd.hip shot.hip sc3d.hip desc_knn.hip registration.hip nn.hip linalg.cpp host_pipeline.cpp capi.cpp"
+SRCS="libm_debug.hip grid.hip filters.hip normals.hip sift.hip harris.hip fpfh.hip pfh.hip rsd.hip shot.hip sc3d.hip desc_knn.hip registration.hip nn.hip linalg.cpp host_pipeline.cpp capi.cpp"
 OBJS=""
 pids=()
 for s in $SRCS; do

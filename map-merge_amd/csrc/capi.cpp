@@ -248,6 +248,11 @@ int mm3d_debug_float_chain(mm3d_ctx *ctx, const float *incr, const unsigned *hit
   if (n < 0 || (n && (!incr || !hits || !out))) return MM3D_EINVAL;
   return guarded(ctx, [&] { debug_float_chain(ctx, incr, hits, n, out); });
 }
+int mm3d_debug_libm(mm3d_ctx *ctx, int fn, const float *x, const float *y, int n, float *out)
+{
+  if (n < 0 || fn < 0 || fn > 4 || (n && (!x || !out || (fn == 4 && !y)))) return MM3D_EINVAL;
+  return guarded(ctx, [&] { debug_libm(ctx, fn, x, y, n, out); });
+}
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed) { if (ctx) ctx->rnd.seed(seed); }
 int mm3d_synchronize(mm3d_ctx *ctx) { return guarded(ctx, [&] { ctx->sync(); }); }
 

@@ -9,6 +9,7 @@
 
 #include <type_traits>
 
+#include "libm_exact.hpp"
 #include "types.hpp"
 
 namespace mm3d {
@@ -342,9 +343,17 @@ __host__ __device__ inline void compute_roots(const float *m /* row-major symmet
     float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
     if (q > 0.0f) q = 0.0f;
     float rho = sqrtf(-a_over_3);
+    // glibc's atan2f / cosf / sinf on both sides: the host calls its libm, the device the restatement of
+    // exactly those functions (libm_exact.hpp), so the roots -- and the normals -- agree bit for bit
+#if defined(__HIP_DEVICE_COMPILE__)
+    float theta = lm::atan2f_glibc(sqrtf(-q), half_b) * s_inv3;
+    float cos_theta = lm::cosf_glibc(theta);
+    float sin_theta = lm::sinf_glibc(theta);
+#else
     float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
     float cos_theta = cosf(theta);
     float sin_theta = sinf(theta);
+#endif
     roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
     roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);

@@ -2,56 +2,95 @@
 //
 // R/src/features.cpp:168-179: pcl::NormalEstimation<PointXYZRGB, Normal>, radius search,
 // viewpoint (0,0,0).  Per point: neighbours with d2 < float(r*r) (self included); fewer than 3
-// => NaN; 3x3 covariance -> pcl::eigen33 smallest eigenpair -> flip towards the viewpoint;
-// curvature = |lambda0 / trace|.
+// => NaN; computeMeanAndCovarianceMatrix (float raw moments accumulated over the neighbours IN THE
+// ORDER radiusSearch returns them: (distance, index)) -> pcl::eigen33 smallest eigenpair ->
+// flipNormalTowardsViewpoint; curvature = |lambda0 / trace|.
 //
-// The covariance is accumulated about the QUERY point (|d| <= r), which is the same matrix as
-// PCL's raw-moment form E[xx^T] - E[x]E[x]^T by translation invariance but does not lose the
-// eigenvalue to cancellation far from the origin.  Algorithmic traffic: 28 B / point
-// (12 B xyz in, 16 B normal out); the neighbourhood walk itself is L1/L2 reuse.
-#include "device_util.hpp"
+// The nine raw-moment sums are float chains, so the kernel builds every point's neighbour list in
+// that order first (sorted_nb.hpp) and then runs the chains one per lane: 16 points per group, four
+// lanes per point, each lane owns two or three of the nine accumulators and walks the point's sorted
+// list.  The closed-form eigen solve uses the restated glibc atan2f / cosf / sinf (libm_exact.hpp), so
+// the normals are the CPU path's, bit for bit.  Algorithmic traffic: 28 B / point (12 B xyz in, 16 B
+// normal out); the lists are L2-resident scratch.
+#include "sorted_nb.hpp"
 
 namespace mm3d {
 
 __global__ void __launch_bounds__(256)
-k_normals(GridView g, float radius, float r2, float4 *__restrict__ out /* by original index */)
+k_normals(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g, const float4 *__restrict__ pts,
+          float radius, float r2, SnScratch sc, float4 *__restrict__ out /* by original index */)
 {
-  unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-  int i = bid * blockDim.x + threadIdx.x;
-  if (i >= g.n) return;
-  const float4 q = g.pts[i];
-  int cnt = 0;
-  float sx = 0.f, sy = 0.f, sz = 0.f, sxx = 0.f, sxy = 0.f, sxz = 0.f, syy = 0.f, syz = 0.f, szz = 0.f;
-  for_each_candidate(g, q.x, q.y, q.z, radius, [&](const float4 &p) {
-    float d2 = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
-    if (d2 < r2) {
-      float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-      ++cnt;
-      sx += dx; sy += dy; sz += dz;
-      sxx = fmaf(dx, dx, sxx); sxy = fmaf(dx, dy, sxy); sxz = fmaf(dx, dz, sxz);
-      syy = fmaf(dy, dy, syy); syz = fmaf(dy, dz, syz); szz = fmaf(dz, dz, szz);
+  __shared__ SnLds lds[4];
+  __shared__ float sums[4][kSnG][9];
+  __shared__ int cnts[4][kSnG];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  SnLds &L = lds[wave];
+  const size_t slot = (size_t)blockIdx.x * 4 + wave;
+  unsigned long long *tmp = sc.tmp + slot * kSnEntries;
+  float4 *fin = (float4 *)sc.fin + slot * kSnEntries;
+  const int n_units = n_items * 4;
+  for (;;) {
+    const int unit = sn_claim_unit(sc.unit_ctr, n_units, lane);
+    if (unit < 0) break;
+    const int2 it = items[unit >> 2];
+    int first = (unit & 3) * kSnG;                       // this quarter's points of the item
+    int left = min(kSnG, it.y - first);
+    while (left > 0) {
+      const int p = lane >> 2, sub = lane & 3;
+      const float4 q = q_pts[it.x + first + (p < left ? p : 0)];
+      const int fit = sn_build_lists<float4>(g, L, q.x, q.y, q.z, left, radius, r2, tmp, fin, sc.error, lane,
+                                             [&](unsigned long long key) { return pts[(unsigned)(key & 0xffffffffull)]; });
+      // chains: lane (p, sub) owns accumulators sub, sub + 4, sub + 8 of a = {xx, xy, xz, yy, yz, zz, x, y, z}
+      if (p < fit) {
+        const int base = L.list_off[p], m = L.list_off[p + 1] - base;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int e = 0; e < m; ++e) {
+          const float4 c = fin[base + e];
+          // u * v per accumulator, rounded, then added (the CPU path's a[k] += p.u * p.v)
+          const float u0 = sub == 3 ? c.y : c.x;                                  // xx, xy, xz | yy
+          const float v0 = sub == 0 ? c.x : (sub == 2 ? c.z : c.y);
+          const float u1 = sub == 0 ? c.y : (sub == 1 ? c.z : (sub == 2 ? c.x : c.y));   // yz, zz, x, y
+          const float v1 = sub <= 1 ? c.z : 1.0f;
+          a0 = __fadd_rn(a0, __fmul_rn(u0, v0));
+          a1 = __fadd_rn(a1, __fmul_rn(u1, v1));
+          if (sub == 0) a2 = __fadd_rn(a2, c.z);                                  // z
+        }
+        sums[wave][p][sub] = a0;
+        sums[wave][p][sub + 4] = a1;
+        if (sub == 0) { sums[wave][p][8] = a2; cnts[wave][p] = m; }
+      }
+      wave_lds_fence();
+      // one lane per point: covariance, eigen33, flip (features/normal_3d.h computePointNormal)
+      if (lane < fit) {
+        const float4 pq = q_pts[it.x + first + lane];
+        const int cnt = cnts[wave][lane];
+        float4 o;
+        if (cnt < 3) {
+          o.x = o.y = o.z = o.w = __uint_as_float(0x7fc00000u);
+        } else {
+          float a[9];
+          const float fc = (float)cnt;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) a[k] = sums[wave][lane][k] / fc;
+          const float cxx = a[0] - a[6] * a[6], cxy = a[1] - a[6] * a[7], cxz = a[2] - a[6] * a[8];
+          const float cyy = a[3] - a[7] * a[7], cyz = a[4] - a[7] * a[8], czz = a[5] - a[8] * a[8];
+          float ev, v[3];
+          eigen33_smallest(cxx, cxy, cxz, cyy, cyz, czz, &ev, v);
+          const float eig_sum = cxx + cyy + czz;
+          o.w = (eig_sum != 0.0f) ? fabsf(ev / eig_sum) : 0.0f;
+          // flipNormalTowardsViewpoint(point, 0, 0, 0)
+          const float vx = 0.0f - pq.x, vy = 0.0f - pq.y, vz = 0.0f - pq.z;
+          const float cos_theta = vx * v[0] + vy * v[1] + vz * v[2];
+          if (cos_theta < 0.0f) { v[0] *= -1.0f; v[1] *= -1.0f; v[2] *= -1.0f; }
+          o.x = v[0]; o.y = v[1]; o.z = v[2];
+        }
+        out[__float_as_int(pq.w)] = o;
+      }
+      wave_lds_fence();
+      first += fit;
+      left -= fit;
     }
-    return true;
-  });
-  float4 o;
-  if (cnt < 3) {
-    o.x = o.y = o.z = o.w = __uint_as_float(0x7fc00000u);
-  } else {
-    const float inv = 1.0f / (float)cnt;
-    const float mx = sx * inv, my = sy * inv, mz = sz * inv;
-    const float cxx = sxx * inv - mx * mx, cxy = sxy * inv - mx * my, cxz = sxz * inv - mx * mz;
-    const float cyy = syy * inv - my * my, cyz = syz * inv - my * mz, czz = szz * inv - mz * mz;
-    float ev, v[3];
-    eigen33_smallest(cxx, cxy, cxz, cyy, cyz, czz, &ev, v);
-    const float eig_sum = cxx + cyy + czz;
-    o.w = (eig_sum != 0.0f) ? fabsf(ev / eig_sum) : 0.0f;
-    // flipNormalTowardsViewpoint(point, 0, 0, 0)
-    const float vx = 0.0f - q.x, vy = 0.0f - q.y, vz = 0.0f - q.z;
-    const float cos_theta = vx * v[0] + vy * v[1] + vz * v[2];
-    const float s = (cos_theta < 0.0f) ? -1.0f : 1.0f;
-    o.x = v[0] * s; o.y = v[1] * s; o.z = v[2] * s;
   }
-  out[__float_as_int(q.w)] = o;
 }
 
 __global__ void k_fill_nan(float4 *out, size_t n)
@@ -70,9 +109,19 @@ mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius)
   if ((size_t)g.n != in->n)   // non-finite inputs have no normal
     MM3D_LAUNCH(c, "fill_nan", 0, k_fill_nan, dim3(div_up(in->n, 256)), dim3(256), 0, res->nrm.get(), in->n);
   const float r2 = (float)(radius * radius);   // KdTreeFLANN::radiusSearch: float(radius*radius)
-  if (g.n)
-    MM3D_LAUNCH(c, "normals_radius", g.n * 28.0, k_normals, dim3(div_up(g.n, 256)), dim3(256), 0, g.view(),
-                (float)radius, r2, res->nrm.get());
+  if (g.n) {
+    cloud_hilbert(c, in);
+    const int n_items = in->n_wave_items;
+    SnLaunch<float4> sn(c, n_items * 4);
+    SnScratch sc{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error()};
+    MM3D_LAUNCH(c, "normals_radius", g.n * 28.0, k_normals, dim3(sn.blocks), dim3(256), 0, (const float4 *)in->hil_pts.get(),
+                (const int2 *)in->wave_items.get(), n_items, g.view(), (const float4 *)in->pts.get(), (float)radius, r2, sc,
+                res->nrm.get());
+    int *h = (int *)c->pin(64);
+    MM3D_HIP(hipMemcpyAsync(h, sn.error(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->sync();                                  // the scratch returns to the pool only after the kernel is done with it
+    if (*h) throw Error(MM3D_EUNSUPPORTED, "computeSurfaceNormals: a point has more than 16384 neighbours within the radius");
+  }
   return res;
 }
 

@@ -1,0 +1,205 @@
+// sorted_nb.hpp -- radius neighbourhoods in the CPU path's order, for float sums that must come out
+// bit for bit.
+//
+// PCL's feature estimators walk the result of KdTreeFLANN::radiusSearch, which FLANN returns sorted by
+// (squared distance, index), and accumulate in float as they go: computeMeanAndCovarianceMatrix
+// (normals), SIFTKeypoint::computeScaleSpace (Gaussian sums with a `break` that relies on the order),
+// FPFHEstimation::weightPointSPFHSignature.  A float sum is only reproducible in its own order, so the
+// kernels that feed such sums build every query's neighbour list in exactly that order first.
+//
+// One wave works on a GROUP of up to kSnG query points that lie close together (a quarter of a
+// Hilbert work item).  The box of grid cells the group can reach is streamed through LDS twice, 256
+// candidates at a time with coalesced loads (wave_stream_box):
+//   pass 1  every (query, candidate) pair inside the radius bumps the query's histogram over kSnNB
+//           equal-width buckets of the squared distance (LDS atomics, two 16-bit counters per word);
+//           a wave-wide scan turns the counts into bucket starts,
+//   pass 2  the same pairs again: the atomic's return value is the pair's slot inside its bucket; the
+//           64-bit key (distance bits << 32 | original index) goes to the wave's scratch list,
+//   rank    inside a bucket (a handful of keys) every key counts the smaller keys of its bucket and
+//           lands at its final place, as the payload the consumer's chains read.
+// The lists live in a per-wave global scratch region that is rewritten for every group (a few tens
+// of KB that stay in L2 / Infinity Cache); LDS holds the tile and the histograms (12.6 KB per wave).
+// The consumer then runs its float chains, one chain per lane, over the sorted payloads.
+//
+// Kernels are persistent: a fixed number of blocks, each wave claims units (work item, quarter) from
+// the counter of its XCD's contiguous slice of the Hilbert order, so one XCD's L2 sees one region.
+#pragma once
+
+#include "device_util.hpp"
+
+namespace mm3d {
+
+constexpr int kSnG = 16;            // query points per group
+constexpr int kSnNB = 128;          // distance buckets per query
+constexpr int kSnTile = 256;        // staged candidates per tile
+constexpr int kSnEntries = 16384;   // scratch list entries per wave (sum over the group's queries)
+
+struct SnLds {
+  float4 tile[kSnTile];
+  int off[64], beg[64];
+  unsigned cnt[kSnG][kSnNB / 2];    // pass 1: counts (2 x u16); then bucket starts
+  unsigned pos[kSnG][kSnNB / 2];    // pass 2: running positions; then bucket ends
+  int list_off[kSnG + 1];
+};
+
+struct SnScratch {
+  unsigned long long *tmp;          // [waves][kSnEntries] keys in bucket order
+  void *fin;                        // [waves][kSnEntries] payloads in final order
+  int *unit_ctr;                    // [kXcds] next unit of every XCD slice
+  int *error;                       // set when one query alone has more than kSnEntries neighbours
+};
+
+__device__ __forceinline__ float sn_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+__device__ __forceinline__ int sn_bucket(float d2, float bscale)
+{
+  const int b = (int)(d2 * bscale);
+  return b < kSnNB - 1 ? b : kSnNB - 1;
+}
+
+// Claims the next unit of this block's XCD slice; -1 when the slice is done.  Wave-uniform.
+__device__ __forceinline__ int sn_claim_unit(int *unit_ctr, int n_units, int lane)
+{
+  const int xcd = blockIdx.x % kXcds;
+  const int q = n_units / kXcds, r = n_units % kXcds;
+  const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int count = xcd < r ? q + 1 : q;
+  int u = 0;
+  if (lane == 0) u = atomicAdd(&unit_ctr[xcd], 1);
+  u = __builtin_amdgcn_readfirstlane(u);
+  return u < count ? first + u : -1;
+}
+
+// Builds the sorted neighbour lists of the group's queries.  Lane l carries query l / 4 in (qx, qy, qz)
+// (4 lanes per query); g <= kSnG queries are live.  On return L.list_off[p] .. L.list_off[p + 1] is query
+// p's range in `fin` (payloads in (d2, index) order) for p < the returned count g' <= g (g' < g only when
+// the scratch region cannot hold the whole group: the caller runs the rest as the next group).
+// make(key) -> Payload is called once per list entry with key = d2 bits << 32 | original index.
+template <class Payload, class Make>
+__device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float qx, float qy, float qz, int n_q, float radius, float r2,
+                                              unsigned long long *tmp, Payload *fin, int *error, int lane, Make &&make)
+{
+  const float ri = radius * 1.0001f + 1e-4f;
+  const bool live = (lane >> 2) < n_q;
+  const float lx = wave_min_f(live ? qx : INFINITY), hx = wave_max_f(live ? qx : -INFINITY);
+  const float ly = wave_min_f(live ? qy : INFINITY), hy = wave_max_f(live ? qy : -INFINITY);
+  const float lz = wave_min_f(live ? qz : INFINITY), hz = wave_max_f(live ? qz : -INFINITY);
+  const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
+  const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
+  const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
+  const KeepInBox keep{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri};
+  const float bscale = (float)kSnNB / r2;
+  for (int p = 0; p < kSnG; ++p) L.cnt[p][lane] = 0u;
+  wave_lds_fence();
+  // pass 1: histograms
+  wave_stream_box<kSnTile, 0>(g, x0, x1, y0, y1, z0, z1, L.tile, (float4 *)nullptr, L.off, L.beg, lane, [](int, float4 (&)[1]) {},
+                              [&](int n) {
+                                float4 c[kSnTile / kWave];
+#pragma unroll
+                                for (int u = 0; u < kSnTile / kWave; ++u) c[u] = L.tile[lane + u * kWave];
+                                for (int p = 0; p < n_q; ++p) {
+                                  const float px = sn_readlane(qx, p * 4), py = sn_readlane(qy, p * 4), pz = sn_readlane(qz, p * 4);
+#pragma unroll
+                                  for (int u = 0; u < kSnTile / kWave; ++u) {
+                                    const float d2 = dist2(px, py, pz, c[u].x, c[u].y, c[u].z);
+                                    if (lane + u * kWave < n && d2 < r2) {
+                                      const int b = sn_bucket(d2, bscale);
+                                      atomicAdd(&L.cnt[p][b >> 1], (b & 1) ? 0x10000u : 1u);
+                                    }
+                                  }
+                                }
+                              },
+                              keep);
+  wave_lds_fence();
+  // counts -> bucket starts; list offsets
+  int total = 0, fit = 0;
+  for (int p = 0; p < n_q; ++p) {
+    const unsigned w = L.cnt[p][lane];
+    const int c0 = (int)(w & 0xffffu), c1 = (int)(w >> 16);
+    int incl = c0 + c1;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const int t = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += t;
+    }
+    const int excl = incl - c0 - c1;
+    const int m = __builtin_amdgcn_readlane(incl, kWave - 1);
+    const bool ok = fit == p && total + m <= kSnEntries && m <= 0xffff;
+    if (ok) {
+      const unsigned st = (unsigned)excl | ((unsigned)(excl + c0) << 16);
+      L.cnt[p][lane] = st;
+      L.pos[p][lane] = st;
+      if (lane == 0) L.list_off[p] = total;
+      total += m;
+      fit = p + 1;
+    }
+  }
+  if (lane == 0) L.list_off[fit] = total;
+  if (fit == 0 && n_q > 0) {                   // one query alone overflows the scratch list: reported, skipped
+    if (lane == 0) *error = 1;
+    if (lane == 0) L.list_off[1] = 0;
+    wave_lds_fence();
+    return 1;
+  }
+  wave_lds_fence();
+  // pass 2: keys into their buckets
+  wave_stream_box<kSnTile, 0>(g, x0, x1, y0, y1, z0, z1, L.tile, (float4 *)nullptr, L.off, L.beg, lane, [](int, float4 (&)[1]) {},
+                              [&](int n) {
+                                float4 c[kSnTile / kWave];
+#pragma unroll
+                                for (int u = 0; u < kSnTile / kWave; ++u) c[u] = L.tile[lane + u * kWave];
+                                for (int p = 0; p < fit; ++p) {
+                                  const float px = sn_readlane(qx, p * 4), py = sn_readlane(qy, p * 4), pz = sn_readlane(qz, p * 4);
+                                  const int base = L.list_off[p];
+#pragma unroll
+                                  for (int u = 0; u < kSnTile / kWave; ++u) {
+                                    const float d2 = dist2(px, py, pz, c[u].x, c[u].y, c[u].z);
+                                    if (lane + u * kWave < n && d2 < r2) {
+                                      const int b = sn_bucket(d2, bscale);
+                                      const unsigned old = atomicAdd(&L.pos[p][b >> 1], (b & 1) ? 0x10000u : 1u);
+                                      const int at = (int)((b & 1) ? (old >> 16) : (old & 0xffffu));
+                                      tmp[base + at] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(c[u].w);
+                                    }
+                                  }
+                                }
+                              },
+                              keep);
+  wave_lds_fence();
+  // rank inside the buckets -> final order
+  for (int p = 0; p < fit; ++p) {
+    const int base = L.list_off[p], m = L.list_off[p + 1] - base;
+    for (int e = lane; e < m; e += kWave) {
+      const unsigned long long key = tmp[base + e];
+      const int b = sn_bucket(__uint_as_float((unsigned)(key >> 32)), bscale);
+      const unsigned ws = L.cnt[p][b >> 1], we = L.pos[p][b >> 1];
+      const int s = (int)((b & 1) ? (ws >> 16) : (ws & 0xffffu)), t = (int)((b & 1) ? (we >> 16) : (we & 0xffffu));
+      int r = 0;
+      for (int j = s; j < t; ++j) r += tmp[base + j] < key ? 1 : 0;
+      fin[base + s + r] = make(key);
+    }
+  }
+  wave_lds_fence();
+  return fit;
+}
+
+// host side: scratch for a persistent launch of `blocks` blocks of 4 waves
+template <class Payload>
+struct SnLaunch {
+  DevBuf<unsigned long long> tmp;
+  DevBuf<Payload> fin;
+  DevBuf<int> ctr;                   // kXcds unit counters + the error flag
+  unsigned blocks = 0;
+  SnLaunch(Context *c, int n_units, int waves_per_block = 4)
+  {
+    // enough blocks to fill the chip three times over, never more than there are units
+    const unsigned want = div_up((size_t)n_units, (size_t)waves_per_block);
+    blocks = want < 768u ? (want ? want : 1u) : 768u;
+    tmp = DevBuf<unsigned long long>(c, (size_t)blocks * waves_per_block * kSnEntries);
+    fin = DevBuf<Payload>(c, (size_t)blocks * waves_per_block * kSnEntries);
+    ctr = DevBuf<int>(c, kXcds + 1);
+    MM3D_HIP(hipMemsetAsync(ctr.get(), 0, (kXcds + 1) * sizeof(int), c->stream));
+  }
+  int *error() const { return ctr.get() + kXcds; }
+};
+
+}  // namespace mm3d

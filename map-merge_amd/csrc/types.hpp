@@ -160,6 +160,7 @@ mm3d_desc *compute_pfh(Context *c, const mm3d_cloud *points, const mm3d_normals 
 mm3d_desc *compute_pfhrgb(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,
                           mm3d_cloud *keypoints, double radius);
 
+void debug_libm(Context *c, int fn, const float *x_host, const float *y_host, int n, float *out_host);
 void debug_float_chain(Context *c, const float *incr_host, const unsigned *hits_host, int n, float *out_host);
 
 // rsd.hip

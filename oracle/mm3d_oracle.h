@@ -179,6 +179,8 @@ void mo_last_pair_trace(mo_pair_trace *out);
 double mo_transform_score(const mo_point *src, int ns, const mo_point *tgt,
                           int nt, const float T[16], double max_distance);
 
+/* the host libm over arrays: fn 0 expf, 1 atanf, 2 sinf, 3 cosf (of x), 4 atan2f(y, x)  (o_libm.c) */
+void mo_libm_eval(int fn, const float *x, const float *y, int n, float *out);
 /* small dense helpers exposed for tests */
 void mo_umeyama_f32(const float *src, const float *dst, int n, float T[16]);
 void mo_umeyama_f64(const double *src, const double *dst, int n, double T[16]);

@@ -354,6 +354,15 @@ def estimate_maps_transforms(clouds, params: Params):
     return [out[i].reshape(4, 4).T.copy() for i in range(m)], pairs[:npairs.value].copy()
 
 
+def libm_eval(fn, x, y=None):
+    """The host libm's expf (0), atanf (1), sinf (2), cosf (3) of x or atan2f(y, x) (4), element by element."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y if y is not None else x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().mo_libm_eval(int(fn), _p(x), _p(y), len(x), _p(out))
+    return out
+
+
 TRACE = np.dtype([("n_correspondences", "<i4"), ("n_inliers", "<i4"), ("icp_iterations", "<i4"), ("icp_correspondences", "<i4")])
 
 
