@@ -10,7 +10,7 @@
 //   3. per keypoint: sum of SPFH rows weighted by 1/d2 (d2 == 0 skipped), each 11-bin block scaled
 //      to sum 100.
 // Algorithmic traffic: SPFH 156 B per support point; weighting 132 B per gathered row.
-#include "device_util.hpp"
+#include "sorted_nb.hpp"
 
 namespace mm3d {
 
@@ -81,7 +81,7 @@ __device__ __forceinline__ void pair_features(const float4 &p1, const float4 &n1
   vx /= v_norm; vy /= v_norm; vz /= v_norm;
   const float wx = ay * vz - az * vy, wy = az * vx - ax * vz, wz = ax * vy - ay * vx;
   f2 = vx * bx + vy * by + vz * bz;
-  f1 = atan2f(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);
+  f1 = lm::atan2f_glibc(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);   // glibc's atan2f, bit for bit (libm_exact.hpp)
 }
 
 // static_cast<int>(floor(x)) with x86 semantics for NaN / out of range (INT_MIN -> clamped to 0)
@@ -217,75 +217,76 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
   }
 }
 
-// 3. weighting: one wave per keypoint.  Lanes scan 64 candidates at a time; for every hit the
-// first 33 lanes each accumulate their own bin of the neighbour's SPFH row (a coalesced 132 B read).
+// 3. weighting (FPFHEstimation::weightPointSPFHSignature): per keypoint, over its neighbours IN radiusSearch's
+// ORDER ((distance, index), d2 == 0 skipped): val = spfh[neighbour][bin] * (1 / d2); the bin takes "+= val" in
+// float, its 11-bin block's sum takes "+= val" in double, neighbour-major, bin-minor.  Both are chains, so the
+// neighbour lists are built in that order first (sorted_nb.hpp, payload = (d2, SPFH row)); a lane then owns one
+// (keypoint, 11-bin block) and walks the keypoint's list: 16 keypoints x 3 blocks = 48 chains per wave.
 __global__ void __launch_bounds__(256)
-k_fpfh_weight(const float4 *__restrict__ kp, int nk, GridView g, const int *__restrict__ row_of_sorted,
-              const float *__restrict__ spfh, float radius, float r2, float *__restrict__ desc /* [nk][33] */,
+k_fpfh_weight(const float4 *__restrict__ q_pts /* keypoints, Hilbert order, .w = keypoint index */, const int2 *__restrict__ items,
+              int n_items, GridView g, const int *__restrict__ row_of /* support row by original point index */,
+              const float *__restrict__ spfh, float radius, float r2, SnScratch scr, float *__restrict__ desc /* [nk][33] */,
               int *__restrict__ valid)
 {
-  const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (k >= nk) return;
-  const int lane = threadIdx.x & 63;
-  const float4 q = kp[k];
-  float acc = 0.0f;
-  double dsum = 0.0;
-  int total = 0;
-  const float ri = radius * 1.0001f + 1e-4f;
-  const bool xin = !(cell_floor(q.x + ri, g.minx, g.inv) < 0 || cell_floor(q.x - ri, g.minx, g.inv) > g.dx - 1);
-  const int x0 = clampi(cell_floor(q.x - ri, g.minx, g.inv), 0, g.dx - 1), x1 = clampi(cell_floor(q.x + ri, g.minx, g.inv), 0, g.dx - 1);
-  int y0 = cell_floor(q.y - ri, g.miny, g.inv), y1 = cell_floor(q.y + ri, g.miny, g.inv);
-  int z0 = cell_floor(q.z - ri, g.minz, g.inv), z1 = cell_floor(q.z + ri, g.minz, g.inv);
-  y0 = y0 < 0 ? 0 : y0; z0 = z0 < 0 ? 0 : z0;
-  y1 = y1 > g.dy - 1 ? g.dy - 1 : y1; z1 = z1 > g.dz - 1 ? g.dz - 1 : z1;
-  if (xin)
-    for (int z = z0; z <= z1; ++z)
-      for (int y = y0; y <= y1; ++y) {
-        const int row = (z * g.dy + y) * g.dx;
-        const int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
-        for (int j0 = b; j0 < e; j0 += kWave) {
-          const int j = j0 + lane;
-          float d2 = INFINITY;
-          int r = -1;
-          if (j < e) {
-            const float4 p = g.pts[j];
-            d2 = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
-            r = row_of_sorted[j];
-          }
-          const bool in = d2 < r2;
-          const unsigned long long m_in = __ballot(in);
-          total += __popcll(m_in);
-          unsigned long long m = __ballot(in && d2 != 0.0f);   // "minus the query point itself"
-          const float w = 1.0f / d2;
-          while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const float ws = __shfl(w, src, kWave);
-            const int rs = __shfl(r, src, kWave);
-            if (lane < kDim) {
-              const float val = spfh[(size_t)rs * kDim + lane] * ws;
-              dsum += (double)val;
-              acc += val;
-            }
+  __shared__ SnLds lds[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  SnLds &L = lds[wave];
+  const size_t slot = (size_t)blockIdx.x * 4 + wave;
+  unsigned long long *tmp = scr.tmp + slot * kSnEntries;
+  float2 *fin = (float2 *)scr.fin + slot * kSnEntries;
+  const int n_units = n_items * 4;
+  for (;;) {
+    const int unit = sn_claim_unit(scr.unit_ctr, n_units, lane);
+    if (unit < 0) break;
+    const int2 it = items[unit >> 2];
+    int first = (unit & 3) * kSnG;
+    int left = min(kSnG, it.y - first);
+    while (left > 0) {
+      const int pq = lane >> 2;
+      const float4 q = q_pts[it.x + first + (pq < left ? pq : 0)];
+      const int fit = sn_build_lists<float2>(g, L, q.x, q.y, q.z, left, radius, r2, tmp, fin, scr.error, lane,
+                                             [&](unsigned long long key) {
+                                               return make_float2(__uint_as_float((unsigned)(key >> 32)),
+                                                                  __int_as_float(row_of[(unsigned)(key & 0xffffffffull)]));
+                                             });
+      // chains: lane = keypoint * 3 + block
+      const int p = lane / 3, f = lane - p * 3;
+      if (p < fit) {
+        const int base = L.list_off[p], m = L.list_off[p + 1] - base;
+        float out[kBins];
+#pragma unroll
+        for (int b = 0; b < kBins; ++b) out[b] = 0.0f;
+        double sum = 0.0;
+        for (int e = 0; e < m; ++e) {
+          const float2 ent = fin[base + e];
+          if (ent.x == 0.0f) continue;                       // "minus the query point itself"
+          const float weight = 1.0f / ent.x;
+          const float *h = spfh + (size_t)__float_as_int(ent.y) * kDim + f * kBins;
+#pragma unroll
+          for (int b = 0; b < kBins; ++b) {
+            const float val = __fmul_rn(h[b], weight);
+            sum += (double)val;
+            out[b] = __fadd_rn(out[b], val);
           }
         }
-      }
-  // block sums over the three 11-bin groups
-  const int base = (lane < kDim) ? (lane / kBins) * kBins : 0;
-  double bs = 0.0;
+        const int k = __float_as_int(q_pts[it.x + first + p].w);
+        float *o = desc + (size_t)k * kDim + f * kBins;
+        if (m == 0) {
 #pragma unroll
-  for (int b = 0; b < kBins; ++b) bs += __shfl(dsum, base + b, kWave);
-  if (lane < kDim) {
-    float out;
-    if (total == 0) {
-      out = __uint_as_float(0x7fc00000u);
-    } else {
-      if (bs != 0.0) bs = 100.0 / bs;
-      out = acc * (float)bs;
+          for (int b = 0; b < kBins; ++b) o[b] = __uint_as_float(0x7fc00000u);
+        } else {
+          if (sum != 0.0) sum = 100.0 / sum;
+          const float sc = (float)sum;
+#pragma unroll
+          for (int b = 0; b < kBins; ++b) o[b] = __fmul_rn(out[b], sc);
+        }
+        if (f == 0) valid[k] = m != 0 ? 1 : 0;
+      }
+      wave_lds_fence();
+      first += fit;
+      left -= fit;
     }
-    desc[(size_t)k * kDim + lane] = out;
   }
-  if (lane == 0) valid[k] = total != 0 ? 1 : 0;
 }
 
 __global__ void k_compact_rows(const float *__restrict__ in, const int *__restrict__ flags, const int *__restrict__ pos,
@@ -316,7 +317,7 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
     // no surface: every descriptor is NaN and gets pruned
     res->n = 0; res->data = DevBuf<float>(c, 0);
     keypoints->pts = DevBuf<float4>(c, 0); keypoints->n = 0; keypoints->grids.clear(); keypoints->host.clear();
-    keypoints->have_bbox = false;
+    keypoints->reset_caches();
     return res;
   }
   DevBuf<int> in_set(c, (size_t)n + 1), pos(c, (size_t)n + 1);
@@ -340,9 +341,21 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
                 (const int2 *)points->wave_items.get(), n_items, g.view(), (const float4 *)normals->nrm.get(),
                 (const float4 *)nrm_sorted.get(), (const int *)in_set.get(), (const int *)pos.get(), (float)radius, r2, spfh.get());
   }
-  MM3D_LAUNCH(c, "fpfh_weight", (double)ns * 132.0 + nk * 132.0, k_fpfh_weight, dim3(div_up(nk, 4)), dim3(256), 0,
-              keypoints->pts.get(), nk, g.view(), (const int *)row_of.get(), (const float *)spfh.get(), (float)radius, r2,
-              raw.get(), valid.get());
+  {
+    // row of the support set by ORIGINAL point index (what a sorted list entry carries)
+    cloud_hilbert(c, keypoints);
+    const int nki = keypoints->n_wave_items;
+    SnLaunch<float2> sn(c, nki * 4);
+    SnScratch scr{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error()};
+    if (keypoints->n_finite)
+      MM3D_LAUNCH(c, "fpfh_weight", (double)ns * 132.0 + nk * 132.0, k_fpfh_weight, dim3(sn.blocks), dim3(256), 0,
+                  (const float4 *)keypoints->hil_pts.get(), (const int2 *)keypoints->wave_items.get(), nki, g.view(),
+                  (const int *)pos.get(), (const float *)spfh.get(), (float)radius, r2, scr, raw.get(), valid.get());
+    int *he = (int *)c->pin(64);
+    MM3D_HIP(hipMemcpyAsync(he, sn.error(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    if (*he) throw Error(MM3D_EUNSUPPORTED, "computeLocalDescriptors(FPFH): a keypoint has more than 16384 neighbours within the radius");
+  }
   // prune invalid descriptors and the same keypoints (features.cpp:118-143)
   DevBuf<int> vpos(c, (size_t)nk + 1);
   exclusive_scan_int(c, valid.get(), vpos.get(), (size_t)nk + 1);
@@ -367,7 +380,7 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
     keypoints->n = (size_t)nv;
     keypoints->grids.clear();
     keypoints->host.clear();
-    keypoints->have_bbox = false;
+    keypoints->reset_caches();
   }
   c->sync();
   return res;

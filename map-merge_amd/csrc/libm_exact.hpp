@@ -57,7 +57,12 @@ MM3D_HD uint64_t exp2f_tab(unsigned i)
   return T[i & 31u];
 }
 
-MM3D_HD float expf_glibc(float x)
+// the table as data, for kernels that keep it in LDS (a per-lane index into a constant array would be a
+// global load per call)
+MM3D_HD void exp2f_tab_copy(uint64_t *dst, int i) { dst[i] = exp2f_tab((unsigned)i); }
+
+template <class Tab>
+MM3D_HD float expf_glibc_t(float x, Tab &&tab)
 {
   const double xd = (double)x;
   const uint32_t abstop = (f2u(x) >> 20) & 0x7ffu;
@@ -77,7 +82,7 @@ MM3D_HD float expf_glibc(float x)
   const uint64_t ki = d2u(kd);
   kd -= Shift;
   const double r = fma(InvLn2N, xd, -kd);                    // the FMA build contracts z - kd with z's product
-  uint64_t t = exp2f_tab((unsigned)(ki & 31u));
+  uint64_t t = tab((unsigned)(ki & 31u));
   t += ki << (52 - 5);
   const double s = u2d(t);
   z = fma(C0, r, C1);
@@ -86,6 +91,11 @@ MM3D_HD float expf_glibc(float x)
   y = fma(z, r2, y);
   y = y * s;
   return (float)y;
+}
+
+MM3D_HD float expf_glibc(float x)
+{
+  return expf_glibc_t(x, [](unsigned i) { return exp2f_tab(i); });
 }
 
 // ---- sinf / cosf (|x| < 120) -----------------------------------------------------------------------

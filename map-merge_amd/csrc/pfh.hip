@@ -54,7 +54,7 @@ __device__ __forceinline__ void pfh_pair_features(const PfhNb &p1, const PfhNb &
   vx /= v_norm; vy /= v_norm; vz /= v_norm;
   const float wx = ay * vz - az * vy, wy = az * vx - ax * vz, wz = ax * vy - ay * vx;
   f2 = vx * bx + vy * by + vz * bz;
-  f1 = atan2f(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);
+  f1 = lm::atan2f_glibc(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);   // glibc's atan2f, bit for bit (libm_exact.hpp)
 }
 
 // pcl::computeRGBPairFeatures (features/src/pfh.cpp), PFHRGB: the frame always sits on p1 (no swap),
@@ -74,7 +74,7 @@ __device__ __forceinline__ void pfhrgb_pair_features(const PfhNb &p1, const PfhN
   vx /= v_norm; vy /= v_norm; vz /= v_norm;
   const float wx = ay * vz - az * vy, wy = az * vx - ax * vz, wz = ax * vy - ay * vx;
   f2 = vx * bx + vy * by + vz * bz;
-  f1 = atan2f(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);
+  f1 = lm::atan2f_glibc(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);   // glibc's atan2f, bit for bit (libm_exact.hpp)
   const unsigned c1 = __float_as_uint(p1.d2), c2 = __float_as_uint(p2.d2);
   float r[3];
 #pragma unroll
@@ -251,7 +251,7 @@ static mm3d_desc *compute_pfh_impl(Context *c, const mm3d_cloud *points, const m
   auto drop_all = [&]() {
     res->n = 0; res->data = DevBuf<float>(c, 0);
     keypoints->pts = DevBuf<float4>(c, 0); keypoints->n = 0; keypoints->grids.clear(); keypoints->host.clear();
-    keypoints->have_bbox = false;
+    keypoints->reset_caches();
   };
   if (g.n == 0 && !kRgb) { drop_all(); return res; }   // no surface: every PFH descriptor is NaN and gets pruned
   DevBuf<float> raw(c, (size_t)nk * kDim);
@@ -305,7 +305,7 @@ static mm3d_desc *compute_pfh_impl(Context *c, const mm3d_cloud *points, const m
     keypoints->n = (size_t)nv;
     keypoints->grids.clear();
     keypoints->host.clear();
-    keypoints->have_bbox = false;
+    keypoints->reset_caches();
   }
   c->sync();
   return res;

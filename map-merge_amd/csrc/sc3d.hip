@@ -165,7 +165,7 @@ k_sc3d(const float4 *__restrict__ kp, int nk, GridView g, const float4 *__restri
         }
         const float c0 = xa1 * pr2 - xa2 * pr1, c1 = xa2 * pr0 - xa0 * pr2, c2 = xa0 * pr1 - xa1 * pr0;
         const float cross_norm = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
-        float phi = atan2f(cross_norm, xa0 * pr0 + xa1 * pr1 + xa2 * pr2) * 57.29578f;
+        float phi = lm::atan2f_glibc(cross_norm, xa0 * pr0 + xa1 * pr1 + xa2 * pr2) * 57.29578f;
         phi = (c0 * nm.x + c1 * nm.y + c2 * nm.z) < 0.f ? (360.0f - phi) : phi;
         float n0 = po0, n1 = po1, n2v = po2;
         {
@@ -250,7 +250,7 @@ mm3d_desc *compute_sc3d(Context *c, const mm3d_cloud *points, const mm3d_normals
   auto drop_all = [&]() {
     res->n = 0; res->data = DevBuf<float>(c, 0);
     keypoints->pts = DevBuf<float4>(c, 0); keypoints->n = 0; keypoints->grids.clear(); keypoints->host.clear();
-    keypoints->have_bbox = false;
+    keypoints->reset_caches();
   };
   const float r2 = (float)(radius * radius);
   const Grid &g = cloud_grid(c, points, (float)(radius * 0.5));
@@ -324,7 +324,7 @@ mm3d_desc *compute_sc3d(Context *c, const mm3d_cloud *points, const mm3d_normals
     keypoints->n = (size_t)nv;
     keypoints->grids.clear();
     keypoints->host.clear();
-    keypoints->have_bbox = false;
+    keypoints->reset_caches();
   }
   c->sync();
   return res;

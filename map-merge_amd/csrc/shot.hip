@@ -480,7 +480,7 @@ mm3d_desc *compute_shot(Context *c, const mm3d_cloud *points, const mm3d_normals
   auto drop_all = [&]() {
     res->n = 0; res->data = DevBuf<float>(c, 0);
     keypoints->pts = DevBuf<float4>(c, 0); keypoints->n = 0; keypoints->grids.clear(); keypoints->host.clear();
-    keypoints->have_bbox = false;
+    keypoints->reset_caches();
   };
   if (g.n == 0) { drop_all(); return res; }
   const int n = (int)points->n;
@@ -545,7 +545,7 @@ mm3d_desc *compute_shot(Context *c, const mm3d_cloud *points, const mm3d_normals
     keypoints->n = (size_t)nv;
     keypoints->grids.clear();
     keypoints->host.clear();
-    keypoints->have_bbox = false;
+    keypoints->reset_caches();
   }
   c->sync();
   return res;

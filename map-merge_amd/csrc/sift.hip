@@ -17,8 +17,7 @@
 // points are closer than it (>= 25 <=> the violator is not among the 25 nearest).
 #include <cfloat>
 
-#include "device_util.hpp"
-
+#include "sorted_nb.hpp"
 
 namespace mm3d {
 
@@ -26,9 +25,6 @@ constexpr int kScales = 6;      // nr_scales_per_octave (3) + 3
 constexpr int kDog = 5;
 constexpr int kKnn = 25;
 constexpr int kSiftTile = 256;
-constexpr int kDogTile = 256;
-constexpr int kDogLanes = 4;               // lanes per query in the scale-space kernel (8: 3 % faster still)
-constexpr int kDogQ = 64 / kDogLanes;      // queries per pass
 
 struct SiftScales {
   float sigma_sqr[kScales];
@@ -42,92 +38,91 @@ __device__ __forceinline__ float intensity_of(float w)
   return (float)(299 * r + 587 * g + 114 * b) / 1000.0f;
 }
 
-// grid-sorted (x, y, z, intensity): what the scale-space walk reads
-__global__ void k_sift_pack(const float4 *__restrict__ sorted, const float4 *__restrict__ pts, int n, float4 *__restrict__ pv)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  float4 s = sorted[j];
-  s.w = intensity_of(pts[__float_as_int(s.w)].w);
-  pv[j] = s;
-}
-
-// computeScaleSpace: Gaussian-weighted mean intensity at 6 scales -> 5 differences
+// computeScaleSpace: Gaussian-weighted mean intensity at 6 scales -> 5 differences.
+// SIFTKeypoint::computeScaleSpace sums "value * w" and "w" over the neighbours IN radiusSearch's ORDER
+// ((distance, index); the loop even leaves with `break` at the first neighbour beyond 3 sigma), in float:
+// the sums are chains, so every point's neighbour list is built in that order first (sorted_nb.hpp) as
+// (d2, intensity) pairs, and the chains then run one per lane: 16 points per group, four lanes per point;
+// the supports are nested (3 sigma grows with the scale), so the lanes of a point take the scales
+// {5}, {4}, {3 then 2}, {1 then 0} -- about equal numbers of neighbours each.  w = expf(-0.5 d2 / sigma2)
+// is glibc's expf restated (libm_exact.hpp, its 2^(i/32) table in LDS).
 __global__ void __launch_bounds__(256)
-k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* pts = (xyz, intensity) */,
-           float radius, float r2, SiftScales sc, float *__restrict__ dog /* [n][5] by original index */)
+k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* .w = original index */,
+           const float4 *__restrict__ pts /* original order: rgba */, float radius, float r2, SiftScales sc, SnScratch scr,
+           float *__restrict__ dog /* [n][5] by original index */)
 {
-  __shared__ float4 s_pts[4][kDogTile];
-  __shared__ int s_off[4][64];
-  __shared__ int s_beg[4][64];
-  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  __shared__ SnLds lds[4];
+  __shared__ float resp[4][kSnG][kScales];
+  __shared__ uint64_t s_tab[32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = bid * 4 + wave;
-  const int2 it = item < n_items ? items[item] : make_int2(0, 0);
-  if (it.y == 0) return;                      // wave-uniform
-  const float ri = radius * 1.0001f + 1e-4f;
-  const float4 *sp = s_pts[wave];
-  // The item's 64 points are taken kDogQ at a time, kDogLanes LANES PER QUERY: a part of the patch has
-  // a tighter box (the candidates a lane tests that lie outside its own sphere are what this kernel
-  // pays for: 71 % of its lane-cycles with 64-query boxes), and the lanes of a query split the staged
-  // candidates (k = j, j + kDogLanes, ...), read kDogLanes different LDS addresses per instruction and
-  // add their partial sums at the end in a fixed order (butterfly: (l0 + l1) + (l2 + l3)).  The gain is
-  // modest (-10 %): lanes that look at different candidates rarely all miss a scale together.
-  const int j = lane & (kDogLanes - 1);
-  for (int sub = 0; sub * kDogQ < it.y; ++sub) {
-    const int qi = sub * kDogQ + lane / kDogLanes;
-    const bool valid = qi < it.y;
-    const float4 q = q_pts[it.x + (valid ? qi : sub * kDogQ)];
-    const float lx = wave_min_f(valid ? q.x : INFINITY), hx = wave_max_f(valid ? q.x : -INFINITY);
-    const float ly = wave_min_f(valid ? q.y : INFINITY), hy = wave_max_f(valid ? q.y : -INFINITY);
-    const float lz = wave_min_f(valid ? q.z : INFINITY), hz = wave_max_f(valid ? q.z : -INFINITY);
-    const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
-    const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
-    const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
-    float num[kScales], den[kScales];
-#pragma unroll
-    for (int s = 0; s < kScales; ++s) { num[s] = 0.f; den[s] = 0.f; }
-    wave_stream_box<kDogTile, 0>(g, x0, x1, y0, y1, z0, z1, s_pts[wave], (float4 *)nullptr, s_off[wave], s_beg[wave], lane,
-                                  [](int, float4 (&)[1]) {},
-                                  [&](int cnt) {
-                                    // The supports are nested (3 sigma_s grows with s), so the scales are
-                                    // visited from the widest down and a candidate outside scale s skips the
-                                    // narrower ones; the wave leaves the chain as soon as no lane is inside.
-                                    // (Per-lane hit bitsets were measured slower here: 90 instructions per
-                                    // gathered hit against ~35 per scale in this loop.)
-                                    if (!valid) return;
-                                    for (int k = j; k < cnt; k += kDogLanes) {
-                                      const float4 c = sp[k];
-                                      const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
-                                      if (!(d2 < r2)) continue;
-#pragma unroll
-                                      for (int s = kScales - 1; s >= 0; --s) {
-                                        if (!(d2 <= sc.thr9[s])) break;
-                                        const float w = expf(-0.5f * d2 / sc.sigma_sqr[s]);
-                                        num[s] += c.w * w;
-                                        den[s] += w;
-                                      }
-                                    }
-                                  },
-                                  // only points inside the quarter patch's bounding box grown by the radius can be in range
-                                  KeepInBox{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri});
-    // the query's four partial sums (all 64 lanes take part in the exchange)
-#pragma unroll
-    for (int s = 0; s < kScales; ++s)
-#pragma unroll
-      for (int o = 1; o < kDogLanes; o <<= 1) {
-        num[s] = __fadd_rn(num[s], __shfl_xor(num[s], o, kWave));
-        den[s] = __fadd_rn(den[s], __shfl_xor(den[s], o, kWave));
+  if (threadIdx.x < 32) lm::exp2f_tab_copy(s_tab, threadIdx.x);
+  __syncthreads();
+  SnLds &L = lds[wave];
+  const size_t slot = (size_t)blockIdx.x * 4 + wave;
+  unsigned long long *tmp = scr.tmp + slot * kSnEntries;
+  float2 *fin = (float2 *)scr.fin + slot * kSnEntries;
+  const int n_units = n_items * 4;
+  const int p = lane >> 2, sub = lane & 3;
+  // this lane's scales: first, then (for sub 2, 3) a second, narrower one
+  const int sA = sub == 0 ? 5 : (sub == 1 ? 4 : (sub == 2 ? 3 : 1));
+  const int sB = sub == 2 ? 2 : (sub == 3 ? 0 : -1);
+  const float sigA = sc.sigma_sqr[sA], thrA = sc.thr9[sA];
+  const float sigB = sB >= 0 ? sc.sigma_sqr[sB] : 1.0f, thrB = sB >= 0 ? sc.thr9[sB] : -1.0f;
+  for (;;) {
+    const int unit = sn_claim_unit(scr.unit_ctr, n_units, lane);
+    if (unit < 0) break;
+    const int2 it = items[unit >> 2];
+    int first = (unit & 3) * kSnG;
+    int left = min(kSnG, it.y - first);
+    while (left > 0) {
+      const float4 q = q_pts[it.x + first + (p < left ? p : 0)];
+      const int fit = sn_build_lists<float2>(g, L, q.x, q.y, q.z, left, radius, r2, tmp, fin, scr.error, lane,
+                                             [&](unsigned long long key) {
+                                               return make_float2(__uint_as_float((unsigned)(key >> 32)),
+                                                                  intensity_of(pts[(unsigned)(key & 0xffffffffull)].w));
+                                             });
+      {
+        const bool mine = p < fit;
+        const int base = mine ? L.list_off[p] : 0, m = mine ? L.list_off[p + 1] - base : 0;
+        int s = sA, e = 0;
+        float sig = sigA, thr = thrA, num = 0.0f, den = 0.0f;
+        bool active = mine;
+        while (__ballot(active)) {
+          if (active) {
+            bool adv = false;
+            if (e < m) {
+              const float2 ent = fin[base + e];
+              if (ent.x <= thr) {
+                const float w = lm::expf_glibc_t(-0.5f * ent.x / sig, [&](unsigned i) { return s_tab[i]; });
+                num = __fadd_rn(num, __fmul_rn(ent.y, w));
+                den = __fadd_rn(den, w);
+                ++e;
+                adv = true;
+              }
+            }
+            if (!adv) {                          // beyond 3 sigma (the CPU loop's break) or end of the list
+              resp[wave][p][s] = num / den;
+              if (s == sA && sB >= 0) { s = sB; sig = sigB; thr = thrB; e = 0; num = 0.0f; den = 0.0f; }
+              else active = false;
+            }
+          }
+        }
       }
-    if (valid && j == 0) {
-      float prev = num[0] / den[0];
-      float *o = dog + (size_t)__float_as_int(q.w) * kDog;
+      wave_lds_fence();
+      if (lane < fit) {
+        const float4 pq = q_pts[it.x + first + lane];
+        float *o = dog + (size_t)__float_as_int(pq.w) * kDog;
+        float prev = resp[wave][lane][0];
 #pragma unroll
-      for (int s = 1; s < kScales; ++s) {
-        const float cur = num[s] / den[s];
-        o[s - 1] = cur - prev;
-        prev = cur;
+        for (int s = 1; s < kScales; ++s) {
+          const float cur = resp[wave][lane][s];
+          o[s - 1] = cur - prev;
+          prev = cur;
+        }
       }
+      wave_lds_fence();
+      first += fit;
+      left -= fit;
     }
   }
 }
@@ -372,17 +367,20 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     const int n = (int)cur->n;
     cloud_hilbert(c, cur.get());                       // query order + wave work items
     const int n_items = cur->n_wave_items;
-    const unsigned nblocks = div_up(n_items, 4);
     // scale space on a grid with cell = r/2
     const Grid &gr = cloud_grid(c, cur.get(), max_radius * 0.5f);
-    DevBuf<float4> pv(c, gr.n);
     DevBuf<float> dog(c, (size_t)n * kDog);
-    MM3D_LAUNCH(c, "sift_pack", gr.n * 36.0, k_sift_pack, dim3(div_up(gr.n, 256)), dim3(256), 0, (const float4 *)gr.sorted.get(),
-                (const float4 *)cur->pts.get(), gr.n, pv.get());
-    GridView gvr = gr.view();
-    gvr.pts = pv.get();
-    MM3D_LAUNCH(c, "sift_dog", gr.n * 36.0, k_sift_dog, dim3(nblocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
-                (const int2 *)cur->wave_items.get(), n_items, gvr, max_radius, r2, sc, dog.get());
+    {
+      SnLaunch<float2> sn(c, n_items * 4);
+      SnScratch scr{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error()};
+      MM3D_LAUNCH(c, "sift_dog", gr.n * 36.0, k_sift_dog, dim3(sn.blocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
+                  (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, scr,
+                  dog.get());
+      int *he = (int *)c->pin(64);
+      MM3D_HIP(hipMemcpyAsync(he, sn.error(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      c->sync();                                // the scratch goes back to the pool after the kernel is done with it
+      if (*he) throw Error(MM3D_EUNSUPPORTED, "detectKeypoints(SIFT): a point has more than 16384 neighbours within 3 sigma");
+    }
     // the extremum test walks the same grid (25 neighbours lie within ~3 leaf sizes on a surface, i.e.
     // within one of these cells): one radix sort per octave instead of two
     const Grid &gk = gr;

@@ -81,6 +81,12 @@ struct mm3d_cloud {
   mm3d::DevBuf<uint32_t> hil_keys;                     // their sort keys: (Hilbert index of the 0.25 m column << 10) | z cell
   mm3d::DevBuf<int2> wave_items;                       // {first point, count <= 64}: one compact patch per wave
   int n_wave_items = 0;
+  // the points were replaced (descriptor pruning): everything derived from them goes
+  void reset_caches()
+  {
+    grids.clear(); host.clear(); have_bbox = false; n_finite = 0;
+    hil_pts = mm3d::DevBuf<float4>(); hil_keys = mm3d::DevBuf<uint32_t>(); wave_items = mm3d::DevBuf<int2>(); n_wave_items = 0;
+  }
 };
 
 struct mm3d_normals {
