@@ -6,12 +6,14 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-parameter"
-mkdir -p build
+BUILD=${BUILD_DIR:-build}
+OUT=${OUT:-libmm3d.so}
+mkdir -p $BUILD
 SRCS="libm_debug.hip grid.hip filters.hip normals.hip sift.hip harris.hip fpfh.hip pfh.hip rsd.hip shot.hip sc3d.hip desc_knn.hip registration.hip nn.hip linalg.cpp host_pipeline.cpp capi.cpp"
 OBJS=""
 pids=()
 for s in $SRCS; do
-  o=build/${s%.*}.o
+  o=$BUILD/${s%.*}.o
   OBJS="$OBJS $o"
   if [ ! -f "$o" ] || [ "csrc/$s" -nt "$o" ] || [ -n "$(find csrc ../include -name '*.h*' -newer "$o" 2>/dev/null)" ]; then
     ( $HIPCC $FLAGS -x hip -c "csrc/$s" -o "$o" ${EXTRA:-} ) &
@@ -19,5 +21,5 @@ for s in $SRCS; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libmm3d.so $OBJS
-echo "built $(pwd)/libmm3d.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
+echo "built $(pwd)/$OUT"

@@ -257,16 +257,28 @@ k_fpfh_weight(const float4 *__restrict__ q_pts /* keypoints, Hilbert order, .w =
 #pragma unroll
         for (int b = 0; b < kBins; ++b) out[b] = 0.0f;
         double sum = 0.0;
-        for (int e = 0; e < m; ++e) {
-          const float2 ent = fin[base + e];
-          if (ent.x == 0.0f) continue;                       // "minus the query point itself"
-          const float weight = 1.0f / ent.x;
-          const float *h = spfh + (size_t)__float_as_int(ent.y) * kDim + f * kBins;
+        // four list entries and their SPFH blocks are requested at a time
+        for (int e0 = 0; e0 < m; e0 += 4) {
+          float2 ent[4];
+          float hv[4][kBins];
 #pragma unroll
-          for (int b = 0; b < kBins; ++b) {
-            const float val = __fmul_rn(h[b], weight);
-            sum += (double)val;
-            out[b] = __fadd_rn(out[b], val);
+          for (int u = 0; u < 4; ++u) ent[u] = fin[base + min(e0 + u, m - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float *h = spfh + (size_t)__float_as_int(ent[u].y) * kDim + f * kBins;
+#pragma unroll
+            for (int b = 0; b < kBins; ++b) hv[u][b] = h[b];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (e0 + u >= m || ent[u].x == 0.0f) continue;  // "minus the query point itself"
+            const float weight = 1.0f / ent[u].x;
+#pragma unroll
+            for (int b = 0; b < kBins; ++b) {
+              const float val = __fmul_rn(hv[u][b], weight);
+              sum += (double)val;
+              out[b] = __fadd_rn(out[b], val);
+            }
           }
         }
         const int k = __float_as_int(q_pts[it.x + first + p].w);
@@ -345,7 +357,7 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
     // row of the support set by ORIGINAL point index (what a sorted list entry carries)
     cloud_hilbert(c, keypoints);
     const int nki = keypoints->n_wave_items;
-    SnLaunch<float2> sn(c, nki * 4);
+    SnLaunch<float2> sn(c, nki * 4, points->n);
     SnScratch scr{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error()};
     if (keypoints->n_finite)
       MM3D_LAUNCH(c, "fpfh_weight", (double)ns * 132.0 + nk * 132.0, k_fpfh_weight, dim3(sn.blocks), dim3(256), 0,

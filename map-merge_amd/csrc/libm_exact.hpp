@@ -61,16 +61,19 @@ MM3D_HD uint64_t exp2f_tab(unsigned i)
 // global load per call)
 MM3D_HD void exp2f_tab_copy(uint64_t *dst, int i) { dst[i] = exp2f_tab((unsigned)i); }
 
-template <class Tab>
+// kCheck = false: the caller guarantees |x| < 88 (no overflow / underflow / NaN handling needed)
+template <bool kCheck = true, class Tab>
 MM3D_HD float expf_glibc_t(float x, Tab &&tab)
 {
   const double xd = (double)x;
-  const uint32_t abstop = (f2u(x) >> 20) & 0x7ffu;
-  if (abstop >= (0x42b00000u >> 20)) {                       // |x| >= 88 or NaN
-    if (f2u(x) == 0xff800000u) return 0.0f;                  // -inf
-    if (abstop >= (0x7f800000u >> 20)) return x + x;         // +inf, NaN
-    if (x > 88.72283172607421875f) return INFINITY;          // 0x1.62e42ep6f: overflow
-    if (x < -103.972076416015625f) return 0.0f;              // -0x1.9fe368p6f: underflow to zero
+  if (kCheck) {
+    const uint32_t abstop = (f2u(x) >> 20) & 0x7ffu;
+    if (abstop >= (0x42b00000u >> 20)) {                     // |x| >= 88 or NaN
+      if (f2u(x) == 0xff800000u) return 0.0f;                // -inf
+      if (abstop >= (0x7f800000u >> 20)) return x + x;       // +inf, NaN
+      if (x > 88.72283172607421875f) return INFINITY;        // 0x1.62e42ep6f: overflow
+      if (x < -103.972076416015625f) return 0.0f;            // -0x1.9fe368p6f: underflow to zero
+    }
   }
   constexpr double InvLn2N = 0x1.71547652b82fep+0 * 32.0;
   constexpr double Shift = 0x1.8p+52;
@@ -95,7 +98,24 @@ MM3D_HD float expf_glibc_t(float x, Tab &&tab)
 
 MM3D_HD float expf_glibc(float x)
 {
-  return expf_glibc_t(x, [](unsigned i) { return exp2f_tab(i); });
+  return expf_glibc_t<true>(x, [](unsigned i) { return exp2f_tab(i); });
+}
+
+// ---- a / b, correctly rounded, for a divisor known in advance --------------------------------------
+// With rcp = RN(1 / b) prepared on the host: q0 = RN(a * rcp) is within 2 ulp of a / b, one Newton step on
+// the exact remainder (fma) makes it faithful, a second one rounds it correctly (Markstein, "Computation of
+// elementary functions on the IBM RISC System/6000 processor", Theorem: the final fma rounds correctly when the
+// reciprocal is the correctly rounded one and the quotient estimate is within one ulp).  Five operations
+// instead of the hardware's division macro (ten).  Valid away from overflow / underflow of a / b and of the
+// remainders, which is what fdiv_const_ok() checks for the callers' ranges; tests/test_libm_exact.py sweeps it
+// against IEEE division.
+MM3D_HD float fdiv_const(float a, float b, float rcp)
+{
+  float q = a * rcp;
+  float r = fmaf(-b, q, a);
+  q = fmaf(r, rcp, q);
+  r = fmaf(-b, q, a);
+  return fmaf(r, rcp, q);
 }
 
 // ---- sinf / cosf (|x| < 120) -----------------------------------------------------------------------

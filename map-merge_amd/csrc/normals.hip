@@ -40,25 +40,36 @@ k_normals(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int 
       const float4 q = q_pts[it.x + first + (p < left ? p : 0)];
       const int fit = sn_build_lists<float4>(g, L, q.x, q.y, q.z, left, radius, r2, tmp, fin, sc.error, lane,
                                              [&](unsigned long long key) { return pts[(unsigned)(key & 0xffffffffull)]; });
+      SN_TICK(t_chain);
       // chains: lane (p, sub) owns accumulators sub, sub + 4, sub + 8 of a = {xx, xy, xz, yy, yz, zz, x, y, z}
       if (p < fit) {
         const int base = L.list_off[p], m = L.list_off[p + 1] - base;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int e = 0; e < m; ++e) {
-          const float4 c = fin[base + e];
-          // u * v per accumulator, rounded, then added (the CPU path's a[k] += p.u * p.v)
-          const float u0 = sub == 3 ? c.y : c.x;                                  // xx, xy, xz | yy
-          const float v0 = sub == 0 ? c.x : (sub == 2 ? c.z : c.y);
-          const float u1 = sub == 0 ? c.y : (sub == 1 ? c.z : (sub == 2 ? c.x : c.y));   // yz, zz, x, y
-          const float v1 = sub <= 1 ? c.z : 1.0f;
-          a0 = __fadd_rn(a0, __fmul_rn(u0, v0));
-          a1 = __fadd_rn(a1, __fmul_rn(u1, v1));
-          if (sub == 0) a2 = __fadd_rn(a2, c.z);                                  // z
+        // eight list entries are requested at a time (the list is L2-resident scratch: one round trip per window)
+        for (int e0 = 0; e0 < m; e0 += 8) {
+          float4 cw[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) cw[u] = fin[base + min(e0 + u, m - 1)];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (e0 + u < m) {
+              const float4 c = cw[u];
+              // u * v per accumulator, rounded, then added (the CPU path's a[k] += p.u * p.v)
+              const float u0 = sub == 3 ? c.y : c.x;                                  // xx, xy, xz | yy
+              const float v0 = sub == 0 ? c.x : (sub == 2 ? c.z : c.y);
+              const float u1 = sub == 0 ? c.y : (sub == 1 ? c.z : (sub == 2 ? c.x : c.y));   // yz, zz, x, y
+              const float v1 = sub <= 1 ? c.z : 1.0f;
+              a0 = __fadd_rn(a0, __fmul_rn(u0, v0));
+              a1 = __fadd_rn(a1, __fmul_rn(u1, v1));
+              if (sub == 0) a2 = __fadd_rn(a2, c.z);                                  // z
+            }
+          }
         }
         sums[wave][p][sub] = a0;
         sums[wave][p][sub + 4] = a1;
         if (sub == 0) { sums[wave][p][8] = a2; cnts[wave][p] = m; }
       }
+      SN_TOCK(5, t_chain);
       wave_lds_fence();
       // one lane per point: covariance, eigen33, flip (features/normal_3d.h computePointNormal)
       if (lane < fit) {
@@ -93,6 +104,15 @@ k_normals(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int 
   }
 }
 
+#ifdef MM3D_SN_STATS
+extern "C" void mm3d_debug_sn_stats(unsigned long long *out, int reset)
+{
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sn_stats), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sn_stats), z, sizeof(z)); }
+}
+#endif
+
 __global__ void k_fill_nan(float4 *out, size_t n)
 {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,7 +132,7 @@ mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius)
   if (g.n) {
     cloud_hilbert(c, in);
     const int n_items = in->n_wave_items;
-    SnLaunch<float4> sn(c, n_items * 4);
+    SnLaunch<float4> sn(c, n_items * 4, in->n);
     SnScratch sc{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error()};
     MM3D_LAUNCH(c, "normals_radius", g.n * 28.0, k_normals, dim3(sn.blocks), dim3(256), 0, (const float4 *)in->hil_pts.get(),
                 (const int2 *)in->wave_items.get(), n_items, g.view(), (const float4 *)in->pts.get(), (float)radius, r2, sc,

@@ -29,6 +29,7 @@ constexpr int kSiftTile = 256;
 struct SiftScales {
   float sigma_sqr[kScales];
   float thr9[kScales];          // 9 * sigma_sqr
+  float rcp[kScales];           // RN(1 / sigma_sqr), for the correctly rounded division by a constant (lm::fdiv_const)
 };
 
 __device__ __forceinline__ float intensity_of(float w)
@@ -66,8 +67,8 @@ k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int
   // this lane's scales: first, then (for sub 2, 3) a second, narrower one
   const int sA = sub == 0 ? 5 : (sub == 1 ? 4 : (sub == 2 ? 3 : 1));
   const int sB = sub == 2 ? 2 : (sub == 3 ? 0 : -1);
-  const float sigA = sc.sigma_sqr[sA], thrA = sc.thr9[sA];
-  const float sigB = sB >= 0 ? sc.sigma_sqr[sB] : 1.0f, thrB = sB >= 0 ? sc.thr9[sB] : -1.0f;
+  const float sigA = sc.sigma_sqr[sA], thrA = sc.thr9[sA], rcpA = sc.rcp[sA];
+  const float sigB = sB >= 0 ? sc.sigma_sqr[sB] : 1.0f, thrB = sB >= 0 ? sc.thr9[sB] : -1.0f, rcpB = sB >= 0 ? sc.rcp[sB] : 1.0f;
   for (;;) {
     const int unit = sn_claim_unit(scr.unit_ctr, n_units, lane);
     if (unit < 0) break;
@@ -81,33 +82,45 @@ k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int
                                                return make_float2(__uint_as_float((unsigned)(key >> 32)),
                                                                   intensity_of(pts[(unsigned)(key & 0xffffffffull)].w));
                                              });
+      SN_TICK(t_chain);
       {
         const bool mine = p < fit;
         const int base = mine ? L.list_off[p] : 0, m = mine ? L.list_off[p + 1] - base : 0;
         int s = sA, e = 0;
-        float sig = sigA, thr = thrA, num = 0.0f, den = 0.0f;
+        float sig = sigA, thr = thrA, rcp = rcpA, num = 0.0f, den = 0.0f;
         bool active = mine;
         while (__ballot(active)) {
           if (active) {
-            bool adv = false;
-            if (e < m) {
-              const float2 ent = fin[base + e];
-              if (ent.x <= thr) {
-                const float w = lm::expf_glibc_t(-0.5f * ent.x / sig, [&](unsigned i) { return s_tab[i]; });
-                num = __fadd_rn(num, __fmul_rn(ent.y, w));
-                den = __fadd_rn(den, w);
-                ++e;
-                adv = true;
+            // eight list entries are requested at a time (L2-resident scratch: one round trip per window);
+            // past the end of the list they read as "beyond 3 sigma"
+            float2 ent[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ent[u] = (e + u < m) ? fin[base + e + u] : make_float2(INFINITY, 0.0f);
+            bool brk = false;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              if (!brk) {
+                if (ent[u].x <= thr) {
+                  // -0.5f * d2 / sigma_sqr with the division correctly rounded (where fdiv_const's remainders would
+                  // underflow, |x| < 2^-96, expf is 1.0f whatever the quotient's last bit); x is in [-4.5, 0]
+                  const float w = lm::expf_glibc_t<false>(lm::fdiv_const(-0.5f * ent[u].x, sig, rcp), [&](unsigned i) { return s_tab[i]; });
+                  num = __fadd_rn(num, __fmul_rn(ent[u].y, w));
+                  den = __fadd_rn(den, w);
+                } else {
+                  brk = true;
+                }
               }
             }
-            if (!adv) {                          // beyond 3 sigma (the CPU loop's break) or end of the list
+            e += 8;
+            if (brk) {                           // beyond 3 sigma (the CPU loop's break) or end of the list
               resp[wave][p][s] = num / den;
-              if (s == sA && sB >= 0) { s = sB; sig = sigB; thr = thrB; e = 0; num = 0.0f; den = 0.0f; }
+              if (s == sA && sB >= 0) { s = sB; sig = sigB; thr = thrB; rcp = rcpB; e = 0; num = 0.0f; den = 0.0f; }
               else active = false;
             }
           }
         }
       }
+      SN_TOCK(5, t_chain);
       wave_lds_fence();
       if (lane < fit) {
         const float4 pq = q_pts[it.x + first + lane];
@@ -126,6 +139,15 @@ k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int
     }
   }
 }
+
+#ifdef MM3D_SN_STATS
+extern "C" void mm3d_debug_sn_stats_sift(unsigned long long *out, int reset)
+{
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sn_stats), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sn_stats), z, sizeof(z)); }
+}
+#endif
 
 // per point, in the grid's sorted order, two float4: (mn1, mn2, mn3, mx1) and (mx2, mx3, -, -)
 __global__ void k_sift_dogx(const float4 *__restrict__ sorted, const float *__restrict__ dog, int n, float4 *__restrict__ dogx)
@@ -361,7 +383,11 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     for (int i = 0; i < kScales; ++i)
       scales[i] = scale * powf(2.0f, (1.0f * (float)i - 1.0f) / (float)nr_scales);
     SiftScales sc;
-    for (int i = 0; i < kScales; ++i) { sc.sigma_sqr[i] = powf(scales[i], 2.0f); sc.thr9[i] = 9 * sc.sigma_sqr[i]; }
+    for (int i = 0; i < kScales; ++i) {
+      sc.sigma_sqr[i] = powf(scales[i], 2.0f);
+      sc.thr9[i] = 9 * sc.sigma_sqr[i];
+      sc.rcp[i] = (float)(1.0 / (double)sc.sigma_sqr[i]);
+    }
     const float max_radius = 3.0f * scales[kScales - 1];
     const float r2 = (float)((double)max_radius * (double)max_radius);
     const int n = (int)cur->n;
@@ -371,7 +397,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     const Grid &gr = cloud_grid(c, cur.get(), max_radius * 0.5f);
     DevBuf<float> dog(c, (size_t)n * kDog);
     {
-      SnLaunch<float2> sn(c, n_items * 4);
+      SnLaunch<float2> sn(c, n_items * 4, cur->n);
       SnScratch scr{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error()};
       MM3D_LAUNCH(c, "sift_dog", gr.n * 36.0, k_sift_dog, dim3(sn.blocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
                   (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, scr,

@@ -16,9 +16,11 @@
 //   pass 2  the same pairs again: the atomic's return value is the pair's slot inside its bucket; the
 //           64-bit key (distance bits << 32 | original index) goes to the wave's scratch list,
 //   rank    inside a bucket (a handful of keys) every key counts the smaller keys of its bucket and
-//           lands at its final place, as the payload the consumer's chains read.
+//           lands at its final place, as the payload the consumer's chains read; the keys of several
+//           queries at a time are pulled into LDS (the tile's memory) for that, so the inner loop
+//           never waits for global memory.
 // The lists live in a per-wave global scratch region that is rewritten for every group (a few tens
-// of KB that stay in L2 / Infinity Cache); LDS holds the tile and the histograms (12.6 KB per wave).
+// of KB that stay in L2 / Infinity Cache); LDS holds the tile and the histograms (8.6 KB per wave).
 // The consumer then runs its float chains, one chain per lane, over the sorted payloads.
 //
 // Kernels are persistent: a fixed number of blocks, each wave claims units (work item, quarter) from
@@ -34,13 +36,39 @@ constexpr int kSnNB = 128;          // distance buckets per query
 constexpr int kSnTile = 256;        // staged candidates per tile
 constexpr int kSnEntries = 16384;   // scratch list entries per wave (sum over the group's queries)
 
+constexpr int kSnRank = kSnTile * 2;   // 64-bit keys that fit the tile's memory
+
 struct SnLds {
-  float4 tile[kSnTile];
+  float4 tile[kSnTile];             // staged candidates; during the rank step: kSnRank keys
   int off[64], beg[64];
-  unsigned cnt[kSnG][kSnNB / 2];    // pass 1: counts (2 x u16); then bucket starts
-  unsigned pos[kSnG][kSnNB / 2];    // pass 2: running positions; then bucket ends
+  unsigned cnt[kSnG][kSnNB / 2];    // pass 1: counts (2 x u16); then bucket starts; after pass 2: bucket ENDS
   int list_off[kSnG + 1];
 };
+
+// start of bucket b = end of bucket b - 1 (cnt holds the ends once pass 2 has filled every bucket)
+__device__ __forceinline__ int sn_bucket_start(const unsigned *ends, int b)
+{
+  if (b == 0) return 0;
+  const unsigned w = ends[(b - 1) >> 1];
+  return (int)(((b - 1) & 1) ? (w >> 16) : (w & 0xffffu));
+}
+__device__ __forceinline__ int sn_bucket_end(const unsigned *ends, int b)
+{
+  const unsigned w = ends[b >> 1];
+  return (int)((b & 1) ? (w >> 16) : (w & 0xffffu));
+}
+
+// instrumentation build (-DMM3D_SN_STATS): 100 MHz ticks per phase, summed over waves (lane 0)
+#ifdef MM3D_SN_STATS
+__device__ unsigned long long g_sn_stats[16];   // 0 groups, 1 pass 1, 2 prefix, 3 pass 2, 4 rank, 5 chains (consumer), 6 queries, 7 list entries, 8 staged candidates
+#define SN_TICK(var_) const long long var_ = wall_clock64()
+#define SN_TOCK(i_, from_) do { if (lane == 0) atomicAdd(&g_sn_stats[i_], (unsigned long long)(wall_clock64() - (from_))); } while (0)
+#define SN_COUNT(i_, v_) do { if (lane == 0) atomicAdd(&g_sn_stats[i_], (unsigned long long)(v_)); } while (0)
+#else
+#define SN_TICK(var_)
+#define SN_TOCK(i_, from_)
+#define SN_COUNT(i_, v_)
+#endif
 
 struct SnScratch {
   unsigned long long *tmp;          // [waves][kSnEntries] keys in bucket order
@@ -74,7 +102,7 @@ __device__ __forceinline__ int sn_claim_unit(int *unit_ctr, int n_units, int lan
 // (4 lanes per query); g <= kSnG queries are live.  On return L.list_off[p] .. L.list_off[p + 1] is query
 // p's range in `fin` (payloads in (d2, index) order) for p < the returned count g' <= g (g' < g only when
 // the scratch region cannot hold the whole group: the caller runs the rest as the next group).
-// make(key) -> Payload is called once per list entry with key = d2 bits << 32 | original index.
+// make(key) -> Payload is called once per list entry with key = d2 bits << 32 | original index (< 2^28).
 template <class Payload, class Make>
 __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float qx, float qy, float qz, int n_q, float radius, float r2,
                                               unsigned long long *tmp, Payload *fin, int *error, int lane, Make &&make)
@@ -91,9 +119,13 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
   const float bscale = (float)kSnNB / r2;
   for (int p = 0; p < kSnG; ++p) L.cnt[p][lane] = 0u;
   wave_lds_fence();
+  SN_TICK(t_p1);
+  SN_COUNT(0, 1);
+  SN_COUNT(6, n_q);
   // pass 1: histograms
   wave_stream_box<kSnTile, 0>(g, x0, x1, y0, y1, z0, z1, L.tile, (float4 *)nullptr, L.off, L.beg, lane, [](int, float4 (&)[1]) {},
                               [&](int n) {
+                                SN_COUNT(8, n);
                                 float4 c[kSnTile / kWave];
 #pragma unroll
                                 for (int u = 0; u < kSnTile / kWave; ++u) c[u] = L.tile[lane + u * kWave];
@@ -101,6 +133,7 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
                                   const float px = sn_readlane(qx, p * 4), py = sn_readlane(qy, p * 4), pz = sn_readlane(qz, p * 4);
 #pragma unroll
                                   for (int u = 0; u < kSnTile / kWave; ++u) {
+                                    if (u * kWave >= n) break;                    // wave-uniform: slots beyond the tile's fill
                                     const float d2 = dist2(px, py, pz, c[u].x, c[u].y, c[u].z);
                                     if (lane + u * kWave < n && d2 < r2) {
                                       const int b = sn_bucket(d2, bscale);
@@ -111,6 +144,8 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
                               },
                               keep);
   wave_lds_fence();
+  SN_TOCK(1, t_p1);
+  SN_TICK(t_pre);
   // counts -> bucket starts; list offsets
   int total = 0, fit = 0;
   for (int p = 0; p < n_q; ++p) {
@@ -126,9 +161,7 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
     const int m = __builtin_amdgcn_readlane(incl, kWave - 1);
     const bool ok = fit == p && total + m <= kSnEntries && m <= 0xffff;
     if (ok) {
-      const unsigned st = (unsigned)excl | ((unsigned)(excl + c0) << 16);
-      L.cnt[p][lane] = st;
-      L.pos[p][lane] = st;
+      L.cnt[p][lane] = (unsigned)excl | ((unsigned)(excl + c0) << 16);
       if (lane == 0) L.list_off[p] = total;
       total += m;
       fit = p + 1;
@@ -142,6 +175,9 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
     return 1;
   }
   wave_lds_fence();
+  SN_TOCK(2, t_pre);
+  SN_COUNT(7, total);
+  SN_TICK(t_p2);
   // pass 2: keys into their buckets
   wave_stream_box<kSnTile, 0>(g, x0, x1, y0, y1, z0, z1, L.tile, (float4 *)nullptr, L.off, L.beg, lane, [](int, float4 (&)[1]) {},
                               [&](int n) {
@@ -153,32 +189,62 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
                                   const int base = L.list_off[p];
 #pragma unroll
                                   for (int u = 0; u < kSnTile / kWave; ++u) {
+                                    if (u * kWave >= n) break;
                                     const float d2 = dist2(px, py, pz, c[u].x, c[u].y, c[u].z);
                                     if (lane + u * kWave < n && d2 < r2) {
                                       const int b = sn_bucket(d2, bscale);
-                                      const unsigned old = atomicAdd(&L.pos[p][b >> 1], (b & 1) ? 0x10000u : 1u);
+                                      const unsigned old = atomicAdd(&L.cnt[p][b >> 1], (b & 1) ? 0x10000u : 1u);
                                       const int at = (int)((b & 1) ? (old >> 16) : (old & 0xffffu));
-                                      tmp[base + at] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(c[u].w);
+                                      // key = distance bits | query (4 bits) | original index (28 bits): inside one query's list the
+                                      // order is (distance, index); the query number spares the rank step a search
+                                      tmp[base + at] = ((unsigned long long)__float_as_uint(d2) << 32) | ((unsigned long long)p << 28) |
+                                                       (unsigned long long)__float_as_uint(c[u].w);
                                     }
                                   }
                                 }
                               },
                               keep);
   wave_lds_fence();
-  // rank inside the buckets -> final order
-  for (int p = 0; p < fit; ++p) {
-    const int base = L.list_off[p], m = L.list_off[p + 1] - base;
-    for (int e = lane; e < m; e += kWave) {
-      const unsigned long long key = tmp[base + e];
-      const int b = sn_bucket(__uint_as_float((unsigned)(key >> 32)), bscale);
-      const unsigned ws = L.cnt[p][b >> 1], we = L.pos[p][b >> 1];
-      const int s = (int)((b & 1) ? (ws >> 16) : (ws & 0xffffu)), t = (int)((b & 1) ? (we >> 16) : (we & 0xffffu));
-      int r = 0;
-      for (int j = s; j < t; ++j) r += tmp[base + j] < key ? 1 : 0;
-      fin[base + s + r] = make(key);
+  SN_TOCK(3, t_p2);
+  SN_TICK(t_rank);
+  // rank inside the buckets -> final order.  Runs of consecutive queries whose keys fit the tile's memory are
+  // pulled into LDS together (one global round trip per run), ranked there and written out as payloads.
+  unsigned long long *kbuf = reinterpret_cast<unsigned long long *>(L.tile);
+  for (int p0 = 0; p0 < fit;) {
+    const int base0 = L.list_off[p0];
+    int p1 = p0 + 1;
+    while (p1 < fit && L.list_off[p1 + 1] - base0 <= kSnRank) ++p1;
+    const int cnt = L.list_off[p1] - base0;
+    if (cnt <= kSnRank) {
+      for (int e = lane; e < cnt; e += kWave) kbuf[e] = tmp[base0 + e];
+      wave_lds_fence();
+      for (int e = lane; e < cnt; e += kWave) {
+        const unsigned long long key = kbuf[e];
+        const int p = (int)((key >> 28) & 15u);
+        const int pb = L.list_off[p] - base0;
+        const int b = sn_bucket(__uint_as_float((unsigned)(key >> 32)), bscale);
+        const int bs = sn_bucket_start(L.cnt[p], b), be = sn_bucket_end(L.cnt[p], b);
+        int r = 0;
+        for (int j = bs; j < be; ++j) r += kbuf[pb + j] < key ? 1 : 0;
+        fin[base0 + pb + bs + r] = make(key & 0xffffffff0fffffffull);
+      }
+      wave_lds_fence();
+    } else {
+      // one query with more keys than the tile holds: rank against global memory
+      const int m = cnt;
+      for (int e = lane; e < m; e += kWave) {
+        const unsigned long long key = tmp[base0 + e];
+        const int b = sn_bucket(__uint_as_float((unsigned)(key >> 32)), bscale);
+        const int bs = sn_bucket_start(L.cnt[p0], b), be = sn_bucket_end(L.cnt[p0], b);
+        int r = 0;
+        for (int j = bs; j < be; ++j) r += tmp[base0 + j] < key ? 1 : 0;
+        fin[base0 + bs + r] = make(key & 0xffffffff0fffffffull);
+      }
     }
+    p0 = p1;
   }
   wave_lds_fence();
+  SN_TOCK(4, t_rank);
   return fit;
 }
 
@@ -189,11 +255,13 @@ struct SnLaunch {
   DevBuf<Payload> fin;
   DevBuf<int> ctr;                   // kXcds unit counters + the error flag
   unsigned blocks = 0;
-  SnLaunch(Context *c, int n_units, int waves_per_block = 4)
+  SnLaunch(Context *c, int n_units, size_t n_surface_points, int waves_per_block = 4)
   {
-    // enough blocks to fill the chip three times over, never more than there are units
+    if (n_surface_points >= ((size_t)1 << 28))
+      throw Error(MM3D_EUNSUPPORTED, "sorted neighbour lists: clouds of 2^28 points or more are not supported");
+    // four blocks of 8.6 KB x 4 per CU fit the LDS; never more blocks than there are units
     const unsigned want = div_up((size_t)n_units, (size_t)waves_per_block);
-    blocks = want < 768u ? (want ? want : 1u) : 768u;
+    blocks = want < 1024u ? (want ? want : 1u) : 1024u;
     tmp = DevBuf<unsigned long long>(c, (size_t)blocks * waves_per_block * kSnEntries);
     fin = DevBuf<Payload>(c, (size_t)blocks * waves_per_block * kSnEntries);
     ctr = DevBuf<int>(c, kXcds + 1);
