@@ -23,10 +23,16 @@
 #include <map_merge_3d/map_merging.h>
 #include <pcl/conversions.h>
 
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
 #include <cstdlib>
-#include <mutex>
+#include <cstring>
+#include <initializer_list>
+#include <ostream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "mm3d.h"
 
@@ -34,41 +40,57 @@ namespace map_merge_3d
 {
 namespace mm3d_shim
 {
-// One engine per process, created on first use (the reference functions are stateless free
-// functions; the context only caches device memory and carries the rand() replay).
+inline mm3d_ctx *make_ctx(int streams)
+{
+  const char *d = std::getenv("MM3D_DEVICE");
+  mm3d_ctx *p = nullptr;
+  if (mm3d_create(d ? std::atoi(d) : 0, &p) != MM3D_OK) throw std::runtime_error("mm3d: no MI355X device");
+  (void)mm3d_set_streams(p, streams);
+  return p;
+}
+// Two engines per process, created on first use (the reference functions are stateless free
+// functions; a context only caches device memory and carries the rand() replay).  A context
+// serialises its calls, and the node runs mapCompositing (0.3 Hz) beside transformsEstimation
+// (0.01 Hz, seconds long) under a MultiThreadedSpinner (R/src/map_merge_node.cpp:32-40,264-265),
+// so composeMaps has a context of its own and never queues behind an estimation.
 inline mm3d_ctx *ctx()
 {
+  // estimateMapsTransforms deals its per-cloud and per-pair loops to 16 HIP streams inside the
+  // library (same bits as one stream, about twice the throughput); MM3D_STREAMS overrides
   static mm3d_ctx *c = [] {
-    mm3d_ctx *p = nullptr;
-    if (mm3d_create(0, &p) != MM3D_OK) throw std::runtime_error("mm3d: no MI355X device");
-    // estimateMapsTransforms deals its per-cloud and per-pair loops to 16 HIP streams inside the
-    // library (same bits as one stream, about twice the throughput); MM3D_STREAMS overrides
     const char *s = std::getenv("MM3D_STREAMS");
     const int n = s ? std::atoi(s) : 16;
-    (void)mm3d_set_streams(p, n >= 1 && n <= 64 ? n : 16);
-    return p;
+    return make_ctx(n >= 1 && n <= 64 ? n : 16);
   }();
   return c;
 }
-inline void check(int st)
+inline mm3d_ctx *compose_ctx()
 {
-  if (st != MM3D_OK) throw std::runtime_error(std::string("mm3d: ") + mm3d_last_error(ctx()));
+  static mm3d_ctx *c = make_ctx(1);
+  return c;
 }
-// pcl::PointXYZRGB is 32 bytes: x,y,z,pad | rgba,pad,pad,pad  -> stride 32, rgba_offset 16
-inline mm3d_cloud *upload(const PointCloud &c)
+inline void check(mm3d_ctx *c, int st)
 {
+  if (st != MM3D_OK) throw std::runtime_error(std::string("mm3d: ") + mm3d_last_error(c));
+}
+inline void check(int st) { check(ctx(), st); }
+// pcl::PointXYZRGB is 32 bytes: x,y,z,pad | rgba,pad,pad,pad  -> stride 32, rgba_offset 16
+inline mm3d_cloud *upload(const PointCloud &c, mm3d_ctx *on = nullptr)
+{
+  mm3d_ctx *e = on ? on : ctx();
   mm3d_cloud *h = nullptr;
-  check(mm3d_cloud_create(ctx(), c.points.data(), c.points.size(), sizeof(PointT), offsetof(PointT, rgba), &h));
+  check(e, mm3d_cloud_create(e, c.points.data(), c.points.size(), sizeof(PointT), offsetof(PointT, rgba), &h));
   return h;
 }
-inline PointCloudPtr download(mm3d_cloud *h)
+inline PointCloudPtr download(mm3d_cloud *h, mm3d_ctx *on = nullptr)
 {
+  mm3d_ctx *e = on ? on : ctx();
   PointCloudPtr out(new PointCloud);
   out->points.resize(mm3d_cloud_size(h));
   out->width = static_cast<uint32_t>(out->points.size());
   out->height = 1;
   out->is_dense = true;
-  check(mm3d_cloud_download(ctx(), h, out->points.data(), sizeof(PointT), offsetof(PointT, rgba)));
+  check(e, mm3d_cloud_download(e, h, out->points.data(), sizeof(PointT), offsetof(PointT, rgba)));
   return out;
 }
 inline mm3d_normals *upload(const SurfaceNormals &n)
@@ -120,9 +142,82 @@ inline mm3d_params to_params(const MapMergingParams &p)
   q.confidence_threshold = p.confidence_threshold; q.output_resolution = p.output_resolution;
   return q;
 }
+inline MapMergingParams from_params(const mm3d_params &q)
+{
+  MapMergingParams p;
+  p.resolution = q.resolution; p.descriptor_radius = q.descriptor_radius;
+  p.outliers_min_neighbours = q.outliers_min_neighbours; p.normal_radius = q.normal_radius;
+  p.keypoint_type = static_cast<Keypoint>(q.keypoint_type); p.keypoint_threshold = q.keypoint_threshold;
+  p.descriptor_type = static_cast<Descriptor>(q.descriptor_type);
+  p.estimation_method = static_cast<EstimationMethod>(q.estimation_method);
+  p.refine_transform = q.refine_transform != 0; p.inlier_threshold = q.inlier_threshold;
+  p.max_correspondence_distance = q.max_correspondence_distance; p.max_iterations = q.max_iterations;
+  p.matching_k = static_cast<size_t>(q.matching_k); p.transform_epsilon = q.transform_epsilon;
+  p.confidence_threshold = q.confidence_threshold; p.output_resolution = q.output_resolution;
+  return p;
+}
+// a ROS parameter that names an enum value: absent or empty keeps the default, an unknown
+// name throws like enums::from_string (R/include/map_merge_3d/enum.h:58)
+inline void enum_param(const ros::NodeHandle &n, const char *key, int (*parse)(const char *), int *value)
+{
+  std::string s;
+  n.getParam(key, s);
+  if (s.empty()) return;
+  const int v = parse(s.c_str());
+  if (v < 0) throw std::runtime_error("string is not a valid enum value: " + s);
+  *value = v;
+}
 }  // namespace mm3d_shim
 
 #ifdef MM3D_SHIM_IMPLEMENTATION
+
+// map_merging.h:53, R/src/map_merging.cpp:10-54 -- the parsing itself lives behind the C ABI
+// (mm3d_params_from_command_line) so that non-C++ callers get the same behaviour
+MapMergingParams MapMergingParams::fromCommandLine(int argc, char **argv)
+{
+  mm3d_params q;
+  if (mm3d_params_from_command_line(argc, argv, &q) != MM3D_OK)
+    throw std::runtime_error("string is not a valid enum value");   // enums::from_string, enum.h:58
+  return mm3d_shim::from_params(q);
+}
+
+// map_merging.h:60, R/src/map_merging.cpp:56-98 -- the same keys read from the node's parameters;
+// a missing key keeps the default, matching_k is applied only when positive
+MapMergingParams MapMergingParams::fromROSNode(const ros::NodeHandle &n)
+{
+  mm3d_params q;
+  mm3d_params_default(&q);
+  bool refine = q.refine_transform != 0;
+  int k = -1;
+  n.getParam("resolution", q.resolution);
+  n.getParam("descriptor_radius", q.descriptor_radius);
+  n.getParam("outliers_min_neighbours", q.outliers_min_neighbours);
+  n.getParam("normal_radius", q.normal_radius);
+  mm3d_shim::enum_param(n, "keypoint_type", mm3d_keypoint_from_string, &q.keypoint_type);
+  n.getParam("keypoint_threshold", q.keypoint_threshold);
+  mm3d_shim::enum_param(n, "descriptor_type", mm3d_descriptor_from_string, &q.descriptor_type);
+  mm3d_shim::enum_param(n, "estimation_method", mm3d_estimation_method_from_string, &q.estimation_method);
+  n.getParam("refine_transform", refine);
+  n.getParam("inlier_threshold", q.inlier_threshold);
+  n.getParam("max_correspondence_distance", q.max_correspondence_distance);
+  n.getParam("max_iterations", q.max_iterations);
+  n.getParam("matching_k", k);
+  n.getParam("transform_epsilon", q.transform_epsilon);
+  n.getParam("confidence_threshold", q.confidence_threshold);
+  n.getParam("output_resolution", q.output_resolution);
+  q.refine_transform = refine;
+  if (k > 0) q.matching_k = static_cast<uint64_t>(k);
+  return mm3d_shim::from_params(q);
+}
+
+// map_merging.h:62, R/src/map_merging.cpp:100-123 -- "name: value" lines, mm3d_params_to_string
+std::ostream &operator<<(std::ostream &stream, const MapMergingParams &params)
+{
+  const mm3d_params q = mm3d_shim::to_params(params);
+  std::vector<char> text(mm3d_params_to_string(&q, nullptr, 0));   // size includes the terminating NUL
+  mm3d_params_to_string(&q, text.data(), text.size());
+  return stream << text.data();
+}
 
 // R/include/map_merge_3d/features.h:34
 PointCloudPtr downSample(const PointCloudConstPtr &input, double resolution)
@@ -300,6 +395,9 @@ double transformScore(const PointCloudPtr &source_points, const PointCloudPtr &t
 std::vector<Eigen::Matrix4f> estimateMapsTransforms(const std::vector<PointCloudConstPtr> &clouds, const MapMergingParams &params)
 {
   using namespace mm3d_shim;
+  // R/src/map_merging.cpp:192-197: nothing to estimate, the clouds are not touched (and no device is needed)
+  if (clouds.empty()) return {};
+  if (clouds.size() == 1) return {Eigen::Matrix4f::Identity()};
   std::vector<mm3d_cloud_view> views(clouds.size());
   for (size_t i = 0; i < clouds.size(); ++i) {
     // a robot that is subscribed but has no map yet hands over nullptr (map_merge_node.cpp:171)
@@ -308,7 +406,7 @@ std::vector<Eigen::Matrix4f> estimateMapsTransforms(const std::vector<PointCloud
     views[i].stride = sizeof(PointT);
     views[i].rgba_offset = offsetof(PointT, rgba);
   }
-  std::vector<float> out(16 * (clouds.size() ? clouds.size() : 1));
+  std::vector<float> out(16 * clouds.size());
   size_t n_out = 0;
   const mm3d_params p = to_params(params);
   check(mm3d_estimate_maps_transforms(ctx(), views.data(), views.size(), &p, out.data(), &n_out, nullptr, nullptr));
@@ -317,24 +415,33 @@ std::vector<Eigen::Matrix4f> estimateMapsTransforms(const std::vector<PointCloud
   return result;
 }
 
-// map_merging.h:99
+// map_merging.h:99 -- on the compositing context (see mm3d_shim::compose_ctx)
 PointCloudPtr composeMaps(const std::vector<PointCloudConstPtr> &clouds, const std::vector<Eigen::Matrix4f> &transforms, double resolution)
 {
   using namespace mm3d_shim;
   if (clouds.empty()) return nullptr;
   if (clouds.size() != transforms.size())
     throw new std::runtime_error("composeMaps: clouds and transforms size must be the same.");   // a pointer, like the reference
+  size_t total = 0;
+  for (const auto &c : clouds) total += c ? c->points.size() : 0;
+  if (total == 0) {                                // nothing to transform or voxelise: an empty cloud, no device needed
+    PointCloudPtr empty(new PointCloud);
+    empty->is_dense = true;
+    return empty;
+  }
+  mm3d_ctx *e = compose_ctx();
+  const PointCloud none;
   std::vector<mm3d_cloud *> h(clouds.size());
   std::vector<float> T(16 * clouds.size());
   for (size_t i = 0; i < clouds.size(); ++i) {
-    h[i] = upload(*clouds[i]);
+    h[i] = upload(clouds[i] ? *clouds[i] : none, e);
     std::memcpy(&T[16 * i], transforms[i].data(), sizeof(float) * 16);
   }
   mm3d_cloud *out = nullptr;
-  check(mm3d_compose_maps(ctx(), h.data(), h.size(), T.data(), transforms.size(), resolution, &out));
-  PointCloudPtr r = download(out);
-  for (mm3d_cloud *c : h) mm3d_cloud_free(ctx(), c);
-  mm3d_cloud_free(ctx(), out);
+  check(e, mm3d_compose_maps(e, h.data(), h.size(), T.data(), transforms.size(), resolution, &out));
+  PointCloudPtr r = download(out, e);
+  for (mm3d_cloud *c : h) mm3d_cloud_free(e, c);
+  mm3d_cloud_free(e, out);
   return r;
 }
 
