@@ -19,7 +19,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmm3d.so")
+# MM3D_LIB: an instrumentation build of the same library (scripts/nn_stats.py, scripts/sn_stats.py)
+LIB_PATH = os.environ.get("MM3D_LIB") or os.path.join(_HERE, "libmm3d.so")
 
 POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
 NORMAL = np.dtype([("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4"), ("curvature", "<f4")])
