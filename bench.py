@@ -40,6 +40,12 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA (v_mfma_f32_32x32x2_f32)
 MFMA_KERNELS = {"desc_knn_mfma"}   # kernels whose profile "bytes" field carries FLOPs (csrc/desc_knn.hip)
+VALU_PEAK_WINSTR_S = 256 * 4 * 2.4e9 / 4   # wave-instructions per second: 256 CUs x 4 SIMDs, 4 cycles per wave64 instruction, 2.4 GHz
+# profile name (MM3D_LAUNCH) of the kernels whose C++ symbol differs from it (scripts/pmc_summary.py prints symbols)
+KERNEL_OF_SYMBOL = {"k_sift_dog": "sift_dog", "k_sift_extrema": "sift_extrema", "k_spfh": "spfh", "k_normals": "normals_radius",
+                    "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_sacia_seq_sum": "sacia_seq_sum",
+                    "k_fpfh_weight": "fpfh_weight", "k_knn_mfma": "desc_knn_mfma", "k_knn_rerank": "desc_knn_rerank",
+                    "k_radius_outlier_count": "radius_outlier_count"}
 
 
 def make_workload(n_maps, n_points, cache=True):
@@ -394,7 +400,7 @@ def main():
     # untimed: the same kernels alone on the GPU (one stream, maps 0 and 1 and their pair).  In the
     # timed region several streams share the CUs, so a kernel's HIP-event duration there includes the
     # time it spent sharing; the isolated figure is what speaks about the kernel itself.
-    iso = {}
+    iso, gpu_sample = {}, None
     if rank == 0:
         ctx.profile_reset()
         ctx.profile(True)
@@ -404,10 +410,13 @@ def main():
             raw = ctx.cloud_from_ptr(dev_raw[i].data_ptr(), len(host[i]))
             two.append(ctx.mapFeatures(raw, params))
             raw.free()
-        ctx.pairEstimate(two[0], two[1], params)
+        rec01 = ctx.pairEstimate(two[0], two[1], params)
         ctx.synchronize()
         ctx.profile(False)
         iso = ctx.profile_entries()
+        # what the device computed for maps 0 and 1 and pair (0, 1): bench's parity_check holds it against the oracle
+        gpu_sample = {"maps": [dict(points=m.points.numpy(), keypoints=m.keypoints.numpy(), descriptors=m.descriptors.numpy())
+                               for m in two], "pair": rec01}
         for m in two:
             m.free()
     # HBM-side traffic per launch from the most recent committed PMC passes (scripts/profile_round.sh)
@@ -419,6 +428,36 @@ def main():
         pmc_source = "profiles/" + os.path.basename(latest).replace("traffic.json", "pmc_hbm_traffic.csv")
     except Exception:
         pass
+
+    # VALU instructions per launch from the most recent committed SQ-counter pass (same maps 0 and 1, one stream)
+    valu_insts, valu_source = {}, None
+    try:
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters.csv")))[-1]
+        import csv
+        with open(latest) as f:
+            for row in csv.DictReader(f):
+                d = float(row.get("dispatches") or 0)
+                if d > 0 and row.get("SQ_INSTS_VALU") not in (None, "", "nan"):
+                    valu_insts[KERNEL_OF_SYMBOL.get(row["kernel"], row["kernel"])] = float(row["SQ_INSTS_VALU"]) / d
+        valu_source = "profiles/" + os.path.basename(latest)
+    except Exception:
+        pass
+
+    def bound_of(name, launch_ms, work):
+        """Which ceiling the kernel is nearest to, from what can be known here: algorithmic bytes (or flops) per launch
+        against HBM (or MFMA) peak, and -- where the committed SQ counters cover the kernel -- VALU wave-instructions per
+        launch against the issue peak (256 CUs x 4 SIMDs, one wave-instruction per 4 cycles at 2.4 GHz)."""
+        out = {}
+        if launch_ms <= 0:
+            return out
+        if name in MFMA_KERNELS:
+            out["mfma_frac"] = round(work / (launch_ms * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12), 5)
+        else:
+            out["hbm_frac"] = round(work / (launch_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 5)
+        if name in valu_insts:
+            out["valu_frac"] = round(valu_insts[name] / (launch_ms * 1e-3) / VALU_PEAK_WINSTR_S, 4)
+        out["nearest"] = max(((v, k[:-5]) for k, v in out.items()), default=(0, None))[1]
+        return out
 
     if rank == 0:
         n_pairs = stats["n_pairs"]
@@ -452,6 +491,12 @@ def main():
                 peak = MFMA_F32_PEAK_TFLOPS * 1e12 if dom[0] in MFMA_KERNELS else HBM_PEAK_GBS * 1e9
                 roofline["isolated_avg_launch_us"] = round(iso_ms * 1e3, 3)
                 roofline["isolated_frac"] = round(iso_work / (iso_ms * 1e-3) / peak, 6) if iso_ms > 0 else None
+            iso_us = roofline.get("isolated_avg_launch_us")
+            if dom[0] in valu_insts and iso_us:
+                v = valu_insts[dom[0]] / (iso_us * 1e-6)
+                roofline["valu"] = {"wave_instructions_per_launch": round(valu_insts[dom[0]]), "achieved": round(v / 1e9, 2),
+                                    "peak": round(VALU_PEAK_WINSTR_S / 1e9, 1), "unit": "G wave-instr/s", "frac": round(v / VALU_PEAK_WINSTR_S, 4),
+                                    "source": valu_source, "timed": "isolated_avg_launch_us"}
             roofline["note"] = ("timed region runs %d streams per GPU, so avg_launch_us includes time shared with other kernels; "
                                 "neighbourhood kernels (sift_dog, spfh, sacia_err, *_nn_reduce) are f32-VALU-bound on "
                                 "in-radius pair work, not HBM-bound: see DESIGN.md section 6" % S)
@@ -482,9 +527,18 @@ def main():
             "mpoints_per_s": {
                 "normals": round(sum(npts_f) / 1e6 / max(prof.get("normals_radius", {}).get("ms", 0) / 1e3 / max(args.steps, 1), 1e-9), 2)
                 if "normals_radius" in prof else None,
+                # FPFH: support points per second of the SPFH kernel (|S| = its algorithmic bytes / 156 B) and
+                # keypoints per second of the weighting kernel
+                "fpfh_spfh": round(prof["spfh"]["bytes"] / 156.0 / 1e6 / max(prof["spfh"]["ms"] / 1e3, 1e-9), 2) if "spfh" in prof else None,
+                "fpfh_weight": round(sum(stats["keypoints"]) / 1e6 / max(prof["fpfh_weight"]["ms"] / 1e3 / max(args.steps, 1), 1e-9), 3)
+                if "fpfh_weight" in prof else None,
                 "icp": round(icp_pts / 1e6 / max(prof.get("icp_corr_reduce", {}).get("ms", 0) / 1e3 / max(args.steps, 1), 1e-9), 2)
                 if "icp_corr_reduce" in prof else None,
             },
+            # per kernel, alone on the GPU (the untimed one-stream pass): launch time and the ceiling it is nearest to
+            "kernel_bounds_isolated": {k: dict(avg_launch_us=round(1e3 * v["ms"] / max(v["launches"], 1), 1),
+                                               **bound_of(k, v["ms"] / max(v["launches"], 1), v["bytes"] / max(v["launches"], 1)))
+                                       for k, v in sorted(iso.items(), key=lambda kv: -kv[1]["ms"])[:10]},
             "stage_seconds_last_step": {k: round(stats[k], 4) for k in ("t_features", "t_exchange", "t_pairs", "t_gather_graph")},
             "top_kernels_ms_per_step": {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in top},
             "maps_estimated": stats["n_estimated"],
@@ -493,7 +547,10 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host, n_maps, n_pairs)
+            b1, b2, parity = cpu_baseline(host, n_maps, n_pairs, gpu_sample, args.descriptor == "FPFH" and args.method == "SAC_IA")
+            out["cpu_baseline"] = b1
+            out["cpu_baseline_all_cores"] = b2
+            out["parity_check"] = parity
         print(json.dumps(out))
     if tpool is not None:
         tpool.shutdown()
@@ -503,12 +560,25 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(host, n_maps, n_pairs):
-    """The CPU oracle (kind "port": our single-threaded restatement of the reference's PCL path) on a
-    bounded sample: the features of ONE map and ONE pair (maps 0 and 1; map 1's features are computed
-    untimed), extrapolated to the whole job as n_maps * t_map + n_pairs * t_pair."""
+def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check):
+    """The CPU oracle (kind "port": our restatement of the reference's PCL path) on a bounded sample of the
+    workload: the features of ONE map and ONE pair (maps 0 and 1), extrapolated to the whole job as
+    n_maps * t_map + n_pairs * t_pair.
+      B1 `cpu_baseline`: one thread, like the reference's hot path (one run: the sample is ~30 s of CPU).
+      B2 `cpu_baseline_all_cores`: the same code with its loops over points on every host core (OpenMP;
+          results identical, tests/test_oracle_cpu.py), median of three runs.
+    The oracle's results for that sample are then held against what the device computed for the same maps
+    and pair in this very run (`parity_check`)."""
+    import statistics
     po = ge.load_oracle()
     p = po.params_default()
+    # B2's threads: the physical cores (SMT siblings do not help these loops), at most 64
+    cores = max(1, min(64, (os.cpu_count() or 2) // 2))
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "?")
+    except Exception:
+        model = "?"
 
     def features(cloud):
         d = po.downsample(cloud, p.resolution)
@@ -518,20 +588,69 @@ def cpu_baseline(host, n_maps, n_pairs):
         kp, desc = po.descriptors_fpfh(f, n, kp, p.descriptor_radius)
         return f, kp, desc
 
+    def pair(f0, k0, d0, f1, k1, d1):
+        po.srand(1)
+        T, _, _ = po.sac_ia(k0, d0, k1, d1, p.inlier_threshold, p.max_correspondence_distance, p.max_iterations)
+        T, it = po.icp(f0, f1, T, p.max_correspondence_distance, p.inlier_threshold, p.max_iterations, p.transform_epsilon)
+        score = po.transform_score(f0, f1, T, p.max_correspondence_distance)
+        return T, it, score
+
+    # B2 first (fast): all cores, median of 3; it also provides map 1's features for B1's pair
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")    # idle OpenMP threads sleep between the oracle's parallel loops
+    po.set_threads(cores)
+    tm, tp = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        f0, k0, d0 = features(host[0])
+        tm.append(time.perf_counter() - t0)
+    f1, k1, d1 = features(host[1])
+    for _ in range(3):
+        t0 = time.perf_counter()
+        T, it, score = pair(f0, k0, d0, f1, k1, d1)
+        tp.append(time.perf_counter() - t0)
+    t_map2, t_pair2 = statistics.median(tm), statistics.median(tp)
+    job2 = n_maps * t_map2 + n_pairs * t_pair2
+    b2 = {"value": round(n_pairs / job2, 6), "unit": "map-pairs/s", "cores": cores, "kind": "port", "cpu": model,
+          "sample": f"median of 3: 1 of {n_maps} maps' features ({t_map2:.2f} s) + 1 of {n_pairs} pairs ({t_pair2:.2f} s) on {cores} OpenMP "
+                    f"threads, extrapolated to the job as {n_maps}*t_map + {n_pairs}*t_pair = {job2:.0f} s"}
+    # B1: one thread, one run
+    po.set_threads(1)
     t0 = time.perf_counter()
-    f0, k0, d0 = features(host[0])
+    g0, h0, e0 = features(host[0])
     t_map = time.perf_counter() - t0
-    f1, k1, d1 = features(host[1])          # untimed: only needed as the pair's target
-    po.srand(1)
     t0 = time.perf_counter()
-    T, _, _ = po.sac_ia(k0, d0, k1, d1, p.inlier_threshold, p.max_correspondence_distance, p.max_iterations)
-    T, _ = po.icp(f0, f1, T, p.max_correspondence_distance, p.inlier_threshold, p.max_iterations, p.transform_epsilon)
-    po.transform_score(f0, f1, T, p.max_correspondence_distance)
+    T1, it1, score1 = pair(g0, h0, e0, f1, k1, d1)
     t_pair = time.perf_counter() - t0
     job = n_maps * t_map + n_pairs * t_pair
-    return {"value": round(n_pairs / job, 6), "unit": "map-pairs/s", "cores": 1, "kind": "port",
-            "sample": f"1 of {n_maps} maps' features ({t_map:.1f} s) + 1 of {n_pairs} pairs ({t_pair:.1f} s), "
-                      f"extrapolated to the job as {n_maps}*t_map + {n_pairs}*t_pair = {job:.0f} s"}
+    b1 = {"value": round(n_pairs / job, 6), "unit": "map-pairs/s", "cores": 1, "kind": "port", "cpu": model,
+          "sample": f"1 of {n_maps} maps' features ({t_map:.1f} s) + 1 of {n_pairs} pairs ({t_pair:.1f} s), "
+                    f"extrapolated to the job as {n_maps}*t_map + {n_pairs}*t_pair = {job:.0f} s"}
+    threads_agree = (g0.tobytes() == f0.tobytes() and h0.tobytes() == k0.tobytes() and e0.tobytes() == d0.tobytes()
+                     and T1.tobytes() == T.tobytes() and it1 == it and score1 == score)
+    parity = None
+    if check and gpu_sample is not None:
+        def same(a, b):
+            return a.shape == b.shape and a.tobytes() == b.tobytes()
+        xyz = lambda a: np.stack([a["x"], a["y"], a["z"]], axis=1)           # noqa: E731
+        g = gpu_sample["maps"]
+        rec = gpu_sample["pair"]
+        T_dev = np.asarray(rec["transform"], dtype=np.float32).reshape(4, 4).T
+        fro = float(np.linalg.norm(T_dev - T))
+        conf_rel = abs(float(rec["confidence"]) * score - 1.0)
+        parity = {
+            "sample": "maps 0 and 1 and pair (0, 1) of the timed workload: device (this run) vs CPU oracle",
+            "filtered_points_bit_equal": bool(same(g[0]["points"], f0) and same(g[1]["points"], f1)),
+            "keypoints_bit_equal": bool(same(xyz(g[0]["keypoints"]), xyz(k0)) and same(xyz(g[1]["keypoints"]), xyz(k1))),
+            "descriptors_bit_equal": bool(same(g[0]["descriptors"], d0) and same(g[1]["descriptors"], d1)),
+            "n_points": [int(len(f0)), int(len(f1))], "n_keypoints": [int(len(k0)), int(len(k1))],
+            "pair_transform_frobenius": round(fro, 9), "pair_transform_tolerance": 1e-3,
+            "confidence_rel_err": round(conf_rel, 9), "confidence_tolerance": 1e-4,
+            "icp_iterations": [int(rec["icp_iterations"]), int(it)],
+            "oracle_threads_agree": bool(threads_agree),
+        }
+        parity["ok"] = bool(parity["filtered_points_bit_equal"] and parity["keypoints_bit_equal"] and parity["descriptors_bit_equal"]
+                            and fro <= 1e-3 and conf_rel <= 1e-4 and int(rec["icp_iterations"]) == int(it) and threads_agree)
+    return b1, b2, parity
 
 
 if __name__ == "__main__":

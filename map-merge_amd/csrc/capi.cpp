@@ -209,7 +209,7 @@ void mm3d_destroy(mm3d_ctx *ctx)
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-  ctx->pool.trim();
+  ctx->pool->trim();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -753,11 +753,16 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
         std::unique_ptr<mm3d_cloud> raw(cloud_from_memory(c, clouds[i].points, clouds[i].points ? clouds[i].n : 0,
                                                           clouds[i].stride ? clouds[i].stride : 16,
                                                           clouds[i].stride ? clouds[i].rgba_offset : 12));
-        mm3d_map *m = map_features_impl(c, raw.get(), params);
+        // owned here until it is published: a throw from map_prepare_impl must not strand the map's buffers
+        struct MapFree {
+          void operator()(mm3d_map *x) const { delete x->points; delete x->keypoints; delete x->desc; delete x; }
+        };
+        std::unique_ptr<mm3d_map, MapFree> held(map_features_impl(c, raw.get(), params));
         raw.reset();
-        map_prepare_impl(c, m, params);
+        map_prepare_impl(c, held.get(), params);
         {
           std::lock_guard<std::mutex> lk(mu);
+          mm3d_map *m = held.release();
           maps[i] = m;
           ready[i] = 1;
           ctx->last_points[i] = m->points->n;

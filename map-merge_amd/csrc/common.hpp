@@ -109,6 +109,9 @@ struct ProfEntry {
 struct Context;
 
 // ---- device memory pool -------------------------------------------------------------------------
+// Thread-safe (its own mutex), and shared: every buffer holds a reference to the pool it came from, so a
+// buffer may be released from another context's thread, or after its context is gone (an object that
+// outlives the mm3d_ctx that made it, a worker context removed by mm3d_set_streams).
 class Pool {
  public:
   void *alloc(size_t bytes);
@@ -118,6 +121,8 @@ class Pool {
 
  private:
   static size_t size_class(size_t bytes);
+  void trim_locked();
+  std::mutex mu_;
   std::unordered_map<size_t, std::vector<void *>> free_;
   std::unordered_map<void *, size_t> live_;
 };
@@ -125,7 +130,7 @@ class Pool {
 struct Context {
   int device = 0;
   hipStream_t stream = nullptr;
-  Pool pool;
+  std::shared_ptr<Pool> pool = std::make_shared<Pool>();
   std::string err;
   std::mutex mu;
   GlibcRand rnd;
@@ -156,26 +161,26 @@ template <typename T>
 class DevBuf {
  public:
   DevBuf() = default;
-  DevBuf(Context *c, size_t n) : ctx_(c), n_(n) { p_ = n ? (T *)c->pool.alloc(n * sizeof(T)) : nullptr; }
+  DevBuf(Context *c, size_t n) : pool_(c->pool), n_(n) { p_ = n ? (T *)pool_->alloc(n * sizeof(T)) : nullptr; }
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  DevBuf(DevBuf &&o) noexcept : ctx_(o.ctx_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+  DevBuf(DevBuf &&o) noexcept : pool_(std::move(o.pool_)), p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
   DevBuf &operator=(DevBuf &&o) noexcept
   {
-    if (this != &o) { reset(); ctx_ = o.ctx_; p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
+    if (this != &o) { reset(); pool_ = std::move(o.pool_); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
     return *this;
   }
   ~DevBuf() { reset(); }
   void reset()
   {
-    if (p_) ctx_->pool.release(p_);
+    if (p_) pool_->release(p_);
     p_ = nullptr; n_ = 0;
   }
   T *get() const { return p_; }
   size_t size() const { return n_; }
 
  private:
-  Context *ctx_ = nullptr;
+  std::shared_ptr<Pool> pool_;     // keeps the pool alive for as long as the buffer
   T *p_ = nullptr;
   size_t n_ = 0;
 };

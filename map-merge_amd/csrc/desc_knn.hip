@@ -885,6 +885,7 @@ static void knn_norm_order(Context *c, const mm3d_desc *B, DevBuf<uint32_t> &nso
 void desc_knn_prepare_target(Context *c, const mm3d_desc *B_)
 {
   auto *B = const_cast<mm3d_desc *>(B_);
+  std::lock_guard<std::mutex> lk(B->cache_mu);
   if (B->n < 64 || B->knn_Bp.get()) return;
   if (B->dim == 33) { knn_target_operands<33>(c, B, B->knn_colsum, B->knn_Bp); knn_norm_order<33>(c, B, B->knn_nsort, B->knn_nperm); }
   else if (B->dim == 2) { knn_target_operands<2>(c, B, B->knn_colsum, B->knn_Bp); knn_norm_order<2>(c, B, B->knn_nsort, B->knn_nperm); }
@@ -1027,11 +1028,77 @@ static void desc_knn_wide_impl(Context *c, const mm3d_desc *A, const mm3d_desc *
   }
 }
 
+// ---------------------------------------------------------------- any k, any row width
+// The reference takes matching_k from the command line / the parameter server as an arbitrary size_t
+// (R/src/map_merging.cpp:43-47) and hands it to FLANN.  The kernels above keep k <= 16 candidates in
+// registers; a larger k goes through this plain exact kernel: one wave per query row (rows dealt to a fixed
+// number of waves), every target's distance in FLANN's accumulation order into the wave's scratch row, then
+// the k smallest (distance, index) keys one after the other (each the minimum of the keys above the last).
+constexpr int kAnyMaxDim = 2048;
+__global__ void __launch_bounds__(256)
+k_knn_any(const float *__restrict__ A, int na, const float *__restrict__ B, int nb, int dim, int k, float *__restrict__ scratch /* [waves][nb] */,
+          int *__restrict__ idx, float *__restrict__ d2out)
+{
+  __shared__ float s_row[4][kAnyMaxDim];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_waves = gridDim.x * 4, w = blockIdx.x * 4 + wave;
+  float *dist = scratch + (size_t)w * nb;
+  float *x = s_row[wave];
+  for (int a = w; a < na; a += n_waves) {
+    wave_lds_fence();
+    for (int d = lane; d < dim; d += kWave) x[d] = A[(size_t)a * dim + d];
+    wave_lds_fence();
+    for (int j = lane; j < nb; j += kWave) {
+      const float *b = B + (size_t)j * dim;
+      float r = 0.0f;
+      for (int d = 0; d < dim; ++d) {
+        const float df = x[d] - b[d];
+        r = __fadd_rn(r, __fmul_rn(df, df));
+      }
+      dist[j] = r;
+    }
+    unsigned long long last = 0;
+    bool first = true;
+    for (int o = 0; o < k; ++o) {
+      unsigned long long best = ~0ull;
+      for (int j = lane; j < nb; j += kWave) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(dist[j]) << 32) | (unsigned)j;   // distances are >= 0
+        if ((first || key > last) && key < best) best = key;
+      }
+#pragma unroll
+      for (int sft = 32; sft > 0; sft >>= 1) {
+        const unsigned long long other = __shfl_xor(best, sft, kWave);
+        best = other < best ? other : best;
+      }
+      const bool found = best != ~0ull;
+      if (lane == 0) {
+        idx[(size_t)a * k + o] = found ? (int)(unsigned)(best & 0xffffffffull) : -1;      // fewer than k targets: the tail is empty
+        d2out[(size_t)a * k + o] = found ? __uint_as_float((unsigned)(best >> 32)) : INFINITY;
+      }
+      last = best;
+      first = false;
+    }
+  }
+}
+
+static void desc_knn_any(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2)
+{
+  const int na = (int)A->n, nb = (int)B->n, dim = A->dim;
+  if (dim > kAnyMaxDim) throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN: rows wider than 2048 floats");
+  idx = DevBuf<int>(c, (size_t)na * k);
+  d2 = DevBuf<float>(c, (size_t)na * k);
+  if (na == 0) return;
+  const int blocks = (int)std::min<size_t>(256, div_up((size_t)na, (size_t)4));
+  DevBuf<float> scratch(c, (size_t)blocks * 4 * (size_t)(nb > 0 ? nb : 1));
+  MM3D_LAUNCH(c, "desc_knn_any", 2.0 * na * (double)nb * dim, k_knn_any, dim3(blocks), dim3(256), 0, (const float *)A->data.get(), na,
+              (const float *)B->data.get(), nb, dim, k, scratch.get(), idx.get(), d2.get());
+}
+
 void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2)
 {
   MM3D_REQUIRE(A->dim == B->dim, "descriptor dimensions differ");
   MM3D_REQUIRE(k >= 1, "k must be positive");
-  if (k > kMaxK) throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN supports k <= 16");
+  if (k > kMaxK) { desc_knn_any(c, A, B, k, idx, d2); return; }
   if (A->dim == 33) desc_knn_impl<33>(c, A, B, k, idx, d2);          // FPFHSignature33
   else if (A->dim == 2) desc_knn_impl<2>(c, A, B, k, idx, d2);       // PrincipalRadiiRSD (r_min, r_max)
   else if (A->dim == 125) desc_knn_impl<125>(c, A, B, k, idx, d2);   // PFHSignature125

@@ -27,6 +27,7 @@ size_t Pool::size_class(size_t bytes)
 
 void *Pool::alloc(size_t bytes)
 {
+  std::lock_guard<std::mutex> lk(mu_);
   size_t cls = size_class(bytes);
   auto it = free_.find(cls);
   void *p = nullptr;
@@ -36,7 +37,7 @@ void *Pool::alloc(size_t bytes)
   } else {
     hipError_t e = hipMalloc(&p, cls);
     if (e != hipSuccess) {
-      trim();
+      trim_locked();
       e = hipMalloc(&p, cls);
       if (e != hipSuccess) throw Error(MM3D_ENOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
     }
@@ -47,6 +48,7 @@ void *Pool::alloc(size_t bytes)
 
 void Pool::release(void *p)
 {
+  std::lock_guard<std::mutex> lk(mu_);
   auto it = live_.find(p);
   if (it == live_.end()) return;
   free_[it->second].push_back(p);
@@ -54,6 +56,12 @@ void Pool::release(void *p)
 }
 
 void Pool::trim()
+{
+  std::lock_guard<std::mutex> lk(mu_);
+  trim_locked();
+}
+
+void Pool::trim_locked()
 {
   for (auto &kv : free_)
     for (void *p : kv.second) (void)hipFree(p);
@@ -224,6 +232,7 @@ void cloud_download(Context *c, const mm3d_cloud *cl, void *dst, size_t stride, 
 const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl)
 {
   auto *m = const_cast<mm3d_cloud *>(cl);
+  std::lock_guard<std::recursive_mutex> lk(m->cache_mu);
   if (m->host.size() != m->n) {
     m->host.resize(m->n);
     if (m->n) {
@@ -278,6 +287,7 @@ __global__ void k_bbox(const float4 *__restrict__ pts, size_t n, unsigned *__res
 
 void cloud_bbox(Context *c, mm3d_cloud *cl)
 {
+  std::lock_guard<std::recursive_mutex> lk(cl->cache_mu);
   if (cl->have_bbox) return;
   cl->have_bbox = true;
   cl->n_finite = 0;
@@ -372,6 +382,7 @@ const Grid &cloud_grid(Context *c, const mm3d_cloud *cl_, float cell)
 {
   auto *cl = const_cast<mm3d_cloud *>(cl_);
   MM3D_REQUIRE(cell > 0.f && std::isfinite(cell), "grid cell size must be positive");
+  std::lock_guard<std::recursive_mutex> lk(cl->cache_mu);
   int key = (int)std::lround((double)cell * 1e4);
   auto it = cl->grids.find(key);
   if (it != cl->grids.end()) return *it->second;
@@ -480,6 +491,7 @@ __global__ void k_dt_axis(const unsigned char *__restrict__ in, int dx, int dy, 
 void grid_ensure_dt(Context *c, const Grid &g_, int R)
 {
   Grid &g = const_cast<Grid &>(g_);
+  std::lock_guard<std::mutex> lk(g.cache_mu);
   if (R > 250) R = 250;
   if (g.dt.get() && g.dt_cap >= R) return;
   const size_t nc = (size_t)g.dims[0] * g.dims[1] * g.dims[2];
@@ -545,6 +557,7 @@ __global__ void k_nb_fill(const int *__restrict__ cell_start, const float4 *__re
 void grid_ensure_nblists(Context *c, const Grid &g_, int R)
 {
   Grid &g = const_cast<Grid &>(g_);
+  std::lock_guard<std::mutex> lk(g.cache_mu);
   if (g.nb_start.get() && g.nb_R == R) return;
   const size_t nc = (size_t)g.dims[0] * g.dims[1] * g.dims[2];
   DevBuf<int> counts(c, nc + 1);
@@ -622,6 +635,7 @@ __global__ void k_item_fill(const int *__restrict__ heads, const int *__restrict
 void cloud_hilbert(Context *c, const mm3d_cloud *cl_)
 {
   auto *cl = const_cast<mm3d_cloud *>(cl_);
+  std::lock_guard<std::recursive_mutex> lk(cl->cache_mu);
   cloud_bbox(c, cl);
   const int n = (int)cl->n_finite;
   if (cl->hil_pts.get() || n == 0) return;

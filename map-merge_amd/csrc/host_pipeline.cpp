@@ -52,7 +52,9 @@ void download(Context *c, const T *d, std::vector<T> &h, size_t n)
 size_t find_correspondences(Context *c, const mm3d_desc *s, const mm3d_desc *t, size_t k_, std::vector<mm3d_corr> &out)
 {
   out.clear();
-  const int ns = (int)s->n, nt = (int)t->n, k = (int)k_;
+  const int ns = (int)s->n, nt = (int)t->n;
+  // any positive k (a size_t in the reference, map_merging.cpp:43-47); more neighbours than rows cannot exist
+  const int k = (int)std::min<size_t>(k_, (size_t)std::max(ns, nt));
   if (ns == 0 || nt == 0 || k <= 0) return 0;
   DevBuf<int> fi, bi;
   DevBuf<float> fd, bd;

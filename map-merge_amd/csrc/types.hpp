@@ -53,6 +53,7 @@ struct Grid {
   DevBuf<int> nb_start;       // built on demand by grid_ensure_nblists
   DevBuf<float> nb_pts;       // packed x, y, z triples
   int nb_R = 0;
+  std::mutex cache_mu;        // grid_ensure_dt / grid_ensure_nblists
   GridView view() const
   {
     GridView v;
@@ -71,7 +72,9 @@ struct Grid {
 struct mm3d_cloud {
   mm3d::DevBuf<float4> pts;
   size_t n = 0;
-  // lazily computed
+  // lazily computed, under cache_mu: several contexts (streams) may ask the same cloud for a structure that
+  // mm3d_map_prepare did not build; the first builds it (and drains its stream), the others wait
+  std::recursive_mutex cache_mu;
   bool have_bbox = false;
   float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
   size_t n_finite = 0;
@@ -103,6 +106,7 @@ struct mm3d_desc {
   // they depend on this set alone, so a map that is the target of 15 pairs prepares them once
   // (desc_knn_prepare_target, called from mm3d_map_prepare)
   mm3d::DevBuf<float> knn_colsum, knn_Bp;
+  std::mutex cache_mu;        // desc_knn_prepare_target
   // the rows' Euclidean norms in ascending order and the row index of each (the exact fallback of the k-NN only
   // visits targets whose norm is within the current k-th distance of the query's: | |a| - |b| | <= |a - b|)
   mm3d::DevBuf<uint32_t> knn_nsort, knn_nperm;

@@ -57,6 +57,12 @@ typedef struct {
 void mo_params_default(mo_params *p);
 
 /* ---------------- exact neighbour search (stands in for FLANN) ------------- */
+/* Baseline B2 (SURVEY 8d "best-effort CPU"): the loops over points / keypoints / rows run on `n` OpenMP
+ * threads; every order-sensitive float sum still runs sequentially, so the results do not depend on n.
+ * The default is 1 thread: the reference's hot path is single-threaded (baseline B1). */
+void mo_set_threads(int n);
+int mo_get_threads(void);
+
 typedef struct mo_grid mo_grid;
 mo_grid *mo_grid_build(const mo_point *pts, int n, float cell);
 void mo_grid_free(mo_grid *g);

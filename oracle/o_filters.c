@@ -102,21 +102,29 @@ int mo_remove_outliers(const mo_point *in, int n, double radius, int min_neighbo
   mo_grid *g = mo_grid_build(in, n, (float)(radius * 0.5));
   const int mean_k = min_neighbors + 1;             /* k includes the query point */
   const double nn_dists_max = radius * radius;      /* double, compared with float d2 */
-  int *idx = (int *)malloc(sizeof(int) * (size_t)(mean_k > 0 ? mean_k : 1));
-  float *d2 = (float *)malloc(sizeof(float) * (size_t)(mean_k > 0 ? mean_k : 1));
-  int nout = 0;
-  for (int i = 0; i < n; ++i) {
-    int keep;
-    if (mean_k <= 0) {
-      keep = 1;
-    } else {
-      int k = mo_knn_search(g, in[i].x, in[i].y, in[i].z, mean_k, INFINITY, idx, d2);
-      if (k == mean_k) keep = !(nn_dists_max < (double)d2[k - 1]);
-      else keep = 0;
+  unsigned char *keep_flag = (unsigned char *)malloc((size_t)n);
+#pragma omp parallel num_threads(mo_get_threads())
+  {
+    int *idx = (int *)malloc(sizeof(int) * (size_t)(mean_k > 0 ? mean_k : 1));
+    float *d2 = (float *)malloc(sizeof(float) * (size_t)(mean_k > 0 ? mean_k : 1));
+#pragma omp for schedule(dynamic, 1024)
+    for (int i = 0; i < n; ++i) {
+      int keep;
+      if (mean_k <= 0) {
+        keep = 1;
+      } else {
+        int k = mo_knn_search(g, in[i].x, in[i].y, in[i].z, mean_k, INFINITY, idx, d2);
+        if (k == mean_k) keep = !(nn_dists_max < (double)d2[k - 1]);
+        else keep = 0;
+      }
+      keep_flag[i] = (unsigned char)keep;
     }
-    if (keep) out[nout++] = in[i];
+    free(idx); free(d2);
   }
-  free(idx); free(d2);
+  int nout = 0;
+  for (int i = 0; i < n; ++i)           /* input order preserved */
+    if (keep_flag[i]) out[nout++] = in[i];
+  free(keep_flag);
   mo_grid_free(g);
   return nout;
 }

@@ -84,9 +84,12 @@ int mo_fpfh_raw(const mo_point *surface, const mo_normal *normals, int n,
 {
   mo_grid *g = mo_grid_build(surface, n, (float)(radius * 0.5));
   const float r2 = (float)(radius * radius);
-  int cap = 4096;
-  int *idx = (int *)malloc(sizeof(int) * (size_t)cap);
-  float *d2 = (float *)malloc(sizeof(float) * (size_t)cap);
+  /* every loop below is over independent keypoints / support points: baseline B2 runs them on
+   * mo_get_threads() threads, each with its own search buffers (SEARCH_BUFFERS) */
+#define SEARCH_BUFFERS                                                               \
+  int cap = 4096;                                                                    \
+  int *idx = (int *)malloc(sizeof(int) * (size_t)cap);                               \
+  float *d2 = (float *)malloc(sizeof(float) * (size_t)cap)
 #define SEARCH(qx, qy, qz, cntvar)                                                   \
   do {                                                                               \
     cntvar = mo_radius_search(g, qx, qy, qz, r2, idx, d2, cap);                      \
@@ -100,26 +103,45 @@ int mo_fpfh_raw(const mo_point *surface, const mo_normal *normals, int n,
 
   /* computeSPFHSignatures: std::set of all neighbours of all keypoints (surface != input) */
   unsigned char *in_set = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
-  for (int k = 0; k < n_kp; ++k) {
-    int cnt;
-    SEARCH(keypoints[k].x, keypoints[k].y, keypoints[k].z, cnt);
-    for (int j = 0; j < cnt; ++j) in_set[idx[j]] = 1;
+#pragma omp parallel num_threads(mo_get_threads())
+  {
+    SEARCH_BUFFERS;
+#pragma omp for schedule(dynamic, 64)
+    for (int k = 0; k < n_kp; ++k) {
+      int cnt;
+      SEARCH(keypoints[k].x, keypoints[k].y, keypoints[k].z, cnt);
+      for (int j = 0; j < cnt; ++j) {
+#pragma omp atomic write
+        in_set[idx[j]] = 1;
+      }
+    }
+    free(idx); free(d2);
   }
   int *lookup = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
   int ns = 0;
   for (int i = 0; i < n; ++i) if (in_set[i]) lookup[i] = ns++; else lookup[i] = -1;
   float *spfh = (float *)calloc((size_t)(ns > 0 ? ns : 1) * 33, sizeof(float));
-  for (int i = 0; i < n; ++i) {
-    if (!in_set[i]) continue;
-    if (support_idx) support_idx[lookup[i]] = i;
-    int cnt;
-    SEARCH(surface[i].x, surface[i].y, surface[i].z, cnt);
-    if (cnt == 0) continue;
-    point_spfh(surface, normals, i, idx, cnt, &spfh[(size_t)lookup[i] * 33]);
+#pragma omp parallel num_threads(mo_get_threads())
+  {
+    SEARCH_BUFFERS;
+#pragma omp for schedule(dynamic, 256)
+    for (int i = 0; i < n; ++i) {
+      if (!in_set[i]) continue;
+      if (support_idx) support_idx[lookup[i]] = i;
+      int cnt;
+      SEARCH(surface[i].x, surface[i].y, surface[i].z, cnt);
+      if (cnt == 0) continue;
+      point_spfh(surface, normals, i, idx, cnt, &spfh[(size_t)lookup[i] * 33]);
+    }
+    free(idx); free(d2);
   }
   if (spfh_out) memcpy(spfh_out, spfh, sizeof(float) * (size_t)ns * 33);
 
   /* computeFeature: weightPointSPFHSignature per keypoint */
+#pragma omp parallel num_threads(mo_get_threads())
+  {
+  SEARCH_BUFFERS;
+#pragma omp for schedule(dynamic, 64)
   for (int k = 0; k < n_kp; ++k) {
     float *out = &desc[(size_t)k * 33];
     int cnt;
@@ -146,8 +168,11 @@ int mo_fpfh_raw(const mo_point *surface, const mo_normal *normals, int n,
       for (int b = 0; b < NB; ++b) out[f * NB + b] *= (float)sum[f];
     }
   }
+  free(idx); free(d2);
+  }
 #undef SEARCH
-  free(idx); free(d2); free(in_set); free(lookup); free(spfh);
+#undef SEARCH_BUFFERS
+  free(in_set); free(lookup); free(spfh);
   mo_grid_free(g);
   return ns;
 }

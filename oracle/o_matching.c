@@ -41,6 +41,7 @@ static inline void xform_point(const float T[16], float x, float y, float z, flo
 void mo_desc_knn(const float *a, int na, const float *b, int nb, int dim, int k, int *idx,
                  float *d2)
 {
+#pragma omp parallel for schedule(dynamic, 32) num_threads(mo_get_threads())
   for (int i = 0; i < na; ++i) {
     int m = 0;
     int *ti = &idx[(size_t)i * k];
@@ -278,6 +279,7 @@ void mo_sac_ia(const mo_point *src_kp, const float *src_desc, int ns, const mo_p
   float lowest_error = 0.0f;
   float best[16];
   memcpy(best, T, sizeof(best));
+  float *err_of = (float *)malloc(sizeof(float) * (size_t)ns);
   for (int it = 0; it < max_iterations; ++it) {
     int sample[3], corr_idx[3];
     /* selectSamples */
@@ -312,17 +314,19 @@ void mo_sac_ia(const mo_point *src_kp, const float *src_desc, int ns, const mo_p
       d[i * 3] = q->x; d[i * 3 + 1] = q->y; d[i * 3 + 2] = q->z;
     }
     mo_umeyama_f32(s, d, 3, Tm);
-    /* computeErrorMetric over all source keypoints */
-    float error = 0.0f;
+    /* computeErrorMetric over all source keypoints: the searches are independent (threads, baseline B2),
+     * the float sum runs in keypoint order */
+    /* (a few thousand short searches per hypothesis: more than 16 threads only add wake-up time) */
+#pragma omp parallel for schedule(static) num_threads(mo_get_threads() < 16 ? mo_get_threads() : 16) if (ns >= 2048)
     for (int i = 0; i < ns; ++i) {
       float p[3];
       xform_point(Tm, src_kp[i].x, src_kp[i].y, src_kp[i].z, p);
       int ni; float nd2;
-      float e;
       int found = mo_knn_search(g, p[0], p[1], p[2], 1, corr_thresh, &ni, &nd2);
-      if (found && nd2 <= corr_thresh) e = nd2 / corr_thresh; else e = 1.0f;
-      error += e;
+      err_of[i] = (found && nd2 <= corr_thresh) ? nd2 / corr_thresh : 1.0f;
     }
+    float error = 0.0f;
+    for (int i = 0; i < ns; ++i) error += err_of[i];
     if (it == 0 || error < lowest_error) {
       lowest_error = error;
       memcpy(best, Tm, sizeof(best));
@@ -331,7 +335,7 @@ void mo_sac_ia(const mo_point *src_kp, const float *src_desc, int ns, const mo_p
   }
   memcpy(T, best, sizeof(best));
   if (best_err_out) *best_err_out = lowest_error;
-  free(nn); free(nd);
+  free(nn); free(nd); free(err_of);
   mo_grid_free(g);
 }
 
@@ -363,16 +367,27 @@ void mo_icp(const mo_point *src, int ns, const mo_point *tgt, int nt, const floa
     mo_grid *g = mo_grid_build(tgt, nt, cell);
     float *cs = (float *)malloc(sizeof(float) * 3 * (size_t)ns), *cd = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
     float *cdist = (float *)malloc(sizeof(float) * (size_t)ns);
+    int *nn_of = (int *)malloc(sizeof(int) * (size_t)ns);       /* per source point: its match, or -1 */
+    float *nd_of = (float *)malloc(sizeof(float) * (size_t)ns);
     double prev_mse = DBL_MAX;
     const double rot_thresh = 1.0 - transformation_epsilon, trans_thresh = transformation_epsilon;
     const double mse_abs = 1e-12;
     int converged = 0;
     do {
-      int cnt = 0;
+      /* the searches are independent (threads, baseline B2); the correspondences are collected in
+       * source order like the sequential loop */
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(mo_get_threads())
       for (int i = 0; i < ns; ++i) {
         int ni; float d2;
         int found = mo_knn_search(g, cur[i * 3], cur[i * 3 + 1], cur[i * 3 + 2], 1, bound, &ni, &d2);
-        if (!found || (double)d2 > max_dist_sqr) continue;
+        nn_of[i] = (!found || (double)d2 > max_dist_sqr) ? -1 : ni;
+        nd_of[i] = d2;
+      }
+      int cnt = 0;
+      for (int i = 0; i < ns; ++i) {
+        const int ni = nn_of[i];
+        const float d2 = nd_of[i];
+        if (ni < 0) continue;
         cs[cnt * 3] = cur[i * 3]; cs[cnt * 3 + 1] = cur[i * 3 + 1]; cs[cnt * 3 + 2] = cur[i * 3 + 2];
         cd[cnt * 3] = tgt[ni].x; cd[cnt * 3 + 1] = tgt[ni].y; cd[cnt * 3 + 2] = tgt[ni].z;
         cdist[cnt] = d2;
@@ -382,6 +397,7 @@ void mo_icp(const mo_point *src, int ns, const mo_point *tgt, int nt, const floa
       if (cnt < 3) { converged = 0; break; }   /* min_number_correspondences_ */
       float Tinc[16];
       mo_umeyama_f32(cs, cd, cnt, Tinc);
+#pragma omp parallel for schedule(static) num_threads(mo_get_threads())
       for (int i = 0; i < ns; ++i) {
         float p[3];
         xform_point(Tinc, cur[i * 3], cur[i * 3 + 1], cur[i * 3 + 2], p);
@@ -402,7 +418,7 @@ void mo_icp(const mo_point *src, int ns, const mo_point *tgt, int nt, const floa
       /* relative MSE test disabled: euclidean_fitness_epsilon_ = -DBL_MAX */
       prev_mse = mse;
     } while (!converged);
-    free(cur); free(cs); free(cd); free(cdist);
+    free(cur); free(cs); free(cd); free(cdist); free(nn_of); free(nd_of);
     mo_grid_free(g);
   }
   if (iters_out) *iters_out = iters;
@@ -421,16 +437,23 @@ double mo_transform_score(const mo_point *src, int ns, const mo_point *tgt, int 
   mo_grid *g = mo_grid_build(tgt, nt, cell);
   double fitness = 0.0;
   int nr = 0;
+  float *nd_of = (float *)malloc(sizeof(float) * (size_t)ns);   /* per source point: its d2, or -1 */
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(mo_get_threads())
   for (int i = 0; i < ns; ++i) {
     float p[3];
     xform_point(T, src[i].x, src[i].y, src[i].z, p);
     int ni; float d2;
     int found = mo_knn_search(g, p[0], p[1], p[2], 1, bound, &ni, &d2);
-    if (!found) continue;
+    nd_of[i] = found ? d2 : -1.0f;
+  }
+  for (int i = 0; i < ns; ++i) {               /* the double sum in source order */
+    const float d2 = nd_of[i];
+    if (d2 < 0.0f) continue;
     if ((double)d2 > max_distance) continue;   /* squared distance vs un-squared max_range_ */
     fitness += d2;
     nr++;
   }
+  free(nd_of);
   mo_grid_free(g);
   return nr > 0 ? fitness / nr : DBL_MAX;
 }

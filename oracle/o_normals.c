@@ -136,9 +136,12 @@ void mo_normals(const mo_point *in, int n, double radius, mo_normal *out)
   if (n <= 0) return;
   mo_grid *g = mo_grid_build(in, n, (float)(radius * 0.5));
   const float r2 = (float)(radius * radius);   /* KdTreeFLANN::radiusSearch: float(radius*radius) */
+#pragma omp parallel num_threads(mo_get_threads())
+  {
   int cap = 4096;
   int *idx = (int *)malloc(sizeof(int) * (size_t)cap);
   float *d2 = (float *)malloc(sizeof(float) * (size_t)cap);
+#pragma omp for schedule(dynamic, 1024)
   for (int i = 0; i < n; ++i) {
     int cnt = mo_radius_search(g, in[i].x, in[i].y, in[i].z, r2, idx, d2, cap);
     if (cnt > cap) {
@@ -164,5 +167,6 @@ void mo_normals(const mo_point *in, int n, double radius, mo_normal *out)
     o->nx = vec[0]; o->ny = vec[1]; o->nz = vec[2];
   }
   free(idx); free(d2);
+  }
   mo_grid_free(g);
 }

@@ -19,6 +19,20 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+static int g_threads = 1;
+void mo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int mo_get_threads(void)
+{
+#ifdef _OPENMP
+  return g_threads;
+#else
+  return 1;
+#endif
+}
+
 struct mo_grid {
   const mo_point *pts;
   int n;
@@ -101,9 +115,9 @@ static int cand_cmp(const void *a, const void *b)
   return (x->idx > y->idx) - (x->idx < y->idx);
 }
 
-/* thread-local scratch would be nicer; the oracle is single-threaded like the reference */
-static cand *g_scratch = NULL;
-static int g_scratch_cap = 0;
+/* one scratch list per thread (baseline B2 searches from several OpenMP threads) */
+static _Thread_local cand *g_scratch = NULL;
+static _Thread_local int g_scratch_cap = 0;
 static cand *scratch(int need)
 {
   if (need > g_scratch_cap) {

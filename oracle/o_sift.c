@@ -48,10 +48,13 @@ static void detect_octave(const mo_point *cloud, int n, float base_scale, int nr
   const float r2 = (float)((double)max_radius * (double)max_radius);
   mo_grid *g = mo_grid_build(cloud, n, max_radius * 0.5f);
 
+  /* computeScaleSpace */
+#pragma omp parallel num_threads(mo_get_threads())
+  {
   int cap = 4096;
   int *idx = (int *)malloc(sizeof(int) * (size_t)cap);
   float *d2 = (float *)malloc(sizeof(float) * (size_t)cap);
-  /* computeScaleSpace */
+#pragma omp for schedule(dynamic, 512)
   for (int i = 0; i < n; ++i) {
     int cnt = mo_radius_search(g, cloud[i].x, cloud[i].y, cloud[i].z, r2, idx, d2, cap);
     if (cnt > cap) {
@@ -80,10 +83,17 @@ static void detect_octave(const mo_point *cloud, int n, float base_scale, int nr
       if (s > 0) dog[(size_t)i * nd + (s - 1)] = filter_response - previous_filter_response;
     }
   }
-  /* findScaleSpaceExtrema */
+  free(idx); free(d2);
+  }
+  /* findScaleSpaceExtrema: the tests run per point (in parallel for baseline B2), the keypoints are
+   * emitted afterwards in point order, scale order -- the order of the sequential loop */
   const int k = 25;
+  unsigned char *is_kp = (unsigned char *)calloc((size_t)n * (size_t)nd + 1, 1);
+#pragma omp parallel num_threads(mo_get_threads())
+  {
   int nn_idx[25]; float nn_d2[25];
   float *min_val = (float *)malloc(sizeof(float) * (size_t)nd), *max_val = (float *)malloc(sizeof(float) * (size_t)nd);
+#pragma omp for schedule(dynamic, 512)
   for (int i = 0; i < n; ++i) {
     int nr_nn = mo_knn_search(g, cloud[i].x, cloud[i].y, cloud[i].z, k, INFINITY, nn_idx, nn_d2);
     for (int s = 0; s < nd; ++s) {
@@ -99,13 +109,18 @@ static void detect_octave(const mo_point *cloud, int n, float base_scale, int nr
       float val = dog[(size_t)i * nd + s];
       if (fabs(val) >= min_contrast) {
         if ((val == min_val[s]) && (val <= min_val[s - 1]) && (val <= min_val[s + 1]))
-          kp_push(out, cloud[i].x, cloud[i].y, cloud[i].z, scales[s]);
+          is_kp[(size_t)i * nd + s] = 1;
         else if ((val == max_val[s]) && (val >= max_val[s - 1]) && (val >= max_val[s + 1]))
-          kp_push(out, cloud[i].x, cloud[i].y, cloud[i].z, scales[s]);
+          is_kp[(size_t)i * nd + s] = 1;
       }
     }
   }
-  free(min_val); free(max_val); free(idx); free(d2); free(dog); free(scales);
+  free(min_val); free(max_val);
+  }
+  for (int i = 0; i < n; ++i)
+    for (int s = 1; s < nd - 1; ++s)
+      if (is_kp[(size_t)i * nd + s]) kp_push(out, cloud[i].x, cloud[i].y, cloud[i].z, scales[s]);
+  free(is_kp); free(dog); free(scales);
   mo_grid_free(g);
 }
 

@@ -261,6 +261,15 @@ def srand(seed):
     lib().mo_srand(C.c_uint(seed))
 
 
+def set_threads(n):
+    """Baseline B2: OpenMP threads for the loops over points / keypoints (results do not depend on it)."""
+    lib().mo_set_threads(int(n))
+
+
+def get_threads():
+    return int(lib().mo_get_threads())
+
+
 def rand():
     return lib().mo_rand()
 

@@ -3,9 +3,10 @@
 import csv, sys, collections, re
 
 def short(name):
-    m = re.search(r"mm3d::(\w+)", name)
+    m = re.search(r"mm3d::(\w+)(<\d+>)?", name)
     if m:
-        return m.group(1)
+        # the ICP / score search is one template (k_nn_wave<0> / <1>): keep its argument apart
+        return m.group(1) + (m.group(2) or "" if m.group(1) == "k_nn_wave" else "")
     m = re.search(r"(\w+)<", name)
     return (m.group(1) if m else name)[:40]
 

@@ -162,6 +162,31 @@ def test_desc_knn_mfma_path_exact(ctx, po, mm, scene):
     assert rows > 0 and fb <= 0.05 * rows, (rows, fb)   # the certificate holds for nearly every row
 
 
+def test_matching_k_is_any_positive_number(ctx, po, mm, scene):
+    """matching_k is an arbitrary size_t in the reference (R/src/map_merging.cpp:43-47 -> FLANN nearestKSearch):
+    beyond the 16 neighbours the register kernels keep, the plain exact kernel takes over; more neighbours than
+    rows exist behave like "all of them".  Indices and distance bits as the oracle's, ties by index."""
+    rng = np.random.default_rng(11)
+    base = np.concatenate([scene[0]["desc"], scene[1]["desc"]])
+    A = (base[rng.integers(0, len(base), 300)] + rng.normal(0, 0.3, (300, 33))).astype(np.float32)
+    B = (base[rng.integers(0, len(base), 260)] + rng.normal(0, 0.3, (260, 33))).astype(np.float32)
+    B[10:30] = B[40:60]
+    A[:8] = B[100:108]
+    da, db = ctx.descriptors(A), ctx.descriptors(B)
+    for k in (17, 40, 260, 5000):
+        got = ctx.findFeatureCorrespondences(da, db, k)
+        ref = po.find_correspondences(A, B, min(k, 300))
+        assert np.array_equal(got["index_query"], ref["index_query"]), k
+        assert np.array_equal(got["index_match"], ref["index_match"]), k
+        assert np.array_equal(got["distance"].view(np.uint32), ref["distance"].view(np.uint32)), k
+    # wide rows through the same kernel
+    W = rng.normal(0, 1, (90, 125)).astype(np.float32)
+    V = rng.normal(0, 1, (70, 125)).astype(np.float32)
+    got = ctx.findFeatureCorrespondences(ctx.descriptors(W, mm.Descriptor.PFH), ctx.descriptors(V, mm.Descriptor.PFH), 24)
+    ref = po.find_correspondences(W, V, 24)
+    assert np.array_equal(got["index_match"], ref["index_match"]) and np.array_equal(got["distance"].view(np.uint32), ref["distance"].view(np.uint32))
+
+
 def test_ransac_exact(ctx, po, scene):
     a, b = scene
     corr = po.find_correspondences(a["desc"], b["desc"], 5)

@@ -32,7 +32,7 @@ class Reader:
 
 
 def bits(a):
-    return np.ascontiguousarray(a).view(np.uint8)
+    return np.ascontiguousarray(a).view(np.uint8).ravel()
 
 
 def test_shim_results_equal_the_c_abi(tmp_path, mm, synth):

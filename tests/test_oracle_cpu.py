@@ -583,3 +583,116 @@ def test_golden_features_fixture(po, synth):
         po.srand(1)
         T, pairs = po.estimate_maps_transforms(raws, p)
         assert np.array_equal(pairs["transform"].view(np.uint32), g[f"pair_transform_d{dt}_m{m}"].view(np.uint32)), (m, dt)
+
+
+def test_threads_do_not_change_a_bit(po, synth):
+    """Baseline B2: the oracle's loops over points run on OpenMP threads, every order-sensitive
+    sum stays sequential -- one thread and four give the same bits at every stage."""
+    _, maps = synth.synth_maps(2, 6000)
+    raws = [synth.pack_points(x, c) for x, c, _ in maps]
+    p = po.params_default()
+
+    def run():
+        out = []
+        feats = []
+        for r in raws:
+            d = po.downsample(r, p.resolution)
+            f = po.remove_outliers(d, p.descriptor_radius, p.outliers_min_neighbours)
+            n = po.normals(f, p.normal_radius)
+            kp, _ = po.keypoints_sift(f, p.resolution, 3, 3, p.keypoint_threshold)
+            kp, desc = po.descriptors_fpfh(f, n, kp, p.descriptor_radius)
+            feats.append((f, kp, desc))
+            out += [f.tobytes(), n.tobytes(), kp.tobytes(), desc.tobytes()]
+        po.srand(1)
+        (f0, k0, d0), (f1, k1, d1) = feats
+        T, _, _ = po.sac_ia(k0, d0, k1, d1, p.inlier_threshold, p.max_correspondence_distance, 50)
+        T2, it = po.icp(f0, f1, T, p.max_correspondence_distance, p.inlier_threshold, p.max_iterations, p.transform_epsilon)
+        s = po.transform_score(f0, f1, T2, p.max_correspondence_distance)
+        corr = po.find_correspondences(d0, d1, 5)
+        out += [T.tobytes(), T2.tobytes(), np.float64(s).tobytes(), corr.tobytes(), bytes([it])]
+        return out
+
+    try:
+        po.set_threads(1)
+        a = run()
+        po.set_threads(4)
+        b = run()
+    finally:
+        po.set_threads(1)
+    assert a == b
+
+
+def test_oracle_against_real_pcl(po, synth, tmp_path):
+    """Baseline B3: where a real PCL is installed, oracle/pcl_harness/build.sh builds
+    oracle/_ref/pcl_oracle -- the reference's own PCL calls -- and every stage of the restatement is held against it.
+    This image has no PCL: the test then reports exactly that and the oracle stays unpinned."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([os.path.join(root, "oracle", "pcl_harness", "build.sh")], capture_output=True)
+    exe = os.path.join(root, "oracle", "_ref", "pcl_oracle")
+    if not os.path.exists(exe):
+        pytest.skip("PCL absent -- oracle = restatement (parity unpinned)")
+    _, maps = synth.synth_maps(2, 12000)
+    raws = [synth.pack_points(x, c) for x, c, _ in maps]
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<Q", len(raws)))
+        for r in raws:
+            f.write(struct.pack("<Q", len(r)) + r.tobytes())
+    assert subprocess.run([exe, inp, outp], timeout=1800).returncode == 0
+    data = open(outp, "rb").read()
+    off = [0]
+
+    def u64():
+        v = struct.unpack_from("<Q", data, off[0])[0]
+        off[0] += 8
+        return v
+
+    def arr(dtype, n):
+        a = np.frombuffer(data, dtype=dtype, count=n, offset=off[0])
+        off[0] += a.nbytes
+        return a
+
+    POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
+    NORMAL = np.dtype([("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4"), ("curvature", "<f4")])
+    p = po.params_default()
+    feats = []
+    for r in raws:
+        d = po.downsample(r, p.resolution)
+        f = po.remove_outliers(d, p.descriptor_radius, p.outliers_min_neighbours)
+        n = po.normals(f, p.normal_radius)
+        kp, _ = po.keypoints_sift(f, p.resolution, 3, 3, p.keypoint_threshold)
+        kp, desc = po.descriptors_fpfh(f, n, kp, p.descriptor_radius)
+        # VoxelGrid sorts with std::sort (unstable): the centroid's summation order inside a voxel may differ, so float
+        # sums may differ in the last bits; everything downstream is held to tolerances, counts exactly
+        pd = arr(POINT, u64())
+        assert len(pd) == len(d) and np.allclose(pd["x"], d["x"], atol=1e-5) and np.allclose(pd["z"], d["z"], atol=1e-5)
+        pf = arr(POINT, u64())
+        assert len(pf) == len(f)
+        pn = arr(NORMAL, u64())
+        dot = np.abs(pn["nx"] * n["nx"] + pn["ny"] * n["ny"] + pn["nz"] * n["nz"])
+        assert np.mean(dot[np.isfinite(dot)] > 1 - 1e-4) > 0.999 and np.array_equal(np.isnan(pn["nx"]), np.isnan(n["nx"]))
+        pk = arr(POINT, u64())
+        assert len(pk) == len(kp) and np.allclose(pk["x"], kp["x"], atol=1e-5)
+        rows, step = u64(), u64()
+        pdsc = arr(np.float32, rows * 33).reshape(-1, 33)
+        assert step == 132 and pdsc.shape == desc.shape and np.max(np.abs(pdsc - desc)) <= 1e-2
+        feats.append((f, kp, desc))
+    (f0, k0, d0), (f1, k1, d1) = feats
+    CORR = np.dtype([("index_query", "<i4"), ("index_match", "<i4"), ("distance", "<f4")])
+    pc = arr(CORR, u64())
+    corr = po.find_correspondences(d0, d1, 5)
+    assert len(pc) == len(corr) and np.array_equal(pc["index_match"], corr["index_match"])
+    T_r, inl, _, _ = po.ransac(k0, k1, corr, p.inlier_threshold)
+    pT = arr(np.float32, 16).reshape(4, 4).T
+    assert u64() == len(inl)                      # inlier count exact (boost::mt19937 seed 12345 replayed)
+    assert np.linalg.norm(pT - T_r) <= 1e-4
+    T_i, _ = po.icp(f0, f1, T_r, p.max_correspondence_distance, p.inlier_threshold, p.max_iterations, p.transform_epsilon)
+    assert np.linalg.norm(arr(np.float32, 16).reshape(4, 4).T - T_i) <= 1e-3
+    arr(np.float32, 16)
+    s = po.transform_score(f0, f1, T_i, p.max_correspondence_distance)
+    assert arr(np.float64, 1)[0] == pytest.approx(s, rel=1e-4)
+    po.srand(1)
+    T_s, _, _ = po.sac_ia(k0, d0, k1, d1, p.inlier_threshold, p.max_correspondence_distance, p.max_iterations)
+    assert np.linalg.norm(arr(np.float32, 16).reshape(4, 4).T - T_s) <= 1e-3
