@@ -547,7 +547,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            b1, b2, parity = cpu_baseline(host, n_maps, n_pairs, gpu_sample, args.descriptor == "FPFH" and args.method == "SAC_IA")
+            b1, b2, parity = cpu_baseline(host, n_maps, n_pairs, gpu_sample, True, args.descriptor, args.method, params)
             out["cpu_baseline"] = b1
             out["cpu_baseline_all_cores"] = b2
             out["parity_check"] = parity
@@ -560,7 +560,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check):
+def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", method="SAC_IA", params=None):
     """The CPU oracle (kind "port": our restatement of the reference's PCL path) on a bounded sample of the
     workload: the features of ONE map and ONE pair (maps 0 and 1), extrapolated to the whole job as
     n_maps * t_map + n_pairs * t_pair.
@@ -571,7 +571,8 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check):
     and pair in this very run (`parity_check`)."""
     import statistics
     po = ge.load_oracle()
-    p = po.params_default()
+    p = params if params is not None else po.params_default()   # the same parameter values the device ran with
+    describe = {"FPFH": po.descriptors_fpfh, "PFH": po.descriptors_pfh, "SHOT": po.descriptors_shot}[descriptor]
     # B2's threads: the physical cores (SMT siblings do not help these loops), at most 64
     cores = max(1, min(64, (os.cpu_count() or 2) // 2))
     try:
@@ -585,12 +586,16 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check):
         f = po.remove_outliers(d, p.descriptor_radius, p.outliers_min_neighbours)
         n = po.normals(f, p.normal_radius)
         kp, _ = po.keypoints_sift(f, p.resolution, 3, 3, p.keypoint_threshold)
-        kp, desc = po.descriptors_fpfh(f, n, kp, p.descriptor_radius)
+        kp, desc = describe(f, n, kp, p.descriptor_radius)
         return f, kp, desc
 
     def pair(f0, k0, d0, f1, k1, d1):
         po.srand(1)
-        T, _, _ = po.sac_ia(k0, d0, k1, d1, p.inlier_threshold, p.max_correspondence_distance, p.max_iterations)
+        if method == "SAC_IA":
+            T, _, _ = po.sac_ia(k0, d0, k1, d1, p.inlier_threshold, p.max_correspondence_distance, p.max_iterations)
+        else:
+            corr = po.find_correspondences(d0, d1, int(p.matching_k))
+            T, _, _, _ = po.ransac(k0, k1, corr, p.inlier_threshold)
         T, it = po.icp(f0, f1, T, p.max_correspondence_distance, p.inlier_threshold, p.max_iterations, p.transform_epsilon)
         score = po.transform_score(f0, f1, T, p.max_correspondence_distance)
         return T, it, score

@@ -128,6 +128,10 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
 
 #ifdef MM3D_NN_STATS
   const long long t_begin = wall_clock64();
+  for (int e = 1; e <= 8; ++e) {          // what ring the lanes ask for before the first pass
+    const int c_ = __popcll(__ballot(active && (e < 8 ? need == e : need >= 8)));
+    if (MM3D_NN_STATS == 1 && lane == 0 && c_) atomicAdd(&g_nn_stats[55 + e], (unsigned long long)c_);
+  }
 #endif
   for (int pass = 0; pass < 64; ++pass) {
     if (!__ballot(active)) break;

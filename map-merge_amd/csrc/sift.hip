@@ -401,6 +401,9 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     {
       SnLaunch<float2> sn(c, n_items * 4, cur->n);
       SnScratch scr{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error()};
+#ifdef MM3D_SN_MODE
+      { int mode = getenv("MM3D_SN_MODE") ? atoi(getenv("MM3D_SN_MODE")) : 4; MM3D_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sn_mode), &mode, sizeof(int))); }
+#endif
       MM3D_LAUNCH(c, "sift_dog", gr.n * 36.0, k_sift_dog, dim3(sn.blocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
                   (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, scr,
                   dog.get());

@@ -70,6 +70,9 @@ __device__ unsigned long long g_sn_stats[16];   // 0 groups, 1 pass 1, 2 prefix,
 #define SN_COUNT(i_, v_)
 #endif
 
+#ifdef MM3D_SN_MODE
+__device__ int g_sn_mode;   // experiment: 2 = stop after pass 2; 3 = after rank; 31 = rank without the payload gather; 32 = rank without the bucket loop; 33 = rank without the key staging
+#endif
 struct SnScratch {
   unsigned long long *tmp;          // [waves][kSnEntries] keys in bucket order
   void *fin;                        // [waves][kSnEntries] payloads in final order
@@ -206,6 +209,9 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
                               keep);
   wave_lds_fence();
   SN_TOCK(3, t_p2);
+#ifdef MM3D_SN_MODE
+  if (g_sn_mode == 2) { if (lane <= kSnG) L.list_off[lane] = 0; wave_lds_fence(); return fit; }
+#endif
   SN_TICK(t_rank);
   // rank inside the buckets -> final order.  Runs of consecutive queries whose keys fit the tile's memory are
   // pulled into LDS together (one global round trip per run), ranked there and written out as payloads.
@@ -216,6 +222,22 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
     while (p1 < fit && L.list_off[p1 + 1] - base0 <= kSnRank) ++p1;
     const int cnt = L.list_off[p1] - base0;
     if (cnt <= kSnRank) {
+#ifdef MM3D_SN_MODE
+      const int md = g_sn_mode;
+      if (md != 33) for (int e = lane; e < cnt; e += kWave) kbuf[e] = tmp[base0 + e];
+      wave_lds_fence();
+      for (int e = lane; e < cnt; e += kWave) {
+        const unsigned long long key = md == 33 ? (((unsigned long long)__float_as_uint(r2 * 0.5f)) << 32 | (unsigned long long)((p0 & 15) << 28) | (unsigned)e) : kbuf[e];
+        const int p = (int)((key >> 28) & 15u);
+        const int pb = L.list_off[p] - base0;
+        const int b = sn_bucket(__uint_as_float((unsigned)(key >> 32)), bscale);
+        const int bs = sn_bucket_start(L.cnt[p], b), be = sn_bucket_end(L.cnt[p], b);
+        int r = 0;
+        if (md != 32) for (int j = bs; j < be; ++j) r += kbuf[pb + j] < key ? 1 : 0;
+        if (md == 31) fin[base0 + pb + bs + r] = Payload();
+        else fin[base0 + pb + bs + r] = make(key & 0xffffffff0fffffffull);
+      }
+#else
       for (int e = lane; e < cnt; e += kWave) kbuf[e] = tmp[base0 + e];
       wave_lds_fence();
       for (int e = lane; e < cnt; e += kWave) {
@@ -228,6 +250,7 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
         for (int j = bs; j < be; ++j) r += kbuf[pb + j] < key ? 1 : 0;
         fin[base0 + pb + bs + r] = make(key & 0xffffffff0fffffffull);
       }
+#endif
       wave_lds_fence();
     } else {
       // one query with more keys than the tile holds: rank against global memory
@@ -245,6 +268,9 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
   }
   wave_lds_fence();
   SN_TOCK(4, t_rank);
+#ifdef MM3D_SN_MODE
+  if (g_sn_mode != 4) { if (lane <= kSnG) L.list_off[lane] = 0; wave_lds_fence(); }
+#endif
   return fit;
 }
 

@@ -1,0 +1,21 @@
+#!/bin/bash
+# BASELINE.md's results table: the five BASELINE.json configurations on one GPU, each with the CPU baselines
+# B1 (one thread) and B2 (all cores) timed in the same run on the same box.  Run through gpurun:
+#   scripts/baseline_table.sh r02        -> gpurun_out/r02_table_cfg{1..5}.json
+# scripts/fill_baseline_table.py r02 then writes the table into BASELINE.md and copies the lines to profiles/.
+set -u
+TAG=${1:-round}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R"
+mkdir -p gpurun_out
+run() {   # run <cfg> <bench args...>
+  local cfg=$1; shift
+  timeout 1500 python3 bench.py "$@" 2> "/tmp/table_cfg$cfg.err" | tail -1 > "gpurun_out/${TAG}_table_cfg$cfg.json"
+  python3 -c "import json; d=json.load(open('gpurun_out/${TAG}_table_cfg$cfg.json')); print('cfg$cfg', d['value'], d['cpu_baseline']['value'], d['cpu_baseline_all_cores']['value'], (d.get('parity_check') or {}).get('ok'))" \
+    || { echo "cfg$cfg failed:"; tail -5 "/tmp/table_cfg$cfg.err"; }
+}
+run 1 --maps 2 --points 10000 --steps 10 --warmup 2
+run 2 --maps 4 --points 200000 --steps 5 --warmup 1
+run 3
+run 5 --maps 64 --points 50000 --steps 2 --warmup 1
+run 4 --maps 8 --points 2000000 --descriptor SHOT --steps 2 --warmup 1

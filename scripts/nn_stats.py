@@ -5,7 +5,7 @@ three phases (row headers, staging, candidate scan)."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import __graft_entry__ as ge
-mm = ge.load()
+mm = ge.load()   # MM3D_LIB selects the instrumentation build
 import bench, numpy as np
 host = bench.make_workload(16, 500000)
 ctx = mm.Context(0)
@@ -24,4 +24,5 @@ print("max wave ticks(100MHz)", v[6], "= us", v[6] / 100.0, " mean us", v[7] / m
 print("hist log2(ticks):", {b: v[8 + b] for b in range(24) if v[8 + b]})
 print("phase ticks: headers", v[32], "staging", v[33], "scan", v[34], " total wave ticks", v[7])
 print("per ring size E: passes", v[40:48], " ticks", v[48:56])
+print("lanes by the ring they ask for before the first pass (1..7, >=8):", v[56:64])
 print("icp iters", r["icp_iterations"])
