@@ -222,9 +222,10 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
 // float, its 11-bin block's sum takes "+= val" in double, neighbour-major, bin-minor.  Both are chains, so the
 // neighbour lists are built in that order first (sorted_nb.hpp, payload = (d2, SPFH row)); a lane then owns one
 // (keypoint, 11-bin block) and walks the keypoint's list: 16 keypoints x 3 blocks = 48 chains per wave.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_fpfh_weight(const float4 *__restrict__ q_pts /* keypoints, Hilbert order, .w = keypoint index */, const int2 *__restrict__ items,
-              int n_items, GridView g, const int *__restrict__ row_of /* support row by original point index */,
+              int n_items, GridView g, const float4 *__restrict__ surface /* the points in original order */,
+              const int *__restrict__ row_of /* support row by original point index */,
               const float *__restrict__ spfh, float radius, float r2, SnScratch scr, float *__restrict__ desc /* [nk][33] */,
               int *__restrict__ valid)
 {
@@ -244,11 +245,8 @@ k_fpfh_weight(const float4 *__restrict__ q_pts /* keypoints, Hilbert order, .w =
     while (left > 0) {
       const int pq = lane >> 2;
       const float4 q = q_pts[it.x + first + (pq < left ? pq : 0)];
-      const int fit = sn_build_lists<float2>(g, L, q.x, q.y, q.z, left, radius, r2, tmp, fin, scr.error, lane,
-                                             [&](unsigned long long key) {
-                                               return make_float2(__uint_as_float((unsigned)(key >> 32)),
-                                                                  __int_as_float(row_of[(unsigned)(key & 0xffffffffull)]));
-                                             });
+      const int fit = sn_build_lists<float2>(g, L, q.x, q.y, q.z, left, radius, r2, surface, tmp, fin, scr.error, lane,
+                                             [&](float d2, unsigned idx, const float4 &) { return make_float2(d2, __int_as_float(row_of[idx])); });
       // chains: lane = keypoint * 3 + block
       const int p = lane / 3, f = lane - p * 3;
       if (p < fit) {
@@ -362,7 +360,7 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
     if (keypoints->n_finite)
       MM3D_LAUNCH(c, "fpfh_weight", (double)ns * 132.0 + nk * 132.0, k_fpfh_weight, dim3(sn.blocks), dim3(256), 0,
                   (const float4 *)keypoints->hil_pts.get(), (const int2 *)keypoints->wave_items.get(), nki, g.view(),
-                  (const int *)pos.get(), (const float *)spfh.get(), (float)radius, r2, scr, raw.get(), valid.get());
+                  (const float4 *)points->pts.get(), (const int *)pos.get(), (const float *)spfh.get(), (float)radius, r2, scr, raw.get(), valid.get());
     int *he = (int *)c->pin(64);
     MM3D_HIP(hipMemcpyAsync(he, sn.error(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->sync();

@@ -16,7 +16,7 @@
 
 namespace mm3d {
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_normals(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g, const float4 *__restrict__ pts,
           float radius, float r2, SnScratch sc, float4 *__restrict__ out /* by original index */)
 {
@@ -38,8 +38,8 @@ k_normals(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int 
     while (left > 0) {
       const int p = lane >> 2, sub = lane & 3;
       const float4 q = q_pts[it.x + first + (p < left ? p : 0)];
-      const int fit = sn_build_lists<float4>(g, L, q.x, q.y, q.z, left, radius, r2, tmp, fin, sc.error, lane,
-                                             [&](unsigned long long key) { return pts[(unsigned)(key & 0xffffffffull)]; });
+      const int fit = sn_build_lists<float4>(g, L, q.x, q.y, q.z, left, radius, r2, pts, tmp, fin, sc.error, lane,
+                                             [](float, unsigned, const float4 &pt) { return pt; });
       SN_TICK(t_chain);
       // chains: lane (p, sub) owns accumulators sub, sub + 4, sub + 8 of a = {xx, xy, xz, yy, yz, zz, x, y, z}
       if (p < fit) {

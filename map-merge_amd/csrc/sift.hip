@@ -79,11 +79,8 @@ k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int
     int left = min(kSnG, it.y - first);
     while (left > 0) {
       const float4 q = q_pts[it.x + first + (p < left ? p : 0)];
-      const int fit = sn_build_lists<float2>(g, L, q.x, q.y, q.z, left, radius, r2, tmp, fin, scr.error, lane,
-                                             [&](unsigned long long key) {
-                                               return make_float2(__uint_as_float((unsigned)(key >> 32)),
-                                                                  intensity_of(pts[(unsigned)(key & 0xffffffffull)].w));
-                                             });
+      const int fit = sn_build_lists<float2>(g, L, q.x, q.y, q.z, left, radius, r2, pts, tmp, fin, scr.error, lane,
+                                             [](float d2, unsigned, const float4 &pt) { return make_float2(d2, intensity_of(pt.w)); });
       SN_TICK(t_chain);
       {
         const bool mine = p < fit;
@@ -401,9 +398,6 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     {
       SnLaunch<float2> sn(c, n_items * 4, cur->n);
       SnScratch scr{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error()};
-#ifdef MM3D_SN_MODE
-      { int mode = getenv("MM3D_SN_MODE") ? atoi(getenv("MM3D_SN_MODE")) : 4; MM3D_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sn_mode), &mode, sizeof(int))); }
-#endif
       MM3D_LAUNCH(c, "sift_dog", gr.n * 36.0, k_sift_dog, dim3(sn.blocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
                   (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, scr,
                   dog.get());

@@ -36,10 +36,14 @@ constexpr int kSnNB = 128;          // distance buckets per query
 constexpr int kSnTile = 256;        // staged candidates per tile
 constexpr int kSnEntries = 16384;   // scratch list entries per wave (sum over the group's queries)
 
-constexpr int kSnRank = kSnTile * 2;   // 64-bit keys that fit the tile's memory
+// entries per rank batch: their 8-byte keys and their payloads share the tile's 4 KB (256 with 8-byte
+// payloads, 128 with 16-byte ones)
+template <class Payload>
+constexpr int sn_batch_cap() { return ((kSnTile * 16) / (8 + (int)sizeof(Payload))) / 64 * 64; }
 
 struct SnLds {
-  float4 tile[kSnTile];             // staged candidates; during the rank step: kSnRank keys
+  float4 tile[kSnTile];             // staged candidates; during the rank step: a batch of keys and payloads
+  float4 q[kSnG];                   // the group's queries
   int off[64], beg[64];
   unsigned cnt[kSnG][kSnNB / 2];    // pass 1: counts (2 x u16); then bucket starts; after pass 2: bucket ENDS
   int list_off[kSnG + 1];
@@ -70,9 +74,6 @@ __device__ unsigned long long g_sn_stats[16];   // 0 groups, 1 pass 1, 2 prefix,
 #define SN_COUNT(i_, v_)
 #endif
 
-#ifdef MM3D_SN_MODE
-__device__ int g_sn_mode;   // experiment: 2 = stop after pass 2; 3 = after rank; 31 = rank without the payload gather; 32 = rank without the bucket loop; 33 = rank without the key staging
-#endif
 struct SnScratch {
   unsigned long long *tmp;          // [waves][kSnEntries] keys in bucket order
   void *fin;                        // [waves][kSnEntries] payloads in final order
@@ -105,10 +106,12 @@ __device__ __forceinline__ int sn_claim_unit(int *unit_ctr, int n_units, int lan
 // (4 lanes per query); g <= kSnG queries are live.  On return L.list_off[p] .. L.list_off[p + 1] is query
 // p's range in `fin` (payloads in (d2, index) order) for p < the returned count g' <= g (g' < g only when
 // the scratch region cannot hold the whole group: the caller runs the rest as the next group).
-// make(key) -> Payload is called once per list entry with key = d2 bits << 32 | original index (< 2^28).
-template <class Payload, class Make>
+// opts = the surface in original order (the lists name points by original index < 2^28);
+// finish(d2, original index, point) -> Payload is called once per list entry.
+template <class Payload, class Finish>
 __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float qx, float qy, float qz, int n_q, float radius, float r2,
-                                              unsigned long long *tmp, Payload *fin, int *error, int lane, Make &&make)
+                                              const float4 *__restrict__ opts, unsigned long long *tmp, Payload *fin, int *error, int lane,
+                                              Finish &&finish)
 {
   const float ri = radius * 1.0001f + 1e-4f;
   const bool live = (lane >> 2) < n_q;
@@ -121,6 +124,7 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
   const KeepInBox keep{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri};
   const float bscale = (float)kSnNB / r2;
   for (int p = 0; p < kSnG; ++p) L.cnt[p][lane] = 0u;
+  if ((lane & 3) == 0) L.q[lane >> 2] = make_float4(qx, qy, qz, 0.0f);
   wave_lds_fence();
   SN_TICK(t_p1);
   SN_COUNT(0, 1);
@@ -198,10 +202,9 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
                                       const int b = sn_bucket(d2, bscale);
                                       const unsigned old = atomicAdd(&L.cnt[p][b >> 1], (b & 1) ? 0x10000u : 1u);
                                       const int at = (int)((b & 1) ? (old >> 16) : (old & 0xffffu));
-                                      // key = distance bits | query (4 bits) | original index (28 bits): inside one query's list the
-                                      // order is (distance, index); the query number spares the rank step a search
-                                      tmp[base + at] = ((unsigned long long)__float_as_uint(d2) << 32) | ((unsigned long long)p << 28) |
-                                                       (unsigned long long)__float_as_uint(c[u].w);
+                                      // only the original index goes to the scratch list (4 bytes): the rank step fetches
+                                      // the point again and recomputes the distance
+                                      reinterpret_cast<unsigned *>(tmp)[base + at] = __float_as_uint(c[u].w);
                                     }
                                   }
                                 }
@@ -209,68 +212,91 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
                               keep);
   wave_lds_fence();
   SN_TOCK(3, t_p2);
-#ifdef MM3D_SN_MODE
-  if (g_sn_mode == 2) { if (lane <= kSnG) L.list_off[lane] = 0; wave_lds_fence(); return fit; }
-#endif
   SN_TICK(t_rank);
-  // rank inside the buckets -> final order.  Runs of consecutive queries whose keys fit the tile's memory are
-  // pulled into LDS together (one global round trip per run), ranked there and written out as payloads.
+  // rank inside the buckets -> final order, one batch of whole buckets (at most kCap entries, normally one
+  // query's whole list) at a time, entirely in LDS: the batch's indices come out of `tmp` with coalesced loads,
+  // every entry fetches its point (L2: the cloud is a few MB), recomputes its distance and builds its payload;
+  // the keys are ranked inside their buckets, the payloads land at their final places in LDS, and the batch
+  // goes to `fin` with coalesced full-line stores.  (Scratch traffic is what bounds these kernels: with 8-byte
+  // keys in `tmp` and payloads scattered straight into `fin` they spent most of their time on it.)
+  constexpr int kCap = sn_batch_cap<Payload>();
+  constexpr int kRU = kCap / kWave;
   unsigned long long *kbuf = reinterpret_cast<unsigned long long *>(L.tile);
-  for (int p0 = 0; p0 < fit;) {
-    const int base0 = L.list_off[p0];
-    int p1 = p0 + 1;
-    while (p1 < fit && L.list_off[p1 + 1] - base0 <= kSnRank) ++p1;
-    const int cnt = L.list_off[p1] - base0;
-    if (cnt <= kSnRank) {
-#ifdef MM3D_SN_MODE
-      const int md = g_sn_mode;
-      if (md != 33) for (int e = lane; e < cnt; e += kWave) kbuf[e] = tmp[base0 + e];
-      wave_lds_fence();
-      for (int e = lane; e < cnt; e += kWave) {
-        const unsigned long long key = md == 33 ? (((unsigned long long)__float_as_uint(r2 * 0.5f)) << 32 | (unsigned long long)((p0 & 15) << 28) | (unsigned)e) : kbuf[e];
-        const int p = (int)((key >> 28) & 15u);
-        const int pb = L.list_off[p] - base0;
-        const int b = sn_bucket(__uint_as_float((unsigned)(key >> 32)), bscale);
-        const int bs = sn_bucket_start(L.cnt[p], b), be = sn_bucket_end(L.cnt[p], b);
-        int r = 0;
-        if (md != 32) for (int j = bs; j < be; ++j) r += kbuf[pb + j] < key ? 1 : 0;
-        if (md == 31) fin[base0 + pb + bs + r] = Payload();
-        else fin[base0 + pb + bs + r] = make(key & 0xffffffff0fffffffull);
+  Payload *obuf = reinterpret_cast<Payload *>(kbuf + kCap);
+  const unsigned *tmp32 = reinterpret_cast<const unsigned *>(tmp);
+  for (int p = 0; p < fit; ++p) {
+    const int lo = L.list_off[p], hi = L.list_off[p + 1];
+    const float4 qp = L.q[p];
+    int s = lo;
+    while (s < hi) {
+      int e_end = hi;
+      if (hi - s > kCap) {
+        // the largest bucket boundary within kCap of s (lane l holds the ends of buckets 2l and 2l + 1)
+        const unsigned w = L.cnt[p][lane];
+        const int target = s - lo + kCap, e0 = (int)(w & 0xffffu), e1 = (int)(w >> 16);
+        const int cut = wave_max_int(e1 <= target ? e1 : (e0 <= target ? e0 : 0));
+        e_end = lo + cut;
       }
-#else
-      for (int e = lane; e < cnt; e += kWave) kbuf[e] = tmp[base0 + e];
-      wave_lds_fence();
-      for (int e = lane; e < cnt; e += kWave) {
-        const unsigned long long key = kbuf[e];
-        const int p = (int)((key >> 28) & 15u);
-        const int pb = L.list_off[p] - base0;
-        const int b = sn_bucket(__uint_as_float((unsigned)(key >> 32)), bscale);
-        const int bs = sn_bucket_start(L.cnt[p], b), be = sn_bucket_end(L.cnt[p], b);
-        int r = 0;
-        for (int j = bs; j < be; ++j) r += kbuf[pb + j] < key ? 1 : 0;
-        fin[base0 + pb + bs + r] = make(key & 0xffffffff0fffffffull);
-      }
-#endif
-      wave_lds_fence();
-    } else {
-      // one query with more keys than the tile holds: rank against global memory
-      const int m = cnt;
-      for (int e = lane; e < m; e += kWave) {
-        const unsigned long long key = tmp[base0 + e];
-        const int b = sn_bucket(__uint_as_float((unsigned)(key >> 32)), bscale);
-        const int bs = sn_bucket_start(L.cnt[p0], b), be = sn_bucket_end(L.cnt[p0], b);
-        int r = 0;
-        for (int j = bs; j < be; ++j) r += tmp[base0 + j] < key ? 1 : 0;
-        fin[base0 + bs + r] = make(key & 0xffffffff0fffffffull);
+      if (e_end > s) {
+        const int n = e_end - s;
+        unsigned long long key[kRU];
+        Payload pay[kRU];
+#pragma unroll
+        for (int u = 0; u < kRU; ++u) {
+          const int i = lane + u * kWave;
+          const unsigned idx = tmp32[s + (i < n ? i : 0)];
+          const float4 pt = opts[idx];
+          const float d2 = dist2(qp.x, qp.y, qp.z, pt.x, pt.y, pt.z);
+          key[u] = ((unsigned long long)__float_as_uint(d2) << 32) | idx;
+          pay[u] = finish(d2, idx, pt);
+          if (i < n) kbuf[i] = key[u];
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < kRU; ++u) {
+          const int i = lane + u * kWave;
+          if (i < n) {
+            const int b = sn_bucket(__uint_as_float((unsigned)(key[u] >> 32)), bscale);
+            const int bs = sn_bucket_start(L.cnt[p], b) - (s - lo), be = sn_bucket_end(L.cnt[p], b) - (s - lo);
+            int r = 0;
+            for (int j = bs; j < be; ++j) r += kbuf[j] < key[u] ? 1 : 0;
+            obuf[bs + r] = pay[u];
+          }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < kRU; ++u) {
+          const int i = lane + u * kWave;
+          if (i < n) fin[s + i] = obuf[i];
+        }
+        wave_lds_fence();
+        s = e_end;
+      } else {
+        // one bucket alone holds more than kCap entries (hundreds of neighbours at the same distance): rank it
+        // against global memory
+        const unsigned w = L.cnt[p][lane];
+        const int e0 = (int)(w & 0xffffu), e1 = (int)(w >> 16), from = s - lo;
+        const int b_end = lo + wave_min_int(e0 > from ? e0 : (e1 > from ? e1 : 0x7fffffff));
+        for (int i = s + lane; i < b_end; i += kWave) {
+          const unsigned idx = tmp32[i];
+          const float4 pt = opts[idx];
+          const float d2 = dist2(qp.x, qp.y, qp.z, pt.x, pt.y, pt.z);
+          const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | idx;
+          int r = 0;
+          for (int j = s; j < b_end; ++j) {
+            const unsigned oj = tmp32[j];
+            const float4 pj = opts[oj];
+            const unsigned long long kj = ((unsigned long long)__float_as_uint(dist2(qp.x, qp.y, qp.z, pj.x, pj.y, pj.z)) << 32) | oj;
+            r += kj < key ? 1 : 0;
+          }
+          fin[s + r] = finish(d2, idx, pt);
+        }
+        s = b_end;
       }
     }
-    p0 = p1;
   }
   wave_lds_fence();
   SN_TOCK(4, t_rank);
-#ifdef MM3D_SN_MODE
-  if (g_sn_mode != 4) { if (lane <= kSnG) L.list_off[lane] = 0; wave_lds_fence(); }
-#endif
   return fit;
 }
 
