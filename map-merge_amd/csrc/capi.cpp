@@ -1,5 +1,6 @@
 // capi.cpp -- the extern "C" boundary of libmm3d.so (include/mm3d.h).  Nothing throws across it.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <condition_variable>
@@ -332,22 +333,26 @@ int mm3d_desc_download_frames(mm3d_ctx *ctx, const mm3d_desc *d, float *dst)
     ctx->sync();
   });
 }
+static mm3d_desc *desc_from_memory(mm3d_ctx *ctx, const float *data, size_t n, int descriptor_type)
+{
+  const int dim = mm3d_descriptor_dim(descriptor_type);
+  if (dim < 0) throw Error(MM3D_EINVAL, "unknown descriptor type");
+  std::unique_ptr<mm3d_desc> r(new mm3d_desc());
+  r->n = n; r->dim = dim; r->type = descriptor_type;
+  r->data = DevBuf<float>(ctx, n * dim);
+  if (n) {
+    MM3D_HIP(hipMemcpyAsync(r->data.get(), data, n * dim * sizeof(float), hipMemcpyDefault, ctx->stream));
+    ctx->sync();
+  }
+  return r.release();
+}
+
 int mm3d_desc_create(mm3d_ctx *ctx, const float *data, size_t n, int descriptor_type, mm3d_desc **out)
 {
   if (!out || (!data && n)) return MM3D_EINVAL;
   *out = nullptr;
-  const int dim = mm3d_descriptor_dim(descriptor_type);
-  if (dim < 0) return MM3D_EINVAL;
-  return guarded(ctx, [&] {
-    auto *r = new mm3d_desc();
-    r->n = n; r->dim = dim; r->type = descriptor_type;
-    r->data = DevBuf<float>(ctx, n * dim);
-    if (n) {
-      MM3D_HIP(hipMemcpyAsync(r->data.get(), data, n * dim * sizeof(float), hipMemcpyDefault, ctx->stream));
-      ctx->sync();
-    }
-    *out = r;
-  });
+  if (mm3d_descriptor_dim(descriptor_type) < 0) return MM3D_EINVAL;
+  return guarded(ctx, [&] { *out = desc_from_memory(ctx, data, n, descriptor_type); });
 }
 void mm3d_desc_free(mm3d_ctx *ctx, mm3d_desc *d)
 {
@@ -828,6 +833,211 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   const int st = global_transforms(pairs.data(), pairs.size(), params->confidence_threshold, n, out_T, n_out);
   if (st != MM3D_OK) throw Error(st, "computeGlobalTransforms failed");
   ctx->last_total_s = since_start();
+}
+
+// ---------------------------------------------------------------- the same job on N processes (one per GPU)
+// The N > 1 driver, inside the library like the N = 1 one (estimate_maps_streams): the caller (bench.py,
+// one process per GPU) only moves bytes between ranks -- one all-gather of the maps' feature bundles, one
+// all-gather of the pair records.  A rank extracts the features of the maps it owns (on its streams),
+// receives the other maps' bundles, and estimates the pairs whose TARGET it owns, so each rank builds
+// target-side search structures (grids, distance transforms, k-NN operands) for n / world maps only.
+// Owners zig-zag over the ranks (0 1 .. w-1 w-1 .. 1 0 0 1 ..): target j has j pairs, and j and its mirror
+// image share a rank, which evens the pair counts out.
+struct mm3d_shard {
+  mm3d_ctx *ctx = nullptr;
+  int rank = 0, world = 1;
+  size_t n = 0;
+  mm3d_params params{};
+  std::vector<mm3d_map *> maps;
+  ~mm3d_shard()
+  {
+    for (mm3d_map *x : maps)
+      if (x) { delete x->points; delete x->keypoints; delete x->desc; delete x; }
+  }
+};
+
+int mm3d_shard_map_owner(size_t map, int world)
+{
+  if (world <= 1) return 0;
+  const size_t j = map % (2 * (size_t)world);
+  return (int)(j < (size_t)world ? j : 2 * (size_t)world - 1 - j);
+}
+
+}  // extern "C" (a template needs C++ linkage)
+// run fn(worker index, context) on the context's streams (the caller's thread is worker 0); the first exception is rethrown
+template <class Fn>
+static void on_streams(mm3d_ctx *ctx, Fn &&fn)
+{
+  std::vector<mm3d_ctx *> cs{ctx};
+  cs.insert(cs.end(), ctx->helpers.begin(), ctx->helpers.end());
+  std::mutex mu;
+  std::exception_ptr first_error;
+  auto body = [&](size_t w) {
+    try {
+      if (hipSetDevice(cs[w]->device) != hipSuccess) throw Error(MM3D_EDEVICE, "hipSetDevice failed");
+      fn(w, cs[w]);
+      cs[w]->sync();
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!first_error) first_error = std::current_exception();
+    }
+  };
+  std::vector<std::thread> threads;
+  for (size_t w = 1; w < cs.size(); ++w) threads.emplace_back(body, w);
+  body(0);
+  for (auto &t : threads) t.join();
+  for (mm3d_ctx *c : cs) (void)hipStreamSynchronize(c->stream);
+  if (first_error) std::rethrow_exception(first_error);
+}
+extern "C" {
+
+int mm3d_shard_begin(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, const mm3d_params *params, int rank, int world,
+                     mm3d_shard **out)
+{
+  if (!ctx || !params || !out || (n && !clouds) || world < 1 || rank < 0 || rank >= world) return MM3D_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    std::unique_ptr<mm3d_shard> sh(new mm3d_shard());
+    sh->ctx = ctx; sh->rank = rank; sh->world = world; sh->n = n; sh->params = *params;
+    sh->maps.assign(n, nullptr);
+    std::vector<size_t> mine;
+    for (size_t i = 0; i < n; ++i)
+      if (mm3d_shard_map_owner(i, world) == rank) mine.push_back(i);
+    std::atomic<size_t> next{0};
+    on_streams(ctx, [&](size_t, mm3d_ctx *c) {
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= mine.size()) break;
+        const size_t i = mine[k];
+        std::unique_ptr<mm3d_cloud> raw(cloud_from_memory(c, clouds[i].points, clouds[i].points ? clouds[i].n : 0,
+                                                          clouds[i].stride ? clouds[i].stride : 16,
+                                                          clouds[i].stride ? clouds[i].rgba_offset : 12));
+        mm3d_map *m = map_features_impl(c, raw.get(), params);
+        sh->maps[i] = m;                         // (distinct slots: no lock needed; the shard owns it from here)
+        map_prepare_impl(c, m, params);          // this rank is the map's target-side owner
+      }
+    });
+    *out = sh.release();
+  });
+}
+
+int mm3d_shard_bundle_sizes(const mm3d_shard *sh, uint64_t *n_points, uint64_t *n_keypoints)
+{
+  if (!sh || !n_points || !n_keypoints) return MM3D_EINVAL;
+  for (size_t i = 0; i < sh->n; ++i) {
+    const bool own = sh->maps[i] && mm3d_shard_map_owner(i, sh->world) == sh->rank;
+    n_points[i] = own ? sh->maps[i]->points->n : 0;
+    n_keypoints[i] = own ? sh->maps[i]->keypoints->n : 0;
+  }
+  return MM3D_OK;
+}
+
+size_t mm3d_shard_bundle_bytes(uint64_t n_points, uint64_t n_keypoints, int descriptor_type)
+{
+  const int dim = mm3d_descriptor_dim(descriptor_type);
+  return (size_t)n_points * 16 + (size_t)n_keypoints * 16 + (size_t)n_keypoints * (size_t)(dim > 0 ? dim : 0) * 4;
+}
+
+int mm3d_shard_pack(mm3d_shard *sh, size_t map, void *dst)
+{
+  if (!sh || map >= sh->n || !sh->maps[map] || !dst) return MM3D_EINVAL;
+  mm3d_ctx *ctx = sh->ctx;
+  return guarded(ctx, [&] {
+    const mm3d_map *m = sh->maps[map];
+    char *d = static_cast<char *>(dst);
+    if (m->points->n) MM3D_HIP(hipMemcpyAsync(d, m->points->pts.get(), m->points->n * 16, hipMemcpyDefault, ctx->stream));
+    d += m->points->n * 16;
+    if (m->keypoints->n) MM3D_HIP(hipMemcpyAsync(d, m->keypoints->pts.get(), m->keypoints->n * 16, hipMemcpyDefault, ctx->stream));
+    d += m->keypoints->n * 16;
+    if (m->desc->n) MM3D_HIP(hipMemcpyAsync(d, m->desc->data.get(), m->desc->n * (size_t)m->desc->dim * 4, hipMemcpyDefault, ctx->stream));
+    ctx->sync();
+  });
+}
+
+int mm3d_shard_unpack(mm3d_shard *sh, size_t map, const void *src, uint64_t n_points, uint64_t n_keypoints)
+{
+  if (!sh || map >= sh->n || (!src && (n_points || n_keypoints))) return MM3D_EINVAL;
+  if (sh->maps[map]) return MM3D_OK;               // an owned map is already here
+  mm3d_ctx *ctx = sh->ctx;
+  return guarded(ctx, [&] {
+    const char *s = static_cast<const char *>(src);
+    std::unique_ptr<mm3d_cloud> pts(cloud_from_memory(ctx, n_points ? s : nullptr, n_points, 16, 12));
+    s += n_points * 16;
+    std::unique_ptr<mm3d_cloud> kp(cloud_from_memory(ctx, n_keypoints ? s : nullptr, n_keypoints, 16, 12));
+    s += n_keypoints * 16;
+    std::unique_ptr<mm3d_desc> desc(desc_from_memory(ctx, reinterpret_cast<const float *>(s), n_keypoints, sh->params.descriptor_type));
+    // source role only: the query orders of ICP / score and of SAC-IA's scoring, and the host copy of the
+    // keypoints that the rand() replay reads; target-side structures are the owner's business
+    if (pts->n) cloud_hilbert(ctx, pts.get());
+    if (kp->n) cloud_hilbert(ctx, kp.get());
+    (void)cloud_host(ctx, kp.get());
+    ctx->sync();
+    auto *m = new mm3d_map();
+    m->points = pts.release(); m->keypoints = kp.release(); m->desc = desc.release();
+    sh->maps[map] = m;
+  });
+}
+
+int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *mine, size_t capacity, size_t *n_pairs)
+{
+  if (!sh || !n_pairs || !pairs || !mine) return MM3D_EINVAL;
+  mm3d_ctx *ctx = sh->ctx;
+  return guarded(ctx, [&] {
+    for (size_t i = 0; i < sh->n; ++i)
+      if (!sh->maps[i]) throw Error(MM3D_EINVAL, "mm3d_shard_pairs: a map has neither been computed here nor unpacked");
+    const mm3d_params *params = &sh->params;
+    // the live pairs in the reference's order, and the generator state before each of them (the draws of a pair
+    // depend on its source keypoints only: every rank replays the whole stream on the host, ~30 us per pair)
+    std::vector<std::pair<size_t, size_t>> live;
+    for (size_t i = 0; i + 1 < sh->n; ++i)
+      for (size_t j = i + 1; j < sh->n; ++j)
+        if (sh->maps[i]->keypoints->n > 0 && sh->maps[j]->keypoints->n > 0) live.emplace_back(i, j);
+    const size_t P = live.size();
+    *n_pairs = P;
+    if (P > capacity) throw Error(MM3D_ECAPACITY, "mm3d_shard_pairs: room for every live pair is needed");
+    std::vector<GlibcRand> state_at(P + 1, ctx->rnd);
+    for (size_t q = 0; q < P; ++q) {
+      GlibcRand r = state_at[q];
+      pair_rand_replay(r, params->estimation_method, cloud_host(ctx, sh->maps[live[q].first]->keypoints), params->inlier_threshold,
+                       params->max_iterations);
+      state_at[q + 1] = r;
+    }
+    std::vector<size_t> todo;
+    for (size_t q = 0; q < P; ++q) {
+      std::memset(&pairs[q], 0, sizeof(mm3d_pair_result));
+      pairs[q].source_idx = live[q].first;
+      pairs[q].target_idx = live[q].second;
+      mine[q] = mm3d_shard_map_owner(live[q].second, sh->world) == sh->rank ? 1 : 0;
+      if (mine[q]) todo.push_back(q);
+    }
+    std::atomic<size_t> next{0};
+    on_streams(ctx, [&](size_t, mm3d_ctx *c) {
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= todo.size()) break;
+        const size_t q = todo[k];
+        c->rnd = state_at[q];
+        mm3d_pair_result r;
+        pair_estimate_impl(c, sh->maps[live[q].first], sh->maps[live[q].second], params, true, &r);
+        r.source_idx = live[q].first;
+        r.target_idx = live[q].second;
+        pairs[q] = r;
+      }
+    });
+    ctx->rnd = state_at[P];                       // where the reference's sequential loop leaves the generator
+  });
+}
+
+void mm3d_shard_end(mm3d_shard *sh)
+{
+  if (!sh) return;
+  mm3d_ctx *ctx = sh->ctx;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (mm3d_ctx *h : ctx->helpers) (void)hipStreamSynchronize(h->stream);
+  }
+  delete sh;
 }
 
 // ---------------------------------------------------------------- map_merging.h

@@ -505,6 +505,7 @@ void grid_ensure_dt(Context *c, const Grid &g_, int R)
               g.dims[2], 2, R, a.get());
   g.dt = std::move(a);
   g.dt_cap = R;
+  c->sync();      // another context may read the table as soon as the lock is gone
 }
 
 // ---------------------------------------------------------------- merged neighbourhood lists

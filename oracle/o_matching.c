@@ -266,9 +266,11 @@ void mo_sac_ia(const mo_point *src_kp, const float *src_desc, int ns, const mo_p
 
   /* feature_tree_: 10-NN of every source feature among target features */
   int kk = k_corr < nt ? k_corr : nt;
+  /* findSimilarFeatures searches the feature tree once per drawn sample (at most 3 x max_iterations rows), not
+   * for every source feature: rows are searched when a sample first needs them */
   int *nn = (int *)malloc(sizeof(int) * (size_t)ns * k_corr);
-  float *nd = (float *)malloc(sizeof(float) * (size_t)ns * k_corr);
-  mo_desc_knn(src_desc, ns, tgt_desc, nt, dim, k_corr, nn, nd);
+  float *nd = (float *)malloc(sizeof(float) * (size_t)k_corr);
+  unsigned char *have_nn = (unsigned char *)calloc((size_t)ns, 1);
 
   /* target keypoint tree for the error metric; a bounded search suffices because the truncated
    * error is 1 whenever d2 > threshold (the un-squared max_correspondence_distance) */
@@ -304,6 +306,10 @@ void mo_sac_ia(const mo_point *src_kp, const float *src_desc, int ns, const mo_p
     for (int i = 0; i < nr_samples; ++i) {
       int rc = get_random_index(k_corr);
       if (rc >= kk) rc = kk - 1;   /* reference reads past the resized result (UB) when nt < 10 */
+      if (!have_nn[sample[i]]) {
+        mo_desc_knn(&src_desc[(size_t)sample[i] * dim], 1, tgt_desc, nt, dim, k_corr, &nn[(size_t)sample[i] * k_corr], nd);
+        have_nn[sample[i]] = 1;
+      }
       corr_idx[i] = nn[(size_t)sample[i] * k_corr + rc];
     }
     /* TransformationEstimationSVD (float) on the 3 pairs */
@@ -335,7 +341,7 @@ void mo_sac_ia(const mo_point *src_kp, const float *src_desc, int ns, const mo_p
   }
   memcpy(T, best, sizeof(best));
   if (best_err_out) *best_err_out = lowest_error;
-  free(nn); free(nd); free(err_of);
+  free(nn); free(nd); free(err_of); free(have_nn);
   mo_grid_free(g);
 }
 

@@ -140,21 +140,42 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 n_maps = 4
 _, maps = synth.synth_maps(n_maps, 2500, overlap_step=0.3)
 clouds = [synth.pack_points(x, c) for x, c, _ in maps]
-# "features" on the owner only (tiny CPU stand-in for the device stage), then broadcast of sizes
+feat_dtype = clouds[0].dtype
+# "features" on the owner only (tiny CPU stand-in for the device stage), then ONE all-gather of the owners'
+# packed bundles, exactly the layout sharding.exchange_bundles uses around the library on the GPU
+import torch
+assert [sharding.map_owner(i, world) for i in range(6)] == [mm.shardMapOwner(i, world) for i in range(6)]
 feat = [po.downsample(c, 0.25) if sharding.map_owner(i, world) == rank else None for i, c in enumerate(clouds)]
-sizes = [sharding.broadcast_sizes([len(f)] if f is not None else [0], sharding.map_owner(i, world), dist)[0] for i, f in enumerate(feat)]
-full = [po.downsample(c, 0.25) for c in clouds]
-assert sizes == [len(f) for f in full]
+sz = torch.tensor([len(f) if f is not None else 0 for f in feat], dtype=torch.int64)
+dist.all_reduce(sz)
+sizes = [int(v) for v in sz]
+offset, total = [0] * n_maps, [0] * world
+for i in range(n_maps):
+    o = sharding.map_owner(i, world)
+    offset[i] = total[o]
+    total[o] += sizes[i] * 16
+buf = torch.zeros(max(total), dtype=torch.uint8)
+for i, f in enumerate(feat):
+    if f is not None:
+        buf[offset[i]:offset[i] + sizes[i] * 16] = torch.from_numpy(f.view(np.uint8).reshape(-1).copy())
+parts = sharding.all_gather_bytes(buf, world, dist)
+full = []
+for i in range(n_maps):
+    o = sharding.map_owner(i, world)
+    full.append(parts[o][offset[i]:offset[i] + sizes[i] * 16].numpy().view(feat_dtype).copy())
+ref = [po.downsample(c, 0.25) for c in clouds]
+assert all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(full, ref))
 live = sharding.live_pairs(n_maps, sizes)
 rec = np.zeros(len(live), dtype=mm.PAIR)
+owners = [sharding.pair_owner(i, j, world) for i, j in live]
 for p, (i, j) in enumerate(live):
     rec[p]["source_idx"], rec[p]["target_idx"] = i, j
-    if sharding.pair_owner(p, world) == rank:
+    if owners[p] == rank:
         T, it = po.icp(full[i], full[j], np.eye(4), 1.0, 0.5, 5, 1e-2)
         rec[p]["transform"] = T.T.reshape(16)
         rec[p]["confidence"] = 1.0 / po.transform_score(full[i], full[j], T, 1.0)
         rec[p]["icp_iterations"] = it
-merged = sharding.gather_pair_records(rec, world, rank, dist)
+merged = sharding.gather_pair_records(rec, owners, world, rank, dist)
 T = mm.globalTransforms(merged, 0.0, n_maps)
 np.save(os.path.join({out!r}, f"T_rank{{rank}}.npy"), np.stack(T))
 np.save(os.path.join({out!r}, f"pairs_rank{{rank}}.npy"), merged.view(np.uint8))

@@ -468,9 +468,15 @@ def test_bench_ranks_and_streams_give_the_same_bits():
     c = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
              "--master-port", "29533", "bench.py", "--gpus", "2", "--streams", "2"] + common,
             env={"MM3D_BENCH_BACKEND": "gloo", "MM3D_BENCH_DEVICE": "0"})
-    assert a["pair_transforms_crc32"] == b["pair_transforms_crc32"] == c["pair_transforms_crc32"]
-    assert a["maps_estimated"] == b["maps_estimated"] == c["maps_estimated"]
-    assert c["n_gpus"] == 2
+    # the N > 1 driver (mm3d_shard_*) on one rank, and on three ranks (uneven ownership: maps 0..3 -> ranks 0 1 2 2)
+    d = run([sys.executable, "bench.py", "--streams", "4", "--engine", "shard"] + common)
+    e = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+             "--master-port", "29534", "bench.py", "--gpus", "3", "--streams", "2"] + common,
+            env={"MM3D_BENCH_BACKEND": "gloo", "MM3D_BENCH_DEVICE": "0"})
+    crcs = [x["pair_transforms_crc32"] for x in (a, b, c, d, e)]
+    assert len(set(crcs)) == 1, crcs
+    assert a["maps_estimated"] == b["maps_estimated"] == c["maps_estimated"] == d["maps_estimated"] == e["maps_estimated"]
+    assert c["n_gpus"] == 2 and e["n_gpus"] == 3
 
 
 def test_pfh_neighbourhoods_beyond_lds(ctx, po, scene):
