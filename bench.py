@@ -91,6 +91,10 @@ def main():
                     help="diagnostic: do not bracket kernels with HIP events in the timed region (no roofline then)")
     ap.add_argument("--descriptor", choices=["FPFH", "PFH", "SHOT"], default="FPFH")
     ap.add_argument("--method", choices=["SAC_IA", "MATCHING"], default="SAC_IA")
+    ap.add_argument("--host-input", choices=["none", "pcl32"], default="none",
+                    help="diagnostic (one GPU, library engine): hand the clouds over as HOST arrays of pcl::PointXYZRGB records "
+                         "(stride 32, rgba at 16) like the reference's callers do, so that the step includes the upload; "
+                         "never the reported configuration (inputs are HBM-resident for `value`)")
     ap.add_argument("--kernel-table", default=None, help="write rank 0's full per-kernel HIP-event table (CSV) here")
     args = ap.parse_args()
 
@@ -131,6 +135,14 @@ def main():
     dev_raw = [torch.from_numpy(h.view(np.uint8).reshape(-1, 16)).to(dev) for h in host]
     torch.cuda.synchronize()
     pairs_idx = [(i, j) for i in range(n_maps - 1) for j in range(i + 1, n_maps)]
+    host_pcl = []
+    if args.host_input == "pcl32":                        # pcl::PointXYZRGB as it lies in memory: x y z 1 | rgba pad pad pad
+        PCL = np.dtype({"names": ["x", "y", "z", "w", "rgba"], "formats": ["<f4", "<f4", "<f4", "<f4", "<u4"], "offsets": [0, 4, 8, 12, 16],
+                        "itemsize": 32})
+        for h in host:
+            a = np.zeros(len(h), dtype=PCL)
+            a["x"], a["y"], a["z"], a["w"], a["rgba"] = h["x"], h["y"], h["z"], 1.0, h["rgba"]
+            host_pcl.append(a)
 
     stats = {}
 
@@ -251,7 +263,10 @@ def main():
         helper contexts inside libmm3d, the same pipelined scheme as step_pipelined without the Python
         in between)."""
         ctx.srand(1)                                       # the reference's process starts at glibc seed 1
-        views = [(dev_raw[i].data_ptr(), len(host[i])) for i in range(n_maps)]
+        if args.host_input == "pcl32":
+            views = [(host_pcl[i].ctypes.data, len(host[i]), 32, 16) for i in range(n_maps)]
+        else:
+            views = [(dev_raw[i].data_ptr(), len(host[i])) for i in range(n_maps)]
         T, mine = ctx.estimateMapsTransforms(views, params, return_pairs=True)
         L = mm.lib()
         f_s, tot_s = C.c_double(), C.c_double()
@@ -402,6 +417,11 @@ def main():
                 roofline["isolated_avg_launch_us"] = round(iso_ms * 1e3, 3)
                 roofline["isolated_frac"] = round(iso_work / (iso_ms * 1e-3) / peak, 6) if iso_ms > 0 else None
             iso_us = roofline.get("isolated_avg_launch_us")
+            if roofline["traffic"] and iso_us:
+                # what the memory side actually moved per launch (PMC) against the same peak: far above the algorithmic
+                # bytes where a kernel keeps scratch lists in global memory (sift_dog, normals_radius)
+                roofline["traffic_gbs"] = round(roofline["traffic"] / (iso_us * 1e-6) / 1e9, 1)
+                roofline["traffic_frac"] = round(roofline["traffic"] / (iso_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
             if dom[0] in valu_insts and iso_us:
                 v = valu_insts[dom[0]] / (iso_us * 1e-6)
                 roofline["valu"] = {"wave_instructions_per_launch": round(valu_insts[dom[0]]), "achieved": round(v / 1e9, 2),
@@ -428,7 +448,8 @@ def main():
             "value": round(value, 4), "unit": "map-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n_maps} maps x {n_pts} raw pts, {args.descriptor} + {args.method} + ICP refine, {n_pairs} pairs",
+            "config": {"workload": f"{n_maps} maps x {n_pts} raw pts, {args.descriptor} + {args.method} + ICP refine, {n_pairs} pairs"
+                                   + (" [DIAGNOSTIC: host pcl::PointXYZRGB input, upload inside the step]" if args.host_input != "none" else ""),
                        "parallelism": (f"one mm3d_estimate_maps_transforms call, {S} streams inside the library"
                                        if world == 1 and args.engine == "library" else
                                        f"mm3d_shard_*: maps by owner, pairs by target owner over {world} GPU(s) x {S} streams inside the library"
@@ -513,7 +534,6 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", me
         return T, it, score
 
     # B2 first (fast): all cores, median of 3; it also provides map 1's features for B1's pair
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")    # idle OpenMP threads sleep between the oracle's parallel loops
     po.set_threads(cores)
     tm, tp = [], []
     for _ in range(3):

@@ -303,8 +303,8 @@ class Context:
         keep = []
         views = (_View * max(n, 1))()
         for i, c in enumerate(clouds):
-            if isinstance(c, tuple):
-                views[i] = _View(C.c_void_p(c[0]), c[1], 16, 12)
+            if isinstance(c, tuple):                      # (ptr, n) packed 16-byte records, or (ptr, n, stride, rgba_offset)
+                views[i] = _View(C.c_void_p(c[0]), c[1], c[2] if len(c) > 2 else 16, c[3] if len(c) > 3 else 12)
             else:
                 a = np.ascontiguousarray(c, dtype=POINT)
                 keep.append(a)

@@ -41,7 +41,7 @@ static inline void xform_point(const float T[16], float x, float y, float z, flo
 void mo_desc_knn(const float *a, int na, const float *b, int nb, int dim, int k, int *idx,
                  float *d2)
 {
-#pragma omp parallel for schedule(dynamic, 32) num_threads(mo_get_threads())
+#pragma omp parallel for schedule(dynamic, 32) num_threads(mo_get_threads()) if (na >= 64)
   for (int i = 0; i < na; ++i) {
     int m = 0;
     int *ti = &idx[(size_t)i * k];
