@@ -471,7 +471,8 @@ def main():
             # per kernel, alone on the GPU (the untimed one-stream pass): launch time and the ceiling it is nearest to
             "kernel_bounds_isolated": {k: dict(avg_launch_us=round(1e3 * v["ms"] / max(v["launches"], 1), 1),
                                                **bound_of(k, v["ms"] / max(v["launches"], 1), v["bytes"] / max(v["launches"], 1)))
-                                       for k, v in sorted(iso.items(), key=lambda kv: -kv[1]["ms"])[:10]},
+                                       for k, v in [kv for n_, kv in enumerate(sorted(iso.items(), key=lambda kv: -kv[1]["ms"]))
+                                                    if n_ < 10 or kv[0] in ("desc_knn_mfma", "normals_radius", "icp_corr_reduce", "score_nn_reduce")]},
             "stage_seconds_last_step": {k: round(stats[k], 4) for k in ("t_features", "t_exchange", "t_pairs", "t_gather_graph")},
             "top_kernels_ms_per_step": {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in top},
             "maps_estimated": stats["n_estimated"],

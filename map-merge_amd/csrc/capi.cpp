@@ -212,6 +212,8 @@ void mm3d_destroy(mm3d_ctx *ctx)
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   ctx->pool->trim();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->scan_status) (void)hipFree(ctx->scan_status);
+  if (ctx->scan_ticket) (void)hipFree(ctx->scan_ticket);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

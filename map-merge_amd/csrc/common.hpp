@@ -142,6 +142,12 @@ struct Context {
   // before the arena wraps around or is replaced
   void *pinned = nullptr;
   size_t pinned_bytes = 0, pinned_off = 0;
+  // exclusive_scan_int (grid.hip): per-tile status words and the ticket counter of the single-launch scan; the
+  // words carry the launch's epoch, so nothing is cleared between launches
+  unsigned long long *scan_status = nullptr;
+  unsigned *scan_ticket = nullptr;
+  size_t scan_tiles_cap = 0;
+  unsigned scan_epoch = 0, scan_tickets_taken = 0;
   // profiling
   bool prof_on = false;
   struct Pending { int slot; hipEvent_t a, b; };

@@ -137,14 +137,123 @@ KernelScope::~KernelScope()
 }
 
 // ---------------------------------------------------------------- rocPRIM-backed primitives
+// Exclusive prefix sum of ints in ONE launch (30 per map: cell tables, compactions, work items): a chained scan
+// with decoupled look-back.  A block takes a ticket (tiles are therefore started in order, whatever the
+// dispatcher does), scans its tile of 4096 elements, publishes its aggregate, adds up its predecessors'
+// published aggregates / prefixes (spinning on the few that are not there yet) and publishes its inclusive
+// prefix.  A status word = epoch << 34 | state << 32 | value: the launch's epoch makes words of earlier launches
+// read as "not there yet", and tickets count on from launch to launch, so nothing is cleared in between.
+constexpr int kScanItems = 16, kScanTile = 256 * kScanItems;
+__global__ void __launch_bounds__(256)
+k_scan_int(const int *__restrict__ in, int *__restrict__ out, size_t n, unsigned long long *status, unsigned *ticket,
+           unsigned ticket_base, unsigned epoch)
+{
+  __shared__ unsigned s_tile;
+  __shared__ int s_wave[4];
+  __shared__ int s_prefix;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+  __syncthreads();
+  const size_t tile = s_tile;
+  const size_t base = tile * kScanTile + (size_t)threadIdx.x * kScanItems;
+  int v[kScanItems];
+  int sum = 0;
+  const bool whole = base + kScanItems <= n && (reinterpret_cast<uintptr_t>(in) & 15u) == 0;   // 16-byte loads where the thread's run is complete
+  if (whole) {
+#pragma unroll
+    for (int k = 0; k < kScanItems; k += 4) {
+      const int4 q = *reinterpret_cast<const int4 *>(in + base + k);
+      v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) v[k] = base + k < n ? in[base + k] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) sum += v[k];
+  // block-wide exclusive scan of the per-thread sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int t = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += t;
+  }
+  if (lane == kWave - 1) s_wave[wave] = incl;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+  const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  if (wave == 0) {
+    // look-back by one wave: 64 predecessors per round, nearest first; the nearest published inclusive prefix ends it
+    const unsigned long long tag = (unsigned long long)epoch << 34;
+    if (lane == 0 && tile > 0)
+      __hip_atomic_store(&status[tile], tag | (1ull << 32) | (unsigned)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // aggregate
+    int prefix = 0;
+    for (long long hi = (long long)tile - 1; hi >= 0; hi -= kWave) {
+      const long long t = hi - lane;
+      unsigned long long w = 2ull << 32;                // lanes before tile 0: an empty prefix
+      if (t >= 0) {
+        do w = __hip_atomic_load(&status[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        while ((w >> 34) != epoch || ((w >> 32) & 3u) == 0u);
+      }
+      const unsigned long long is_prefix = __ballot(((w >> 32) & 3u) == 2u);
+      const int first = __ffsll((long long)is_prefix) - 1;          // nearest predecessor that carries a prefix (-1: none)
+      const int take = (first < 0 || lane <= first) ? (int)(unsigned)(w & 0xffffffffull) : 0;
+      prefix += wave_sum(take);
+      if (first >= 0) break;
+    }
+    prefix = __shfl(prefix, 0, kWave);
+    if (lane == 0) {
+      __hip_atomic_store(&status[tile], tag | (2ull << 32) | (unsigned)(prefix + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      s_prefix = prefix;
+    }
+  }
+  __syncthreads();
+  int run = s_prefix + wave_off + incl - sum;
+  if (whole && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+#pragma unroll
+    for (int k = 0; k < kScanItems; k += 4) {
+      int4 q;
+      q.x = run; run += v[k];
+      q.y = run; run += v[k + 1];
+      q.z = run; run += v[k + 2];
+      q.w = run; run += v[k + 3];
+      *reinterpret_cast<int4 *>(out + base + k) = q;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      if (base + k < n) out[base + k] = run;
+      run += v[k];
+    }
+  }
+}
+
 void exclusive_scan_int(Context *c, const int *in, int *out, size_t n)
 {
   if (n == 0) return;
-  size_t tmp_bytes = 0;
-  MM3D_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, 0, n, rocprim::plus<int>(), c->stream));
-  DevBuf<char> tmp(c, tmp_bytes ? tmp_bytes : 1);
-  KernelScope ks(c, "rocprim_exclusive_scan", (double)n * 8.0);
-  MM3D_HIP(rocprim::exclusive_scan(tmp.get(), tmp_bytes, in, out, 0, n, rocprim::plus<int>(), c->stream));
+  const size_t tiles = (n + kScanTile - 1) / kScanTile;
+  if (tiles > c->scan_tiles_cap) {
+    c->sync();                                   // earlier scans on this stream are done with the old buffers
+    if (c->scan_status) (void)hipFree(c->scan_status);
+    if (!c->scan_ticket) {
+      MM3D_HIP(hipMalloc((void **)&c->scan_ticket, sizeof(unsigned)));
+      MM3D_HIP(hipMemsetAsync(c->scan_ticket, 0, sizeof(unsigned), c->stream));
+      c->scan_tickets_taken = 0;
+    }
+    c->scan_tiles_cap = tiles * 2 < 4096 ? 4096 : tiles * 2;
+    MM3D_HIP(hipMalloc((void **)&c->scan_status, c->scan_tiles_cap * sizeof(unsigned long long)));
+    MM3D_HIP(hipMemsetAsync(c->scan_status, 0, c->scan_tiles_cap * sizeof(unsigned long long), c->stream));
+    c->scan_epoch = 0;
+  }
+  c->scan_epoch = (c->scan_epoch + 1) & 0x3fffffffu;
+  if (c->scan_epoch == 0) {                      // the epoch wrapped: clear once, start over
+    MM3D_HIP(hipMemsetAsync(c->scan_status, 0, c->scan_tiles_cap * sizeof(unsigned long long), c->stream));
+    c->scan_epoch = 1;
+  }
+  MM3D_LAUNCH(c, "scan_int", (double)n * 8.0, k_scan_int, dim3((unsigned)tiles), dim3(256), 0, in, out, n, c->scan_status, c->scan_ticket,
+              c->scan_tickets_taken, c->scan_epoch);
+  c->scan_tickets_taken += (unsigned)tiles;      // unsigned wrap-around matches the device counter's
 }
 
 void sort_pairs_u32(Context *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
