@@ -87,6 +87,27 @@ def test_normals(ctx, scene):
     assert np.isnan(got["nx"]).all() and np.isnan(got["curvature"]).all()
 
 
+def test_neighbour_lists_longer_than_a_rank_batch(ctx, po, scene):
+    """Neighbourhoods of several hundred points (more than the 128 / 256 entries one rank batch of sorted_nb.hpp holds):
+    the lists are then written bucket by bucket and ranked in bucket-aligned batches.  Same bits as the oracle for
+    normals (raw-moment chains), FPFH rows (weighting chains) and SIFT keypoints (Gaussian chains)."""
+    m = scene[0]
+    big_r = 1.9                                           # ~ 1000 neighbours on this scene
+    cloud = ctx.cloud(m["filt"])
+    got = ctx.computeSurfaceNormals(cloud, big_r).numpy()
+    ref = po.normals(m["filt"], big_r)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    kp = m["kp_raw"][:300].copy()
+    kp_ref, ref_d = po.descriptors_fpfh(m["filt"], m["nrm"], kp, big_r)
+    k = ctx.cloud(kp)
+    got_d = ctx.computeLocalDescriptors(cloud, ctx.normals(m["nrm"]), k, 2, big_r).numpy()
+    assert got_d.shape == ref_d.shape and np.array_equal(got_d.view(np.uint32), ref_d.view(np.uint32))
+    # SIFT with a coarse base scale: 3 sigma of the widest scale is ~ 2.3 m
+    got_k = ctx.detectKeypoints(cloud, None, 0, 2.0, R_NRM, 0.3).numpy()
+    ref_k, _ = po.keypoints_sift(m["filt"], 0.3, 3, 3, 2.0)
+    assert len(got_k) == len(ref_k) and np.array_equal(xyz(got_k).view(np.uint32), xyz(ref_k).view(np.uint32))
+
+
 def test_sift_keypoints(ctx, scene):
     """detectKeypoints(SIFT): the Gaussian sums run in radiusSearch's order with glibc's expf restated, so the
     keypoints are the oracle's, in the oracle's (octave, index, scale) order."""
