@@ -109,3 +109,75 @@ def test_every_feature_type_under_the_stream_scheduler(mm, clouds, kp_type, thr,
     assert len(out[0][1]) == 6
     assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
     assert np.array_equal(out[0][1].view(np.uint8), out[1][1].view(np.uint8))
+
+
+def _run_sharded(mm, clouds, params, world, streams):
+    """The N > 1 driver (mm3d_shard_*) with `world` ranks played by `world` contexts of this one GPU; the exchange
+    is done with host buffers in place of the all-gather.  Returns the merged pair records."""
+    from map_merge_amd import sharding
+    n = len(clouds)
+    ctxs, shards = [], []
+    try:
+        for r in range(world):
+            c = mm.Context(0)
+            c.setStreams(streams)
+            c.srand(1)
+            ctxs.append(c)
+            shards.append(c.shardBegin(clouds, params, r, world))
+        npts, nkp = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        for sh in shards:
+            a, b = sh.bundleSizes()
+            npts += a
+            nkp += b
+        bundles = {}
+        for i in range(n):
+            o = sharding.map_owner(i, world)
+            buf = np.zeros(max(shards[o].bundleBytes(int(npts[i]), int(nkp[i])), 16), dtype=np.uint8)
+            shards[o].pack(i, buf.ctypes.data)
+            bundles[i] = buf
+        for r, sh in enumerate(shards):
+            for i in range(n):
+                if sharding.map_owner(i, world) != r:
+                    sh.unpack(i, bundles[i].ctypes.data, int(npts[i]), int(nkp[i]))
+        merged, counts = None, []
+        for r, sh in enumerate(shards):
+            rec, mine = sh.pairs()
+            counts.append(int(mine.sum()))
+            if merged is None:
+                merged = rec.copy()
+            assert np.array_equal(rec["source_idx"], merged["source_idx"]) and np.array_equal(rec["target_idx"], merged["target_idx"])
+            owners = np.array([sharding.pair_owner(int(a), int(b), world) for a, b in zip(rec["source_idx"], rec["target_idx"])])
+            assert np.array_equal(mine, owners == r)
+            merged[mine] = rec[mine]
+        return merged, counts
+    finally:
+        for sh in shards:
+            sh.end()
+        for c in ctxs:
+            c.close()
+
+
+def test_sharded_driver_equals_the_one_call_path(mm, clouds):
+    """mm3d_shard_* with 1, 2 and 3 ranks (owner-computes targets, packed bundles, rand() states replayed per rank)
+    gives the records of ONE mm3d_estimate_maps_transforms call bit for bit -- also with a map that has no keypoint
+    at all in the middle of the list (its pairs do not exist, the generator must not move for them)."""
+    rng = np.random.default_rng(7)
+    flat = np.zeros(60000, dtype=mm.POINT)
+    flat["x"], flat["y"] = rng.uniform(0, 30, 60000), rng.uniform(0, 30, 60000)
+    flat["rgba"] = 0xFF808080
+    order = [clouds[0], clouds[1], flat, clouds[2], clouds[3]]
+    params = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
+    c = mm.Context(0)
+    try:
+        c.setStreams(4)
+        c.srand(1)
+        T_ref, ref = c.estimateMapsTransforms(order, params, return_pairs=True)
+    finally:
+        c.close()
+    assert len(ref) == 6
+    for world in (1, 2, 3):
+        merged, counts = _run_sharded(mm, order, params, world, 3)
+        assert np.array_equal(merged.view(np.uint8), ref.view(np.uint8)), world
+        assert sum(counts) == len(ref)
+        T = mm.globalTransforms(merged, params.confidence_threshold, len(order))
+        assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(T, T_ref))
