@@ -289,6 +289,9 @@ int mm3d_shard_bundle_sizes(const mm3d_shard *sh, uint64_t *n_points /* [n] */, 
 size_t mm3d_shard_bundle_bytes(uint64_t n_points, uint64_t n_keypoints, int descriptor_type);
 int mm3d_shard_pack(mm3d_shard *sh, size_t map, void *dst);
 int mm3d_shard_unpack(mm3d_shard *sh, size_t map, const void *src, uint64_t n_points, uint64_t n_keypoints);
+/* the same for several maps at once, dealt to the context's streams */
+int mm3d_shard_unpack_many(mm3d_shard *sh, size_t count, const size_t *maps, const void *const *srcs, const uint64_t *n_points,
+                           const uint64_t *n_keypoints);
 int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *mine, size_t capacity, size_t *n_pairs);
 void mm3d_shard_end(mm3d_shard *sh);
 

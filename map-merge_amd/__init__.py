@@ -422,6 +422,17 @@ class Shard:
         self._ctx._ck(lib().mm3d_shard_unpack(self._h, C.c_size_t(i), C.c_void_p(src_ptr), C.c_uint64(int(n_points)),
                                               C.c_uint64(int(n_keypoints))))
 
+    def unpackMany(self, items):
+        """items: (map index, source pointer, n_points, n_keypoints) of the maps other ranks own; on the context's streams."""
+        n = len(items)
+        if n == 0:
+            return
+        maps = (C.c_size_t * n)(*[int(i[0]) for i in items])
+        srcs = (C.c_void_p * n)(*[int(i[1]) for i in items])
+        a = (C.c_uint64 * n)(*[int(i[2]) for i in items])
+        b = (C.c_uint64 * n)(*[int(i[3]) for i in items])
+        self._ctx._ck(lib().mm3d_shard_unpack_many(self._h, C.c_size_t(n), maps, srcs, a, b))
+
     def pairs(self):
         """(records of every live pair in the reference's order, mine[q]): the pairs whose target this rank owns
         are estimated, the other slots carry only the pair's indices."""

@@ -980,6 +980,40 @@ int mm3d_shard_unpack(mm3d_shard *sh, size_t map, const void *src, uint64_t n_po
   });
 }
 
+// every map another rank owns, on the context's streams (at 8 ranks that is 14 of 16 maps per rank)
+int mm3d_shard_unpack_many(mm3d_shard *sh, size_t count, const size_t *maps, const void *const *srcs, const uint64_t *n_points,
+                           const uint64_t *n_keypoints)
+{
+  if (!sh || (count && (!maps || !srcs || !n_points || !n_keypoints))) return MM3D_EINVAL;
+  mm3d_ctx *ctx = sh->ctx;
+  return guarded(ctx, [&] {
+    for (size_t k = 0; k < count; ++k)
+      if (maps[k] >= sh->n || (!srcs[k] && (n_points[k] || n_keypoints[k]))) throw Error(MM3D_EINVAL, "mm3d_shard_unpack_many: bad item");
+    std::atomic<size_t> next{0};
+    on_streams(ctx, [&](size_t, mm3d_ctx *c) {
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= count) break;
+        const size_t i = maps[k];
+        if (sh->maps[i]) continue;                    // an owned map is already here
+        const char *s = static_cast<const char *>(srcs[k]);
+        std::unique_ptr<mm3d_cloud> pts(cloud_from_memory(c, n_points[k] ? s : nullptr, n_points[k], 16, 12));
+        s += n_points[k] * 16;
+        std::unique_ptr<mm3d_cloud> kp(cloud_from_memory(c, n_keypoints[k] ? s : nullptr, n_keypoints[k], 16, 12));
+        s += n_keypoints[k] * 16;
+        std::unique_ptr<mm3d_desc> desc(desc_from_memory(c, reinterpret_cast<const float *>(s), n_keypoints[k], sh->params.descriptor_type));
+        if (pts->n) cloud_hilbert(c, pts.get());      // source role only, as in mm3d_shard_unpack
+        if (kp->n) cloud_hilbert(c, kp.get());
+        (void)cloud_host(c, kp.get());
+        c->sync();
+        auto *m = new mm3d_map();
+        m->points = pts.release(); m->keypoints = kp.release(); m->desc = desc.release();
+        sh->maps[i] = m;                              // distinct slots
+      }
+    });
+  });
+}
+
 int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *mine, size_t capacity, size_t *n_pairs)
 {
   if (!sh || !n_pairs || !pairs || !mine) return MM3D_EINVAL;

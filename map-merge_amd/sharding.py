@@ -91,8 +91,6 @@ def exchange_bundles(shard, world: int, rank: int, dist, device):
     parts = all_gather_bytes(buf, world, dist)
     if device is not None:
         torch.cuda.synchronize()
-    for i in range(n):
-        o = map_owner(i, world)
-        if o != rank:
-            shard.unpack(i, parts[o].data_ptr() + offset[i], int(npts[i]), int(nkp[i]))
+    shard.unpackMany([(i, parts[map_owner(i, world)].data_ptr() + offset[i], int(npts[i]), int(nkp[i]))
+                      for i in range(n) if map_owner(i, world) != rank])
     return npts, nkp
