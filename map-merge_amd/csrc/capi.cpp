@@ -1031,13 +1031,21 @@ int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *min
     const size_t P = live.size();
     *n_pairs = P;
     if (P > capacity) throw Error(MM3D_ECAPACITY, "mm3d_shard_pairs: room for every live pair is needed");
+    // state_at[q] = the generator before pair q, advanced on demand (under rng_mu) as far as a worker needs it:
+    // the first pairs start at once, the table's tail (~30 us of host work per pair) is filled in while they run
     std::vector<GlibcRand> state_at(P + 1, ctx->rnd);
-    for (size_t q = 0; q < P; ++q) {
-      GlibcRand r = state_at[q];
-      pair_rand_replay(r, params->estimation_method, cloud_host(ctx, sh->maps[live[q].first]->keypoints), params->inlier_threshold,
-                       params->max_iterations);
-      state_at[q + 1] = r;
-    }
+    size_t known_upto = 0;
+    std::mutex rng_mu;
+    std::vector<const std::vector<float4> *> src_kp(sh->n, nullptr);
+    for (size_t i = 0; i < sh->n; ++i) src_kp[i] = &cloud_host(ctx, sh->maps[i]->keypoints);   // (cached at prepare / unpack time)
+    auto advance_states = [&](size_t upto) {
+      std::lock_guard<std::mutex> lk(rng_mu);
+      while (known_upto < upto) {
+        GlibcRand r = state_at[known_upto];
+        pair_rand_replay(r, params->estimation_method, *src_kp[live[known_upto].first], params->inlier_threshold, params->max_iterations);
+        state_at[++known_upto] = r;
+      }
+    };
     std::vector<size_t> todo;
     for (size_t q = 0; q < P; ++q) {
       std::memset(&pairs[q], 0, sizeof(mm3d_pair_result));
@@ -1052,6 +1060,7 @@ int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *min
         const size_t k = next.fetch_add(1);
         if (k >= todo.size()) break;
         const size_t q = todo[k];
+        advance_states(q);
         c->rnd = state_at[q];
         mm3d_pair_result r;
         pair_estimate_impl(c, sh->maps[live[q].first], sh->maps[live[q].second], params, true, &r);
@@ -1060,6 +1069,7 @@ int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *min
         pairs[q] = r;
       }
     });
+    advance_states(P);
     ctx->rnd = state_at[P];                       // where the reference's sequential loop leaves the generator
   });
 }

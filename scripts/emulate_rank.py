@@ -1,0 +1,65 @@
+"""What ONE rank of an N-GPU run does per step, measured on one GPU: the features of the maps it owns
+(mm3d_shard_begin), unpacking the other maps' bundles (already in HBM: the all-gather itself is not emulated),
+the pairs whose target it owns (mm3d_shard_pairs).  Prints ms per stage for every rank of world = 2, 4, 8 and the
+step time an N-GPU run would be bounded by (the slowest rank), i.e. a prediction of the scaling curve without
+the interconnect.   usage: python3 scripts/emulate_rank.py [maps] [points]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import __graft_entry__ as ge  # noqa: E402
+import bench  # noqa: E402
+import torch  # noqa: E402
+
+mm = ge.load()
+from map_merge_amd import sharding  # noqa: E402
+
+n_maps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+n_pts = int(sys.argv[2]) if len(sys.argv) > 2 else 500000
+host = bench.make_workload(n_maps, n_pts)
+dev = torch.device("cuda", 0)
+dev_raw = [torch.from_numpy(h.view(np.uint8).reshape(-1, 16)).to(dev) for h in host]
+views = [(dev_raw[i].data_ptr(), len(host[i])) for i in range(n_maps)]
+params = mm.MapMergingParams(descriptor_type=mm.Descriptor.FPFH, estimation_method=mm.EstimationMethod.SAC_IA, refine_transform=1)
+ctx = mm.Context(0)
+ctx.setStreams(16)
+
+# every map's bundle once, untimed
+sh = ctx.shardBegin(views, params, 0, 1)
+npts, nkp = sh.bundleSizes()
+bundles = []
+for i in range(n_maps):
+    b = torch.zeros(max(sh.bundleBytes(int(npts[i]), int(nkp[i])), 16), dtype=torch.uint8, device=dev)
+    sh.pack(i, b.data_ptr())
+    bundles.append(b)
+t0 = time.perf_counter()
+rec1, _ = sh.pairs()
+sh.end()
+print(f"world 1: {len(rec1)} pairs")
+
+for world in (2, 4, 8):
+    worst = 0.0
+    for rank in range(world):
+        best = None
+        for rep in range(2):
+            ctx.srand(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            s = ctx.shardBegin(views, params, rank, world)
+            t1 = time.perf_counter()
+            s.unpackMany([(i, bundles[i].data_ptr(), int(npts[i]), int(nkp[i])) for i in range(n_maps) if sharding.map_owner(i, world) != rank])
+            t2 = time.perf_counter()
+            rec, mine = s.pairs()
+            t3 = time.perf_counter()
+            s.end()
+            assert np.array_equal(rec[mine].view(np.uint8), rec1[mine].view(np.uint8))      # the one-rank run's records, bit for bit
+            cur = (t1 - t0, t2 - t1, t3 - t2, int(mine.sum()))
+            if best is None or sum(cur[:3]) < sum(best[:3]):
+                best = cur
+        worst = max(worst, sum(best[:3]))
+        print(f"world {world} rank {rank}: features {best[0] * 1e3:6.1f} ms ({sum(1 for i in range(n_maps) if sharding.map_owner(i, world) == rank)} maps)"
+              f"  unpack {best[1] * 1e3:5.1f} ms  pairs {best[2] * 1e3:6.1f} ms ({best[3]} pairs)  total {sum(best[:3]) * 1e3:6.1f} ms")
+    print(f"world {world}: slowest rank {worst * 1e3:.1f} ms per step -> {len(rec1) / worst:.0f} map-pairs/s without the interconnect")
