@@ -143,6 +143,8 @@ KernelScope::~KernelScope()
 // published aggregates / prefixes (spinning on the few that are not there yet) and publishes its inclusive
 // prefix.  A status word = epoch << 34 | state << 32 | value: the launch's epoch makes words of earlier launches
 // read as "not there yet", and tickets count on from launch to launch, so nothing is cleared in between.
+// The words carry their payload themselves and nothing else is read from another block, so the atomics are
+// relaxed: an agent-scope release / acquire per tile would write back / invalidate caches on this multi-XCD part.
 constexpr int kScanItems = 16, kScanTile = 256 * kScanItems;
 __global__ void __launch_bounds__(256)
 k_scan_int(const int *__restrict__ in, int *__restrict__ out, size_t n, unsigned long long *status, unsigned *ticket,
@@ -187,13 +189,13 @@ k_scan_int(const int *__restrict__ in, int *__restrict__ out, size_t n, unsigned
     // look-back by one wave: 64 predecessors per round, nearest first; the nearest published inclusive prefix ends it
     const unsigned long long tag = (unsigned long long)epoch << 34;
     if (lane == 0 && tile > 0)
-      __hip_atomic_store(&status[tile], tag | (1ull << 32) | (unsigned)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // aggregate
+      __hip_atomic_store(&status[tile], tag | (1ull << 32) | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // aggregate
     int prefix = 0;
     for (long long hi = (long long)tile - 1; hi >= 0; hi -= kWave) {
       const long long t = hi - lane;
       unsigned long long w = 2ull << 32;                // lanes before tile 0: an empty prefix
       if (t >= 0) {
-        do w = __hip_atomic_load(&status[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        do w = __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while ((w >> 34) != epoch || ((w >> 32) & 3u) == 0u);
       }
       const unsigned long long is_prefix = __ballot(((w >> 32) & 3u) == 2u);
@@ -204,7 +206,7 @@ k_scan_int(const int *__restrict__ in, int *__restrict__ out, size_t n, unsigned
     }
     prefix = __shfl(prefix, 0, kWave);
     if (lane == 0) {
-      __hip_atomic_store(&status[tile], tag | (2ull << 32) | (unsigned)(prefix + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&status[tile], tag | (2ull << 32) | (unsigned)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_prefix = prefix;
     }
   }
