@@ -744,6 +744,52 @@ __global__ void k_item_fill(const int *__restrict__ heads, const int *__restrict
   items[pos[j]] = make_int2(j, cnt);
 }
 
+// Hilbert order by counting sort on the column index (key >> 10, at most 2^20 columns): a point's arrival rank in
+// its column comes with the histogram, a scan gives the columns' starts, and inside its column (a handful of
+// points; a wall: a hundred) every point counts the smaller (key, index) pairs -- the order a stable radix sort
+// of the keys gives, in four small launches instead of rocPRIM's seven.
+constexpr int kHilColumns = 1 << 20;
+constexpr int kHilColumnMax = 1024;      // longer columns (degenerate clouds) leave it to the radix sort
+__global__ void k_hil_count(const uint32_t *__restrict__ keys, int n, int *__restrict__ counts, uint32_t *__restrict__ ranks)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = keys[i];
+  if (key == 0xFFFFFFFFu) return;               // non-finite point
+  ranks[i] = (uint32_t)atomicAdd(&counts[key >> 10], 1);
+}
+__global__ void k_hil_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ranks, const int *__restrict__ col_start, int n,
+                              int *__restrict__ slots, int *__restrict__ too_long)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = keys[i];
+  if (key == 0xFFFFFFFFu) return;
+  const int b = col_start[key >> 10];
+  slots[b + (int)ranks[i]] = i;
+  if (col_start[(key >> 10) + 1] - b > kHilColumnMax) *too_long = 1;
+}
+__global__ void k_hil_place(const float4 *__restrict__ pts, const uint32_t *__restrict__ keys, const int *__restrict__ col_start,
+                            const int *__restrict__ slots, int n, const int *__restrict__ too_long, float4 *__restrict__ out,
+                            uint32_t *__restrict__ out_keys)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || *too_long) return;
+  const uint32_t key = keys[i];
+  if (key == 0xFFFFFFFFu) return;
+  const int b = col_start[key >> 10], e = col_start[(key >> 10) + 1];
+  int r = 0;
+  for (int j = b; j < e; ++j) {
+    const int o = slots[j];
+    const uint32_t ko = keys[o];
+    r += (ko < key || (ko == key && o < i)) ? 1 : 0;
+  }
+  float4 p = pts[i];
+  p.w = __int_as_float(i);
+  out[b + r] = p;
+  out_keys[b + r] = key;
+}
+
 void cloud_hilbert(Context *c, const mm3d_cloud *cl_)
 {
   auto *cl = const_cast<mm3d_cloud *>(cl_);
@@ -756,20 +802,39 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl_)
   float ext = 0.f;
   for (int a = 0; a < 3; ++a) ext = std::fmax(ext, cl->bmax[a] - cl->bmin[a]);
   const float cell = std::fmax(0.25f, ext / 1023.0f);
-  DevBuf<uint32_t> keys(c, total), vals(c, total), keys2(c, total), vals2(c, total);
+  DevBuf<uint32_t> keys(c, total), vals(c, total), keys2(c, total);
   MM3D_LAUNCH(c, "hilbert_keys", total * 24.0, k_hilbert_keys, dim3(div_up(total, 256)), dim3(256), 0, cl->pts.get(), total,
               cl->bmin[0], cl->bmin[1], cl->bmin[2], 1.0f / cell, keys.get(), vals.get());
-  sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), total, 32);
   cl->hil_pts = DevBuf<float4>(c, n);
-  MM3D_LAUNCH(c, "hilbert_gather", n * 36.0, k_hilbert_gather, dim3(div_up(n, 256)), dim3(256), 0, cl->pts.get(),
-              (const uint32_t *)vals2.get(), n, cl->hil_pts.get());
+  DevBuf<int> counts(c, kHilColumns + 1), col_start(c, kHilColumns + 1), slots(c, n), too_long(c, 1);
+  DevBuf<uint32_t> ranks(c, total);
+  MM3D_HIP(hipMemsetAsync(counts.get(), 0, (kHilColumns + 1) * sizeof(int), c->stream));
+  MM3D_HIP(hipMemsetAsync(too_long.get(), 0, sizeof(int), c->stream));
+  MM3D_LAUNCH(c, "hilbert_sort", total * 12.0, k_hil_count, dim3(div_up(total, 256)), dim3(256), 0, (const uint32_t *)keys.get(), total,
+              counts.get(), ranks.get());
+  exclusive_scan_int(c, counts.get(), col_start.get(), kHilColumns + 1);
+  MM3D_LAUNCH(c, "hilbert_sort", total * 16.0, k_hil_scatter, dim3(div_up(total, 256)), dim3(256), 0, (const uint32_t *)keys.get(),
+              (const uint32_t *)ranks.get(), (const int *)col_start.get(), total, slots.get(), too_long.get());
+  MM3D_LAUNCH(c, "hilbert_sort", total * 44.0, k_hil_place, dim3(div_up(total, 256)), dim3(256), 0, cl->pts.get(),
+              (const uint32_t *)keys.get(), (const int *)col_start.get(), (const int *)slots.get(), total, (const int *)too_long.get(),
+              cl->hil_pts.get(), keys2.get());
   DevBuf<int> heads(c, (size_t)n + 1), blk(c, (size_t)n + 1);
-  MM3D_LAUNCH(c, "hilbert_items", n * 8.0, k_item_heads, dim3(div_up(n + 1, 256)), dim3(256), 0, (const uint32_t *)keys2.get(), n,
-              heads.get());
-  exclusive_scan_int(c, heads.get(), blk.get(), (size_t)n + 1);
   int *h = (int *)c->pin(64);
-  MM3D_HIP(hipMemcpyAsync(h, blk.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  c->sync();
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    MM3D_LAUNCH(c, "hilbert_items", n * 8.0, k_item_heads, dim3(div_up(n + 1, 256)), dim3(256), 0, (const uint32_t *)keys2.get(), n,
+                heads.get());
+    exclusive_scan_int(c, heads.get(), blk.get(), (size_t)n + 1);
+    MM3D_HIP(hipMemcpyAsync(h, blk.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MM3D_HIP(hipMemcpyAsync(h + 1, too_long.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    if (attempt == 1 || !h[1]) break;
+    // a column with more than a thousand points (the counting sort gave up): stable radix sort instead, then once more
+    DevBuf<uint32_t> vals2(c, total);
+    sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), total, 32);
+    MM3D_LAUNCH(c, "hilbert_gather", n * 36.0, k_hilbert_gather, dim3(div_up(n, 256)), dim3(256), 0, cl->pts.get(),
+                (const uint32_t *)vals2.get(), n, cl->hil_pts.get());
+    c->sync();                                    // vals2 goes back to the pool after the gather
+  }
   cl->n_wave_items = h[0];
   cl->hil_keys = std::move(keys2);
   cl->wave_items = DevBuf<int2>(c, (size_t)h[0]);

@@ -94,3 +94,27 @@ def test_degenerate_inputs_for_the_other_feature_types(ctx, mm, textured):
     assert len(ctx.computeLocalDescriptors(pts, nrm, k, 5, 0.8)) == 0 and len(k) == 0
     with pytest.raises(Exception):
         ctx.computeLocalDescriptors(pts, nrm, ctx.cloud(far), 9, 0.8)
+
+
+def test_a_column_of_thousands_of_points(ctx, po, mm, textured):
+    """A thin vertical structure: thousands of points in one 0.25 m column of the query order (the counting sort of the
+    Hilbert order gives up there and the stable radix sort takes over).  ICP, score and normals as the oracle's."""
+    rng = np.random.default_rng(3)
+    pole = np.zeros(5000, dtype=mm.POINT)
+    pole["x"] = 1.0 + rng.normal(0, 0.01, 5000)
+    pole["y"] = 2.0 + rng.normal(0, 0.01, 5000)
+    pole["z"] = rng.uniform(0, 40, 5000)
+    pole["rgba"] = 0xFF000000 | rng.integers(0, 1 << 24, 5000).astype(np.uint32)
+    src = np.concatenate([pole, textured[:3000]])
+    tgt = src.copy()
+    tgt["x"] += 0.05
+    T0 = np.eye(4, dtype=np.float32)
+    s_ref = po.transform_score(src, tgt, T0, 1.0)
+    s_got = ctx.transformScore(ctx.cloud(src), ctx.cloud(tgt), T0, 1.0)
+    assert s_got == pytest.approx(s_ref, rel=1e-6)
+    T_ref, it_ref = po.icp(src, tgt, T0, 1.0, 0.5, 50, 1e-2)
+    T_got = ctx.estimateTransformICP(ctx.cloud(src), ctx.cloud(tgt), T0, 1.0, 0.5, 50, 1e-2)
+    assert np.linalg.norm(T_got - T_ref) < 1e-3 and ctx.last_icp_iterations == it_ref
+    n_ref = po.normals(src, 0.3)
+    n_got = ctx.computeSurfaceNormals(ctx.cloud(src), 0.3).numpy()
+    assert np.array_equal(n_got.view(np.uint32), n_ref.view(np.uint32))
