@@ -109,13 +109,22 @@ mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
   DevBuf<uint32_t> keys(c, n), vals(c, n), keys2(c, n), vals2(c, n);
   MM3D_LAUNCH(c, "voxel_keys", n * 24.0, k_voxel_keys, dim3(div_up(n, 256)), dim3(256), 0, in->pts.get(), n, inv,
               min_b[0], min_b[1], min_b[2], mul1, mul2, keys.get(), vals.get());
-  sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), n, 32);
+  // pcl::VoxelGrid sorts (voxel index, point) pairs; the order inside a voxel is the input order here (stable),
+  // by counting sort (grid.hip), or by rocPRIM's radix sort when some bin of the counting sort is very long
+  DevBuf<int> too_long(c, 1);
+  counting_sort_pairs_u32(c, keys.get(), n, (uint64_t)div_b[0] * (uint64_t)div_b[1] * (uint64_t)div_b[2], keys2.get(), vals2.get(),
+                          too_long.get());
   DevBuf<int> heads(c, n + 1), pos(c, n + 1);
-  MM3D_LAUNCH(c, "voxel_heads", n * 8.0, k_voxel_heads, dim3(div_up(n + 1, 256)), dim3(256), 0, keys2.get(), n, heads.get());
-  exclusive_scan_int(c, heads.get(), pos.get(), n + 1);
   int *h = (int *)c->pin(64);
-  MM3D_HIP(hipMemcpyAsync(h, pos.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  c->sync();
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    MM3D_LAUNCH(c, "voxel_heads", n * 8.0, k_voxel_heads, dim3(div_up(n + 1, 256)), dim3(256), 0, keys2.get(), n, heads.get());
+    exclusive_scan_int(c, heads.get(), pos.get(), n + 1);
+    MM3D_HIP(hipMemcpyAsync(h, pos.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MM3D_HIP(hipMemcpyAsync(h + 1, too_long.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    if (attempt == 1 || !h[1]) break;
+    sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), n, 32);
+  }
   const int nvox = h[0];
   DevBuf<int> starts(c, nvox + 1);
   MM3D_LAUNCH(c, "voxel_starts", n * 12.0, k_voxel_starts, dim3(div_up(n, 256)), dim3(256), 0, heads.get(), pos.get(), n, starts.get());

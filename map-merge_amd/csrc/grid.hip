@@ -744,6 +744,75 @@ __global__ void k_item_fill(const int *__restrict__ heads, const int *__restrict
   items[pos[j]] = make_int2(j, cnt);
 }
 
+// ---------------------------------------------------------------- counting sort of (key, index) pairs
+// Stable sort of sparse 32-bit keys whose equal-or-near values are few (voxel indices, Hilbert keys): bin = key /
+// divisor with at most 2^22 bins; a point's arrival rank in its bin comes with the histogram (one atomic), a scan
+// gives the bins' starts, and inside its bin (tens of points) every point counts the smaller (key, index) pairs.
+// Four small launches; the result is the order rocPRIM's stable radix sort of the keys gives.  A bin longer than
+// kCountSortBinMax sets *too_long and nothing is written: the caller falls back to the radix sort.
+constexpr int kCountSortBinMax = 1024;
+__global__ void k_cs_count(const uint32_t *__restrict__ keys, int n, uint32_t divisor, int *__restrict__ counts, uint32_t *__restrict__ ranks)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = keys[i];
+  if (key == 0xFFFFFFFFu) return;               // non-finite point: stays out (the output's tail keeps its fill value)
+  ranks[i] = (uint32_t)atomicAdd(&counts[key / divisor], 1);
+}
+__global__ void k_cs_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ranks, const int *__restrict__ bin_start, int n,
+                             uint32_t divisor, int *__restrict__ slots, int *__restrict__ too_long)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = keys[i];
+  if (key == 0xFFFFFFFFu) return;
+  const uint32_t bin = key / divisor;
+  const int b = bin_start[bin];
+  slots[b + (int)ranks[i]] = i;
+  if (bin_start[bin + 1] - b > kCountSortBinMax) *too_long = 1;
+}
+__global__ void k_cs_place(const uint32_t *__restrict__ keys, const int *__restrict__ bin_start, const int *__restrict__ slots, int n,
+                           uint32_t divisor, const int *__restrict__ too_long, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ idx_out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || *too_long) return;
+  const uint32_t key = keys[i];
+  if (key == 0xFFFFFFFFu) return;
+  const uint32_t bin = key / divisor;
+  const int b = bin_start[bin], e = bin_start[bin + 1];
+  int r = 0;
+  for (int j = b; j < e; ++j) {
+    const int o = slots[j];
+    const uint32_t ko = keys[o];
+    r += (ko < key || (ko == key && o < i)) ? 1 : 0;
+  }
+  keys_out[b + r] = key;
+  idx_out[b + r] = (uint32_t)i;
+}
+
+// keys_out / idx_out: n entries; entries beyond the finite keys read 0xFFFFFFFF / are unspecified.  too_long (device)
+// must be checked by the caller after its next synchronisation.
+void counting_sort_pairs_u32(Context *c, const uint32_t *keys, int n, uint64_t key_range, uint32_t *keys_out, uint32_t *idx_out,
+                             int *too_long)
+{
+  uint32_t divisor = (uint32_t)((key_range + ((uint64_t)1 << 22) - 1) >> 22);
+  if (divisor == 0) divisor = 1;
+  const int nbins = (int)(key_range / divisor) + 1;
+  DevBuf<int> counts(c, (size_t)nbins + 1), bin_start(c, (size_t)nbins + 1), slots(c, (size_t)n);
+  DevBuf<uint32_t> ranks(c, (size_t)n);
+  MM3D_HIP(hipMemsetAsync(counts.get(), 0, ((size_t)nbins + 1) * sizeof(int), c->stream));
+  MM3D_HIP(hipMemsetAsync(too_long, 0, sizeof(int), c->stream));
+  MM3D_HIP(hipMemsetAsync(keys_out, 0xFF, (size_t)n * sizeof(uint32_t), c->stream));
+  MM3D_LAUNCH(c, "count_sort", n * 12.0, k_cs_count, dim3(div_up(n, 256)), dim3(256), 0, keys, n, divisor, counts.get(), ranks.get());
+  exclusive_scan_int(c, counts.get(), bin_start.get(), (size_t)nbins + 1);
+  MM3D_LAUNCH(c, "count_sort", n * 16.0, k_cs_scatter, dim3(div_up(n, 256)), dim3(256), 0, keys, (const uint32_t *)ranks.get(),
+              (const int *)bin_start.get(), n, divisor, slots.get(), too_long);
+  MM3D_LAUNCH(c, "count_sort", n * 24.0, k_cs_place, dim3(div_up(n, 256)), dim3(256), 0, keys, (const int *)bin_start.get(),
+              (const int *)slots.get(), n, divisor, (const int *)too_long, keys_out, idx_out);
+  // (the temporaries return to the pool when this function ends: the pool is stream-ordered per context, and the
+  // next user of these blocks runs on the same stream)
+}
+
 // Hilbert order by counting sort on the column index (key >> 10, at most 2^20 columns): a point's arrival rank in
 // its column comes with the histogram, a scan gives the columns' starts, and inside its column (a handful of
 // points; a wall: a hundred) every point counts the smaller (key, index) pairs -- the order a stable radix sort

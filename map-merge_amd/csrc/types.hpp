@@ -139,6 +139,8 @@ const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl);
 // ordered compaction: keeps in[i] where flags[i] != 0, preserving order; returns kept count
 size_t compact_points(Context *c, const float4 *in, const int *flags, size_t n, DevBuf<float4> &out);
 void exclusive_scan_int(Context *c, const int *in, int *out, size_t n);
+void counting_sort_pairs_u32(Context *c, const uint32_t *keys, int n, uint64_t key_range, uint32_t *keys_out, uint32_t *idx_out,
+                             int *too_long);
 void sort_pairs_u32(Context *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
                     size_t n, int end_bit);
 

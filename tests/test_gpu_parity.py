@@ -43,6 +43,19 @@ def test_downsample_bit_exact(ctx, scene):
         assert np.array_equal(got.view(np.uint32), m["down"].view(np.uint32))
 
 
+def test_downsample_of_a_very_dense_spot(ctx, po, mm):
+    """Thousands of raw points inside one voxel (a bin of the counting sort overflows and the stable radix sort takes
+    over): the centroid is still summed in input order, bit for bit."""
+    rng = np.random.default_rng(5)
+    a = np.zeros(9000, dtype=mm.POINT)
+    a["x"][:6000] = 3.0 + rng.uniform(0, 0.09, 6000); a["y"][:6000] = 1.0 + rng.uniform(0, 0.09, 6000); a["z"][:6000] = rng.uniform(0, 0.09, 6000)
+    a["x"][6000:] = rng.uniform(-20, 20, 3000); a["y"][6000:] = rng.uniform(-20, 20, 3000); a["z"][6000:] = rng.uniform(0, 3, 3000)
+    a["rgba"] = 0xFF000000 | rng.integers(0, 1 << 24, 9000).astype(np.uint32)
+    got = ctx.downSample(ctx.cloud(a), 0.1).numpy()
+    ref = po.downsample(a, 0.1)
+    assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 def test_downsample_edge_cases(ctx, po, mm):
     empty = np.empty(0, dtype=mm.POINT)
     assert len(ctx.downSample(ctx.cloud(empty), 0.1)) == 0
