@@ -6,7 +6,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dir
 import __graft_entry__ as ge
 import bench, torch
 mm = ge.load()
-host = bench.make_workload(16, 500000)
+PTS = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
+host = bench.make_workload(16, PTS)
 dev = torch.device("cuda", 0)
 raw_t = torch.from_numpy(host[0].view(np.uint8).reshape(-1, 16)).to(dev)
 ctx = mm.Context(0)
