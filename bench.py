@@ -49,6 +49,26 @@ KERNEL_OF_SYMBOL = {"k_sift_dog": "sift_dog", "k_sift_extrema": "sift_extrema", 
                     "k_radius_outlier_count": "radius_outlier_count"}
 
 
+def cgroup_cpu_limit():
+    """CPUs this process may use at a time (cgroup v2 cpu.max quota / period), None if unlimited or unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except Exception:
+        return None
+
+
+def cgroup_throttle():
+    """Microseconds this cgroup's threads have spent throttled by the CPU quota so far (0 if unknown)."""
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("throttled_usec"):
+                return int(line.split()[1])
+    except Exception:
+        pass
+    return 0
+
+
 def make_workload(n_maps, n_points, cache=True):
     from map_merge_amd import synth
     path = f"/tmp/mm3d_bench_{n_maps}x{n_points}.npy"
@@ -304,11 +324,14 @@ def main():
         c.profile_reset()
         c.profile(not args.no_kernel_events)
     barrier()
+    cpu0, thr0 = time.process_time(), cgroup_throttle()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    host_cpu = {"cores_busy": round((time.process_time() - cpu0) / max(elapsed, 1e-9), 2), "cgroup_cpu_limit": cgroup_cpu_limit(),
+                "cgroup_throttled_ms_per_step": round((cgroup_throttle() - thr0) / 1e3 / max(args.steps, 1), 2)}
     for c in ctxs:
         c.profile(False)
     if world > 1:
@@ -477,6 +500,7 @@ def main():
             "top_kernels_ms_per_step": {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in top},
             "maps_estimated": stats["n_estimated"],
             "icp_iterations_histogram": {str(k): int(v) for k, v in zip(*np.unique(stats["icp_iters"], return_counts=True))},
+            "host_cpu": host_cpu,                           # the box's CPU quota bounds how many host threads can wait at once
             "pair_transforms_crc32": stats["crc"],          # same job, same bits: independent of --gpus / --streams
             "roofline": roofline,
         }
@@ -507,8 +531,13 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", me
     po = ge.load_oracle()
     p = params if params is not None else po.params_default()   # the same parameter values the device ran with
     describe = {"FPFH": po.descriptors_fpfh, "PFH": po.descriptors_pfh, "SHOT": po.descriptors_shot}[descriptor]
-    # B2's threads: the physical cores (SMT siblings do not help these loops), at most 64
+    # B2's threads: the physical cores (SMT siblings do not help these loops), at most 64 -- and not more than the
+    # container's CPU quota lets run at once (the GPU boxes show 256 CPUs and grant 16: threads beyond the quota
+    # only get the whole group throttled)
     cores = max(1, min(64, (os.cpu_count() or 2) // 2))
+    quota = cgroup_cpu_limit()
+    if quota is not None:
+        cores = max(1, min(cores, int(quota)))
     try:
         with open("/proc/cpuinfo") as f:
             model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "?")

@@ -5,6 +5,7 @@
 // context's own stream.
 #pragma once
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 

@@ -75,7 +75,12 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // MODE 0: ICP (transform from the device state, accumulate Umeyama moments)
 // MODE 1: transformScore (transform from Tc, accumulate sum d2 / count for d2 <= max_d2)
-template <int MODE>
+// SPLIT 1: one work item per wave, four items per block.
+// SPLIT 4: one work item per BLOCK: its four waves hold the same 64 points and the same box, each stages and
+//          scans a quarter of the box's candidates, and the four minima meet in LDS after every pass.  Same
+//          result, a quarter of the time per item: for a source of a few hundred items (a 50 k point map) the
+//          chip is mostly idle and the kernel's duration IS one wave's scan.
+template <int MODE, int SPLIT>
 __global__ void __launch_bounds__(256)
 k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_items, GridView g,
           const float4 *__restrict__ tgt_ref /* target points in reference order */,
@@ -90,12 +95,13 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
   __shared__ __attribute__((aligned(16))) unsigned s_cw[4][kTile];
   __shared__ int s_off[4][64];
   __shared__ int s_beg[4][64];
+  __shared__ unsigned long long s_merge[SPLIT == 4 ? 4 : 1][64];
   if (MODE == 0 && st->done) return;
   if (threadIdx.x < 16) Ts[threadIdx.x] = (MODE == 0) ? st->T[threadIdx.x] : Tc[threadIdx.x];
   __syncthreads();
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = bid * 4 + wave;                       // one work item (<= 64 points of one coarse block) per wave
+  const int item = SPLIT == 4 ? (int)bid : (int)bid * 4 + wave;   // one work item (<= 64 points of one coarse block)
   const int2 it = item < n_items ? items[item] : make_int2(0, 0);
   const int i = it.x + lane;
   const bool valid = lane < it.y;
@@ -175,9 +181,13 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
       s_beg[wave][lane] = b;
       wave_lds_sync();
       MM3D_TOCK(32, t_hdr);
-      for (int t0 = 0; t0 < total; t0 += kTile) {
+      // SPLIT 4: this wave's quarter of the chunk's candidates (a multiple of four, so the padding stays at the end)
+      const int share = SPLIT == 4 ? ((total + 15) >> 4) << 2 : total;
+      const int t_first = SPLIT == 4 ? min(total, wave * share) : 0;
+      const int t_last = SPLIT == 4 ? min(total, t_first + share) : total;
+      for (int t0 = t_first; t0 < t_last; t0 += kTile) {
         MM3D_TICK(t_stage);
-        const int cnt = min(kTile, total - t0);
+        const int cnt = min(kTile, t_last - t0);
         // stage: slot -> (row by binary search over the 64 offsets) -> sorted target index
         // (all of a lane's gathers are issued before the first LDS store: one memory round trip per tile)
         // two fully unrolled variants (4 or 8 slots per lane): most chunks stage < 256 points, and the short
@@ -216,21 +226,31 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
         MM3D_TOCK(33, t_stage);
         MM3D_TICK(t_scan);
         if (active) {
+          // two candidates per packed instruction; the sums are dist2()'s: ((dx*dx + dy*dy) + dz*dz)
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          const f2 px2 = {p.x, p.x}, py2 = {p.y, p.y}, pz2 = {p.z, p.z};
+          auto d2_pair = [&](float xa, float xb, float ya, float yb, float za, float zb) {
+            const f2 dx = px2 - f2{xa, xb}, dy = py2 - f2{ya, yb}, dz = pz2 - f2{za, zb};
+            f2 r = dx * dx;
+            r += dy * dy;
+            r += dz * dz;
+            return r;
+          };
+#pragma unroll 2
           for (int k = 0; k < cnt; k += 4) {
             const float4 X = *reinterpret_cast<const float4 *>(&s_cx[wave][k]);
             const float4 Y = *reinterpret_cast<const float4 *>(&s_cy[wave][k]);
             const float4 Z = *reinterpret_cast<const float4 *>(&s_cz[wave][k]);
-            const float d0 = dist2(p.x, p.y, p.z, X.x, Y.x, Z.x), d1 = dist2(p.x, p.y, p.z, X.y, Y.y, Z.y);
-            const float d2 = dist2(p.x, p.y, p.z, X.z, Y.z, Z.z), d3 = dist2(p.x, p.y, p.z, X.w, Y.w, Z.w);
+            const f2 da = d2_pair(X.x, X.y, Y.x, Y.y, Z.x, Z.y), db = d2_pair(X.z, X.w, Y.z, Y.w, Z.z, Z.w);
             if (MODE == 1) {
               // transformScore only needs the distance
-              bestd = fminf(fminf(bestd, fminf(d0, d1)), fminf(d2, d3));
+              bestd = fminf(fminf(bestd, fminf(da.x, da.y)), fminf(db.x, db.y));
             } else {
               const uint4 W = *reinterpret_cast<const uint4 *>(&s_cw[wave][k]);
-              const unsigned long long k0 = ((unsigned long long)__float_as_uint(d0) << 32) | W.x;
-              const unsigned long long k1 = ((unsigned long long)__float_as_uint(d1) << 32) | W.y;
-              const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2) << 32) | W.z;
-              const unsigned long long k3 = ((unsigned long long)__float_as_uint(d3) << 32) | W.w;
+              const unsigned long long k0 = ((unsigned long long)__float_as_uint(da.x) << 32) | W.x;
+              const unsigned long long k1 = ((unsigned long long)__float_as_uint(da.y) << 32) | W.y;
+              const unsigned long long k2 = ((unsigned long long)__float_as_uint(db.x) << 32) | W.z;
+              const unsigned long long k3 = ((unsigned long long)__float_as_uint(db.y) << 32) | W.w;
               const unsigned long long a = k0 < k1 ? k0 : k1, b2 = k2 < k3 ? k2 : k3;
               const unsigned long long m = a < b2 ? a : b2;
               bkey = m < bkey ? m : bkey;
@@ -240,6 +260,16 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
         wave_lds_sync();
         MM3D_TOCK(34, t_scan);
       }
+    }
+    if (SPLIT == 4) {      // the four quarters' minima (every wave then goes on with the same state)
+      s_merge[wave][lane] = MODE == 1 ? (unsigned long long)__float_as_uint(bestd) : bkey;   // d2 >= 0: bits order like values
+      __syncthreads();
+      const unsigned long long m0 = s_merge[0][lane], m1 = s_merge[1 % SPLIT][lane], m2 = s_merge[2 % SPLIT][lane],
+                               m3 = s_merge[3 % SPLIT][lane];
+      const unsigned long long ma = m0 < m1 ? m0 : m1, mb = m2 < m3 ? m2 : m3, m = ma < mb ? ma : mb;
+      __syncthreads();
+      if (MODE == 1) bestd = __uint_as_float((unsigned)m);
+      else bkey = m;
     }
     // what the scanned box proves: every target point closer than `guard` to this lane has been seen
     best = MODE == 1 ? bestd : ((bkey == ~0ull) ? INFINITY : __uint_as_float((unsigned)(bkey >> 32)));
@@ -278,6 +308,7 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
     atomicAdd(&g_nn_stats[8 + b], 1ull);
   }
 #endif
+  if (SPLIT == 4 && wave != 0) return;     // the four waves hold the same result
   double acc[kAcc];
 #pragma unroll
   for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
@@ -293,6 +324,14 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
     }
     acc[15] = best;
     acc[16] = 1.0;
+  }
+  if (SPLIT == 4) {
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) {
+      const double v = (MODE == 0 || k >= 15) ? wave_sum(acc[k]) : 0.0;
+      if (lane == 0) partials[(size_t)bid * kAcc + k] = v;
+    }
+    return;
   }
 #pragma unroll
   for (int k = (MODE == 0 ? 0 : 15); k < kAcc; ++k) {
@@ -418,6 +457,12 @@ static float nn_cell_for(double radius)
   return cell;
 }
 
+// One work item per block (k_nn_wave's SPLIT 4) when the source has too few items to keep the chip busy with one
+// wave each: 256 CUs x 4 SIMDs take 1024 waves before any two share a SIMD.  Measured on MI355X, pairs/s with
+// the split off / on: 16 x 100 k points (1.3 k items) 1765 / 1823, 4 x 200 k (2.5 k items) 245 / 257,
+// 64 x 50 k (0.6 k items) 4135 / 4925, 16 x 500 k (7.8 k items) 706 / 669.
+static bool nn_split_items(int n_items) { return n_items <= 4096; }
+
 // ICP from `guess` and, if wanted, transformScore of the result -- the tail of every pair estimate --
 // with ONE host synchronisation: the guess may already live on the device (SAC-IA's winning
 // hypothesis), the score kernel reads the transform straight out of the ICP state, and state + score
@@ -483,7 +528,8 @@ PairTail icp_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, con
   MM3D_HIP(hipMemcpyAsync(st.get(), hp, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
   if (guess_dev) MM3D_HIP(hipMemcpyAsync(st.get(), guess_dev, 64, hipMemcpyDeviceToDevice, c->stream));
   const int n_items = src->n_wave_items;
-  const unsigned nblocks = div_up(n_items, 4);
+  const bool split = nn_split_items(n_items);
+  const unsigned nblocks = split ? (unsigned)n_items : div_up(n_items, 4);
   DevBuf<double> partials(c, (size_t)nblocks * kAcc), s_partials(c, want_score ? (size_t)nblocks * kAcc : 1);
   DevBuf<double> out(c, 2);
   // iterations launched between two looks at the `done` flag: with the reference's loose epsilon 90 % of
@@ -493,16 +539,25 @@ PairTail icp_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, con
     if (run_icp) {
       const GridView gv = tg->view();
       for (int k = 0; k < chunk; ++k) {
-        MM3D_LAUNCH(c, "icp_corr_reduce", ns * 12.0, k_nn_wave<0>, dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items, gv,
-                    (const float4 *)tgt->pts.get(), (const IcpState *)st.get(), (const float *)nullptr, max_d2, rmax, max_ring, partials.get());
+        if (split)
+          MM3D_LAUNCH(c, "icp_corr_reduce", ns * 12.0, (k_nn_wave<0, 4>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items,
+                      gv, (const float4 *)tgt->pts.get(), (const IcpState *)st.get(), (const float *)nullptr, max_d2, rmax, max_ring, partials.get());
+        else
+          MM3D_LAUNCH(c, "icp_corr_reduce", ns * 12.0, (k_nn_wave<0, 1>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items,
+                      gv, (const float4 *)tgt->pts.get(), (const IcpState *)st.get(), (const float *)nullptr, max_d2, rmax, max_ring, partials.get());
         MM3D_LAUNCH(c, "icp_finalize", nblocks * kAcc * 8.0, k_icp_finalize, dim3(1), dim3(256), 0, (const double *)partials.get(),
                     (int)nblocks, st.get());
       }
     }
     if (want_score) {
-      MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + sg->n * 12.0, k_nn_wave<1>, dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items,
-                  sg->view(), (const float4 *)tgt->pts.get(), (const IcpState *)nullptr, (const float *)st.get(), s_max_d2, s_rmax, s_ring,
-                  s_partials.get());
+      if (split)
+        MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + sg->n * 12.0, (k_nn_wave<1, 4>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(),
+                    n_items, sg->view(), (const float4 *)tgt->pts.get(), (const IcpState *)nullptr, (const float *)st.get(), s_max_d2, s_rmax, s_ring,
+                    s_partials.get());
+      else
+        MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + sg->n * 12.0, (k_nn_wave<1, 1>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(),
+                    n_items, sg->view(), (const float4 *)tgt->pts.get(), (const IcpState *)nullptr, (const float *)st.get(), s_max_d2, s_rmax, s_ring,
+                    s_partials.get());
       MM3D_LAUNCH(c, "score_finalize", 0, k_score_finalize, dim3(1), dim3(256), 0, (const double *)s_partials.get(), (int)nblocks, out.get());
       MM3D_HIP(hipMemcpyAsync(ho, out.get(), 16, hipMemcpyDeviceToHost, c->stream));
     }
@@ -546,15 +601,20 @@ double transform_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt,
   const int max_ring = (int)std::ceil(rmax / tg.cell) + 1;
   grid_ensure_dt(c, tg, max_ring);
   const int n_items = src->n_wave_items;
-  const unsigned nblocks = div_up(n_items, 4);
+  const bool split = nn_split_items(n_items);
+  const unsigned nblocks = split ? (unsigned)n_items : div_up(n_items, 4);
   DevBuf<double> partials(c, (size_t)nblocks * kAcc);
   DevBuf<float> dT(c, 16);
   DevBuf<double> out(c, 2);
   float *hT = (float *)c->pin(256);
   memcpy(hT, T, 64);
   MM3D_HIP(hipMemcpyAsync(dT.get(), hT, 64, hipMemcpyHostToDevice, c->stream));
-  MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + tg.n * 12.0, k_nn_wave<1>, dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items, tg.view(), (const float4 *)tgt->pts.get(),
-              (const IcpState *)nullptr, (const float *)dT.get(), max_d2, rmax, max_ring, partials.get());
+  if (split)
+    MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + tg.n * 12.0, (k_nn_wave<1, 4>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items,
+                tg.view(), (const float4 *)tgt->pts.get(), (const IcpState *)nullptr, (const float *)dT.get(), max_d2, rmax, max_ring, partials.get());
+  else
+    MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + tg.n * 12.0, (k_nn_wave<1, 1>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items,
+                tg.view(), (const float4 *)tgt->pts.get(), (const IcpState *)nullptr, (const float *)dT.get(), max_d2, rmax, max_ring, partials.get());
   MM3D_LAUNCH(c, "score_finalize", 0, k_score_finalize, dim3(1), dim3(256), 0, (const double *)partials.get(), (int)nblocks, out.get());
   double *ho = (double *)((char *)c->pin(256) + 128);
   MM3D_HIP(hipMemcpyAsync(ho, out.get(), 16, hipMemcpyDeviceToHost, c->stream));
