@@ -613,6 +613,53 @@ static void pair_estimate_impl(mm3d_ctx *ctx, const mm3d_map *s, const mm3d_map 
   out->confidence = 1.0 / score;
 }
 
+// Several pairs on one context: the initial estimates one after the other (each from its own generator state),
+// then every pair's ICP + score tail in lockstep, one launch per step for the whole batch (icp_score_batch).
+struct PairWork { const mm3d_map *s, *t; mm3d_pair_result *out; GlibcRand rnd; };
+static void pairs_estimate_batch(mm3d_ctx *ctx, PairWork *w, size_t n, const mm3d_params *p)
+{
+  std::vector<PairFront> fronts(n);
+  std::vector<IcpScoreJob> jobs(n);
+  std::vector<SacPrepared> prepared;
+  for (size_t i = 0; i < n; ++i) {
+    mm3d_pair_result *out = w[i].out;
+    std::memset(out->transform, 0, sizeof(out->transform));
+    out->confidence = 0.0;
+    out->icp_iterations = 0;
+    out->n_correspondences = out->n_inliers = out->icp_correspondences = 0;
+    ctx->rnd = w[i].rnd;
+    if (p->estimation_method == MM3D_EST_SAC_IA) {
+      // argument mapping of matching.cpp:243-246: min_sample_distance := inlier_threshold
+      sac_ia_prepare(ctx, w[i].s->keypoints, w[i].s->desc, w[i].t->keypoints, w[i].t->desc, p->inlier_threshold,
+                     p->max_correspondence_distance, p->max_iterations, true, fronts[i]);
+      prepared.push_back(SacPrepared{w[i].s->keypoints, w[i].t->keypoints, &fronts[i]});
+    } else {
+      estimate_pair_front(ctx, w[i].s->keypoints, w[i].s->desc, w[i].t->keypoints, w[i].t->desc, p->estimation_method,
+                          p->inlier_threshold, p->max_correspondence_distance, p->max_iterations, (size_t)p->matching_k, true, fronts[i]);
+    }
+  }
+  // the hypotheses of every SAC-IA pair of the batch are scored by the same four launches
+  if (!prepared.empty()) sac_ia_finish(ctx, prepared.data(), (int)prepared.size(), p->max_correspondence_distance);
+  for (size_t i = 0; i < n; ++i) {
+    jobs[i].src = w[i].s->points;
+    jobs[i].tgt = w[i].t->points;
+    jobs[i].guess_dev = fronts[i].on_device ? fronts[i].dT0.get() : nullptr;
+    std::memcpy(jobs[i].guess_host, fronts[i].T0, sizeof(fronts[i].T0));
+  }
+  // estimateTransform's ICP and transformScore of its result (R/src/map_merging.cpp:91-107), max_distance = max_correspondence_distance
+  icp_score_batch(ctx, jobs.data(), (int)n, p->refine_transform != 0, p->max_correspondence_distance, p->max_iterations, p->transform_epsilon,
+                  true, p->max_correspondence_distance);
+  for (size_t i = 0; i < n; ++i) {
+    mm3d_pair_result *out = w[i].out;
+    std::memcpy(out->transform, jobs[i].out.T, sizeof(out->transform));
+    out->icp_iterations = jobs[i].out.iterations;
+    out->n_correspondences = fronts[i].counts.n_correspondences;
+    out->n_inliers = fronts[i].counts.n_inliers;
+    out->icp_correspondences = jobs[i].out.n_corr;
+    out->confidence = 1.0 / jobs[i].out.score;
+  }
+}
+
 int mm3d_pair_estimate(mm3d_ctx *ctx, const mm3d_map *source, const mm3d_map *target, const mm3d_params *params, int execute,
                        mm3d_pair_result *out)
 {
@@ -660,7 +707,9 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   std::vector<mm3d_ctx *> cs{ctx};
   cs.insert(cs.end(), ctx->helpers.begin(), ctx->helpers.end());
   const size_t S = cs.size();
-  size_t F = S <= 4 ? S : std::max<size_t>(4, S * 3 / 8);
+  // many small maps (at least two per worker): every worker extracts features first, and the pairs then start in
+  // batches; otherwise (few large maps) 3/8 of the workers do, and the others begin with the pairs of the first maps
+  size_t F = (S <= 4 || n >= 2 * S) ? S : std::max<size_t>(4, S * 3 / 8);
   if (const char *e = std::getenv("MM3D_FEATURE_WORKERS")) {     // tuning knob: how many workers start on features
     const long v = std::atol(e);
     if (v >= 1) F = std::min<size_t>(S, (size_t)v);
@@ -727,21 +776,32 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
       known_upto = q + 1;
     }
   };
-  // the next pair to work on: the first unclaimed one, in the reference's order, whose two maps and all
-  // earlier sources exist (maps finish roughly in index order, so that is rarely a restriction)
-  auto claim_pair = [&](size_t &p) -> bool {
+  // the next pairs to work on: the first unclaimed ones, in the reference's order, whose two maps and all
+  // earlier sources exist (maps finish roughly in index order, so that is rarely a restriction).  A worker takes
+  // its share of what can start right now, up to kPairBatch pairs: their ICP / score tails then run as one batch
+  // (many small maps: thousands of pairs are ready at once and a launch per pair leaves the chip idle), while a
+  // job whose pairs trickle in behind the feature stage keeps dealing them out one by one.
+  constexpr size_t kPairBatch = 8;
+  auto claim_pairs = [&](std::vector<size_t> &out) -> bool {
+    out.clear();
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
       if (abort) return false;
       bool any_left = false;
-      size_t prefix = 0;
+      size_t prefix = 0, avail = 0;
       while (prefix < n && ready[prefix]) ++prefix;      // maps [0, prefix) exist
       for (size_t q = 0; q < P; ++q) {
         if (claimed[q]) continue;
         any_left = true;
-        if (all[q].first < prefix && ready[all[q].second]) { claimed[q] = 1; p = q; return true; }
+        if (all[q].first < prefix && ready[all[q].second]) ++avail;
       }
       if (!any_left) return false;
+      if (avail) {
+        const size_t take = std::min(kPairBatch, std::max<size_t>(1, avail / (2 * S)));
+        for (size_t q = 0; q < P && out.size() < take; ++q)
+          if (!claimed[q] && all[q].first < prefix && ready[all[q].second]) { claimed[q] = 1; out.push_back(q); }
+        return true;
+      }
       cv.wait(lk);
     }
   };
@@ -778,17 +838,22 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
         }
         cv.notify_all();
       }
-      size_t p;
-      while (claim_pair(p)) {
-        const mm3d_map *ms = maps[all[p].first], *mt = maps[all[p].second];
-        if (ms->keypoints->n > 0 && mt->keypoints->n > 0) {
-          advance_states(p);
-          c->rnd = state_at[p];
-          pair_estimate_impl(c, ms, mt, params, true, &rec[p]);
-          rec[p].source_idx = all[p].first;
-          rec[p].target_idx = all[p].second;
-          done[p] = 1;
+      std::vector<size_t> mine;
+      std::vector<PairWork> work;
+      while (claim_pairs(mine)) {
+        work.clear();
+        for (size_t p : mine) {
+          const mm3d_map *ms = maps[all[p].first], *mt = maps[all[p].second];
+          if (ms->keypoints->n > 0 && mt->keypoints->n > 0) {
+            advance_states(p);
+            rec[p].source_idx = all[p].first;
+            rec[p].target_idx = all[p].second;
+            work.push_back(PairWork{ms, mt, &rec[p], state_at[p]});
+          }
         }
+        if (!work.empty()) pairs_estimate_batch(c, work.data(), work.size(), params);
+        for (size_t p : mine)
+          if (maps[all[p].first]->keypoints->n > 0 && maps[all[p].second]->keypoints->n > 0) done[p] = 1;
       }
       c->sync();
     } catch (...) {

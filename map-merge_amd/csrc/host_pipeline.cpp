@@ -282,21 +282,18 @@ void pair_rand_replay(GlibcRand &rnd, int method, const std::vector<float4> &skp
   sac_ia_draws(rnd, skp_host, ns, (float)inlier_threshold, max_iterations > 0 ? max_iterations : 0, 10, nullptr, nullptr);
 }
 
-// ---------------------------------------------------------------- SAC-IA
-// R/src/matching.cpp:142-194 -> pcl::SampleConsensusInitialAlignment (nr_samples 3,
-// k_correspondences 10, TruncatedError(max_correspondence_distance)).
-bool sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_cloud *tkp_, const mm3d_desc *td,
-            double min_sample_distance_d, double max_corr_dist, int max_iterations, float T[16], bool execute,
-            DevBuf<float> *T_dev)
+void sac_ia_prepare(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_cloud *tkp_, const mm3d_desc *td,
+                    double min_sample_distance_d, double max_corr_dist, int max_iterations, bool execute, PairFront &f)
 {
-  std::memset(T, 0, sizeof(float) * 16);
-  T[0] = T[5] = T[10] = T[15] = 1.0f;   // final_transformation_ = guess = Identity
+  std::memset(f.T0, 0, sizeof(f.T0));
+  f.T0[0] = f.T0[5] = f.T0[10] = f.T0[15] = 1.0f;   // final_transformation_ = guess = Identity
+  f.on_device = false;
+  f.sac_h = 0;
   const int ns = (int)skp_->n, nt = (int)tkp_->n;
   const int nr_samples = 3, k_corr = 10;
-  if (ns < nr_samples || nt < 1) return false;
+  if (ns < nr_samples || nt < 1) return;
   MM3D_REQUIRE(sd->n == (size_t)ns && td->n == (size_t)nt, "SAC-IA: keypoints and descriptors differ in size");
   float min_sample_distance = (float)min_sample_distance_d;
-  const float corr_thresh = (float)max_corr_dist;
   const std::vector<float4> &skp = cloud_host(c, skp_);
   const int kk = std::min(k_corr, nt);
   const int H = max_iterations > 0 ? max_iterations : 0;
@@ -307,7 +304,7 @@ bool sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
   // replayed picks up in its own table and builds the 500 three-point Umeyama models.
   std::vector<int> samp((size_t)H * 3), pick((size_t)H * 3);
   sac_ia_draws(c->rnd, skp, ns, min_sample_distance, H, kk, samp.data(), pick.data());
-  if (!execute || H == 0) return false;
+  if (!execute || H == 0) return;
   // distinct sampled rows -> position in the subset table
   std::vector<int> rows, row_pos((size_t)ns, -1), corr_ref((size_t)H * 3);
   for (size_t e = 0; e < samp.size(); ++e) {
@@ -315,27 +312,54 @@ bool sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
     if (pos < 0) { pos = (int)rows.size(); rows.push_back(samp[e]); }
     corr_ref[e] = pos * k_corr + pick[e];
   }
-  // one pinned upload for the three index lists
+  // one pinned upload for the three index lists: samp | corr_ref | rows
   const size_t n3 = (size_t)H * 3, nr = rows.size();
   int *hp = (int *)c->pin((2 * n3 + nr) * sizeof(int));
   std::memcpy(hp, samp.data(), n3 * sizeof(int));
   std::memcpy(hp + n3, corr_ref.data(), n3 * sizeof(int));
   std::memcpy(hp + 2 * n3, rows.data(), nr * sizeof(int));
-  DevBuf<int> d_idx(c, 2 * n3 + nr), d_nn;
-  MM3D_HIP(hipMemcpyAsync(d_idx.get(), hp, (2 * n3 + nr) * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  const int *d_samp = d_idx.get(), *d_ref = d_idx.get() + n3, *d_rows = d_idx.get() + 2 * n3;
-  DevBuf<float> d_nd, d_T(c, (size_t)H * 16), d_err(c, H), d_best(c, 16);
-  desc_knn_rows(c, sd, d_rows, (int)nr, td, k_corr, d_nn, d_nd);
-  sacia_models(c, skp_, tkp_, d_samp, d_ref, d_nn.get(), H, d_T.get());
-  sacia_errors(c, skp_, tkp_, d_T.get(), H, corr_thresh, d_err.get());
-  // "if (i_iter == 0 || error < lowest_error)": the first minimum, picked on the device
-  sacia_pick(c, d_err.get(), H, d_T.get(), d_best.get());
+  f.sac_idx = DevBuf<int>(c, 2 * n3 + nr);
+  MM3D_HIP(hipMemcpyAsync(f.sac_idx.get(), hp, (2 * n3 + nr) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  desc_knn_rows(c, sd, f.sac_idx.get() + 2 * n3, (int)nr, td, k_corr, f.sac_nn, f.sac_nd);
+  f.dT0 = DevBuf<float>(c, 16);
+  f.sac_h = H;
+}
+
+void sac_ia_finish(Context *c, SacPrepared *pairs, int n, double max_corr_dist)
+{
+  std::vector<SacPair> jobs;
+  int H = 0;
+  for (int i = 0; i < n; ++i) {
+    PairFront &f = *pairs[i].front;
+    if (f.sac_h == 0) continue;
+    MM3D_REQUIRE(H == 0 || H == f.sac_h, "SAC-IA batch: pairs differ in their iteration count");
+    H = f.sac_h;
+    const size_t n3 = (size_t)H * 3;
+    jobs.push_back(SacPair{pairs[i].skp, pairs[i].tkp, f.sac_idx.get(), f.sac_idx.get() + n3, f.sac_nn.get(), f.dT0.get()});
+    f.on_device = true;              // the caller keeps going on the device (ICP reads the winner there)
+  }
+  sacia_score_batch(c, jobs.data(), (int)jobs.size(), H, (float)max_corr_dist);
+}
+
+// ---------------------------------------------------------------- SAC-IA
+// R/src/matching.cpp:142-194 -> pcl::SampleConsensusInitialAlignment (nr_samples 3,
+// k_correspondences 10, TruncatedError(max_correspondence_distance)).
+bool sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_cloud *tkp_, const mm3d_desc *td,
+            double min_sample_distance_d, double max_corr_dist, int max_iterations, float T[16], bool execute,
+            DevBuf<float> *T_dev)
+{
+  PairFront f;
+  sac_ia_prepare(c, skp_, sd, tkp_, td, min_sample_distance_d, max_corr_dist, max_iterations, execute, f);
+  std::memcpy(T, f.T0, sizeof(f.T0));
+  if (f.sac_h == 0) return false;
+  SacPrepared one{skp_, tkp_, &f};
+  sac_ia_finish(c, &one, 1, max_corr_dist);
   if (T_dev) {
-    *T_dev = std::move(d_best);      // the caller keeps going on the device (ICP reads it there)
+    *T_dev = std::move(f.dT0);
     return true;
   }
   float *hT = (float *)c->pin(64);
-  MM3D_HIP(hipMemcpyAsync(hT, d_best.get(), sizeof(float) * 16, hipMemcpyDeviceToHost, c->stream));
+  MM3D_HIP(hipMemcpyAsync(hT, f.dT0.get(), sizeof(float) * 16, hipMemcpyDeviceToHost, c->stream));
   c->sync();
   std::memcpy(T, hT, sizeof(float) * 16);
   return false;
@@ -343,31 +367,40 @@ bool sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
 
 // ---------------------------------------------------------------- estimateTransform
 // R/src/matching.cpp:223-257
+// the part of estimateTransform before ICP: the initial estimate, on the host (T0) or on the device (dT0)
+void estimate_pair_front(Context *c, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tkp, const mm3d_desc *td, int method,
+                         double inlier_threshold, double max_corr_dist, int max_iterations, size_t matching_k, bool execute, PairFront &f)
+{
+  std::memset(f.T0, 0, sizeof(f.T0));
+  f.on_device = false;
+  f.counts = PairCounts();
+  if (method == MM3D_EST_MATCHING) {
+    if (execute) {
+      std::vector<mm3d_corr> corr, inl;
+      find_correspondences(c, sd, td, matching_k, corr);
+      ransac_transform(c, skp, tkp, corr.data(), corr.size(), inlier_threshold, f.T0, inl);
+      f.counts.n_correspondences = (int)corr.size();
+      f.counts.n_inliers = (int)inl.size();
+    }
+  } else if (method == MM3D_EST_SAC_IA) {
+    // argument mapping of matching.cpp:243-246: min_sample_distance := inlier_threshold
+    f.on_device = sac_ia(c, skp, sd, tkp, td, inlier_threshold, max_corr_dist, max_iterations, f.T0, execute, &f.dT0);
+  } else {
+    throw Error(MM3D_EINVAL, "unknown estimation method");
+  }
+}
+
 int estimate_pair(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tp,
                   const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine, double inlier_threshold,
                   double max_corr_dist, int max_iterations, size_t matching_k, double eps, float T[16], bool execute,
                   bool want_score, double score_max_distance, double *score, PairCounts *counts)
 {
-  float T0[16];
-  std::memset(T0, 0, sizeof(T0));
-  DevBuf<float> dT0;
-  bool on_device = false;
-  if (method == MM3D_EST_MATCHING) {
-    if (execute) {
-      std::vector<mm3d_corr> corr, inl;
-      find_correspondences(c, sd, td, matching_k, corr);
-      ransac_transform(c, skp, tkp, corr.data(), corr.size(), inlier_threshold, T0, inl);
-      if (counts) { counts->n_correspondences = (int)corr.size(); counts->n_inliers = (int)inl.size(); }
-    }
-  } else if (method == MM3D_EST_SAC_IA) {
-    // argument mapping of matching.cpp:243-246: min_sample_distance := inlier_threshold
-    on_device = sac_ia(c, skp, sd, tkp, td, inlier_threshold, max_corr_dist, max_iterations, T0, execute, &dT0);
-  } else {
-    throw Error(MM3D_EINVAL, "unknown estimation method");
-  }
+  PairFront f;
+  estimate_pair_front(c, skp, sd, tkp, td, method, inlier_threshold, max_corr_dist, max_iterations, matching_k, execute, f);
+  if (counts) *counts = f.counts;
   if (!execute) { std::memset(T, 0, sizeof(float) * 16); return 0; }
   // no guard in the reference: ICP also runs from a zero matrix (and returns zero)
-  const PairTail r = icp_score(c, sp, tp, on_device ? dT0.get() : nullptr, T0, refine != 0, max_corr_dist, max_iterations, eps,
+  const PairTail r = icp_score(c, sp, tp, f.on_device ? f.dT0.get() : nullptr, f.T0, refine != 0, max_corr_dist, max_iterations, eps,
                                want_score, score_max_distance);
   std::memcpy(T, r.T, sizeof(r.T));
   if (score) *score = r.score;

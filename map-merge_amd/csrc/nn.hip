@@ -49,7 +49,24 @@ struct IcpState {
   float Tinc[16];
   double prev_mse;
   double rot_thresh, trans_thresh;
-  int iters, done, converged, n_corr, max_iter, pad;
+  int iters, done, converged, n_corr, max_iter;
+  int scored;      // the score of the final transform has been taken (k_score_finalize)
+};
+
+// One (source cloud, target grid) search of a launch: blockIdx.y picks the job, so the searches of several map
+// pairs that are ready at the same time share one launch (many small maps: a launch per pair leaves most of the
+// chip idle, and only four launches run at a time).
+struct NnJob {
+  const float4 *src;          // source points in Hilbert order
+  const int2 *items;          // their work items
+  int n_items, nblocks;       // blocks this job uses of the launch's grid.x
+  GridView g;                 // target grid
+  const float4 *tgt_ref;      // target points in reference order
+  IcpState *st;               // ICP: the pair's state; score: T is read from its head (or from Tc)
+  const float *Tc;            // score: the transform, when it is not the ICP state's
+  double *partials;           // [nblocks][kAcc]
+  double *out;                // score: {sum d2, count}
+  int max_ring;
 };
 
 __device__ __forceinline__ int wave_min_i(int v)
@@ -82,11 +99,19 @@ __device__ __forceinline__ void wave_lds_sync()
 //          chip is mostly idle and the kernel's duration IS one wave's scan.
 template <int MODE, int SPLIT>
 __global__ void __launch_bounds__(256)
-k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_items, GridView g,
-          const float4 *__restrict__ tgt_ref /* target points in reference order */,
-          const IcpState *__restrict__ st, const float *__restrict__ Tc, float max_d2, float rmax, int max_ring,
-          double *__restrict__ partials)
+k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
 {
+  const NnJob &job = jobs[blockIdx.y];
+  if ((int)blockIdx.x >= job.nblocks) return;            // the grid is as wide as the batch's largest job
+  const float4 *__restrict__ src = job.src;
+  const int2 *__restrict__ items = job.items;
+  const int n_items = job.n_items;
+  const GridView g = job.g;
+  const float4 *__restrict__ tgt_ref = job.tgt_ref;
+  const IcpState *__restrict__ st = job.st;
+  const float *__restrict__ Tc = job.Tc ? job.Tc : job.st->T;
+  double *__restrict__ partials = job.partials;
+  const int max_ring = job.max_ring;
   __shared__ float Ts[16];
   __shared__ double red[4][kAcc];
   // staged candidates, one array per component: four candidates' x (y, z, index) are ONE 16-byte
@@ -97,9 +122,11 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
   __shared__ int s_beg[4][64];
   __shared__ unsigned long long s_merge[SPLIT == 4 ? 4 : 1][64];
   if (MODE == 0 && st->done) return;
+  // the score of a pair's ICP result: once, in the first round after its ICP has finished
+  if (MODE == 1 && st && (!st->done || st->scored)) return;
   if (threadIdx.x < 16) Ts[threadIdx.x] = (MODE == 0) ? st->T[threadIdx.x] : Tc[threadIdx.x];
   __syncthreads();
-  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned bid = xcd_remap(blockIdx.x, (unsigned)job.nblocks);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = SPLIT == 4 ? (int)bid : (int)bid * 4 + wave;   // one work item (<= 64 points of one coarse block)
   const int2 it = item < n_items ? items[item] : make_int2(0, 0);
@@ -348,10 +375,13 @@ k_nn_wave(const float4 *__restrict__ src, const int2 *__restrict__ items, int n_
 }
 
 // one block: reduce partials, Umeyama, accumulate, convergence (DefaultConvergenceCriteria)
-__global__ void __launch_bounds__(256) k_icp_finalize(const double *__restrict__ partials, int nblocks, IcpState *st)
+__global__ void __launch_bounds__(256) k_icp_finalize(const NnJob *__restrict__ jobs)
 {
   __shared__ double red[4][kAcc];
   __shared__ double tot[kAcc];
+  const double *__restrict__ partials = jobs[blockIdx.x].partials;
+  const int nblocks = jobs[blockIdx.x].nblocks;
+  IcpState *st = jobs[blockIdx.x].st;
   if (st->done) return;
   double acc[kAcc];
 #pragma unroll
@@ -424,9 +454,14 @@ __global__ void __launch_bounds__(256) k_icp_finalize(const double *__restrict__
   st->prev_mse = mse;
 }
 
-__global__ void __launch_bounds__(256) k_score_finalize(const double *__restrict__ partials, int nblocks, double *out)
+__global__ void __launch_bounds__(256) k_score_finalize(const NnJob *__restrict__ jobs)
 {
   __shared__ double red[4][2];
+  const double *__restrict__ partials = jobs[blockIdx.x].partials;
+  const int nblocks = jobs[blockIdx.x].nblocks;
+  double *out = jobs[blockIdx.x].out;
+  IcpState *st = jobs[blockIdx.x].st;
+  if (st && (!st->done || st->scored)) return;
   double s = 0.0, n = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
     s += partials[(size_t)b * kAcc + 15];
@@ -439,6 +474,7 @@ __global__ void __launch_bounds__(256) k_score_finalize(const double *__restrict
   if (threadIdx.x == 0) {
     out[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
     out[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    if (st) st->scored = 1;
   }
 }
 
@@ -463,116 +499,193 @@ static float nn_cell_for(double radius)
 // 64 x 50 k (0.6 k items) 4135 / 4925, 16 x 500 k (7.8 k items) 706 / 669.
 static bool nn_split_items(int n_items) { return n_items <= 4096; }
 
-// ICP from `guess` and, if wanted, transformScore of the result -- the tail of every pair estimate --
-// with ONE host synchronisation: the guess may already live on the device (SAC-IA's winning
-// hypothesis), the score kernel reads the transform straight out of the ICP state, and state + score
-// come back in one copy.  The score is launched speculatively after each chunk of iterations; it is
-// only kept when ICP has finished (it nearly always has: the reference's epsilon is loose).
-PairTail icp_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float *guess_dev, const float guess_host[16],
-                   bool run_icp, double max_corr_dist, int max_iterations, double eps, bool want_score, double score_max_distance)
+// launches k_nn_wave<MODE> over `count` jobs (device array), picking the one-item-per-block variant for small sources
+template <int MODE>
+static void launch_nn(Context *c, const char *name, double bytes, const NnJob *jobs_dev, int count, unsigned grid_x, bool split, float max_d2,
+                      float rmax)
+{
+  if (split)
+    MM3D_LAUNCH(c, name, bytes, (k_nn_wave<MODE, 4>), dim3(grid_x, count), dim3(256), 0, jobs_dev, max_d2, rmax);
+  else
+    MM3D_LAUNCH(c, name, bytes, (k_nn_wave<MODE, 1>), dim3(grid_x, count), dim3(256), 0, jobs_dev, max_d2, rmax);
+}
+
+// ICP from a guess and, if wanted, transformScore of the result -- the tail of every pair estimate -- for a BATCH
+// of pairs in lockstep: one launch per step serves every pair of the batch (blockIdx.y = the pair), and the batch
+// shares ONE host synchronisation per chunk of iterations.  A guess may already live on the device (SAC-IA's
+// winning hypothesis), the score kernel reads the transform straight out of the ICP state, and the states and
+// scores come back in one copy.  The score is launched speculatively after each chunk of iterations; a pair's
+// score is only kept once its ICP has finished (it nearly always has: the reference's epsilon is loose).
+void icp_score_batch(Context *c, IcpScoreJob *jobs, int n_jobs, bool run_icp, double max_corr_dist, int max_iterations, double eps,
+                     bool want_score, double score_max_distance)
 {
   static_assert(offsetof(IcpState, T) == 0, "the score kernel reads T at the head of the state");
-  PairTail res;
-  res.iterations = 0;
-  res.converged = 0;
-  res.n_corr = 0;
-  res.score = DBL_MAX;
   c->last_icp_iterations = 0;
   c->last_icp_converged = 0;
-  int ns = 0;
-  const float4 *sp = (src->n && tgt->n) ? morton_source(c, src, ns) : nullptr;
-  const Grid *tg = (ns && run_icp) ? &cloud_grid(c, tgt, nn_cell_for(max_corr_dist)) : nullptr;
   const double score_radius = std::sqrt(score_max_distance > 0 ? score_max_distance : 0.0);
-  const Grid *sg = (ns && want_score) ? &cloud_grid(c, tgt, nn_cell_for(score_radius)) : nullptr;
-  if (ns == 0 || (tg && tg->n == 0) || (sg && sg->n == 0) || (!tg && !sg)) {
-    // nothing to search: Identity * guess, and the score of an empty search
-    if (guess_dev) {
-      float *hT = (float *)c->pin(256);
-      MM3D_HIP(hipMemcpyAsync(hT, guess_dev, 64, hipMemcpyDeviceToHost, c->stream));
-      c->sync();
-      memcpy(res.T, hT, sizeof(res.T));
-    } else {
-      memcpy(res.T, guess_host, sizeof(res.T));
-    }
-    return res;
-  }
   // ICP search parameters
   const double max_dist_sqr = max_corr_dist * max_corr_dist;
   // (double)d2 > max_dist_sqr rejects: accept d2 <= largest float not above max_dist_sqr
   float max_d2 = (float)max_dist_sqr;
   if ((double)max_d2 > max_dist_sqr) max_d2 = std::nextafterf(max_d2, -INFINITY);
   const float rmax = (float)(max_corr_dist * 1.0001 + 1e-5);
-  const int max_ring = tg ? (int)std::ceil(rmax / tg->cell) + 1 : 0;
-  if (tg) grid_ensure_dt(c, *tg, max_ring);
   // score search parameters: max_range_ is compared with the SQUARED distance (PCL quirk), so the
   // search radius is sqrt(max_distance)
   float s_max_d2 = (float)score_max_distance;
   if ((double)s_max_d2 > score_max_distance) s_max_d2 = std::nextafterf(s_max_d2, -INFINITY);
   const float s_rmax = (float)(score_radius * 1.0001 + 1e-5);
-  const int s_ring = sg ? (int)std::ceil(s_rmax / sg->cell) + 1 : 0;
-  if (sg) grid_ensure_dt(c, *sg, s_ring);
 
-  char *pinned = (char *)c->pin(1024);
+  struct Live { int job; const float4 *sp; int ns, n_items; const Grid *tg, *sg; int max_ring, s_ring; };
+  std::vector<Live> live;
+  for (int j = 0; j < n_jobs; ++j) {
+    IcpScoreJob &J = jobs[j];
+    J.out.iterations = 0; J.out.converged = 0; J.out.n_corr = 0; J.out.score = DBL_MAX;
+    int ns = 0;
+    const float4 *sp = (J.src->n && J.tgt->n) ? morton_source(c, J.src, ns) : nullptr;
+    const Grid *tg = (ns && run_icp) ? &cloud_grid(c, J.tgt, nn_cell_for(max_corr_dist)) : nullptr;
+    const Grid *sg = (ns && want_score) ? &cloud_grid(c, J.tgt, nn_cell_for(score_radius)) : nullptr;
+    if (ns == 0 || (tg && tg->n == 0) || (sg && sg->n == 0) || (!tg && !sg)) {
+      // nothing to search: Identity * guess, and the score of an empty search
+      if (J.guess_dev) {
+        float *hT = (float *)c->pin(256);
+        MM3D_HIP(hipMemcpyAsync(hT, J.guess_dev, 64, hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+        memcpy(J.out.T, hT, sizeof(J.out.T));
+      } else {
+        memcpy(J.out.T, J.guess_host, sizeof(J.out.T));
+      }
+      continue;
+    }
+    Live L{j, sp, ns, J.src->n_wave_items, tg, sg, 0, 0};
+    L.max_ring = tg ? (int)std::ceil(rmax / tg->cell) + 1 : 0;
+    if (tg) grid_ensure_dt(c, *tg, L.max_ring);
+    L.s_ring = sg ? (int)std::ceil(s_rmax / sg->cell) + 1 : 0;
+    if (sg) grid_ensure_dt(c, *sg, L.s_ring);
+    live.push_back(L);
+  }
+  const int B = (int)live.size();
+  if (B == 0) return;
+
+  // one kernel variant per launch: a batch that mixes small and large sources runs as two batches, so a pair's
+  // sums never depend on what it happened to be batched with
+  const bool split = nn_split_items(live[0].n_items);
+  bool mixed = false;
+  for (const Live &L : live) mixed = mixed || nn_split_items(L.n_items) != split;
+  if (mixed) {
+    for (int pass = 0; pass < 2; ++pass) {
+      std::vector<IcpScoreJob> part;
+      std::vector<int> where;
+      for (const Live &L : live)
+        if (nn_split_items(L.n_items) == (pass == 0)) { part.push_back(jobs[L.job]); where.push_back(L.job); }
+      icp_score_batch(c, part.data(), (int)part.size(), run_icp, max_corr_dist, max_iterations, eps, want_score, score_max_distance);
+      for (size_t k = 0; k < part.size(); ++k) jobs[where[k]] = part[k];
+    }
+    return;
+  }
+  size_t part_total = 0;
+  unsigned grid_x = 0;
+  double icp_bytes = 0.0, score_bytes = 0.0;
+  std::vector<unsigned> nb(B);
+  for (int b = 0; b < B; ++b) {
+    nb[b] = split ? (unsigned)live[b].n_items : div_up(live[b].n_items, 4);
+    part_total += (size_t)nb[b] * kAcc;
+    grid_x = std::max(grid_x, nb[b]);
+    icp_bytes += live[b].ns * 12.0;
+    score_bytes += live[b].ns * 12.0 + (live[b].sg ? live[b].sg->n * 12.0 : 0.0);
+  }
+  DevBuf<double> partials(c, part_total), s_partials(c, want_score ? part_total : 1);
+  DevBuf<double> out(c, (size_t)2 * B);
+  DevBuf<IcpState> st(c, B);
+  DevBuf<NnJob> d_jobs(c, (size_t)2 * B);                 // [0, B): ICP, [B, 2B): score
+
+  // host images, in the pinned arena: states | ICP jobs | score jobs | scores back
+  const size_t st_bytes = sizeof(IcpState) * B, job_bytes = sizeof(NnJob) * 2 * B, out_bytes = 16 * (size_t)B;
+  char *pinned = (char *)c->pin(st_bytes + job_bytes + out_bytes + 64);
   IcpState *hp = (IcpState *)pinned;
-  double *ho = (double *)(pinned + 512);
-  IcpState h;
-  memset(&h, 0, sizeof(h));
-  if (!guess_dev) memcpy(h.T, guess_host, sizeof(h.T));
-  h.prev_mse = DBL_MAX;
-  h.rot_thresh = 1.0 - eps;
-  h.trans_thresh = eps;
-  h.max_iter = max_iterations;
-  h.done = run_icp ? 0 : 1;
-  *hp = h;
-  DevBuf<IcpState> st(c, 1);
-  MM3D_HIP(hipMemcpyAsync(st.get(), hp, sizeof(IcpState), hipMemcpyHostToDevice, c->stream));
-  if (guess_dev) MM3D_HIP(hipMemcpyAsync(st.get(), guess_dev, 64, hipMemcpyDeviceToDevice, c->stream));
-  const int n_items = src->n_wave_items;
-  const bool split = nn_split_items(n_items);
-  const unsigned nblocks = split ? (unsigned)n_items : div_up(n_items, 4);
-  DevBuf<double> partials(c, (size_t)nblocks * kAcc), s_partials(c, want_score ? (size_t)nblocks * kAcc : 1);
-  DevBuf<double> out(c, 2);
-  // iterations launched between two looks at the `done` flag: with the reference's loose epsilon 90 % of
+  NnJob *hj = (NnJob *)(pinned + ((st_bytes + 15) & ~(size_t)15));
+  double *ho = (double *)((char *)hj + job_bytes);
+  size_t off = 0;
+  for (int b = 0; b < B; ++b) {
+    const Live &L = live[b];
+    const IcpScoreJob &J = jobs[L.job];
+    IcpState h;
+    memset(&h, 0, sizeof(h));
+    if (!J.guess_dev) memcpy(h.T, J.guess_host, sizeof(h.T));
+    h.prev_mse = DBL_MAX;
+    h.rot_thresh = 1.0 - eps;
+    h.trans_thresh = eps;
+    h.max_iter = max_iterations;
+    h.done = run_icp ? 0 : 1;
+    hp[b] = h;
+    NnJob q;
+    memset(&q, 0, sizeof(q));
+    q.src = L.sp;
+    q.items = (const int2 *)J.src->wave_items.get();
+    q.n_items = L.n_items;
+    q.nblocks = (int)nb[b];
+    q.tgt_ref = (const float4 *)J.tgt->pts.get();
+    q.st = st.get() + b;
+    q.Tc = nullptr;
+    q.out = out.get() + 2 * b;
+    if (L.tg) { q.g = L.tg->view(); q.max_ring = L.max_ring; }
+    q.partials = partials.get() + off;
+    hj[b] = q;
+    if (L.sg) { q.g = L.sg->view(); q.max_ring = L.s_ring; }
+    q.partials = s_partials.get() + (want_score ? off : 0);
+    hj[B + b] = q;
+    off += (size_t)nb[b] * kAcc;
+  }
+  MM3D_HIP(hipMemcpyAsync(st.get(), hp, st_bytes, hipMemcpyHostToDevice, c->stream));
+  MM3D_HIP(hipMemcpyAsync(d_jobs.get(), hj, job_bytes, hipMemcpyHostToDevice, c->stream));
+  for (int b = 0; b < B; ++b)
+    if (jobs[live[b].job].guess_dev)
+      MM3D_HIP(hipMemcpyAsync(st.get() + b, jobs[live[b].job].guess_dev, 64, hipMemcpyDeviceToDevice, c->stream));
+  // iterations launched between two looks at the `done` flags: with the reference's loose epsilon 90 % of
   // the pairs converge in one iteration and 98 % in two (launches after `done` are no-ops)
   const int chunk = 2;
   for (;;) {
     if (run_icp) {
-      const GridView gv = tg->view();
       for (int k = 0; k < chunk; ++k) {
-        if (split)
-          MM3D_LAUNCH(c, "icp_corr_reduce", ns * 12.0, (k_nn_wave<0, 4>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items,
-                      gv, (const float4 *)tgt->pts.get(), (const IcpState *)st.get(), (const float *)nullptr, max_d2, rmax, max_ring, partials.get());
-        else
-          MM3D_LAUNCH(c, "icp_corr_reduce", ns * 12.0, (k_nn_wave<0, 1>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items,
-                      gv, (const float4 *)tgt->pts.get(), (const IcpState *)st.get(), (const float *)nullptr, max_d2, rmax, max_ring, partials.get());
-        MM3D_LAUNCH(c, "icp_finalize", nblocks * kAcc * 8.0, k_icp_finalize, dim3(1), dim3(256), 0, (const double *)partials.get(),
-                    (int)nblocks, st.get());
+        launch_nn<0>(c, "icp_corr_reduce", icp_bytes, d_jobs.get(), B, grid_x, split, max_d2, rmax);
+        MM3D_LAUNCH(c, "icp_finalize", part_total * 8.0, k_icp_finalize, dim3(B), dim3(256), 0, (const NnJob *)d_jobs.get());
       }
     }
     if (want_score) {
-      if (split)
-        MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + sg->n * 12.0, (k_nn_wave<1, 4>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(),
-                    n_items, sg->view(), (const float4 *)tgt->pts.get(), (const IcpState *)nullptr, (const float *)st.get(), s_max_d2, s_rmax, s_ring,
-                    s_partials.get());
-      else
-        MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + sg->n * 12.0, (k_nn_wave<1, 1>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(),
-                    n_items, sg->view(), (const float4 *)tgt->pts.get(), (const IcpState *)nullptr, (const float *)st.get(), s_max_d2, s_rmax, s_ring,
-                    s_partials.get());
-      MM3D_LAUNCH(c, "score_finalize", 0, k_score_finalize, dim3(1), dim3(256), 0, (const double *)s_partials.get(), (int)nblocks, out.get());
-      MM3D_HIP(hipMemcpyAsync(ho, out.get(), 16, hipMemcpyDeviceToHost, c->stream));
+      launch_nn<1>(c, "score_nn_reduce", score_bytes, d_jobs.get() + B, B, grid_x, split, s_max_d2, s_rmax);
+      MM3D_LAUNCH(c, "score_finalize", 0, k_score_finalize, dim3(B), dim3(256), 0, (const NnJob *)(d_jobs.get() + B));
+      MM3D_HIP(hipMemcpyAsync(ho, out.get(), out_bytes, hipMemcpyDeviceToHost, c->stream));
     }
-    MM3D_HIP(hipMemcpyAsync(hp, st.get(), sizeof(IcpState), hipMemcpyDeviceToHost, c->stream));
+    MM3D_HIP(hipMemcpyAsync(hp, st.get(), st_bytes, hipMemcpyDeviceToHost, c->stream));
     c->sync();
-    if (hp->done) break;
+    bool all_done = true;
+    for (int b = 0; b < B; ++b) {
+      IcpScoreJob &J = jobs[live[b].job];
+      if (hp[b].done && !J.closed) {
+        // first chunk after which this pair is finished: its state and score are final
+        memcpy(J.out.T, hp[b].T, sizeof(J.out.T));
+        J.out.iterations = hp[b].iters;
+        J.out.converged = hp[b].converged;
+        J.out.n_corr = hp[b].n_corr;
+        if (want_score) J.out.score = ho[2 * b + 1] > 0.0 ? ho[2 * b] / ho[2 * b + 1] : DBL_MAX;
+        J.closed = true;
+      }
+      if (!hp[b].done) all_done = false;
+    }
+    if (all_done) break;
   }
-  memcpy(res.T, hp->T, sizeof(res.T));
-  res.iterations = hp->iters;
-  res.converged = hp->converged;
-  res.n_corr = hp->n_corr;
-  if (want_score) res.score = ho[1] > 0.0 ? ho[0] / ho[1] : DBL_MAX;
-  c->last_icp_iterations = res.iterations;
-  c->last_icp_converged = res.converged;
-  return res;
+  const IcpScoreJob &last = jobs[live[B - 1].job];
+  c->last_icp_iterations = last.out.iterations;
+  c->last_icp_converged = last.out.converged;
+}
+
+PairTail icp_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float *guess_dev, const float guess_host[16],
+                   bool run_icp, double max_corr_dist, int max_iterations, double eps, bool want_score, double score_max_distance)
+{
+  IcpScoreJob J;
+  J.src = src; J.tgt = tgt; J.guess_dev = guess_dev;
+  if (guess_host) memcpy(J.guess_host, guess_host, sizeof(J.guess_host));
+  icp_score_batch(c, &J, 1, run_icp, max_corr_dist, max_iterations, eps, want_score, score_max_distance);
+  return J.out;
 }
 
 IcpResult icp(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt, const float guess[16],
@@ -606,17 +719,29 @@ double transform_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt,
   DevBuf<double> partials(c, (size_t)nblocks * kAcc);
   DevBuf<float> dT(c, 16);
   DevBuf<double> out(c, 2);
-  float *hT = (float *)c->pin(256);
+  DevBuf<NnJob> d_job(c, 1);
+  char *pinned = (char *)c->pin(512 + sizeof(NnJob));
+  float *hT = (float *)pinned;
+  double *ho = (double *)(pinned + 128);
+  NnJob *hj = (NnJob *)(pinned + 256);
   memcpy(hT, T, 64);
+  NnJob q;
+  memset(&q, 0, sizeof(q));
+  q.src = sp;
+  q.items = (const int2 *)src->wave_items.get();
+  q.n_items = n_items;
+  q.nblocks = (int)nblocks;
+  q.g = tg.view();
+  q.tgt_ref = (const float4 *)tgt->pts.get();
+  q.Tc = dT.get();
+  q.partials = partials.get();
+  q.out = out.get();
+  q.max_ring = max_ring;
+  *hj = q;
   MM3D_HIP(hipMemcpyAsync(dT.get(), hT, 64, hipMemcpyHostToDevice, c->stream));
-  if (split)
-    MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + tg.n * 12.0, (k_nn_wave<1, 4>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items,
-                tg.view(), (const float4 *)tgt->pts.get(), (const IcpState *)nullptr, (const float *)dT.get(), max_d2, rmax, max_ring, partials.get());
-  else
-    MM3D_LAUNCH(c, "score_nn_reduce", ns * 12.0 + tg.n * 12.0, (k_nn_wave<1, 1>), dim3(nblocks), dim3(256), 0, sp, (const int2 *)src->wave_items.get(), n_items,
-                tg.view(), (const float4 *)tgt->pts.get(), (const IcpState *)nullptr, (const float *)dT.get(), max_d2, rmax, max_ring, partials.get());
-  MM3D_LAUNCH(c, "score_finalize", 0, k_score_finalize, dim3(1), dim3(256), 0, (const double *)partials.get(), (int)nblocks, out.get());
-  double *ho = (double *)((char *)c->pin(256) + 128);
+  MM3D_HIP(hipMemcpyAsync(d_job.get(), hj, sizeof(NnJob), hipMemcpyHostToDevice, c->stream));
+  launch_nn<1>(c, "score_nn_reduce", ns * 12.0 + tg.n * 12.0, d_job.get(), 1, nblocks, split, max_d2, rmax);
+  MM3D_LAUNCH(c, "score_finalize", 0, k_score_finalize, dim3(1), dim3(256), 0, (const NnJob *)d_job.get());
   MM3D_HIP(hipMemcpyAsync(ho, out.get(), 16, hipMemcpyDeviceToHost, c->stream));
   c->sync();
   return ho[1] > 0.0 ? ho[0] / ho[1] : DBL_MAX;

@@ -56,9 +56,26 @@ void ransac_count(Context *c, const float4 *src_kp, const float4 *tgt_kp, const 
 // host+device source the CPU side uses (linalg_shared.hpp), so T is bit-identical to a host build.
 // corr_ref[e] indexes the k-NN table of the sampled rows (row * k + the replayed random pick), so the
 // correspondence itself never travels to the host.
-__global__ void k_sacia_models(const float4 *__restrict__ skp, const float4 *__restrict__ tkp, const int *__restrict__ samp,
-                               const int *__restrict__ corr_ref, const int *__restrict__ nn, int H, float *__restrict__ T_all)
+// One pair's SAC-IA scoring inside a batched launch (blockIdx.y / .z picks the pair): thousands of small pairs
+// would otherwise cost four latency-bound launches each.
+struct SacJob {
+  const float4 *skp, *tkp;       // keypoints in reference order (the models' samples)
+  const int *samp, *corr_ref, *nn;
+  float *T_all;                  // [H][16]
+  const float4 *skp_q;           // the queries of the error kernel (any order; .w = keypoint index when `permuted`)
+  int permuted, ns, ns_pad;
+  GridView g;                    // target keypoint grid with merged 3x3x3 lists
+  float *E;                      // [H][ns_pad]
+  float *err;                    // [H]
+  float *T_best;                 // [16]
+};
+
+__global__ void k_sacia_models(const SacJob *__restrict__ jobs, int H)
 {
+  const SacJob &J = jobs[blockIdx.y];
+  const float4 *__restrict__ skp = J.skp, *__restrict__ tkp = J.tkp;
+  const int *__restrict__ samp = J.samp, *__restrict__ corr_ref = J.corr_ref, *__restrict__ nn = J.nn;
+  float *__restrict__ T_all = J.T_all;
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
   float s[9], d[9], T[16];
@@ -73,20 +90,18 @@ __global__ void k_sacia_models(const float4 *__restrict__ skp, const float4 *__r
   for (int i = 0; i < 16; ++i) T_all[(size_t)h * 16 + i] = T[i];
 }
 
-void sacia_models(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const int *samp, const int *corr_ref,
-                  const int *nn, int H, float *T_all)
-{
-  MM3D_LAUNCH(c, "sacia_models", H * 88.0, k_sacia_models, dim3(div_up(H, 64)), dim3(64), 0, (const float4 *)src_kp->pts.get(),
-              (const float4 *)tgt_kp->pts.get(), samp, corr_ref, nn, H, T_all);
-}
-
 // ---------------------------------------------------------------- SAC-IA hypothesis scoring
 // E[h][i] = TruncatedError(d2 of (T_h * src_i) to its nearest target keypoint); rows padded to a
 // multiple of 4 floats so the summation kernel can stream them with 16-byte loads.
 __global__ void __launch_bounds__(256)
-k_sacia_err(const float4 *__restrict__ skp /* any order; .w = the keypoint's index when `permuted` */, int permuted, int ns, int ns_pad,
-            GridView g, const float *__restrict__ T_all, int H, float thresh, float radius, float *__restrict__ E)
+k_sacia_err(const SacJob *__restrict__ jobs, int H, float thresh, float radius)
 {
+  const SacJob &J = jobs[blockIdx.z];
+  const float4 *__restrict__ skp = J.skp_q;
+  const int permuted = J.permuted, ns = J.ns, ns_pad = J.ns_pad;
+  const GridView g = J.g;
+  const float *__restrict__ T_all = J.T_all;
+  float *__restrict__ E = J.E;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ns) return;
   const int h = blockIdx.y;                           // uniform: the model sits in scalar registers
@@ -138,8 +153,11 @@ k_sacia_err(const float4 *__restrict__ skp /* any order; .w = the keypoint's ind
 constexpr int kSumRows = 8;
 constexpr int kSumTile = 1024;
 constexpr int kSumPad = 36;
-__global__ void __launch_bounds__(256) k_seq_sum(const float *__restrict__ E, int ns, int ns_pad, int H, float *__restrict__ err)
+__global__ void __launch_bounds__(256) k_seq_sum(const SacJob *__restrict__ jobs, int H)
 {
+  const float *__restrict__ E = jobs[blockIdx.y].E;
+  const int ns = jobs[blockIdx.y].ns, ns_pad = jobs[blockIdx.y].ns_pad;
+  float *__restrict__ err = jobs[blockIdx.y].err;
   // row stride = tile + 36 floats: lane r's 16-byte reads land on banks 36 r mod 64 (all distinct), and
   // the zeroed tail lets the chain prefetch two groups past the end without a branch
   __shared__ __attribute__((aligned(16))) float buf[2][kSumRows][kSumTile + kSumPad];
@@ -221,29 +239,66 @@ void prepare_sacia_target(Context *c, const mm3d_cloud *kp, float corr_thresh)
   }
 }
 
-void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const float *T_all, int H,
-                  float corr_thresh, float *errors)
+__global__ void k_sacia_pick(const SacJob *__restrict__ jobs, int H);
+
+// Models, errors, error sums and the pick for a batch of pairs: four launches whatever the batch size.
+// pairs[i].samp / corr_ref / nn and .T_best (16 floats) are device memory of the caller's; T_all, E and err are
+// scratch of this call (pool buffers of this context: whoever gets them next is enqueued behind these kernels).
+void sacia_score_batch(Context *c, const SacPair *pairs, int n, int H, float corr_thresh)
 {
-  const int ns = (int)src_kp->n;
-  const int ns_pad = (ns + 3) & ~3;
+  if (n == 0 || H == 0) return;
   const float radius = std::sqrt(corr_thresh > 0.f ? corr_thresh : 0.f);
-  const Grid &g = sacia_target_grid(c, tgt_kp, corr_thresh);
-  DevBuf<float> E(c, (size_t)ns_pad * H);
-  const size_t total = (size_t)ns * H;
-  cloud_hilbert(c, src_kp);                    // cached on the cloud (prepare_sacia_target)
-  const bool permuted = src_kp->hil_pts.get() && src_kp->n_finite == src_kp->n;
-  MM3D_LAUNCH(c, "sacia_err", total * 4.0 + ns * 16.0, k_sacia_err, dim3(div_up(ns, 256), H), dim3(256), 0,
-              permuted ? (const float4 *)src_kp->hil_pts.get() : (const float4 *)src_kp->pts.get(), permuted ? 1 : 0, ns, ns_pad, g.view(), T_all,
-              H, corr_thresh, radius, E.get());
-  MM3D_LAUNCH(c, "sacia_seq_sum", total * 4.0, k_seq_sum, dim3(div_up(H, kSumRows)), dim3(256), 0, (const float *)E.get(), ns,
-              ns_pad, H, errors);
+  std::vector<DevBuf<float>> bufs;
+  bufs.reserve((size_t)n * 3);
+  SacJob *hj = (SacJob *)c->pin(sizeof(SacJob) * (size_t)n);
+  int max_ns = 0;
+  double err_bytes = 0.0, sum_bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const SacPair &P = pairs[i];
+    const int ns = (int)P.src_kp->n;
+    const int ns_pad = (ns + 3) & ~3;
+    const Grid &g = sacia_target_grid(c, P.tgt_kp, corr_thresh);
+    cloud_hilbert(c, P.src_kp);                    // cached on the cloud (prepare_sacia_target)
+    const bool permuted = P.src_kp->hil_pts.get() && P.src_kp->n_finite == P.src_kp->n;
+    bufs.emplace_back(c, (size_t)H * 16);
+    float *T_all = bufs.back().get();
+    bufs.emplace_back(c, (size_t)ns_pad * H);
+    float *E = bufs.back().get();
+    bufs.emplace_back(c, (size_t)H);
+    float *err = bufs.back().get();
+    SacJob q;
+    std::memset(&q, 0, sizeof(q));
+    q.skp = (const float4 *)P.src_kp->pts.get();
+    q.tkp = (const float4 *)P.tgt_kp->pts.get();
+    q.samp = P.samp; q.corr_ref = P.corr_ref; q.nn = P.nn;
+    q.T_all = T_all;
+    q.skp_q = permuted ? (const float4 *)P.src_kp->hil_pts.get() : (const float4 *)P.src_kp->pts.get();
+    q.permuted = permuted ? 1 : 0;
+    q.ns = ns; q.ns_pad = ns_pad;
+    q.g = g.view();
+    q.E = E; q.err = err; q.T_best = P.T_best;
+    hj[i] = q;
+    max_ns = std::max(max_ns, ns);
+    err_bytes += (double)ns * H * 4.0 + ns * 16.0;
+    sum_bytes += (double)ns * H * 4.0;
+  }
+  DevBuf<SacJob> d_jobs(c, (size_t)n);
+  MM3D_HIP(hipMemcpyAsync(d_jobs.get(), hj, sizeof(SacJob) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  const SacJob *dj = d_jobs.get();
+  MM3D_LAUNCH(c, "sacia_models", n * H * 88.0, k_sacia_models, dim3(div_up(H, 64), n), dim3(64), 0, dj, H);
+  MM3D_LAUNCH(c, "sacia_err", err_bytes, k_sacia_err, dim3(div_up(max_ns, 256), H, n), dim3(256), 0, dj, H, corr_thresh, radius);
+  MM3D_LAUNCH(c, "sacia_seq_sum", sum_bytes, k_seq_sum, dim3(div_up(H, kSumRows), n), dim3(256), 0, dj, H);
+  // "if (i_iter == 0 || error < lowest_error)": the first minimum, picked on the device
+  MM3D_LAUNCH(c, "sacia_pick", n * (H * 4.0 + 128.0), k_sacia_pick, dim3(n), dim3(64), 0, dj, H);
 }
 
 // "if (i == 0 || error < lowest_error) keep": the first minimum, by one wave.  A NaN never wins a
 // '<', and a NaN at i == 0 is never beaten.
-__global__ void __launch_bounds__(64) k_sacia_pick(const float *__restrict__ err, int H, const float *__restrict__ T_all,
-                                                   float *__restrict__ T_best)
+__global__ void __launch_bounds__(64) k_sacia_pick(const SacJob *__restrict__ jobs, int H)
 {
+  const float *__restrict__ err = jobs[blockIdx.x].err;
+  const float *__restrict__ T_all = jobs[blockIdx.x].T_all;
+  float *__restrict__ T_best = jobs[blockIdx.x].T_best;
   const int lane = threadIdx.x;
   const float e0 = err[0];
   unsigned long long best = ~0ull;
@@ -266,9 +321,5 @@ __global__ void __launch_bounds__(64) k_sacia_pick(const float *__restrict__ err
   if (lane < 16) T_best[lane] = T_all[(size_t)h * 16 + lane];
 }
 
-void sacia_pick(Context *c, const float *errors, int H, const float *T_all, float *T_best)
-{
-  MM3D_LAUNCH(c, "sacia_pick", H * 4.0 + 128.0, k_sacia_pick, dim3(1), dim3(64), 0, errors, H, T_all, T_best);
-}
 
 }  // namespace mm3d

@@ -199,6 +199,16 @@ void desc_knn_rows(Context *c, const mm3d_desc *A, const int *rows_dev, int n_ro
 // registration.hip
 struct IcpResult { float T[16]; int iterations; int converged; };
 struct PairTail { float T[16]; int iterations; int converged; int n_corr; double score; };
+// one pair of a batch of ICP + score tails (icp_score_batch): inputs, then the result
+struct IcpScoreJob {
+  const mm3d_cloud *src = nullptr, *tgt = nullptr;
+  const float *guess_dev = nullptr;     // the guess on the device, or
+  float guess_host[16] = {0};           // on the host
+  PairTail out{};
+  bool closed = false;
+};
+void icp_score_batch(Context *c, IcpScoreJob *jobs, int n_jobs, bool run_icp, double max_corr_dist, int max_iterations, double eps,
+                     bool want_score, double score_max_distance);
 struct PairCounts { int n_correspondences = 0, n_inliers = 0, icp_correspondences = 0; };
 // ICP (optional) from a guess on the device (guess_dev != null) or on the host, then transformScore
 // (optional) of the result, with one host synchronisation
@@ -213,16 +223,19 @@ double transform_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt,
 void ransac_count(Context *c, const float4 *src_kp, const float4 *tgt_kp, const int *idx_src,
                   const int *idx_tgt, int n_corr, const float *T_all /* H*16 device */, int H,
                   double thr2, int *counts /* device H */);
-void sacia_models(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const int *samp /* H*3 dev */,
-                  const int *corr_ref /* H*3 dev: index into nn */, const int *nn /* dev k-NN table */, int H,
-                  float *T_all /* H*16 dev */);
-void sacia_errors(Context *c, const mm3d_cloud *src_kp, const mm3d_cloud *tgt_kp, const float *T_all /* H*16 dev */,
-                  int H, float corr_thresh, float *errors /* device H */);   // asynchronous
+// SAC-IA scoring of a batch of pairs (models from the replayed samples, truncated errors, their ordered sums, the
+// first minimum): everything is device memory of the caller's, asynchronous
+struct SacPair {
+  const mm3d_cloud *src_kp, *tgt_kp;
+  const int *samp;        // H*3: sampled source keypoints
+  const int *corr_ref;    // H*3: index into nn
+  const int *nn;          // k-NN table of the sampled rows
+  float *T_best;          // out: the winning model, 16 floats
+};
+void sacia_score_batch(Context *c, const SacPair *pairs, int n, int H, float corr_thresh);
 // build (and cache on the clouds) every search structure pair estimates with these parameters read
 void prepare_pair_search(Context *c, const mm3d_cloud *points, double max_corr_dist, double score_max_distance);
 void prepare_sacia_target(Context *c, const mm3d_cloud *kp, float corr_thresh);
-// first minimum of errors[0..H) -> its model copied to T_best (16 floats, device)
-void sacia_pick(Context *c, const float *errors /* dev */, int H, const float *T_all /* dev */, float *T_best /* dev */);
 
 // host_pipeline.cpp
 size_t find_correspondences(Context *c, const mm3d_desc *s, const mm3d_desc *t, size_t k, std::vector<mm3d_corr> &out);
@@ -238,6 +251,25 @@ void sac_ia_draws(GlibcRand &rnd, const std::vector<float4> &skp, int ns, float 
 // advances rnd by the rand() draws one estimateTransform(source -> any non-empty target) consumes (host only)
 void pair_rand_replay(GlibcRand &rnd, int method, const std::vector<float4> &skp_host, double inlier_threshold, int max_iterations);
 // estimateTransform + (optionally) transformScore of the result; returns the ICP iteration count
+// estimateTransform up to its initial estimate (correspondences + RANSAC, or SAC-IA): T0 on the host, or dT0 on the device
+struct PairFront {
+  float T0[16];
+  DevBuf<float> dT0;
+  bool on_device = false;
+  PairCounts counts;
+  // SAC-IA between its two halves (sac_ia_prepare / sac_ia_finish): the replayed samples and the k-NN table
+  DevBuf<int> sac_idx, sac_nn;
+  DevBuf<float> sac_nd;
+  int sac_h = 0;             // hypotheses to score; 0: nothing to do (too few keypoints, or not executed)
+};
+// SAC-IA in two halves, so that the scoring of several pairs can share its launches: prepare = the rand() replay,
+// the uploads and the descriptor k-NN of the sampled rows; finish = sacia_score_batch over the prepared pairs
+void sac_ia_prepare(Context *c, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tkp, const mm3d_desc *td,
+                    double min_sample_distance, double max_corr_dist, int max_iterations, bool execute, PairFront &f);
+struct SacPrepared { const mm3d_cloud *skp, *tkp; PairFront *front; };
+void sac_ia_finish(Context *c, SacPrepared *pairs, int n, double max_corr_dist);
+void estimate_pair_front(Context *c, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tkp, const mm3d_desc *td, int method,
+                         double inlier_threshold, double max_corr_dist, int max_iterations, size_t matching_k, bool execute, PairFront &f);
 int estimate_pair(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tp,
                   const mm3d_cloud *tkp, const mm3d_desc *td, int method, int refine, double inlier_threshold,
                   double max_corr_dist, int max_iterations, size_t matching_k, double eps, float T[16], bool execute,
