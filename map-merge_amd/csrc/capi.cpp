@@ -630,16 +630,30 @@ static void pairs_estimate_batch(mm3d_ctx *ctx, PairWork *w, size_t n, const mm3
     ctx->rnd = w[i].rnd;
     if (p->estimation_method == MM3D_EST_SAC_IA) {
       // argument mapping of matching.cpp:243-246: min_sample_distance := inlier_threshold
-      sac_ia_prepare(ctx, w[i].s->keypoints, w[i].s->desc, w[i].t->keypoints, w[i].t->desc, p->inlier_threshold,
-                     p->max_correspondence_distance, p->max_iterations, true, fronts[i]);
-      prepared.push_back(SacPrepared{w[i].s->keypoints, w[i].t->keypoints, &fronts[i]});
+      sac_ia_replay(ctx, w[i].s->keypoints, w[i].s->desc, w[i].t->keypoints, w[i].t->desc, p->inlier_threshold, p->max_iterations, true,
+                    fronts[i]);
+      prepared.push_back(SacPrepared{w[i].s->keypoints, w[i].t->keypoints, w[i].s->desc, w[i].t->desc, &fronts[i]});
     } else {
       estimate_pair_front(ctx, w[i].s->keypoints, w[i].s->desc, w[i].t->keypoints, w[i].t->desc, p->estimation_method,
                           p->inlier_threshold, p->max_correspondence_distance, p->max_iterations, (size_t)p->matching_k, true, fronts[i]);
     }
   }
-  // the hypotheses of every SAC-IA pair of the batch are scored by the same four launches
-  if (!prepared.empty()) sac_ia_finish(ctx, prepared.data(), (int)prepared.size(), p->max_correspondence_distance);
+  if (!prepared.empty()) {
+    // the sampled rows of every pair with the same target go through one descriptor search, and the hypotheses of
+    // all the batch's pairs are scored by the same four launches
+    std::stable_sort(prepared.begin(), prepared.end(), [](const SacPrepared &a, const SacPrepared &b) { return a.td < b.td; });
+    std::vector<DevBuf<int>> nn_owners;
+    std::vector<DevBuf<float>> nd_owners;
+    for (size_t a = 0; a < prepared.size();) {
+      size_t b = a;
+      while (b < prepared.size() && prepared[b].td == prepared[a].td) ++b;
+      nn_owners.emplace_back();
+      nd_owners.emplace_back();
+      sac_ia_knn(ctx, &prepared[a], (int)(b - a), nn_owners.back(), nd_owners.back());
+      a = b;
+    }
+    sac_ia_finish(ctx, prepared.data(), (int)prepared.size(), p->max_correspondence_distance);
+  }
   for (size_t i = 0; i < n; ++i) {
     jobs[i].src = w[i].s->points;
     jobs[i].tgt = w[i].t->points;
@@ -797,9 +811,16 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
       }
       if (!any_left) return false;
       if (avail) {
+        // a batch shares its TARGET (the pairs (i, t) of one t): one descriptor search for the sampled rows of all
+        // its sources, and one target grid under every search of the batch
         const size_t take = std::min(kPairBatch, std::max<size_t>(1, avail / (2 * S)));
+        size_t target = n;
         for (size_t q = 0; q < P && out.size() < take; ++q)
-          if (!claimed[q] && all[q].first < prefix && ready[all[q].second]) { claimed[q] = 1; out.push_back(q); }
+          if (!claimed[q] && all[q].first < prefix && ready[all[q].second] && (target == n || all[q].second == target)) {
+            target = all[q].second;
+            claimed[q] = 1;
+            out.push_back(q);
+          }
         return true;
       }
       cv.wait(lk);

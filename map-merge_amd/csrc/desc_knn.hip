@@ -1131,4 +1131,30 @@ void desc_knn_rows(Context *c, const mm3d_desc *A, const int *rows_dev, int n_ro
   desc_knn(c, &sub, B, k, idx, d2);
 }
 
+// The same for rows taken from several descriptor sets (the sampled rows of several sources against ONE target):
+// one query matrix, one search; source i's rows start at the sum of the earlier sources' row counts.
+void desc_knn_rows_multi(Context *c, const KnnRows *srcs, int n_srcs, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2)
+{
+  MM3D_REQUIRE(n_srcs > 0, "desc_knn_rows_multi: no sources");
+  mm3d_desc sub;
+  sub.dim = srcs[0].A->dim;
+  sub.type = srcs[0].A->type;
+  size_t total = 0;
+  for (int i = 0; i < n_srcs; ++i) {
+    MM3D_REQUIRE(srcs[i].A->dim == sub.dim, "desc_knn_rows_multi: descriptor sizes differ");
+    total += (size_t)srcs[i].n_rows;
+  }
+  sub.n = total;
+  sub.data = DevBuf<float>(c, total * sub.dim);
+  size_t off = 0;
+  for (int i = 0; i < n_srcs; ++i) {
+    const int n_rows = srcs[i].n_rows;
+    if (n_rows > 0)
+      MM3D_LAUNCH(c, "desc_knn_prep", n_rows * sub.dim * 8.0, k_gather_desc_rows, dim3(div_up((size_t)n_rows * sub.dim, 256)), dim3(256), 0,
+                  (const float *)srcs[i].A->data.get(), srcs[i].rows_dev, n_rows, sub.dim, sub.data.get() + off * sub.dim);
+    off += (size_t)n_rows;
+  }
+  desc_knn(c, &sub, B, k, idx, d2);
+}
+
 }  // namespace mm3d

@@ -282,13 +282,15 @@ void pair_rand_replay(GlibcRand &rnd, int method, const std::vector<float4> &skp
   sac_ia_draws(rnd, skp_host, ns, (float)inlier_threshold, max_iterations > 0 ? max_iterations : 0, 10, nullptr, nullptr);
 }
 
-void sac_ia_prepare(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_cloud *tkp_, const mm3d_desc *td,
-                    double min_sample_distance_d, double max_corr_dist, int max_iterations, bool execute, PairFront &f)
+void sac_ia_replay(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_cloud *tkp_, const mm3d_desc *td,
+                   double min_sample_distance_d, int max_iterations, bool execute, PairFront &f)
 {
   std::memset(f.T0, 0, sizeof(f.T0));
   f.T0[0] = f.T0[5] = f.T0[10] = f.T0[15] = 1.0f;   // final_transformation_ = guess = Identity
   f.on_device = false;
   f.sac_h = 0;
+  f.sac_rows = 0;
+  f.sac_nn_ptr = nullptr;
   const int ns = (int)skp_->n, nt = (int)tkp_->n;
   const int nr_samples = 3, k_corr = 10;
   if (ns < nr_samples || nt < 1) return;
@@ -320,9 +322,30 @@ void sac_ia_prepare(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, con
   std::memcpy(hp + 2 * n3, rows.data(), nr * sizeof(int));
   f.sac_idx = DevBuf<int>(c, 2 * n3 + nr);
   MM3D_HIP(hipMemcpyAsync(f.sac_idx.get(), hp, (2 * n3 + nr) * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  desc_knn_rows(c, sd, f.sac_idx.get() + 2 * n3, (int)nr, td, k_corr, f.sac_nn, f.sac_nd);
   f.dT0 = DevBuf<float>(c, 16);
+  f.sac_rows = (int)nr;
   f.sac_h = H;
+}
+
+void sac_ia_knn(Context *c, SacPrepared *same_target, int n, DevBuf<int> &nn_owner, DevBuf<float> &nd_owner)
+{
+  const int k_corr = 10;
+  std::vector<KnnRows> srcs;
+  std::vector<int> who;
+  for (int i = 0; i < n; ++i) {
+    PairFront &f = *same_target[i].front;
+    if (f.sac_h == 0) continue;
+    MM3D_REQUIRE(same_target[i].td == same_target[0].td, "sac_ia_knn: the pairs of a group share their target");
+    srcs.push_back(KnnRows{same_target[i].sd, f.sac_idx.get() + 2 * (size_t)f.sac_h * 3, f.sac_rows});
+    who.push_back(i);
+  }
+  if (srcs.empty()) return;
+  desc_knn_rows_multi(c, srcs.data(), (int)srcs.size(), same_target[0].td, k_corr, nn_owner, nd_owner);
+  size_t off = 0;
+  for (size_t j = 0; j < who.size(); ++j) {
+    same_target[who[j]].front->sac_nn_ptr = nn_owner.get() + off * k_corr;
+    off += (size_t)srcs[j].n_rows;
+  }
 }
 
 void sac_ia_finish(Context *c, SacPrepared *pairs, int n, double max_corr_dist)
@@ -335,7 +358,8 @@ void sac_ia_finish(Context *c, SacPrepared *pairs, int n, double max_corr_dist)
     MM3D_REQUIRE(H == 0 || H == f.sac_h, "SAC-IA batch: pairs differ in their iteration count");
     H = f.sac_h;
     const size_t n3 = (size_t)H * 3;
-    jobs.push_back(SacPair{pairs[i].skp, pairs[i].tkp, f.sac_idx.get(), f.sac_idx.get() + n3, f.sac_nn.get(), f.dT0.get()});
+    MM3D_REQUIRE(f.sac_nn_ptr != nullptr, "SAC-IA: the k-NN step has not run");
+    jobs.push_back(SacPair{pairs[i].skp, pairs[i].tkp, f.sac_idx.get(), f.sac_idx.get() + n3, f.sac_nn_ptr, f.dT0.get()});
     f.on_device = true;              // the caller keeps going on the device (ICP reads the winner there)
   }
   sacia_score_batch(c, jobs.data(), (int)jobs.size(), H, (float)max_corr_dist);
@@ -349,10 +373,11 @@ bool sac_ia(Context *c, const mm3d_cloud *skp_, const mm3d_desc *sd, const mm3d_
             DevBuf<float> *T_dev)
 {
   PairFront f;
-  sac_ia_prepare(c, skp_, sd, tkp_, td, min_sample_distance_d, max_corr_dist, max_iterations, execute, f);
+  sac_ia_replay(c, skp_, sd, tkp_, td, min_sample_distance_d, max_iterations, execute, f);
   std::memcpy(T, f.T0, sizeof(f.T0));
   if (f.sac_h == 0) return false;
-  SacPrepared one{skp_, tkp_, &f};
+  SacPrepared one{skp_, tkp_, sd, td, &f};
+  sac_ia_knn(c, &one, 1, f.sac_nn, f.sac_nd);
   sac_ia_finish(c, &one, 1, max_corr_dist);
   if (T_dev) {
     *T_dev = std::move(f.dT0);

@@ -60,6 +60,7 @@ struct NnJob {
   const float4 *src;          // source points in Hilbert order
   const int2 *items;          // their work items
   int n_items, nblocks;       // blocks this job uses of the launch's grid.x
+  int split;                  // 1: one work item per block (partials per item), 0: four items per block
   GridView g;                 // target grid
   const float4 *tgt_ref;      // target points in reference order
   IcpState *st;               // ICP: the pair's state; score: T is read from its head (or from Tc)
@@ -375,12 +376,27 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
 }
 
 // one block: reduce partials, Umeyama, accumulate, convergence (DefaultConvergenceCriteria)
+// Partial sums of "block" b as the four-items-per-block kernel writes them.  The one-item-per-block kernel leaves
+// one partial per item; adding four neighbours here, in the order that kernel's last step does, gives the same
+// bits -- so which variant ran (a choice that depends on what else was ready at the time) never shows in a result.
+__device__ __forceinline__ double nn_block_partial(const double *__restrict__ p, int b, int k, int split, int n_items)
+{
+  if (!split) return p[(size_t)b * kAcc + k];
+  const int i = b * 4;
+  double v = p[(size_t)i * kAcc + k];
+  v += (i + 1 < n_items) ? p[(size_t)(i + 1) * kAcc + k] : 0.0;
+  v += (i + 2 < n_items) ? p[(size_t)(i + 2) * kAcc + k] : 0.0;
+  v += (i + 3 < n_items) ? p[(size_t)(i + 3) * kAcc + k] : 0.0;
+  return v;
+}
+
 __global__ void __launch_bounds__(256) k_icp_finalize(const NnJob *__restrict__ jobs)
 {
   __shared__ double red[4][kAcc];
   __shared__ double tot[kAcc];
   const double *__restrict__ partials = jobs[blockIdx.x].partials;
-  const int nblocks = jobs[blockIdx.x].nblocks;
+  const int split = jobs[blockIdx.x].split, n_items = jobs[blockIdx.x].n_items;
+  const int nblocks = (n_items + 3) >> 2;              // in units of four items, whichever kernel wrote them
   IcpState *st = jobs[blockIdx.x].st;
   if (st->done) return;
   double acc[kAcc];
@@ -388,7 +404,7 @@ __global__ void __launch_bounds__(256) k_icp_finalize(const NnJob *__restrict__ 
   for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
 #pragma unroll
-    for (int k = 0; k < kAcc; ++k) acc[k] += partials[(size_t)b * kAcc + k];
+    for (int k = 0; k < kAcc; ++k) acc[k] += nn_block_partial(partials, b, k, split, n_items);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < kAcc; ++k) {
@@ -458,14 +474,15 @@ __global__ void __launch_bounds__(256) k_score_finalize(const NnJob *__restrict_
 {
   __shared__ double red[4][2];
   const double *__restrict__ partials = jobs[blockIdx.x].partials;
-  const int nblocks = jobs[blockIdx.x].nblocks;
+  const int split = jobs[blockIdx.x].split, n_items = jobs[blockIdx.x].n_items;
+  const int nblocks = (n_items + 3) >> 2;
   double *out = jobs[blockIdx.x].out;
   IcpState *st = jobs[blockIdx.x].st;
   if (st && (!st->done || st->scored)) return;
   double s = 0.0, n = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-    s += partials[(size_t)b * kAcc + 15];
-    n += partials[(size_t)b * kAcc + 16];
+    s += nn_block_partial(partials, b, 15, split, n_items);
+    n += nn_block_partial(partials, b, 16, split, n_items);
   }
   s = wave_sum(s); n = wave_sum(n);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -566,22 +583,11 @@ void icp_score_batch(Context *c, IcpScoreJob *jobs, int n_jobs, bool run_icp, do
   const int B = (int)live.size();
   if (B == 0) return;
 
-  // one kernel variant per launch: a batch that mixes small and large sources runs as two batches, so a pair's
-  // sums never depend on what it happened to be batched with
-  const bool split = nn_split_items(live[0].n_items);
-  bool mixed = false;
-  for (const Live &L : live) mixed = mixed || nn_split_items(L.n_items) != split;
-  if (mixed) {
-    for (int pass = 0; pass < 2; ++pass) {
-      std::vector<IcpScoreJob> part;
-      std::vector<int> where;
-      for (const Live &L : live)
-        if (nn_split_items(L.n_items) == (pass == 0)) { part.push_back(jobs[L.job]); where.push_back(L.job); }
-      icp_score_batch(c, part.data(), (int)part.size(), run_icp, max_corr_dist, max_iterations, eps, want_score, score_max_distance);
-      for (size_t k = 0; k < part.size(); ++k) jobs[where[k]] = part[k];
-    }
-    return;
-  }
+  // one work item per block while the whole batch has too few items to fill the chip with one wave each
+  // (the finalize kernels add the partials up in one fixed order, so the choice never shows in a result)
+  int total_items = 0;
+  for (const Live &L : live) total_items += L.n_items;
+  const bool split = nn_split_items(total_items);
   size_t part_total = 0;
   unsigned grid_x = 0;
   double icp_bytes = 0.0, score_bytes = 0.0;
@@ -623,6 +629,7 @@ void icp_score_batch(Context *c, IcpScoreJob *jobs, int n_jobs, bool run_icp, do
     q.items = (const int2 *)J.src->wave_items.get();
     q.n_items = L.n_items;
     q.nblocks = (int)nb[b];
+    q.split = split ? 1 : 0;
     q.tgt_ref = (const float4 *)J.tgt->pts.get();
     q.st = st.get() + b;
     q.Tc = nullptr;
@@ -731,6 +738,7 @@ double transform_score(Context *c, const mm3d_cloud *src, const mm3d_cloud *tgt,
   q.items = (const int2 *)src->wave_items.get();
   q.n_items = n_items;
   q.nblocks = (int)nblocks;
+  q.split = split ? 1 : 0;
   q.g = tg.view();
   q.tgt_ref = (const float4 *)tgt->pts.get();
   q.Tc = dT.get();

@@ -193,6 +193,8 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
 // cache the target-side operands of B on the set itself (a no-op for small or already prepared sets)
 void desc_knn_prepare_target(Context *c, const mm3d_desc *B);
 // the same for a subset of A's rows given as a device index list; result row r belongs to rows[r]
+struct KnnRows { const mm3d_desc *A; const int *rows_dev; int n_rows; };
+void desc_knn_rows_multi(Context *c, const KnnRows *srcs, int n_srcs, const mm3d_desc *B, int k, DevBuf<int> &idx, DevBuf<float> &d2);
 void desc_knn_rows(Context *c, const mm3d_desc *A, const int *rows_dev, int n_rows, const mm3d_desc *B, int k,
                    DevBuf<int> &idx, DevBuf<float> &d2);
 
@@ -257,16 +259,21 @@ struct PairFront {
   DevBuf<float> dT0;
   bool on_device = false;
   PairCounts counts;
-  // SAC-IA between its two halves (sac_ia_prepare / sac_ia_finish): the replayed samples and the k-NN table
+  // SAC-IA between its steps (sac_ia_replay / sac_ia_knn / sac_ia_finish): the replayed samples (samp | corr_ref |
+  // rows, device) and the k-NN table of the sampled rows (its own buffer, or a slice of a batch's)
   DevBuf<int> sac_idx, sac_nn;
   DevBuf<float> sac_nd;
+  const int *sac_nn_ptr = nullptr;
+  int sac_rows = 0;          // distinct sampled rows
   int sac_h = 0;             // hypotheses to score; 0: nothing to do (too few keypoints, or not executed)
 };
-// SAC-IA in two halves, so that the scoring of several pairs can share its launches: prepare = the rand() replay,
-// the uploads and the descriptor k-NN of the sampled rows; finish = sacia_score_batch over the prepared pairs
-void sac_ia_prepare(Context *c, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tkp, const mm3d_desc *td,
-                    double min_sample_distance, double max_corr_dist, int max_iterations, bool execute, PairFront &f);
-struct SacPrepared { const mm3d_cloud *skp, *tkp; PairFront *front; };
+// SAC-IA in steps, so that several pairs can share launches: replay = the rand() stream and the upload of the
+// sampled rows; knn = the descriptor k-NN of the sampled rows of every pair with the SAME target (td) as one search;
+// finish = sacia_score_batch over the prepared pairs
+void sac_ia_replay(Context *c, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tkp, const mm3d_desc *td,
+                   double min_sample_distance, int max_iterations, bool execute, PairFront &f);
+struct SacPrepared { const mm3d_cloud *skp, *tkp; const mm3d_desc *sd, *td; PairFront *front; };
+void sac_ia_knn(Context *c, SacPrepared *same_target, int n, DevBuf<int> &nn_owner, DevBuf<float> &nd_owner);
 void sac_ia_finish(Context *c, SacPrepared *pairs, int n, double max_corr_dist);
 void estimate_pair_front(Context *c, const mm3d_cloud *skp, const mm3d_desc *sd, const mm3d_cloud *tkp, const mm3d_desc *td, int method,
                          double inlier_threshold, double max_corr_dist, int max_iterations, size_t matching_k, bool execute, PairFront &f);
