@@ -613,6 +613,8 @@ static void pair_estimate_impl(mm3d_ctx *ctx, const mm3d_map *s, const mm3d_map 
   out->confidence = 1.0 / score;
 }
 
+constexpr size_t kPairBatch = 16;     // pairs whose tails and scoring share launches
+
 // Several pairs on one context: the initial estimates one after the other (each from its own generator state),
 // then every pair's ICP + score tail in lockstep, one launch per step for the whole batch (icp_score_batch).
 struct PairWork { const mm3d_map *s, *t; mm3d_pair_result *out; GlibcRand rnd; };
@@ -795,7 +797,6 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   // its share of what can start right now, up to kPairBatch pairs: their ICP / score tails then run as one batch
   // (many small maps: thousands of pairs are ready at once and a launch per pair leaves the chip idle), while a
   // job whose pairs trickle in behind the feature stage keeps dealing them out one by one.
-  constexpr size_t kPairBatch = 8;
   auto claim_pairs = [&](std::vector<size_t> &out) -> bool {
     out.clear();
     std::unique_lock<std::mutex> lk(mu);
@@ -1140,19 +1141,31 @@ int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *min
       mine[q] = mm3d_shard_map_owner(live[q].second, sh->world) == sh->rank ? 1 : 0;
       if (mine[q]) todo.push_back(q);
     }
+    // batches of pairs with the same target (pairs_estimate_batch), at most kPairBatch of them and not so many that
+    // a stream runs dry: every map exists already, so the whole list can be cut up front
+    const size_t S = ctx->helpers.size() + 1;
+    const size_t take = std::min(kPairBatch, std::max<size_t>(1, todo.size() / (2 * S)));
+    std::stable_sort(todo.begin(), todo.end(), [&](size_t a, size_t b) { return live[a].second < live[b].second; });
+    std::vector<std::pair<size_t, size_t>> batches;           // [first, last) into todo
+    for (size_t a = 0; a < todo.size();) {
+      size_t b = a + 1;
+      while (b < todo.size() && b - a < take && live[todo[b]].second == live[todo[a]].second) ++b;
+      batches.emplace_back(a, b);
+      a = b;
+    }
     std::atomic<size_t> next{0};
     on_streams(ctx, [&](size_t, mm3d_ctx *c) {
+      std::vector<PairWork> work;
       for (;;) {
         const size_t k = next.fetch_add(1);
-        if (k >= todo.size()) break;
-        const size_t q = todo[k];
-        advance_states(q);
-        c->rnd = state_at[q];
-        mm3d_pair_result r;
-        pair_estimate_impl(c, sh->maps[live[q].first], sh->maps[live[q].second], params, true, &r);
-        r.source_idx = live[q].first;
-        r.target_idx = live[q].second;
-        pairs[q] = r;
+        if (k >= batches.size()) break;
+        work.clear();
+        for (size_t e = batches[k].first; e < batches[k].second; ++e) {
+          const size_t q = todo[e];
+          advance_states(q);
+          work.push_back(PairWork{sh->maps[live[q].first], sh->maps[live[q].second], &pairs[q], state_at[q]});
+        }
+        pairs_estimate_batch(c, work.data(), work.size(), params);
       }
     });
     advance_states(P);

@@ -7,7 +7,8 @@ sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import __graft_entry__ as ge
 mm = ge.load()
 import bench, numpy as np
-host = bench.make_workload(16, 500000)
+PTS = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
+host = bench.make_workload(64 if PTS == 50000 else 16, PTS)
 ctx = mm.Context(0)
 P = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
 L = mm.lib()
