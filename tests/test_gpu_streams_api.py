@@ -181,3 +181,32 @@ def test_sharded_driver_equals_the_one_call_path(mm, clouds):
         assert sum(counts) == len(ref)
         T = mm.globalTransforms(merged, params.confidence_threshold, len(order))
         assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(T, T_ref))
+
+
+@pytest.mark.parametrize("method", [1, 0])
+def test_pairs_in_batches_equal_the_sequential_loop(mm, synth, method):
+    """Many small maps on few streams: every worker extracts features first (n >= 2 S) and the pairs then run in
+    batches of up to 16 that share a target -- one descriptor search, one SAC-IA scoring, one ICP / score launch per
+    step for the whole batch.  The one-stream call is the reference's sequential loop (no batches); every pair
+    record and the generator's end state must be the same bits.  One map has no keypoints (too few points), so
+    batches with gaps and the rand() bookkeeping around dead pairs are covered too."""
+    _, maps = synth.synth_maps(12, 9000, overlap_step=0.25)
+    clouds = [synth.pack_points(x, c) for x, c, _ in maps]
+    clouds[5] = clouds[5][:40]                                  # survives the filters with no keypoint at all
+    params = mm.MapMergingParams(descriptor_type=2, estimation_method=method)
+    results = []
+    for n_streams in (1, 2, 5):
+        c = mm.Context(0)
+        try:
+            c.setStreams(n_streams)
+            c.srand(7)
+            T, pairs = c.estimateMapsTransforms(clouds, params, return_pairs=True)
+            T2, pairs2 = c.estimateMapsTransforms(clouds[:3], params, return_pairs=True)
+            results.append((np.stack(T), pairs.copy(), pairs2.copy()))
+        finally:
+            c.close()
+    assert len(results[0][1]) >= 40                             # 55 pairs without the dead map's
+    for T, pairs, pairs2 in results[1:]:
+        assert np.array_equal(pairs.view(np.uint8), results[0][1].view(np.uint8))
+        assert np.array_equal(T.view(np.uint32), results[0][0].view(np.uint32))
+        assert np.array_equal(pairs2.view(np.uint8), results[0][2].view(np.uint8))
