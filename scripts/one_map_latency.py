@@ -26,5 +26,5 @@ for rep in range(3):
 e = ctx.profile_entries()
 tot = sum(v["ms"] for v in e.values()); n = sum(v["launches"] for v in e.values())
 print(f"features {1e3 * (t1 - t0):.2f} ms + prepare {1e3 * (t2 - t1):.2f} ms wall; kernels {tot:.2f} ms in {n} launches")
-for k, v in sorted(e.items(), key=lambda kv: -kv[1]["ms"])[:14]:
+for k, v in sorted(e.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("TOPN", "14"))]:
     print(f"   {k:26s} {v['launches']:4d}  {v['ms']:.3f} ms")
