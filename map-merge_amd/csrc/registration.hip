@@ -94,7 +94,7 @@ __global__ void k_sacia_models(const SacJob *__restrict__ jobs, int H)
 // E[h][i] = TruncatedError(d2 of (T_h * src_i) to its nearest target keypoint); rows padded to a
 // multiple of 4 floats so the summation kernel can stream them with 16-byte loads.
 __global__ void __launch_bounds__(256)
-k_sacia_err(const SacJob *__restrict__ jobs, int H, float thresh, float radius)
+k_sacia_err(const SacJob *__restrict__ jobs, int h_first, float thresh, float radius)
 {
   const SacJob &J = jobs[blockIdx.z];
   const float4 *__restrict__ skp = J.skp_q;
@@ -104,7 +104,7 @@ k_sacia_err(const SacJob *__restrict__ jobs, int H, float thresh, float radius)
   float *__restrict__ E = J.E;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ns) return;
-  const int h = blockIdx.y;                           // uniform: the model sits in scalar registers
+  const int h = h_first + (int)blockIdx.y;            // uniform: the model sits in scalar registers
   const float *T = T_all + (size_t)h * 16;
   float Tl[16];
 #pragma unroll
@@ -286,7 +286,10 @@ void sacia_score_batch(Context *c, const SacPair *pairs, int n, int H, float cor
   MM3D_HIP(hipMemcpyAsync(d_jobs.get(), hj, sizeof(SacJob) * (size_t)n, hipMemcpyHostToDevice, c->stream));
   const SacJob *dj = d_jobs.get();
   MM3D_LAUNCH(c, "sacia_models", n * H * 88.0, k_sacia_models, dim3(div_up(H, 64), n), dim3(64), 0, dj, H);
-  MM3D_LAUNCH(c, "sacia_err", err_bytes, k_sacia_err, dim3(div_up(max_ns, 256), H, n), dim3(256), 0, dj, H, corr_thresh, radius);
+  for (int h0 = 0; h0 < H; h0 += 65535) {               // gridDim.y holds at most 65535 hypotheses
+    const int hn = std::min(65535, H - h0);
+    MM3D_LAUNCH(c, "sacia_err", err_bytes * hn / H, k_sacia_err, dim3(div_up(max_ns, 256), hn, n), dim3(256), 0, dj, h0, corr_thresh, radius);
+  }
   MM3D_LAUNCH(c, "sacia_seq_sum", sum_bytes, k_seq_sum, dim3(div_up(H, kSumRows), n), dim3(256), 0, dj, H);
   // "if (i_iter == 0 || error < lowest_error)": the first minimum, picked on the device
   MM3D_LAUNCH(c, "sacia_pick", n * (H * 4.0 + 128.0), k_sacia_pick, dim3(n), dim3(64), 0, dj, H);

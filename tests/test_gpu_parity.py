@@ -261,6 +261,19 @@ def test_sac_ia_exact(ctx, po, scene):
     assert np.array_equal(T2.view(np.uint32), T_ref2.view(np.uint32))
 
 
+def test_sac_ia_more_hypotheses_than_a_grid_dimension(ctx, po, scene):
+    """max_iterations is any positive int in the reference (matching.cpp:142-194 hands it to setMaximumIterations);
+    70 000 hypotheses do not fit gridDim.y of one launch, so the error kernel runs in slices.  A subset of the
+    keypoints keeps the oracle's 70 000 x K nearest-keypoint lookups to seconds."""
+    a, b = scene
+    ka, da, kb, db = a["kp"][:160], a["desc"][:160], b["kp"][:200], b["desc"][:200]
+    po.srand(3)
+    T_ref, _, _ = po.sac_ia(ka, da, kb, db, 0.5, 1.0, 70000)
+    ctx.srand(3)
+    T = ctx.estimateTransformFromDescriptorsSets(ctx.cloud(ka), ctx.descriptors(da), ctx.cloud(kb), ctx.descriptors(db), 0.5, 1.0, 70000)
+    assert np.array_equal(T.view(np.uint32), T_ref.view(np.uint32))
+
+
 def _small_rot(ax, ay, az, t):
     cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
     Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
