@@ -25,7 +25,7 @@ dev_raw = [torch.from_numpy(h.view(np.uint8).reshape(-1, 16)).to(dev) for h in h
 views = [(dev_raw[i].data_ptr(), len(host[i])) for i in range(n_maps)]
 params = mm.MapMergingParams(descriptor_type=mm.Descriptor.FPFH, estimation_method=mm.EstimationMethod.SAC_IA, refine_transform=1)
 ctx = mm.Context(0)
-ctx.setStreams(16)
+ctx.setStreams(int(os.environ.get("MM3D_STREAMS", "16")))
 
 # every map's bundle once, untimed
 sh = ctx.shardBegin(views, params, 0, 1)
