@@ -22,9 +22,21 @@ int guarded(mm3d_ctx *ctx, F &&f)
 {
   if (!ctx) return MM3D_EINVAL;
   std::lock_guard<std::mutex> lock(ctx->mu);
+  // error flags waiting for the next sync() belong to the call that recorded them: a call that ends with an
+  // exception must not leave them (their pinned words get reused) to the next one, on this context or its helpers
+  struct Clean {
+    mm3d_ctx *c;
+    ~Clean()
+    {
+      c->deferred.clear();
+      c->private_objects = false;
+      for (mm3d_ctx *h : c->helpers) { h->deferred.clear(); h->private_objects = false; }
+    }
+  } clean{ctx};
   try {
     if (hipSetDevice(ctx->device) != hipSuccess) throw Error(MM3D_EDEVICE, "hipSetDevice failed");
     f();
+    if (!ctx->deferred.empty()) ctx->sync();      // nothing recorded by this call is left unchecked
     return MM3D_OK;
   } catch (const Error &e) {
     ctx->err = e.what();
@@ -846,9 +858,14 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
         struct MapFree {
           void operator()(mm3d_map *x) const { delete x->points; delete x->keypoints; delete x->desc; delete x; }
         };
+        // the map is this worker's alone until it is published: no waits for other contexts' sake while it is built
+        // (Context::settle), one full wait -- which also looks at the recorded error flags -- before it is published
+        c->private_objects = true;
         std::unique_ptr<mm3d_map, MapFree> held(map_features_impl(c, raw.get(), params));
         raw.reset();
         map_prepare_impl(c, held.get(), params);
+        c->private_objects = false;
+        c->sync();
         {
           std::lock_guard<std::mutex> lk(mu);
           mm3d_map *m = held.release();
@@ -1001,9 +1018,13 @@ int mm3d_shard_begin(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, con
         std::unique_ptr<mm3d_cloud> raw(cloud_from_memory(c, clouds[i].points, clouds[i].points ? clouds[i].n : 0,
                                                           clouds[i].stride ? clouds[i].stride : 16,
                                                           clouds[i].stride ? clouds[i].rgba_offset : 12));
+        // nobody else sees the map before on_streams has drained every stream: no waits for other contexts' sake
+        c->private_objects = true;
         mm3d_map *m = map_features_impl(c, raw.get(), params);
         sh->maps[i] = m;                         // (distinct slots: no lock needed; the shard owns it from here)
         map_prepare_impl(c, m, params);          // this rank is the map's target-side owner
+        c->private_objects = false;
+        c->sync();                               // also looks at the error flags the kernels left
       }
     });
     *out = sh.release();

@@ -159,7 +159,24 @@ struct Context {
   std::unordered_map<std::string, int> prof_index;
 
   void *pin(size_t bytes);
-  void sync() { MM3D_HIP(hipStreamSynchronize(stream)); }
+  // sync(): wait for the stream; also the moment at which device-side error flags recorded with check_later() are
+  // looked at (throws Error).
+  // settle(): a wait whose only purpose is that OTHER contexts may see what was just built (a cache published under
+  // its lock) or that buffers go back to the pool.  A driver that keeps its objects private to this context until it
+  // has drained the stream itself (estimate_maps_streams, mm3d_shard_begin: a map is published after a full sync())
+  // sets private_objects, and these waits are skipped: the pool belongs to this context and hands memory out in this
+  // stream's order, so whoever gets a released block next is enqueued behind its last user.
+  bool private_objects = false;
+  struct Deferred { const int *flag; int status; const char *what; };
+  std::vector<Deferred> deferred;
+  void sync();
+  void settle() { if (!private_objects) sync(); }
+  // flag: pinned host memory a D2H copy of a device error word has been enqueued into
+  void check_later(const int *flag, int status, const char *what)
+  {
+    deferred.push_back(Deferred{flag, status, what});
+    if (!private_objects) sync();
+  }
   int prof_slot(const char *name);
   void prof_resolve();
 };

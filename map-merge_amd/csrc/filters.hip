@@ -132,7 +132,7 @@ mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
   // 16 B read per raw point + 16 B written per voxel
   MM3D_LAUNCH(c, "voxel_centroid", in->n_finite * 16.0 + nvox * 16.0, k_voxel_centroid, dim3(div_up(nvox, 256)), dim3(256), 0,
               in->pts.get(), vals2.get(), starts.get(), nvox, (int)in->n_finite, out.get());
-  c->sync();
+  c->settle();
   return cloud_from_device(c, std::move(out), (size_t)nvox);
 }
 

@@ -363,8 +363,7 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
                   (const float4 *)points->pts.get(), (const int *)pos.get(), (const float *)spfh.get(), (float)radius, r2, scr, raw.get(), valid.get());
     int *he = (int *)c->pin(64);
     MM3D_HIP(hipMemcpyAsync(he, sn.error(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    c->sync();
-    if (*he) throw Error(MM3D_EUNSUPPORTED, "computeLocalDescriptors(FPFH): a keypoint has more than 16384 neighbours within the radius");
+    c->check_later(he, MM3D_EUNSUPPORTED, "computeLocalDescriptors(FPFH): a keypoint has more than 16384 neighbours within the radius");
   }
   // prune invalid descriptors and the same keypoints (features.cpp:118-143)
   DevBuf<int> vpos(c, (size_t)nk + 1);
@@ -385,14 +384,14 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
                   (const float *)keypoints->pts.get(), (const int *)valid.get(), (const int *)vpos.get(), nk, 4,
                   (float *)kp2.get());
     }
-    c->sync();
+    c->settle();
     keypoints->pts = std::move(kp2);
     keypoints->n = (size_t)nv;
     keypoints->grids.clear();
     keypoints->host.clear();
     keypoints->reset_caches();
   }
-  c->sync();
+  c->settle();
   return res;
 }
 

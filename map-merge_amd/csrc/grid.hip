@@ -68,6 +68,17 @@ void Pool::trim_locked()
   free_.clear();
 }
 
+void Context::sync()
+{
+  MM3D_HIP(hipStreamSynchronize(stream));
+  if (!deferred.empty()) {
+    std::vector<Deferred> d;
+    d.swap(deferred);
+    for (const Deferred &e : d)
+      if (*e.flag) throw Error(e.status, e.what);
+  }
+}
+
 void *Context::pin(size_t bytes)
 {
   bytes = (bytes + 255) & ~(size_t)255;
@@ -317,7 +328,7 @@ mm3d_cloud *cloud_from_memory(Context *c, const void *src, size_t n, size_t stri
       DevBuf<unsigned char> stage(c, n * stride);
       MM3D_HIP(hipMemcpyAsync(stage.get(), src, n * stride, hipMemcpyDefault, c->stream));
       MM3D_LAUNCH(c, "repack", 0, k_repack, dim3(div_up(n, 256)), dim3(256), 0, stage.get(), n, stride, rgba_off, pts.get());
-      c->sync();   // stage goes back to the pool only after the kernel is done with it
+      c->settle();   // stage goes back to the pool only after the kernel is done with it
     }
   }
   return cloud_from_device(c, std::move(pts), n);
@@ -550,7 +561,7 @@ const Grid &cloud_grid(Context *c, const mm3d_cloud *cl_, float cell)
                   vals2.get(), (int)nfin, g->sorted.get());
     }
     g->n = (int)nfin;
-    c->sync();   // temporaries return to the pool after the stream is done with them
+    c->settle();   // temporaries return to the pool after the stream is done with them
   }
   auto &ref = *g;
   cl->grids[key] = std::move(g);
@@ -616,7 +627,7 @@ void grid_ensure_dt(Context *c, const Grid &g_, int R)
               g.dims[2], 2, R, a.get());
   g.dt = std::move(a);
   g.dt_cap = R;
-  c->sync();      // another context may read the table as soon as the lock is gone
+  c->settle();      // another context may read the table as soon as the lock is gone
 }
 
 // ---------------------------------------------------------------- merged neighbourhood lists
@@ -686,7 +697,7 @@ void grid_ensure_nblists(Context *c, const Grid &g_, int R)
     MM3D_LAUNCH(c, "grid_nblists", total * 32.0, k_nb_fill, dim3(div_up(nc, 4)), dim3(256), 0, (const int *)g.cell_start.get(),
                 (const float4 *)g.sorted.get(), g.dims[0], g.dims[1], g.dims[2], R, (const int *)g.nb_start.get(), g.nb_pts.get());
   g.nb_R = R;
-  c->sync();
+  c->settle();
 }
 
 // ---------------------------------------------------------------- Hilbert order + wave work items
@@ -902,14 +913,14 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl_)
     sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), total, 32);
     MM3D_LAUNCH(c, "hilbert_gather", n * 36.0, k_hilbert_gather, dim3(div_up(n, 256)), dim3(256), 0, cl->pts.get(),
                 (const uint32_t *)vals2.get(), n, cl->hil_pts.get());
-    c->sync();                                    // vals2 goes back to the pool after the gather
+    c->settle();                                    // vals2 goes back to the pool after the gather
   }
   cl->n_wave_items = h[0];
   cl->hil_keys = std::move(keys2);
   cl->wave_items = DevBuf<int2>(c, (size_t)h[0]);
   MM3D_LAUNCH(c, "hilbert_items", n * 12.0, k_item_fill, dim3(div_up(n, 256)), dim3(256), 0, (const int *)heads.get(),
               (const int *)blk.get(), n, cl->wave_items.get());
-  c->sync();
+  c->settle();
 }
 
 // ---------------------------------------------------------------- ordered compaction
@@ -934,7 +945,7 @@ size_t compact_points(Context *c, const float4 *in, const int *flags, size_t n, 
   out = DevBuf<float4>(c, m);
   if (m) {
     MM3D_LAUNCH(c, "compact", n * 24.0, k_compact, dim3(div_up(n, 256)), dim3(256), 0, in, flags, pos.get(), n, out.get());
-    c->sync();
+    c->settle();
   }
   return m;
 }

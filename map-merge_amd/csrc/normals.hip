@@ -139,8 +139,8 @@ mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius)
                 res->nrm.get());
     int *h = (int *)c->pin(64);
     MM3D_HIP(hipMemcpyAsync(h, sn.error(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    c->sync();                                  // the scratch returns to the pool only after the kernel is done with it
-    if (*h) throw Error(MM3D_EUNSUPPORTED, "computeSurfaceNormals: a point has more than 16384 neighbours within the radius");
+    // (the scratch goes back to this context's pool; whoever gets it next is enqueued behind the kernel)
+    c->check_later(h, MM3D_EUNSUPPORTED, "computeSurfaceNormals: a point has more than 16384 neighbours within the radius");
   }
   return res;
 }

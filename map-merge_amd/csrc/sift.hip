@@ -457,8 +457,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
                   dog.get());
       int *he = (int *)c->pin(64);
       MM3D_HIP(hipMemcpyAsync(he, sn.error(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      c->sync();                                // the scratch goes back to the pool after the kernel is done with it
-      if (*he) throw Error(MM3D_EUNSUPPORTED, "detectKeypoints(SIFT): a point has more than 16384 neighbours within 3 sigma");
+      c->check_later(he, MM3D_EUNSUPPORTED, "detectKeypoints(SIFT): a point has more than 16384 neighbours within 3 sigma");
     }
     // the extremum test walks the same grid (25 neighbours lie within ~3 leaf sizes on a surface, i.e.
     // within one of these cells): one radix sort per octave instead of two
@@ -500,7 +499,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     if (nk)
       MM3D_LAUNCH(c, "sift_emit", n * 3 * 8.0, k_sift_emit, dim3(div_up((size_t)n * 3, 256)), dim3(256), 0, cur->pts.get(),
                   flags.get(), pos.get(), (size_t)n * 3, kp.get());
-    c->sync();
+    c->settle();
     parts.emplace_back(std::move(kp));
     part_n.push_back(nk);
     scale *= 2;
@@ -514,7 +513,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
       MM3D_HIP(hipMemcpyAsync(all.get() + off, parts[i].get(), part_n[i] * 16, hipMemcpyDeviceToDevice, c->stream));
     off += part_n[i];
   }
-  c->sync();
+  c->settle();
   return cloud_from_device(c, std::move(all), total);
 }
 
