@@ -210,3 +210,42 @@ def test_pairs_in_batches_equal_the_sequential_loop(mm, synth, method):
         assert np.array_equal(pairs.view(np.uint8), results[0][1].view(np.uint8))
         assert np.array_equal(T.view(np.uint32), results[0][0].view(np.uint32))
         assert np.array_equal(pairs2.view(np.uint8), results[0][2].view(np.uint8))
+
+
+def test_device_error_flags_come_back_from_every_path(mm, clouds):
+    """A point with more than 16384 neighbours inside the normal radius is more than the sorted-neighbour scratch
+    holds: the kernel raises a device-side flag.  The standalone call looks at it at once; inside
+    estimateMapsTransforms the map is private to its worker and the flag is only looked at at the next real wait
+    (Context::check_later) -- either way the call must come back with MM3D_EUNSUPPORTED (-4), nothing may hang, and
+    the context must work afterwards."""
+    rng = np.random.default_rng(5)
+    blob = np.zeros(20000, dtype=mm.POINT)
+    xyz = rng.uniform(0.0, 0.5, size=(20000, 3)).astype(np.float32)
+    blob["x"], blob["y"], blob["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    blob["rgba"] = rng.integers(0, 1 << 24, size=20000, dtype=np.uint32)
+    dense = mm.MapMergingParams(descriptor_type=2, estimation_method=1, resolution=0.01, descriptor_radius=0.08,
+                                outliers_min_neighbours=1, normal_radius=0.6)
+    c = mm.Context(0)
+    try:
+        with pytest.raises(mm.Mm3dError) as e1:
+            c.computeSurfaceNormals(c.cloud(blob), 0.6)
+        assert e1.value.status == -4
+        for n_streams in (1, 2):
+            c.setStreams(n_streams)
+            with pytest.raises(mm.Mm3dError) as e2:
+                c.estimateMapsTransforms([blob, blob.copy(), clouds[0]], dense)
+            assert e2.value.status == -4
+        # the context (and its helper) go on working, and give what a fresh context gives
+        params = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
+        c.srand(1)
+        T, pairs = c.estimateMapsTransforms(clouds[:3], params, return_pairs=True)
+        fresh = mm.Context(0)
+        try:
+            fresh.setStreams(2)
+            T1, pairs1 = fresh.estimateMapsTransforms(clouds[:3], params, return_pairs=True)
+        finally:
+            fresh.close()
+        assert np.array_equal(pairs.view(np.uint8), pairs1.view(np.uint8))
+        assert np.array_equal(np.stack(T).view(np.uint32), np.stack(T1).view(np.uint32))
+    finally:
+        c.close()
