@@ -3,10 +3,10 @@
 import csv, sys, collections, re
 
 def short(name):
-    m = re.search(r"mm3d::(\w+)(<\d+>)?", name)
+    m = re.search(r"mm3d::(\w+)(?:<(\d+)(?:, *\d+)*>)?", name)
     if m:
-        # the ICP / score search is one template (k_nn_wave<0> / <1>): keep its argument apart
-        return m.group(1) + (m.group(2) or "" if m.group(1) == "k_nn_wave" else "")
+        # the ICP / score search is one template (k_nn_wave<MODE, SPLIT>, MODE 0 / 1): keep the two modes apart
+        return m.group(1) + ("<%s>" % m.group(2) if m.group(1) == "k_nn_wave" and m.group(2) else "")
     m = re.search(r"(\w+)<", name)
     return (m.group(1) if m else name)[:40]
 
