@@ -116,7 +116,12 @@ void mm3d_srand(mm3d_ctx *ctx, unsigned seed);
  * map_merging.cpp:212-242,256-269 to.  1 (the default) = the reference's sequential loops on one
  * stream.  One pair is a chain of dependent kernels that cannot fill an MI355X by itself; 16 streams
  * roughly double the throughput.  The results do not depend on the setting, bit for bit: every
- * stream replays the rand() draws of the pairs it does not run.  1 <= n <= 64. */
+ * stream replays the rand() draws of the pairs it does not run.  When many pairs are ready at once (many small
+ * maps) a stream takes up to 16 of them that share their target and runs them as one batch (one descriptor
+ * search, one launch per step for all of them); the results are the sequential loop's all the same.
+ * A stream's host thread spins while it waits for the device: more streams than the process has CPUs (a
+ * container's quota counts) slow everything down, and the device runs four kernels at a time anyway.
+ * 1 <= n <= 64. */
 int mm3d_set_streams(mm3d_ctx *ctx, int n_streams);
 int mm3d_get_streams(const mm3d_ctx *ctx);
 /* diagnostics of the most recent mm3d_estimate_maps_transforms on this context: seconds from entry
