@@ -192,6 +192,11 @@ def test_pairs_in_batches_equal_the_sequential_loop(mm, synth, method):
     batches with gaps and the rand() bookkeeping around dead pairs are covered too."""
     _, maps = synth.synth_maps(12, 9000, overlap_step=0.25)
     clouds = [synth.pack_points(x, c) for x, c, _ in maps]
+    # maps of different sizes in one batch: different item counts per search job, different keypoint counts per
+    # scoring job, different numbers of sampled rows in the merged descriptor search
+    rng = np.random.default_rng(11)
+    for i, keep in ((1, 3500), (4, 5000), (8, 2500)):
+        clouds[i] = clouds[i][np.sort(rng.choice(len(clouds[i]), keep, replace=False))]
     clouds[5] = clouds[5][:40]                                  # survives the filters with no keypoint at all
     params = mm.MapMergingParams(descriptor_type=2, estimation_method=method)
     results = []
