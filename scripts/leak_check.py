@@ -6,7 +6,8 @@ import __graft_entry__ as ge
 mm = ge.load()
 import torch, numpy as np
 from map_merge_amd import synth
-_, maps = synth.synth_maps(5, 60000, overlap_step=0.4)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+_, maps = synth.synth_maps(N, 60000 if N <= 8 else 12000, overlap_step=0.4 if N <= 8 else 0.25)
 clouds = [synth.pack_points(x, c) for x, c, _ in maps]
 ctx = mm.Context(0); ctx.setStreams(8)
 P = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
