@@ -1110,9 +1110,11 @@ int mm3d_shard_unpack_many(mm3d_shard *sh, size_t count, const size_t *maps, con
         std::unique_ptr<mm3d_cloud> kp(cloud_from_memory(c, n_keypoints[k] ? s : nullptr, n_keypoints[k], 16, 12));
         s += n_keypoints[k] * 16;
         std::unique_ptr<mm3d_desc> desc(desc_from_memory(c, reinterpret_cast<const float *>(s), n_keypoints[k], sh->params.descriptor_type));
+        c->private_objects = true;                    // nobody sees the map before this worker's wait below
         if (pts->n) cloud_hilbert(c, pts.get());      // source role only, as in mm3d_shard_unpack
         if (kp->n) cloud_hilbert(c, kp.get());
         (void)cloud_host(c, kp.get());
+        c->private_objects = false;
         c->sync();
         auto *m = new mm3d_map();
         m->points = pts.release(); m->keypoints = kp.release(); m->desc = desc.release();
