@@ -970,7 +970,8 @@ int mm3d_shard_map_owner(size_t map, int world)
 }
 
 }  // extern "C" (a template needs C++ linkage)
-// run fn(worker index, context) on the context's streams (the caller's thread is worker 0); the first exception is rethrown
+// run fn(worker index, context, failed) on the context's streams (the caller's thread is worker 0); the first
+// exception is rethrown.  `failed` is set when any worker has thrown: the others stop taking work.
 template <class Fn>
 static void on_streams(mm3d_ctx *ctx, Fn &&fn)
 {
@@ -978,12 +979,15 @@ static void on_streams(mm3d_ctx *ctx, Fn &&fn)
   cs.insert(cs.end(), ctx->helpers.begin(), ctx->helpers.end());
   std::mutex mu;
   std::exception_ptr first_error;
+  std::atomic<bool> failed{false};
   auto body = [&](size_t w) {
     try {
       if (hipSetDevice(cs[w]->device) != hipSuccess) throw Error(MM3D_EDEVICE, "hipSetDevice failed");
-      fn(w, cs[w]);
+      fn(w, cs[w], failed);
       cs[w]->sync();
     } catch (...) {
+      failed.store(true);
+      cs[w]->private_objects = false;
       std::lock_guard<std::mutex> lk(mu);
       if (!first_error) first_error = std::current_exception();
     }
@@ -1010,10 +1014,10 @@ int mm3d_shard_begin(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, con
     for (size_t i = 0; i < n; ++i)
       if (mm3d_shard_map_owner(i, world) == rank) mine.push_back(i);
     std::atomic<size_t> next{0};
-    on_streams(ctx, [&](size_t, mm3d_ctx *c) {
+    on_streams(ctx, [&](size_t, mm3d_ctx *c, const std::atomic<bool> &failed) {
       for (;;) {
         const size_t k = next.fetch_add(1);
-        if (k >= mine.size()) break;
+        if (k >= mine.size() || failed.load()) break;
         const size_t i = mine[k];
         std::unique_ptr<mm3d_cloud> raw(cloud_from_memory(c, clouds[i].points, clouds[i].points ? clouds[i].n : 0,
                                                           clouds[i].stride ? clouds[i].stride : 16,
@@ -1098,10 +1102,10 @@ int mm3d_shard_unpack_many(mm3d_shard *sh, size_t count, const size_t *maps, con
     for (size_t k = 0; k < count; ++k)
       if (maps[k] >= sh->n || (!srcs[k] && (n_points[k] || n_keypoints[k]))) throw Error(MM3D_EINVAL, "mm3d_shard_unpack_many: bad item");
     std::atomic<size_t> next{0};
-    on_streams(ctx, [&](size_t, mm3d_ctx *c) {
+    on_streams(ctx, [&](size_t, mm3d_ctx *c, const std::atomic<bool> &failed) {
       for (;;) {
         const size_t k = next.fetch_add(1);
-        if (k >= count) break;
+        if (k >= count || failed.load()) break;
         const size_t i = maps[k];
         if (sh->maps[i]) continue;                    // an owned map is already here
         const char *s = static_cast<const char *>(srcs[k]);
@@ -1177,11 +1181,11 @@ int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *min
       a = b;
     }
     std::atomic<size_t> next{0};
-    on_streams(ctx, [&](size_t, mm3d_ctx *c) {
+    on_streams(ctx, [&](size_t, mm3d_ctx *c, const std::atomic<bool> &failed) {
       std::vector<PairWork> work;
       for (;;) {
         const size_t k = next.fetch_add(1);
-        if (k >= batches.size()) break;
+        if (k >= batches.size() || failed.load()) break;
         work.clear();
         for (size_t e = batches[k].first; e < batches[k].second; ++e) {
           const size_t q = todo[e];

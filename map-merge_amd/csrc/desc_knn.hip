@@ -893,6 +893,8 @@ void desc_knn_prepare_target(Context *c, const mm3d_desc *B_)
   else if (B->dim == 250) knn_target_operands<250>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 1344) knn_target_operands<1344>(c, B, B->knn_colsum, B->knn_Bp);
   else if (B->dim == 1980) knn_target_operands<1980>(c, B, B->knn_colsum, B->knn_Bp);
+  // another context may read the operands the moment the lock is released (a pair estimate without mm3d_map_prepare)
+  c->settle();
 }
 
 template <int kD>

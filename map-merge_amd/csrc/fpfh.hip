@@ -235,11 +235,11 @@ k_fpfh_weight(const float4 *__restrict__ q_pts /* keypoints, Hilbert order, .w =
   const size_t slot = (size_t)blockIdx.x * 4 + wave;
   unsigned long long *tmp = scr.tmp + slot * kSnEntries;
   float2 *fin = (float2 *)scr.fin + slot * kSnEntries;
-  const int n_units = n_items * 4;
+  const int n_units = sn_unit_count(scr, n_items);
   for (;;) {
     const int unit = sn_claim_unit(scr.unit_ctr, n_units, lane);
     if (unit < 0) break;
-    const int2 it = items[unit >> 2];
+    const int2 it = items[sn_unit_item(scr, unit)];
     int first = (unit & 3) * kSnG;
     int left = min(kSnG, it.y - first);
     while (left > 0) {

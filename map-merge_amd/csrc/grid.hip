@@ -248,14 +248,18 @@ void exclusive_scan_int(Context *c, const int *in, int *out, size_t n)
   const size_t tiles = (n + kScanTile - 1) / kScanTile;
   if (tiles > c->scan_tiles_cap) {
     c->sync();                                   // earlier scans on this stream are done with the old buffers
-    if (c->scan_status) (void)hipFree(c->scan_status);
     if (!c->scan_ticket) {
       MM3D_HIP(hipMalloc((void **)&c->scan_ticket, sizeof(unsigned)));
       MM3D_HIP(hipMemsetAsync(c->scan_ticket, 0, sizeof(unsigned), c->stream));
       c->scan_tickets_taken = 0;
     }
-    c->scan_tiles_cap = tiles * 2 < 4096 ? 4096 : tiles * 2;
-    MM3D_HIP(hipMalloc((void **)&c->scan_status, c->scan_tiles_cap * sizeof(unsigned long long)));
+    // the new buffer first: if the allocation fails the old one (and its capacity) stay valid
+    const size_t cap = tiles * 2 < 4096 ? 4096 : tiles * 2;
+    unsigned long long *fresh = nullptr;
+    MM3D_HIP(hipMalloc((void **)&fresh, cap * sizeof(unsigned long long)));
+    if (c->scan_status) (void)hipFree(c->scan_status);
+    c->scan_status = fresh;
+    c->scan_tiles_cap = cap;
     MM3D_HIP(hipMemsetAsync(c->scan_status, 0, c->scan_tiles_cap * sizeof(unsigned long long), c->stream));
     c->scan_epoch = 0;
   }
@@ -948,6 +952,20 @@ size_t compact_points(Context *c, const float4 *in, const int *flags, size_t n, 
     c->settle();
   }
   return m;
+}
+
+// compute units of a device (the persistent grids of snb_lds.hpp are sized from it)
+int snb_cu_count(int device)
+{
+  static std::mutex mu;
+  static std::map<int, int> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(device);
+  if (it != cache.end()) return it->second;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
+  cache[device] = n;
+  return n;
 }
 
 }  // namespace mm3d

@@ -13,6 +13,7 @@
 // the normals are the CPU path's, bit for bit.  Algorithmic traffic: 28 B / point (12 B xyz in, 16 B
 // normal out); the lists are L2-resident scratch.
 #include "sorted_nb.hpp"
+#include "snb_lds.hpp"
 
 namespace mm3d {
 
@@ -28,11 +29,11 @@ k_normals(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int 
   const size_t slot = (size_t)blockIdx.x * 4 + wave;
   unsigned long long *tmp = sc.tmp + slot * kSnEntries;
   float4 *fin = (float4 *)sc.fin + slot * kSnEntries;
-  const int n_units = n_items * 4;
+  const int n_units = sn_unit_count(sc, n_items);
   for (;;) {
     const int unit = sn_claim_unit(sc.unit_ctr, n_units, lane);
     if (unit < 0) break;
-    const int2 it = items[unit >> 2];
+    const int2 it = items[sn_unit_item(sc, unit)];
     int first = (unit & 3) * kSnG;                       // this quarter's points of the item
     int left = min(kSnG, it.y - first);
     while (left > 0) {
@@ -104,6 +105,88 @@ k_normals(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int 
   }
 }
 
+
+// ---- the same sums on LDS-resident neighbour lists (snb_lds.hpp) ------------------------------------------
+// 8 points per wave, eight lanes per point; lane (p, sub) owns accumulator sub of a = {xx, xy, xz, yy, yz, zz,
+// x, y} (and every lane sums z; sub 0's copy is read) and walks the point's list: 16-bit slots into the block's
+// tile, every read an LDS read.  Bit for bit k_normals' chains.
+using NormalsCfg = SnbCfg<8, 1792, 1024, 256, 128, false>;      // lists of ~70 (up to 256), 2 blocks of 8 waves per CU
+
+__global__ void __launch_bounds__(512)
+k_normals_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g, float radius, float r2, SnbCtl *ctl,
+              int *__restrict__ ov_items, float4 *__restrict__ out /* by original index */)
+{
+  using Cfg = NormalsCfg;
+  __shared__ SnbLds<Cfg> S;
+  __shared__ float sums[Cfg::kWaves][Cfg::kQ][9];
+  __shared__ int cnts[Cfg::kWaves][Cfg::kQ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  SnbWave<Cfg> &W = S.w[wave];
+  snb_run<Cfg>(
+      g, S, q_pts, items, n_items, radius, r2, ctl, ov_items, [](const float4 &) { return 0.0f; },
+      [&](int q_first, int fit, const float4 &) {
+        const int p = lane >> 3, sub = lane & 7;
+        if (p < fit) {
+          const int base = W.list_off[p], m = W.list_off[p + 1] - base;
+          // the factors of this lane's product, picked once: a += u v; v = 1 for the plain sums x and y
+          const float *up = sub <= 2 ? S.tx : (sub <= 4 ? S.ty : (sub == 5 ? S.tz : (sub == 6 ? S.tx : S.ty)));
+          const float *vp = sub == 0 ? S.tx : ((sub == 1 || sub == 3) ? S.ty : S.tz);
+          const bool v1 = sub >= 6;
+          float a0 = 0.f, a2 = 0.f;
+          int e0 = 0;
+          for (; e0 + 4 <= m; e0 += 4) {
+            unsigned sl[4];
+            float fu[4], fv[4], fz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sl[u] = W.arena[base + e0 + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { fu[u] = up[sl[u]]; fv[u] = vp[sl[u]]; fz[u] = S.tz[sl[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              // u * v, rounded, then added (the CPU path's a[k] += p.u * p.v; x * 1 is x)
+              a0 = __fadd_rn(a0, __fmul_rn(fu[u], v1 ? 1.0f : fv[u]));
+              a2 = __fadd_rn(a2, fz[u]);
+            }
+          }
+          for (; e0 < m; ++e0) {
+            const unsigned sl = W.arena[base + e0];
+            a0 = __fadd_rn(a0, __fmul_rn(up[sl], v1 ? 1.0f : vp[sl]));
+            a2 = __fadd_rn(a2, S.tz[sl]);
+          }
+          sums[wave][p][sub] = a0;
+          if (sub == 0) { sums[wave][p][8] = a2; cnts[wave][p] = m; }
+        }
+        wave_lds_fence();
+        // one lane per point: covariance, eigen33, flip (features/normal_3d.h computePointNormal)
+        if (lane < fit) {
+          const float4 pq = q_pts[q_first + lane];
+          const int cnt = cnts[wave][lane];
+          float4 o;
+          if (cnt < 3) {
+            o.x = o.y = o.z = o.w = __uint_as_float(0x7fc00000u);
+          } else {
+            float a[9];
+            const float fc = (float)cnt;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a[k] = sums[wave][lane][k] / fc;
+            const float cxx = a[0] - a[6] * a[6], cxy = a[1] - a[6] * a[7], cxz = a[2] - a[6] * a[8];
+            const float cyy = a[3] - a[7] * a[7], cyz = a[4] - a[7] * a[8], czz = a[5] - a[8] * a[8];
+            float ev, v[3];
+            eigen33_smallest(cxx, cxy, cxz, cyy, cyz, czz, &ev, v);
+            const float eig_sum = cxx + cyy + czz;
+            o.w = (eig_sum != 0.0f) ? fabsf(ev / eig_sum) : 0.0f;
+            // flipNormalTowardsViewpoint(point, 0, 0, 0)
+            const float vx = 0.0f - pq.x, vy = 0.0f - pq.y, vz = 0.0f - pq.z;
+            const float cos_theta = vx * v[0] + vy * v[1] + vz * v[2];
+            if (cos_theta < 0.0f) { v[0] *= -1.0f; v[1] *= -1.0f; v[2] *= -1.0f; }
+            o.x = v[0]; o.y = v[1]; o.z = v[2];
+          }
+          out[__float_as_int(pq.w)] = o;
+        }
+        wave_lds_fence();
+      });
+}
+
 #ifdef MM3D_SN_STATS
 extern "C" void mm3d_debug_sn_stats(unsigned long long *out, int reset)
 {
@@ -132,17 +215,37 @@ mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius)
   if (g.n) {
     cloud_hilbert(c, in);
     const int n_items = in->n_wave_items;
-    SnLaunch<float4> sn(c, n_items * 4, in->n);
-    SnScratch sc{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error()};
-    MM3D_LAUNCH(c, "normals_radius", g.n * 28.0, k_normals, dim3(sn.blocks), dim3(256), 0, (const float4 *)in->hil_pts.get(),
+    // the LDS path, then the (normally empty) launch over the items it could not hold
+    SnbLaunch<NormalsCfg> sl(c, n_items, sizeof(float) * 64 * 10 + 256);
+    SnbCtl *ctl = sl.ctl_dev();
+    MM3D_LAUNCH(c, "normals_radius", g.n * 28.0, k_normals_lds, dim3(sl.blocks), dim3(64 * NormalsCfg::kWaves), 0, (const float4 *)in->hil_pts.get(),
+                (const int2 *)in->wave_items.get(), n_items, g.view(), (float)radius, r2, ctl, sl.ov_items.get(), res->nrm.get());
+    SnLaunch<float4> sn(c, n_items * 4, in->n, 4, kSnFallbackBlocks);
+    SnScratch sc{sn.tmp.get(), sn.fin.get(), ctl->fb_ctr, &ctl->error, sl.ov_items.get(), &ctl->ov_count};
+    MM3D_LAUNCH(c, "normals_radius_big", 0.0, k_normals, dim3(sn.blocks), dim3(256), 0, (const float4 *)in->hil_pts.get(),
                 (const int2 *)in->wave_items.get(), n_items, g.view(), (const float4 *)in->pts.get(), (float)radius, r2, sc,
                 res->nrm.get());
     int *h = (int *)c->pin(64);
-    MM3D_HIP(hipMemcpyAsync(h, sn.error(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MM3D_HIP(hipMemcpyAsync(h, &ctl->error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (getenv("MM3D_SNB_DEBUG")) {
+      int *ho = (int *)c->pin(64);
+      MM3D_HIP(hipMemcpyAsync(ho, &ctl->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      c->sync();
+      fprintf(stderr, "normals: n=%d items=%d blocks=%u overflow items=%d\n", g.n, n_items, sl.blocks, ho[0]);
+    }
     // (the scratch goes back to this context's pool; whoever gets it next is enqueued behind the kernel)
     c->check_later(h, MM3D_EUNSUPPORTED, "computeSurfaceNormals: a point has more than 16384 neighbours within the radius");
   }
   return res;
 }
+
+#ifdef MM3D_SNB_STATS
+extern "C" void mm3d_debug_snb_stats_normals(unsigned long long *out, int reset)
+{
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_snb_stats), sizeof(unsigned long long) * 32);
+  if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_snb_stats), z, sizeof(z)); }
+}
+#endif
 
 }  // namespace mm3d

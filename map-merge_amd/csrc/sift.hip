@@ -18,6 +18,7 @@
 #include <cfloat>
 
 #include "sorted_nb.hpp"
+#include "snb_lds.hpp"
 
 namespace mm3d {
 
@@ -64,7 +65,7 @@ k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int
   const size_t slot = (size_t)blockIdx.x * 4 + wave;
   unsigned long long *tmp = scr.tmp + slot * kSnEntries;
   float2 *fin = (float2 *)scr.fin + slot * kSnEntries;
-  const int n_units = n_items * 4;
+  const int n_units = sn_unit_count(scr, n_items);
   const int p = lane >> 2, sub = lane & 3;
   // this lane's scales: first, then (for sub 2, 3) a second, narrower one
   const int sA = sub == 0 ? 5 : (sub == 1 ? 4 : (sub == 2 ? 3 : 1));
@@ -74,7 +75,7 @@ k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int
   for (;;) {
     const int unit = sn_claim_unit(scr.unit_ctr, n_units, lane);
     if (unit < 0) break;
-    const int2 it = items[unit >> 2];
+    const int2 it = items[sn_unit_item(scr, unit)];
     int first = (unit & 3) * kSnG;
     int left = min(kSnG, it.y - first);
     while (left > 0) {
@@ -137,6 +138,151 @@ k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int
       left -= fit;
     }
   }
+}
+
+
+// ---- computeScaleSpace on LDS-resident neighbour lists (snb_lds.hpp) ------------------------------------
+// The same sums as k_sift_dog, bit for bit, with the lists as 16-bit tile slots in LDS and the candidates'
+// intensities staged beside the tile.  Eight lanes per query (8 queries per wave) form two quads that take the
+// scales {5, 2, 1} and {4, 3, 0}; lane `sub4` of a quad takes the list entries e = sub4 (mod 4) and computes
+// their Gaussian weights for the quad's scales (all lanes busy: the supports are nested, a lane that walked one
+// scale alone idled through a third of the steps), and the additions of a (query, scale) then run in list order
+// through the quad: entry 4t, 4t+1, 4t+2, 4t+3 come from lanes 0..3 by DPP quad broadcasts, every lane of the
+// quad carrying the same running sums.  An entry beyond 3 sigma (or past the end) contributes +0.0f, which
+// changes no sum: the CPU loop's `break`.
+// (Measured and dropped: one query at a time on the whole wave, the weights of 64 entries through LDS to twelve
+// adding lanes -- no arena, four waves per SIMD for every octave, but three times the add instructions:
+// 4.7 ms for the three octaves of a 500 k map against 3.4 ms.)
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J * 0x55, 0xf, 0xf, false));
+}
+
+using SiftCfgSmall = SnbCfg<8, 1792, 1280, 384, 128, true>;     // first octave: lists of ~100, 2 blocks of 8 waves per CU
+using SiftCfgLarge = SnbCfg<8, 2048, 3584, 1024, 256, true>;    // later octaves: lists of 300-900, 1 block of 8 waves per CU
+
+template <class Cfg>
+__global__ void __launch_bounds__(64 * Cfg::kWaves)
+k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* .w = original index */,
+               const float4 *__restrict__ pts /* original order: rgba */, float radius, float r2, SiftScales sc, SnbCtl *ctl,
+               int *__restrict__ ov_items, float *__restrict__ dog /* [n][5] by original index */)
+{
+  __shared__ SnbLds<Cfg> S;
+  __shared__ float resp[Cfg::kWaves][Cfg::kQ][kScales];
+  __shared__ uint64_t s_tab[32];
+  constexpr int LPQ = Cfg::kLpq;
+  static_assert(LPQ == 8, "two quads per query");
+  constexpr int NS = 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 32) lm::exp2f_tab_copy(s_tab, threadIdx.x);       // (snb_run's first barrier publishes it)
+  const int sub4 = lane & 3, quad = (lane >> 2) & 1;
+  // this quad's scales, widest first
+  float sig[NS], thr[NS], rcp[NS];
+  int ss[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int a = k == 0 ? 5 : (k == 1 ? 2 : 1), b = k == 0 ? 4 : (k == 1 ? 3 : 0);
+    ss[k] = quad ? b : a;
+    sig[k] = quad ? sc.sigma_sqr[b] : sc.sigma_sqr[a];
+    thr[k] = quad ? sc.thr9[b] : sc.thr9[a];
+    rcp[k] = quad ? sc.rcp[b] : sc.rcp[a];
+  }
+  SnbWave<Cfg> &W = S.w[wave];
+  snb_run<Cfg>(
+      g, S, q_pts, items, n_items, radius, r2, ctl, ov_items,
+      [&](const float4 &c) { return intensity_of(pts[__float_as_int(c.w)].w); },
+      [&](int q_first, int fit, const float4 &q) {
+        const int p = lane / LPQ;
+        const bool mine = p < fit;
+        const int base = mine ? W.list_off[p] : 0, m = mine ? W.list_off[p + 1] - base : 0;
+        float num[NS], den[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { num[k] = 0.0f; den[k] = 0.0f; }
+        // four quad steps (sixteen list entries of a query) per iteration: their slots, points and intensities
+        // are requested together, the four weights of a scale are independent instruction streams (no divergent
+        // branch: a lane outside 3 sigma computes a weight nobody uses), and only the additions are a chain
+        for (int t0 = 0;; t0 += 4) {
+          bool valid[4];
+          unsigned slot[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = 4 * (t0 + j) + sub4;
+            valid[j] = e < m;
+            slot[j] = valid[j] ? (unsigned)W.arena[base + e] : 0u;
+          }
+          if (!__ballot(valid[0])) break;          // wave-uniform: every list is exhausted
+          float d2[4], val[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            val[j] = S.pay[slot[j]];
+            d2[j] = dist2(q.x, q.y, q.z, S.tx[slot[j]], S.ty[slot[j]], S.tz[slot[j]]);
+          }
+#pragma unroll
+          for (int k = 0; k < NS; ++k) {
+            // the lists are sorted: if no lane's first entry of the four is inside 3 sigma, none of the others is
+            if (__ballot(valid[0] && d2[0] <= thr[k])) {
+              float w[4], vw[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                // -0.5f * d2 / sigma_sqr, the division correctly rounded (k_sift_dog has the argument)
+                const float wj = lm::expf_glibc_t<false>(lm::fdiv_const(-0.5f * d2[j], sig[k], rcp[k]), [&](unsigned i) { return s_tab[i]; });
+                w[j] = (valid[j] && d2[j] <= thr[k]) ? wj : 0.0f;
+                vw[j] = (valid[j] && d2[j] <= thr[k]) ? __fmul_rn(val[j], wj) : 0.0f;
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                num[k] = __fadd_rn(num[k], quad_bcast<0>(vw[j])); den[k] = __fadd_rn(den[k], quad_bcast<0>(w[j]));
+                num[k] = __fadd_rn(num[k], quad_bcast<1>(vw[j])); den[k] = __fadd_rn(den[k], quad_bcast<1>(w[j]));
+                num[k] = __fadd_rn(num[k], quad_bcast<2>(vw[j])); den[k] = __fadd_rn(den[k], quad_bcast<2>(w[j]));
+                num[k] = __fadd_rn(num[k], quad_bcast<3>(vw[j])); den[k] = __fadd_rn(den[k], quad_bcast<3>(w[j]));
+              }
+            }
+          }
+        }
+        if (mine && sub4 == 0) {
+#pragma unroll
+          for (int k = 0; k < NS; ++k) resp[wave][p][ss[k]] = num[k] / den[k];
+        }
+        wave_lds_fence();
+        if (lane < fit) {
+          const float4 pq = q_pts[q_first + lane];
+          float *o = dog + (size_t)__float_as_int(pq.w) * kDog;
+          float prev = resp[wave][lane][0];
+#pragma unroll
+          for (int s = 1; s < kScales; ++s) {
+            const float cur = resp[wave][lane][s];
+            o[s - 1] = cur - prev;
+            prev = cur;
+          }
+        }
+        wave_lds_fence();
+      });
+}
+
+// one octave's scale space: the LDS path, then the (normally empty) launch over the items it could not hold
+template <class Cfg>
+static void sift_dog_octave(Context *c, const mm3d_cloud *cur, const Grid &gr, int n_items, float max_radius, float r2, const SiftScales &sc,
+                            float *dog)
+{
+  SnbLaunch<Cfg> sl(c, n_items, sizeof(float) * 64 * kScales + 256);
+  MM3D_LAUNCH(c, getenv("MM3D_SNB_DEBUG") ? (gr.n > 300000 ? "sift_dog_oct0" : (gr.n > 150000 ? "sift_dog_oct1" : "sift_dog_oct2")) : "sift_dog", gr.n * 36.0, k_sift_dog_lds<Cfg>, dim3(sl.blocks), dim3(64 * Cfg::kWaves), 0, (const float4 *)cur->hil_pts.get(),
+              (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, sl.ctl_dev(),
+              sl.ov_items.get(), dog);
+  SnbCtl *ctl = sl.ctl_dev();
+  SnLaunch<float2> sn(c, n_items * 4, cur->n, 4, kSnFallbackBlocks);
+  SnScratch scr{sn.tmp.get(), sn.fin.get(), ctl->fb_ctr, &ctl->error, sl.ov_items.get(), &ctl->ov_count};
+  MM3D_LAUNCH(c, "sift_dog_big", 0.0, k_sift_dog, dim3(sn.blocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
+              (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, scr, dog);
+  int *he = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(he, &ctl->error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (getenv("MM3D_SNB_DEBUG")) {
+    int *ho = (int *)c->pin(64);
+    MM3D_HIP(hipMemcpyAsync(ho, &ctl->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    fprintf(stderr, "sift_dog: n=%d items=%d blocks=%u overflow items=%d\n", gr.n, n_items, sl.blocks, ho[0]);
+  }
+  c->check_later(he, MM3D_EUNSUPPORTED, "detectKeypoints(SIFT): a point has more than 16384 neighbours within 3 sigma");
 }
 
 #ifdef MM3D_SN_STATS
@@ -449,16 +595,8 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     // scale space on a grid with cell = r/2
     const Grid &gr = cloud_grid(c, cur.get(), max_radius * 0.5f);
     DevBuf<float> dog(c, (size_t)n * kDog);
-    {
-      SnLaunch<float2> sn(c, n_items * 4, cur->n);
-      SnScratch scr{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error()};
-      MM3D_LAUNCH(c, "sift_dog", gr.n * 36.0, k_sift_dog, dim3(sn.blocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
-                  (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, scr,
-                  dog.get());
-      int *he = (int *)c->pin(64);
-      MM3D_HIP(hipMemcpyAsync(he, sn.error(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      c->check_later(he, MM3D_EUNSUPPORTED, "detectKeypoints(SIFT): a point has more than 16384 neighbours within 3 sigma");
-    }
+    if (oct == 0) sift_dog_octave<SiftCfgSmall>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get());
+    else sift_dog_octave<SiftCfgLarge>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get());
     // the extremum test walks the same grid (25 neighbours lie within ~3 leaf sizes on a surface, i.e.
     // within one of these cells): one radix sort per octave instead of two
     const Grid &gk = gr;
@@ -516,5 +654,14 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
   c->settle();
   return cloud_from_device(c, std::move(all), total);
 }
+
+#ifdef MM3D_SNB_STATS
+extern "C" void mm3d_debug_snb_stats_sift(unsigned long long *out, int reset)
+{
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_snb_stats), sizeof(unsigned long long) * 32);
+  if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_snb_stats), z, sizeof(z)); }
+}
+#endif
 
 }  // namespace mm3d

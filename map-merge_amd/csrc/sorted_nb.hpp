@@ -79,7 +79,14 @@ struct SnScratch {
   void *fin;                        // [waves][kSnEntries] payloads in final order
   int *unit_ctr;                    // [kXcds] next unit of every XCD slice
   int *error;                       // set when one query alone has more than kSnEntries neighbours
+  // fallback launches (snb_lds.hpp): only the work items the LDS path could not hold, *ov_count of them
+  const int *ov_items = nullptr;
+  const int *ov_count = nullptr;
 };
+
+// the launch's units (work item, quarter) and the item a unit belongs to
+__device__ __forceinline__ int sn_unit_count(const SnScratch &s, int n_items) { return (s.ov_count ? *s.ov_count : n_items) * 4; }
+__device__ __forceinline__ int sn_unit_item(const SnScratch &s, int unit) { return s.ov_items ? s.ov_items[unit >> 2] : (unit >> 2); }
 
 __device__ __forceinline__ float sn_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
@@ -89,17 +96,22 @@ __device__ __forceinline__ int sn_bucket(float d2, float bscale)
   return b < kSnNB - 1 ? b : kSnNB - 1;
 }
 
-// Claims the next unit of this block's XCD slice; -1 when the slice is done.  Wave-uniform.
+// Claims the next unit: this block's XCD slice first, then the other slices (a grid of fewer than kXcds
+// blocks, uneven slices); -1 when every slice is done.  Wave-uniform.
 __device__ __forceinline__ int sn_claim_unit(int *unit_ctr, int n_units, int lane)
 {
-  const int xcd = blockIdx.x % kXcds;
   const int q = n_units / kXcds, r = n_units % kXcds;
-  const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int count = xcd < r ? q + 1 : q;
-  int u = 0;
-  if (lane == 0) u = atomicAdd(&unit_ctr[xcd], 1);
-  u = __builtin_amdgcn_readfirstlane(u);
-  return u < count ? first + u : -1;
+  for (int k = 0; k < kXcds; ++k) {
+    const int xcd = (int)((blockIdx.x + k) % kXcds);
+    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int count = xcd < r ? q + 1 : q;
+    if (count == 0) continue;
+    int u = count;
+    if (lane == 0 && *(volatile int *)&unit_ctr[xcd] < count) u = atomicAdd(&unit_ctr[xcd], 1);
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (u < count) return first + u;
+  }
+  return -1;
 }
 
 // Builds the sorted neighbour lists of the group's queries.  Lane l carries query l / 4 in (qx, qy, qz)
@@ -307,13 +319,13 @@ struct SnLaunch {
   DevBuf<Payload> fin;
   DevBuf<int> ctr;                   // kXcds unit counters + the error flag
   unsigned blocks = 0;
-  SnLaunch(Context *c, int n_units, size_t n_surface_points, int waves_per_block = 4)
+  SnLaunch(Context *c, int n_units, size_t n_surface_points, int waves_per_block = 4, unsigned max_blocks = 1024u)
   {
     if (n_surface_points >= ((size_t)1 << 28))
       throw Error(MM3D_EUNSUPPORTED, "sorted neighbour lists: clouds of 2^28 points or more are not supported");
     // four blocks of 8.6 KB x 4 per CU fit the LDS; never more blocks than there are units
     const unsigned want = div_up((size_t)n_units, (size_t)waves_per_block);
-    blocks = want < 1024u ? (want ? want : 1u) : 1024u;
+    blocks = want < max_blocks ? (want ? want : 1u) : max_blocks;
     tmp = DevBuf<unsigned long long>(c, (size_t)blocks * waves_per_block * kSnEntries);
     fin = DevBuf<Payload>(c, (size_t)blocks * waves_per_block * kSnEntries);
     ctr = DevBuf<int>(c, kXcds + 1);

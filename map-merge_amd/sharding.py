@@ -84,7 +84,9 @@ def exchange_bundles(shard, world: int, rank: int, dist, device):
         offset[i] = total[o]
         total[o] += (nbytes[i] + 255) // 256 * 256
     width = max(max(total), 256)
-    buf = torch.zeros(width, dtype=torch.uint8, device=device if device is not None else "cpu")
+    # torch.empty, not zeros: a fill kernel would run on torch's current stream, unordered with the library's own
+    # stream that shard.pack copies on; the padding between bundles is never read (unpack uses offset[i] and the sizes)
+    buf = torch.empty(width, dtype=torch.uint8, device=device if device is not None else "cpu")
     for i in range(n):
         if map_owner(i, world) == rank and nbytes[i]:
             shard.pack(i, buf.data_ptr() + offset[i])
