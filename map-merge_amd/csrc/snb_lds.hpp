@@ -67,7 +67,7 @@ struct SnbCfg {
   static constexpr int kNB = NB_;                // distance buckets per query
   static constexpr bool kPay = PAY_;
   static_assert(64 % WAVES_ == 0 && (WAVES_ == 4 || WAVES_ == 8), "4 or 8 waves per block");
-  static_assert(TILE_CAP_ % 128 == 0 && TILE_CAP_ <= 65536, "the tile is read 128 candidates at a time; slots are 16 bits");
+  static_assert(TILE_CAP_ % 256 == 0 && TILE_CAP_ <= 65536, "the tile is read 256 candidates at a time; slots are 16 bits");
   static_assert(HIT_CAP_ % 128 == 0 && NB_ % 64 == 0 && (ARENA_ == 0 || ARENA_ >= HIT_CAP_), "sizes (kArena = 0: per-query consumers, snb_run_each)");
   static_assert(HIT_CAP_ + 8 >= 128, "the staging offsets live in d2buf");
 };
@@ -78,7 +78,7 @@ template <class Cfg>
 struct alignas(16) SnbWave {
   unsigned short arena[Cfg::kArena ? Cfg::kArena : 8];   // sorted lists (tile slots), back to back
   float d2buf[Cfg::kHitCap + 8];                 // the current query's hits: d2 in arrival, then in bucket order, +inf behind the last
-  unsigned short sbuf[Cfg::kHitCap];             // their tile slots, same order
+  unsigned short sbuf[Cfg::kHitCap + 8];         // their tile slots, same order (the last entry of both: a dump for masked stores)
   unsigned hist[Cfg::kNB + 4];                   // bucket counts, then bucket starts; [kNB] = total
   int list_off[Cfg::kQ + 1];
   // staging (before any list is built): the row offsets / first points of the current 64 rows live in d2buf
@@ -262,28 +262,41 @@ __device__ __forceinline__ int snb_sort_one(SnbLds<Cfg> &S, SnbWave<Cfg> &W, flo
   // the histogram is cleared here so that the stores are long done when phase B needs them
 #pragma unroll
   for (int k = 0; k < WPL; ++k) W.hist[k * kWave + lane] = 0u;
+  if (lane < 4) W.hist[NB + lane] = 0u;
   // A: hits, compacted; a lane tests candidates 2 l and 2 l + 1 of every 128 (FLANN's L2_Simple order
   // ((dx dx + dy dy) + dz dz), two at a time: the packed operations round each half like the scalar ones)
   SNB_TICK(t_a);
   int nh = 0;
   {
+    // Two steps of 128 candidates per iteration, straight-line: a lane that has no hit stores to the dump entry
+    // instead of branching around the store, so the two steps' instruction streams interleave (a wave is a chain
+    // of dependent operations; what it gains here it gains in latency, not in instruction count).
+    constexpr int kDump = Cfg::kHitCap + 7;
     const snb_v2f vx = {px, px}, vy = {py, py}, vz = {pz, pz};
-    for (int c0 = 0; c0 < n_pad; c0 += 2 * kWave) {
-      const int s = c0 + 2 * lane;
-      const snb_v2f cx = *reinterpret_cast<const snb_v2f *>(&S.tx[s]);
-      const snb_v2f cy = *reinterpret_cast<const snb_v2f *>(&S.ty[s]);
-      const snb_v2f cz = *reinterpret_cast<const snb_v2f *>(&S.tz[s]);
-      const snb_v2f dx = vx - cx, dy = vy - cy, dz = vz - cz;
-      const snb_v2f d2 = (dx * dx + dy * dy) + dz * dz;
-      const bool h0 = d2.x < hi2 && d2.x >= lo2, h1 = d2.y < hi2 && d2.y >= lo2;
-      const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
-      // (positions past the buffer are folded onto its last entry: nh > kHitCap is looked at after the loop)
-      const int p0 = min(snb_mbcnt(m0, nh), Cfg::kHitCap - 1);
-      nh += __popcll(m0);
-      const int p1 = min(snb_mbcnt(m1, nh), Cfg::kHitCap - 1);
-      nh += __popcll(m1);
-      if (h0) { W.d2buf[p0] = d2.x; W.sbuf[p0] = (unsigned short)s; }
-      if (h1) { W.d2buf[p1] = d2.y; W.sbuf[p1] = (unsigned short)(s + 1); }
+    for (int c0 = 0; c0 < n_pad; c0 += 4 * kWave) {
+      snb_v2f d2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int s = c0 + u * 2 * kWave + 2 * lane;
+        const snb_v2f cx = *reinterpret_cast<const snb_v2f *>(&S.tx[s]);
+        const snb_v2f cy = *reinterpret_cast<const snb_v2f *>(&S.ty[s]);
+        const snb_v2f cz = *reinterpret_cast<const snb_v2f *>(&S.tz[s]);
+        const snb_v2f dx = vx - cx, dy = vy - cy, dz = vz - cz;
+        d2[u] = (dx * dx + dy * dy) + dz * dz;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int s = c0 + u * 2 * kWave + 2 * lane;
+        const bool h0 = d2[u].x < hi2 && d2[u].x >= lo2, h1 = d2[u].y < hi2 && d2[u].y >= lo2;
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+        // (positions past the buffer are folded onto its last entry: nh > kHitCap is looked at after the loop)
+        const int p0 = h0 ? min(snb_mbcnt(m0, nh), Cfg::kHitCap - 1) : kDump;
+        nh += __popcll(m0);
+        const int p1 = h1 ? min(snb_mbcnt(m1, nh), Cfg::kHitCap - 1) : kDump;
+        nh += __popcll(m1);
+        W.d2buf[p0] = d2[u].x; W.sbuf[p0] = (unsigned short)s;
+        W.d2buf[p1] = d2[u].y; W.sbuf[p1] = (unsigned short)(s + 1);
+      }
     }
   }
   wave_lds_fence();
@@ -310,8 +323,8 @@ __device__ __forceinline__ int snb_sort_one(SnbLds<Cfg> &S, SnbWave<Cfg> &W, flo
 #pragma unroll
       for (int u = u0; u < u0 + 2; ++u) {
         const int h = u * kWave + lane;
-        bkt[u] = snb_bucket<NB>(d2r[u] - lo2, bscale);
-        if (h < nh) arr[u] = (int)atomicAdd(&W.hist[bkt[u]], 1u);
+        bkt[u] = h < nh ? snb_bucket<NB>(d2r[u] - lo2, bscale) : NB + 1;     // (rows past the hits count in a spare word)
+        arr[u] = (int)atomicAdd(&W.hist[bkt[u]], 1u);
       }
     }
   }
@@ -353,15 +366,14 @@ __device__ __forceinline__ int snb_sort_one(SnbLds<Cfg> &S, SnbWave<Cfg> &W, flo
 #pragma unroll
       for (int u = u0; u < u0 + 2; ++u) {
         const int h = u * kWave + lane;
-        if (h < nh) {
-          const int pos = st[u - u0] + arr[u];
-          W.d2buf[pos] = d2r[u];
-          W.sbuf[pos] = (unsigned short)slot[u];
-        }
+        const int pos = h < nh ? st[u - u0] + arr[u] : Cfg::kHitCap + 7;
+        W.d2buf[pos] = d2r[u];
+        W.sbuf[pos] = (unsigned short)slot[u];
       }
     }
   }
-  if (lane < 8) W.d2buf[nh + lane] = INFINITY;
+  wave_lds_fence();
+  if (lane < 8) W.d2buf[nh + lane] = INFINITY;   // (after the dump stores: the last of these is the dump entry when nh = kHitCap)
   wave_lds_fence();
   SNB_TOCK(7, t_d);
   SNB_TICK(t_e);
@@ -427,9 +439,11 @@ __device__ __forceinline__ int snb_sort_one(SnbLds<Cfg> &S, SnbWave<Cfg> &W, flo
   for (int u = 0; u < R; ++u) {
     if (u * kWave < nh) {
       const int h = u * kWave + lane;
-      if (h < nh) {
-        if (kInPlace) { W.d2buf[fin[u]] = d2r[u]; W.sbuf[fin[u]] = (unsigned short)slot[u]; }
-        else list_out[fin[u]] = (unsigned short)slot[u];
+      if (kInPlace) {
+        const int pos = h < nh ? fin[u] : Cfg::kHitCap + 7;
+        W.d2buf[pos] = d2r[u]; W.sbuf[pos] = (unsigned short)slot[u];
+      } else if (h < nh) {
+        list_out[fin[u]] = (unsigned short)slot[u];
       }
     }
   }
@@ -560,9 +574,9 @@ __device__ __forceinline__ void snb_run(const GridView &g, SnbLds<Cfg> &S, const
         }
         continue;
       }
-      // pad the tile to a multiple of 128 with candidates nobody reaches (every wave writes the same values and
+      // pad the tile to a multiple of 256 with candidates nobody reaches (every wave writes the same values and
       // needs only its own writes)
-      const int n_pad = (n_tile + 127) & ~127;
+      const int n_pad = (n_tile + 255) & ~255;
       for (int s = n_tile + lane; s < n_pad; s += kWave) { S.tx[s] = kSnbFar; S.ty[s] = kSnbFar; S.tz[s] = kSnbFar; }
       wave_lds_fence();
       // the part's queries in equal shares (a part of 40 points is five per wave, not 8 + ... + 0)
