@@ -31,7 +31,18 @@
 namespace mm3d {
 
 constexpr int kAcc = 17;     // sum p(3) | sum q(3) | sum q p^T (9, row = q) | sum d2 | count
-constexpr int kTile = 512;   // staged target points per wave and tile (8 KiB of LDS)
+#ifndef MM3D_NN_TILE
+#define MM3D_NN_TILE 256
+#endif
+#ifndef MM3D_NN_WPE
+#define MM3D_NN_WPE 4
+#endif
+#ifdef MM3D_NN_WPE
+#define MM3D_NN_ATTR __attribute__((amdgpu_waves_per_eu(MM3D_NN_WPE, MM3D_NN_WPE)))
+#else
+#define MM3D_NN_ATTR
+#endif
+constexpr int kTile = MM3D_NN_TILE;   // staged target points per wave and tile (8 KiB of LDS)
 
 #ifdef MM3D_NN_STATS
 __device__ unsigned long long g_nn_stats[64];   // 0 waves, 1 passes, 2 row chunks, 3 staged points, 4 active lanes at pass, 5 rows, 6 max wave cycles, 7 sum wave cycles, 8.. log2 histogram of wave cycles
@@ -99,7 +110,7 @@ __device__ __forceinline__ void wave_lds_sync()
 //          result, a quarter of the time per item: for a source of a few hundred items (a 50 k point map) the
 //          chip is mostly idle and the kernel's duration IS one wave's scan.
 template <int MODE, int SPLIT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) MM3D_NN_ATTR
 k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
 {
   const NnJob &job = jobs[blockIdx.y];

@@ -25,7 +25,15 @@ namespace mm3d {
 constexpr int kScales = 6;      // nr_scales_per_octave (3) + 3
 constexpr int kDog = 5;
 constexpr int kKnn = 25;
-constexpr int kSiftTile = 256;
+#ifndef MM3D_EXT_TILE
+#define MM3D_EXT_TILE 256
+#endif
+#ifdef MM3D_EXT_WPE
+#define MM3D_EXT_ATTR __attribute__((amdgpu_waves_per_eu(MM3D_EXT_WPE, MM3D_EXT_WPE)))
+#else
+#define MM3D_EXT_ATTR
+#endif
+constexpr int kSiftTile = MM3D_EXT_TILE;
 
 struct SiftScales {
   float sigma_sqr[kScales];
@@ -363,7 +371,7 @@ constexpr int kExtremaSpan = 8;   // a run that still jumps farther than this ma
 // violators / the counts meet in LDS.  The live points of an octave are a few hundred to two thousand items, far
 // fewer than the chip has SIMDs, and an item's passes are a long dependent chain: the split shortens the chain.
 template <int SPLIT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) MM3D_EXT_ATTR
 k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, const int *__restrict__ n_items_dev,
                GridView g /* .w = original index */,
                const float4 *__restrict__ dogx, const float *__restrict__ dog, float min_contrast, int *__restrict__ flags /* [n*3] */)

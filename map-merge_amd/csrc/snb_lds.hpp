@@ -621,7 +621,8 @@ struct SnbLaunch {
   SnbLaunch(Context *c, int n_items, size_t extra_lds)
   {
     const size_t lds = sizeof(SnbLds<Cfg>) + extra_lds;
-    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)(32 / Cfg::kWaves), (size_t)163840 / lds));
+    unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)(32 / Cfg::kWaves), (size_t)163840 / lds));
+    if (const char *e = getenv("MM3D_SNB_PER_CU")) per_cu = std::min<unsigned>(per_cu, (unsigned)std::max(1, atoi(e)));   // experiment: leave LDS to other streams' kernels
     const unsigned cap = (unsigned)snb_cu_count(c->device) * per_cu;
     blocks = (unsigned)std::max(1, std::min<int>(n_items, (int)cap));
     ctl = DevBuf<int>(c, sizeof(SnbCtl) / sizeof(int));
