@@ -169,12 +169,14 @@ def main():
     # Within a rank the maps and pairs are dealt once more over S contexts (one HIP stream, one host
     # thread each): a pair is a chain of dependent launches with a few host round trips, so one
     # stream leaves SIMDs idle that another stream's kernels can use.
-    # a stream is a host thread that spins while it waits: the ranks of one node share the container's CPU quota, and
-    # more spinning threads than CPUs get every rank throttled ("Small maps")
+    # A stream's host thread no longer spins while it waits (stream_wait in csrc/grid.hip polls and naps: ~0.15 of
+    # a core per stream), so every rank keeps its --streams whatever the container's CPU quota is; a thread that
+    # spun (MM3D_WAIT=spin) held a core, and eight ranks x 16 streams on a 16-CPU quota got every rank throttled.
     S = max(1, args.streams)
-    quota = cgroup_cpu_limit()
-    cpus = quota if quota is not None else float(os.cpu_count() or 16)
-    S = max(1, min(S, max(2, int(cpus // max(world, 1)) - (1 if world > 1 else 0))))
+    if os.environ.get("MM3D_WAIT") == "spin":
+        quota = cgroup_cpu_limit()
+        cpus = quota if quota is not None else float(os.cpu_count() or 16)
+        S = max(1, min(S, max(2, int(cpus // max(world, 1)) - (1 if world > 1 else 0))))
     ctxs = [ctx] + [mm.Context(local_rank) for _ in range(S - 1)]
     tpool = ThreadPoolExecutor(S) if S > 1 else None
 

@@ -219,7 +219,7 @@ void mm3d_destroy(mm3d_ctx *ctx)
   for (mm3d_ctx *h : ctx->helpers) mm3d_destroy(h);
   ctx->helpers.clear();
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)stream_wait(ctx->stream);
   for (auto &p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   ctx->pool->trim();
@@ -288,7 +288,7 @@ void mm3d_cloud_free(mm3d_ctx *ctx, mm3d_cloud *c)
 {
   if (!ctx || !c) return;
   std::lock_guard<std::mutex> lock(ctx->mu);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)stream_wait(ctx->stream);
   delete c;
 }
 
@@ -321,7 +321,7 @@ void mm3d_normals_free(mm3d_ctx *ctx, mm3d_normals *n)
 {
   if (!ctx || !n) return;
   std::lock_guard<std::mutex> lock(ctx->mu);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)stream_wait(ctx->stream);
   delete n;
 }
 
@@ -372,7 +372,7 @@ void mm3d_desc_free(mm3d_ctx *ctx, mm3d_desc *d)
 {
   if (!ctx || !d) return;
   std::lock_guard<std::mutex> lock(ctx->mu);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)stream_wait(ctx->stream);
   delete d;
 }
 
@@ -597,7 +597,7 @@ void mm3d_map_free(mm3d_ctx *ctx, mm3d_map *m)
 {
   if (!ctx || !m) return;
   std::lock_guard<std::mutex> lock(ctx->mu);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)stream_wait(ctx->stream);
   delete m->points; delete m->keypoints; delete m->desc;
   delete m;
 }
@@ -907,7 +907,7 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   worker(0);
   for (auto &t : threads) t.join();
   // every stream has been synchronised by its worker (or the run was aborted): the maps can go
-  for (size_t w = 0; w < S; ++w) (void)hipStreamSynchronize(cs[w]->stream);
+  for (size_t w = 0; w < S; ++w) (void)stream_wait(cs[w]->stream);
   if (first_error) std::rethrow_exception(first_error);
   // all maps exist now: finish the generator states and check what was assumed about late targets
   advance_states(P);
@@ -996,7 +996,7 @@ static void on_streams(mm3d_ctx *ctx, Fn &&fn)
   for (size_t w = 1; w < cs.size(); ++w) threads.emplace_back(body, w);
   body(0);
   for (auto &t : threads) t.join();
-  for (mm3d_ctx *c : cs) (void)hipStreamSynchronize(c->stream);
+  for (mm3d_ctx *c : cs) (void)stream_wait(c->stream);
   if (first_error) std::rethrow_exception(first_error);
 }
 extern "C" {
@@ -1206,8 +1206,8 @@ void mm3d_shard_end(mm3d_shard *sh)
   mm3d_ctx *ctx = sh->ctx;
   {
     std::lock_guard<std::mutex> lock(ctx->mu);
-    (void)hipStreamSynchronize(ctx->stream);
-    for (mm3d_ctx *h : ctx->helpers) (void)hipStreamSynchronize(h->stream);
+    (void)stream_wait(ctx->stream);
+    for (mm3d_ctx *h : ctx->helpers) (void)stream_wait(h->stream);
   }
   delete sh;
 }

@@ -6,7 +6,10 @@
 // cloud; PCL rebuilds its tree per call and per pair.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <sys/prctl.h>
 #include <cstring>
+#include <thread>
 
 #include <rocprim/rocprim.hpp>
 
@@ -68,9 +71,29 @@ void Pool::trim_locked()
   free_.clear();
 }
 
+hipError_t stream_wait(hipStream_t stream)
+{
+  static const bool spin_only = [] { const char *e = getenv("MM3D_WAIT"); return e && std::string(e) == "spin"; }();
+  if (spin_only) return hipStreamSynchronize(stream);
+  static const long spin_us = [] { const char *e = getenv("MM3D_WAIT_SPIN_US"); return e ? atol(e) : 200L; }();
+  // (a nap of 10 us lasts 60 with Linux's default timer slack of 50 us: the waiting thread asks for 1 us once)
+  static thread_local bool slack_set = false;
+  if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }
+  const auto t0 = std::chrono::steady_clock::now();
+  long nap_us = 5;
+  for (;;) {
+    const hipError_t e = hipStreamQuery(stream);
+    if (e != hipErrorNotReady) return e;
+    const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (waited < spin_us) continue;                              // most readbacks of a size are over by now
+    std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
+    if (nap_us < 60) nap_us += 5;
+  }
+}
+
 void Context::sync()
 {
-  MM3D_HIP(hipStreamSynchronize(stream));
+  MM3D_HIP(stream_wait(stream));
   if (!deferred.empty()) {
     std::vector<Deferred> d;
     d.swap(deferred);
@@ -111,7 +134,7 @@ int Context::prof_slot(const char *name)
 void Context::prof_resolve()
 {
   if (pending.empty()) return;
-  MM3D_HIP(hipStreamSynchronize(stream));
+  MM3D_HIP(stream_wait(stream));
   for (auto &p : pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) prof[p.slot].ms += ms;
