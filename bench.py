@@ -43,10 +43,57 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA (v_mf
 MFMA_KERNELS = {"desc_knn_mfma"}   # kernels whose profile "bytes" field carries FLOPs (csrc/desc_knn.hip)
 VALU_PEAK_WINSTR_S = 256 * 4 * 2.4e9 / 4   # wave-instructions per second: 256 CUs x 4 SIMDs, 4 cycles per wave64 instruction, 2.4 GHz
 # profile name (MM3D_LAUNCH) of the kernels whose C++ symbol differs from it (scripts/pmc_summary.py prints symbols)
-KERNEL_OF_SYMBOL = {"k_sift_dog": "sift_dog", "k_sift_extrema": "sift_extrema", "k_spfh": "spfh", "k_normals": "normals_radius",
+KERNEL_OF_SYMBOL = {"k_sift_dog_lds": "sift_dog", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_sift_extrema": "sift_extrema", "k_spfh": "spfh", "k_normals": "normals_radius_big",
                     "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_sacia_seq_sum": "sacia_seq_sum",
                     "k_fpfh_weight": "fpfh_weight", "k_knn_mfma": "desc_knn_mfma", "k_knn_rerank": "desc_knn_rerank",
                     "k_radius_outlier_count": "radius_outlier_count"}
+
+
+# the sources a kernel's instruction stream comes from: the PMC / SQ figures under profiles/ carry the hashes of these
+# files as they were when the counters were collected (scripts/assemble_profiles.py); a figure whose files have changed
+# since is reported with "stale": true instead of passing for a measurement of the code that ran
+_CS = "map-merge_amd/csrc/"
+KERNEL_SOURCES = {
+    "sift_dog": ["sift.hip", "snb_lds.hpp", "libm_exact.hpp"], "sift_extrema": ["sift.hip", "device_util.hpp"],
+    "normals_radius": ["normals.hip", "snb_lds.hpp", "device_util.hpp"], "spfh": ["fpfh.hip", "device_util.hpp", "libm_exact.hpp"],
+    "fpfh_weight": ["fpfh.hip", "sorted_nb.hpp"], "fpfh_mark": ["fpfh.hip"], "icp_corr_reduce": ["nn.hip"], "score_nn_reduce": ["nn.hip"],
+    "sacia_err": ["registration.hip"], "sacia_seq_sum": ["registration.hip"], "desc_knn_mfma": ["desc_knn.hip"],
+    "desc_knn_rerank": ["desc_knn.hip"], "radius_outlier_count": ["filters.hip"], "voxel_centroid": ["filters.hip"],
+}
+
+
+# registration_visualisation's stage boundaries (R/src/registration_visualisation.cpp:51-158): which stage a kernel's
+# time belongs to.  PCL builds a kd-tree inside each of its stages; here the grids / Hilbert orders / scans are shared
+# between stages and cached, so they are their own line.
+STAGE_OF_PREFIX = [("voxel", "downSample"), ("radius_outlier", "removeOutliers"), ("compact", "removeOutliers"),
+                   ("normals", "computeSurfaceNormals"), ("fill_nan", "computeSurfaceNormals"), ("sift", "detectKeypoints"),
+                   ("fpfh", "computeLocalDescriptors"), ("spfh", "computeLocalDescriptors"), ("pfh", "computeLocalDescriptors"),
+                   ("shot", "computeLocalDescriptors"), ("desc_knn", "estimateTransform: initial (k-NN + SAC-IA | RANSAC)"),
+                   ("sacia", "estimateTransform: initial (k-NN + SAC-IA | RANSAC)"), ("ransac", "estimateTransform: initial (k-NN + SAC-IA | RANSAC)"),
+                   ("icp", "estimateTransform: ICP"), ("score", "transformScore")]
+
+
+def stage_of(kernel):
+    for pre, st in STAGE_OF_PREFIX:
+        if kernel.startswith(pre):
+            return st
+    return "search structures (grids, Hilbert order, scans, sorts)"
+
+
+def kernel_source_hash(kernel):
+    """sha256 over the kernel's source files (None for kernels without an entry in KERNEL_SOURCES)."""
+    import hashlib
+    files = KERNEL_SOURCES.get(kernel)
+    if not files:
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        try:
+            with open(os.path.join(ROOT, _CS + f), "rb") as fh:
+                h.update(fh.read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
 
 
 def cgroup_cpu_limit():
@@ -67,6 +114,15 @@ def cgroup_throttle():
     except Exception:
         pass
     return 0
+
+
+def make_workload_gt(n_maps, n_points, cache=True, scenes="independent", overlap_step=0.5):
+    """The synthetic maps as packed records plus their ground-truth poses.  scenes: 'independent' = every map draws its
+    own surface samples (synth.synth_map; the headline workload), 'lattice' = the maps share the samples of one
+    world-anchored lattice (synth.lattice_map)."""
+    from map_merge_amd import synth
+    kw = {} if overlap_step == 0.5 else {"overlap_step": overlap_step}
+    return synth.cached_maps(n_maps, n_points, cache_dir="/tmp" if cache else None, family=scenes, **kw)
 
 
 def make_workload(n_maps, n_points, cache=True):
@@ -116,6 +172,13 @@ def main():
                          "(stride 32, rgba at 16) like the reference's callers do, so that the step includes the upload; "
                          "never the reported configuration (inputs are HBM-resident for `value`)")
     ap.add_argument("--kernel-table", default=None, help="write rank 0's full per-kernel HIP-event table (CSV) here")
+    ap.add_argument("--scenes", choices=["independent", "lattice"], default="independent",
+                    help="synthetic scene family: 'independent' (default, the headline workload: every map samples the world on its own) "
+                         "or 'lattice' (overlapping maps share the samples of one world-anchored lattice: repeatable keypoints)")
+    ap.add_argument("--overlap-step", type=float, default=0.5,
+                    help="distance between consecutive map windows in window sides (0.5 = about half of a window shared)")
+    ap.add_argument("--sac-iterations", type=int, default=0, help="MapMergingParams.max_iterations (0 = the reference's default, 500)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the extra PCIe-inclusive step (host pcl::PointXYZRGB input) at N = 1")
     args = ap.parse_args()
 
     import torch
@@ -148,15 +211,18 @@ def main():
     desc_dim = {"FPFH": 33, "PFH": 125, "SHOT": 1344}[args.descriptor]
     params = mm.MapMergingParams(descriptor_type=desc_type, estimation_method=mm.EstimationMethod[args.method],
                                  refine_transform=1)
+    if args.sac_iterations > 0:
+        params.max_iterations = args.sac_iterations
 
     # ---- synthetic workload, resident in HBM before timing ---------------------------------
     n_maps, n_pts = args.maps, args.points
-    host = make_workload(n_maps, n_pts, cache=not args.no_cache)
+    host, T_gt, _ = make_workload_gt(n_maps, n_pts, cache=not args.no_cache, scenes=args.scenes, overlap_step=args.overlap_step)
     dev_raw = [torch.from_numpy(h.view(np.uint8).reshape(-1, 16)).to(dev) for h in host]
     torch.cuda.synchronize()
     pairs_idx = [(i, j) for i in range(n_maps - 1) for j in range(i + 1, n_maps)]
     host_pcl = []
-    if args.host_input == "pcl32":                        # pcl::PointXYZRGB as it lies in memory: x y z 1 | rgba pad pad pad
+    want_pcie = world == 1 and args.engine == "library" and not args.no_pcie and args.host_input == "none"
+    if args.host_input == "pcl32" or want_pcie:           # pcl::PointXYZRGB as it lies in memory: x y z 1 | rgba pad pad pad
         PCL = np.dtype({"names": ["x", "y", "z", "w", "rgba"], "formats": ["<f4", "<f4", "<f4", "<f4", "<u4"], "offsets": [0, 4, 8, 12, 16],
                         "itemsize": 32})
         for h in host:
@@ -305,7 +371,7 @@ def main():
                           t_gather_graph=0.0, pts_filtered=list(pts), keypoints=list(kps),
                           icp_iters=[int(x) for x in mine["icp_iterations"]],
                           n_estimated=int(sum(1 for t in T if np.any(t))),
-                          crc=zlib.crc32(np.ascontiguousarray(mine["transform"]).tobytes()) & 0xffffffff))
+                          crc=zlib.crc32(np.ascontiguousarray(mine["transform"]).tobytes()) & 0xffffffff, records=mine))
         return T
 
     if world > 1 or args.engine in ("library", "shard"):
@@ -341,6 +407,24 @@ def main():
                 "cgroup_throttled_ms_per_step": round((cgroup_throttle() - thr0) / 1e3 / max(args.steps, 1), 2)}
     for c in ctxs:
         c.profile(False)
+    # N = 1: the same step with the clouds handed over the way the reference's callers hold them -- host arrays of
+    # pcl::PointXYZRGB (stride 32) in pageable memory, uploaded inside the step.  A secondary figure, never `value`.
+    pcie = None
+    if want_pcie and rank == 0:
+        saved = dict(stats)
+        args.host_input = "pcl32"
+        step()                                             # (untimed: first touch of the host arrays)
+        barrier()
+        tp0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        barrier()
+        tp = (time.perf_counter() - tp0) / 2
+        pcie = {"value": round(saved["n_pairs"] / tp, 4), "unit": "map-pairs/s", "ms_per_step": round(1e3 * tp, 3), "steps": 2,
+                "input": "host pcl::PointXYZRGB arrays (stride 32, pageable), %d MB uploaded inside the step" % (sum(len(h) for h in host) * 32 // 1000000),
+                "pair_transforms_crc32": stats["crc"]}
+        args.host_input = "none"
+        stats.clear(); stats.update(saved)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -375,14 +459,20 @@ def main():
         for m in two:
             m.free()
     # HBM-side traffic per launch from the most recent committed PMC passes (scripts/profile_round.sh)
-    pmc_traffic, pmc_source = {}, None
+    pmc_traffic, pmc_source, pmc_hashes = {}, None, {}
     try:
         latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
         with open(latest) as f:
-            pmc_traffic = json.load(f)["bytes_per_launch"]
+            doc = json.load(f)
+        pmc_traffic, pmc_hashes = doc["bytes_per_launch"], doc.get("source_sha256", {})
         pmc_source = "profiles/" + os.path.basename(latest).replace("traffic.json", "pmc_hbm_traffic.csv")
     except Exception:
         pass
+
+    def stale(kernel):
+        """True when the kernel's sources are not the ones the committed counters were collected on (or that is unknown)."""
+        now = kernel_source_hash(kernel)
+        return not (now and pmc_hashes.get(kernel) == now)
 
     # VALU instructions per launch from the most recent committed SQ-counter pass (same maps 0 and 1, one stream)
     valu_insts, valu_source = {}, None
@@ -409,7 +499,7 @@ def main():
             out["mfma_frac"] = round(work / (launch_ms * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12), 5)
         else:
             out["hbm_frac"] = round(work / (launch_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 5)
-        if name in valu_insts:
+        if name in valu_insts and not stale(name):
             out["valu_frac"] = round(valu_insts[name] / (launch_ms * 1e-3) / VALU_PEAK_WINSTR_S, 4)
         out["nearest"] = max(((v, k[:-5]) for k, v in out.items()), default=(0, None))[1]
         return out
@@ -440,6 +530,9 @@ def main():
             # the gfx950 note + WRITE_SIZE); null when that kernel was not in the counted run
             roofline["traffic"] = pmc_traffic.get(dom[0])
             roofline["traffic_source"] = pmc_source if dom[0] in pmc_traffic else None
+            # the counters under profiles/ were collected on some commit: "stale" says whether the kernel's sources have
+            # changed since (hashes in the traffic file against the files of this tree)
+            roofline["traffic_stale"] = stale(dom[0]) if dom[0] in pmc_traffic else None
             if dom[0] in iso and iso[dom[0]]["launches"]:
                 iso_ms = iso[dom[0]]["ms"] / iso[dom[0]]["launches"]
                 iso_work = iso[dom[0]]["bytes"] / iso[dom[0]]["launches"]
@@ -447,7 +540,7 @@ def main():
                 roofline["isolated_avg_launch_us"] = round(iso_ms * 1e3, 3)
                 roofline["isolated_frac"] = round(iso_work / (iso_ms * 1e-3) / peak, 6) if iso_ms > 0 else None
             iso_us = roofline.get("isolated_avg_launch_us")
-            if roofline["traffic"] and iso_us:
+            if roofline["traffic"] and iso_us and not roofline["traffic_stale"]:
                 # what the memory side actually moved per launch (PMC) against the same peak: far above the algorithmic
                 # bytes where a kernel keeps scratch lists in global memory (sift_dog, normals_radius)
                 roofline["traffic_gbs"] = round(roofline["traffic"] / (iso_us * 1e-6) / 1e9, 1)
@@ -456,7 +549,14 @@ def main():
                 v = valu_insts[dom[0]] / (iso_us * 1e-6)
                 roofline["valu"] = {"wave_instructions_per_launch": round(valu_insts[dom[0]]), "achieved": round(v / 1e9, 2),
                                     "peak": round(VALU_PEAK_WINSTR_S / 1e9, 1), "unit": "G wave-instr/s", "frac": round(v / VALU_PEAK_WINSTR_S, 4),
-                                    "source": valu_source, "timed": "isolated_avg_launch_us"}
+                                    "source": valu_source, "timed": "isolated_avg_launch_us", "stale": stale(dom[0])}
+            # `bound`: the ceiling the kernel is nearest to alone on the GPU -- "hbm" by algorithmic or by measured memory-side
+            # bytes, "valu" by issued wave-instructions, "mfma" by flops -- the fractions beside it say how near
+            cand = {"hbm": max(roofline.get("isolated_frac") or 0.0, roofline.get("traffic_frac") or 0.0) if dom[0] not in MFMA_KERNELS else 0.0,
+                    "mfma": (roofline.get("isolated_frac") or 0.0) if dom[0] in MFMA_KERNELS else 0.0,
+                    "valu": (roofline.get("valu") or {}).get("frac", 0.0) if not (roofline.get("valu") or {}).get("stale") else 0.0}
+            roofline["bound"] = max(cand.items(), key=lambda kv: kv[1])[0] if any(cand.values()) else roofline["bound"]
+            roofline["bound_fractions"] = {k: round(v, 5) for k, v in cand.items()}
             roofline["note"] = ("timed region runs %d streams per GPU, so avg_launch_us includes time shared with other kernels; "
                                 "neighbourhood kernels (sift_dog, spfh, sacia_err, *_nn_reduce) are f32-VALU-bound on "
                                 "in-radius pair work, not HBM-bound: see DESIGN.md section 6" % S)
@@ -511,11 +611,34 @@ def main():
             "pair_transforms_crc32": stats["crc"],          # same job, same bits: independent of --gpus / --streams
             "roofline": roofline,
         }
+        # ground truth: the generator knows every map's pose.  Error of the estimated pair transforms (source -> target)
+        # against it, over the pairs whose windows overlap by at least 30 %
+        from map_merge_amd import synth
+        errs = []
+        for rec in stats.get("records", []):
+            i, j = int(rec["source_idx"]), int(rec["target_idx"])
+            if synth.window_overlap(n_maps, n_pts, i, j, overlap_step=args.overlap_step) >= 0.3:
+                errs.append(float(np.linalg.norm(np.asarray(rec["transform"], dtype=np.float64).reshape(4, 4).T - synth.relative_gt(T_gt[i], T_gt[j]))))
+        out["gt_error"] = {"pairs_with_overlap_ge_0.3": len(errs),
+                           "median_frobenius": round(float(np.median(errs)), 4) if errs else None,
+                           "max_frobenius": round(float(np.max(errs)), 4) if errs else None,
+                           "recovered_within_0.5": int(sum(e <= 0.5 for e in errs)),
+                           "scenes": args.scenes, "overlap_step": args.overlap_step,
+                           "note": "||T_pair - T_gt||_F; the reference's FPFH + SAC-IA (500 hypotheses) does not find the basin on the "
+                                   "'independent' scenes, on the device or on the CPU path alike (DESIGN.md section 6)"}
+        # GPU seconds per step at registration_visualisation's stage boundaries: kernel time summed over the streams
+        gpu_stage = {}
+        for k, v in prof.items():
+            gpu_stage[stage_of(k)] = gpu_stage.get(stage_of(k), 0.0) + v["ms"] / 1e3 / max(args.steps, 1)
+        out["stage_seconds"] = {"gpu_kernel_time_per_step": {k: round(v, 4) for k, v in sorted(gpu_stage.items(), key=lambda kv: -kv[1])}}
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
-            b1, b2, parity = cpu_baseline(host, n_maps, n_pairs, gpu_sample, True, args.descriptor, args.method, params)
+            b1, b2, parity, cpu_stages = cpu_baseline(host, n_maps, n_pairs, gpu_sample, True, args.descriptor, args.method, params)
             out["cpu_baseline"] = b1
             out["cpu_baseline_all_cores"] = b2
             out["parity_check"] = parity
+            out["stage_seconds"].update(cpu_stages)
         print(json.dumps(out))
     if tpool is not None:
         tpool.shutdown()
@@ -527,14 +650,13 @@ def main():
 
 def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", method="SAC_IA", params=None):
     """The CPU oracle (kind "port": our restatement of the reference's PCL path) on a bounded sample of the
-    workload: the features of ONE map and ONE pair (maps 0 and 1), extrapolated to the whole job as
-    n_maps * t_map + n_pairs * t_pair.
-      B1 `cpu_baseline`: one thread, like the reference's hot path (one run: the sample is ~30 s of CPU).
-      B2 `cpu_baseline_all_cores`: the same code with its loops over points on every host core (OpenMP;
-          results identical, tests/test_oracle_cpu.py), median of three runs.
-    The oracle's results for that sample are then held against what the device computed for the same maps
-    and pair in this very run (`parity_check`)."""
-    import statistics
+    workload, extrapolated to the whole job as n_maps * t_map + n_pairs * t_pair (means over the sample):
+      B2 `cpu_baseline_all_cores`: the features of maps 0, 1, 2 and the pairs (0,1), (0,2), (1,2) with the oracle's
+          loops over points on every host core (OpenMP; results identical, tests/test_oracle_cpu.py).
+      B1 `cpu_baseline`: one thread, like the reference's hot path: the features of maps 0 and 1 and the same three
+          pairs (map 2's features are B2's: the same bits).
+    Both report the seconds per stage at registration_visualisation's boundaries.  The oracle's results for maps 0, 1
+    and pair (0, 1) are then held against what the device computed for them in this very run (`parity_check`)."""
     po = ge.load_oracle()
     p = params if params is not None else po.params_default()   # the same parameter values the device ran with
     describe = {"FPFH": po.descriptors_fpfh, "PFH": po.descriptors_pfh, "SHOT": po.descriptors_shot}[descriptor]
@@ -551,54 +673,74 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", me
     except Exception:
         model = "?"
 
-    def features(cloud):
-        d = po.downsample(cloud, p.resolution)
-        f = po.remove_outliers(d, p.descriptor_radius, p.outliers_min_neighbours)
-        n = po.normals(f, p.normal_radius)
-        kp, _ = po.keypoints_sift(f, p.resolution, 3, 3, p.keypoint_threshold)
-        kp, desc = describe(f, n, kp, p.descriptor_radius)
+    def timed(acc, key, fn, *a):
+        t0 = time.perf_counter()
+        r = fn(*a)
+        acc[key] = acc.get(key, 0.0) + time.perf_counter() - t0
+        return r
+
+    def features(cloud, acc):
+        d = timed(acc, "downSample", po.downsample, cloud, p.resolution)
+        f = timed(acc, "removeOutliers", po.remove_outliers, d, p.descriptor_radius, p.outliers_min_neighbours)
+        n = timed(acc, "computeSurfaceNormals", po.normals, f, p.normal_radius)
+        kp, _ = timed(acc, "detectKeypoints", po.keypoints_sift, f, p.resolution, 3, 3, p.keypoint_threshold)
+        kp, desc = timed(acc, "computeLocalDescriptors", describe, f, n, kp, p.descriptor_radius)
         return f, kp, desc
 
-    def pair(f0, k0, d0, f1, k1, d1):
+    def pair(A, B, acc):
+        (f0, k0, d0), (f1, k1, d1) = A, B
         po.srand(1)
         if method == "SAC_IA":
-            T, _, _ = po.sac_ia(k0, d0, k1, d1, p.inlier_threshold, p.max_correspondence_distance, p.max_iterations)
+            T, _, _ = timed(acc, "estimateTransform: initial (k-NN + SAC-IA | RANSAC)", po.sac_ia, k0, d0, k1, d1, p.inlier_threshold,
+                            p.max_correspondence_distance, p.max_iterations)
         else:
-            corr = po.find_correspondences(d0, d1, int(p.matching_k))
-            T, _, _, _ = po.ransac(k0, k1, corr, p.inlier_threshold)
-        T, it = po.icp(f0, f1, T, p.max_correspondence_distance, p.inlier_threshold, p.max_iterations, p.transform_epsilon)
-        score = po.transform_score(f0, f1, T, p.max_correspondence_distance)
+            def initial():
+                corr = po.find_correspondences(d0, d1, int(p.matching_k))
+                return po.ransac(k0, k1, corr, p.inlier_threshold)[0]
+            T = timed(acc, "estimateTransform: initial (k-NN + SAC-IA | RANSAC)", initial)
+        T, it = timed(acc, "estimateTransform: ICP", po.icp, f0, f1, T, p.max_correspondence_distance, p.inlier_threshold, p.max_iterations,
+                      p.transform_epsilon)
+        score = timed(acc, "transformScore", po.transform_score, f0, f1, T, p.max_correspondence_distance)
         return T, it, score
 
-    # B2 first (fast): all cores, median of 3; it also provides map 1's features for B1's pair
+    n_sample = min(3, len(host))
+    sample_pairs = [(i, j) for i in range(n_sample - 1) for j in range(i + 1, n_sample)]
+    # B2 (fast): all cores; it also provides map 2's features for B1's pairs
     po.set_threads(cores)
-    tm, tp = [], []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        f0, k0, d0 = features(host[0])
-        tm.append(time.perf_counter() - t0)
-    f1, k1, d1 = features(host[1])
-    for _ in range(3):
-        t0 = time.perf_counter()
-        T, it, score = pair(f0, k0, d0, f1, k1, d1)
-        tp.append(time.perf_counter() - t0)
-    t_map2, t_pair2 = statistics.median(tm), statistics.median(tp)
+    st2 = {}
+    t0 = time.perf_counter()
+    F2 = [features(host[i], st2) for i in range(n_sample)]
+    t_maps2 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    R2 = [pair(F2[i], F2[j], st2) for i, j in sample_pairs]
+    t_pairs2 = time.perf_counter() - t0
+    t_map2, t_pair2 = t_maps2 / n_sample, t_pairs2 / max(len(sample_pairs), 1)
     job2 = n_maps * t_map2 + n_pairs * t_pair2
     b2 = {"value": round(n_pairs / job2, 6), "unit": "map-pairs/s", "cores": cores, "kind": "port", "cpu": model,
-          "sample": f"median of 3: 1 of {n_maps} maps' features ({t_map2:.2f} s) + 1 of {n_pairs} pairs ({t_pair2:.2f} s) on {cores} OpenMP "
-                    f"threads, extrapolated to the job as {n_maps}*t_map + {n_pairs}*t_pair = {job2:.0f} s"}
-    # B1: one thread, one run
+          "sample": f"{n_sample} of {n_maps} maps' features ({t_map2:.2f} s each) + {len(sample_pairs)} of {n_pairs} pairs ({t_pair2:.2f} s each) on "
+                    f"{cores} OpenMP threads, extrapolated to the job as {n_maps}*t_map + {n_pairs}*t_pair = {job2:.0f} s"}
+    # B1: one thread; maps 0 and 1 (map 2's features are B2's, the same bits), the same pairs
     po.set_threads(1)
+    st1 = {}
+    n_b1 = min(2, n_sample)
     t0 = time.perf_counter()
-    g0, h0, e0 = features(host[0])
-    t_map = time.perf_counter() - t0
+    F1 = [features(host[i], st1) for i in range(n_b1)] + F2[n_b1:]
+    t_map = (time.perf_counter() - t0) / n_b1
     t0 = time.perf_counter()
-    T1, it1, score1 = pair(g0, h0, e0, f1, k1, d1)
-    t_pair = time.perf_counter() - t0
+    R1 = [pair(F1[i], F1[j], st1) for i, j in sample_pairs]
+    t_pair = (time.perf_counter() - t0) / max(len(sample_pairs), 1)
     job = n_maps * t_map + n_pairs * t_pair
     b1 = {"value": round(n_pairs / job, 6), "unit": "map-pairs/s", "cores": 1, "kind": "port", "cpu": model,
-          "sample": f"1 of {n_maps} maps' features ({t_map:.1f} s) + 1 of {n_pairs} pairs ({t_pair:.1f} s), "
+          "sample": f"{n_b1} of {n_maps} maps' features ({t_map:.1f} s each) + {len(sample_pairs)} of {n_pairs} pairs ({t_pair:.1f} s each), "
                     f"extrapolated to the job as {n_maps}*t_map + {n_pairs}*t_pair = {job:.0f} s"}
+    # seconds per map (feature stages) / per pair (pair stages), means over the sample
+    feat_keys = ("downSample", "removeOutliers", "computeSurfaceNormals", "detectKeypoints", "computeLocalDescriptors")
+    per_unit = lambda st, nm: {k: round(v / (nm if k in feat_keys else max(len(sample_pairs), 1)), 4) for k, v in st.items()}   # noqa: E731
+    cpu_stages = {"cpu_1_thread_per_map_or_pair": per_unit(st1, n_b1), "cpu_all_cores_per_map_or_pair": per_unit(st2, n_sample)}
+    (f0, k0, d0), (f1, k1, d1) = F2[0], F2[1]
+    (g0, h0, e0) = F1[0]
+    T, it, score = R2[0]
+    T1, it1, score1 = R1[0]
     threads_agree = (g0.tobytes() == f0.tobytes() and h0.tobytes() == k0.tobytes() and e0.tobytes() == d0.tobytes()
                      and T1.tobytes() == T.tobytes() and it1 == it and score1 == score)
     parity = None
@@ -627,7 +769,7 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", me
         }
         parity["ok"] = bool(parity["filtered_points_bit_equal"] and parity["keypoints_bit_equal"] and parity["descriptors_bit_equal"]
                             and fro <= t_tol and conf_rel <= 1e-4 and int(rec["icp_iterations"]) == int(it) and threads_agree)
-    return b1, b2, parity
+    return b1, b2, parity, cpu_stages
 
 
 if __name__ == "__main__":

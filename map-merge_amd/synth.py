@@ -12,8 +12,8 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["World", "synth_world", "synth_map", "synth_maps", "cached_maps", "window_overlap", "pack_points",
-           "relative_gt", "POINT_DTYPE"]
+__all__ = ["World", "synth_world", "synth_map", "synth_maps", "lattice_map", "lattice_maps", "cached_maps", "window_overlap",
+           "pack_points", "relative_gt", "POINT_DTYPE"]
 
 POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
 
@@ -211,27 +211,28 @@ def synth_maps(n_maps: int, n_points: int, world_seed: int = 1234, **kw):
     return world, maps
 
 
-def cached_maps(n_maps: int, n_points: int, cache_dir: str | None = "/tmp", **kw):
-    """synth_maps as packed records plus the ground-truth poses, kept in `cache_dir` between runs (generating
-    16 x 500 000 points takes ~20 s of CPU).  Returns (list of POINT_DTYPE arrays, list of 4x4 T_gt, window)."""
+def cached_maps(n_maps: int, n_points: int, cache_dir: str | None = "/tmp", family: str = "independent", **kw):
+    """synth_maps (family 'independent') or lattice_maps (family 'lattice') as packed records plus the ground-truth
+    poses, kept in `cache_dir` between runs (generating 16 x 500 000 points takes ~20 s of CPU).
+    Returns (list of POINT_DTYPE arrays, list of 4x4 T_gt, window)."""
     import os
     w = kw.get("window") or window_for(n_points)
-    tag = "_".join(f"{k}{v}" for k, v in sorted(kw.items()))
+    tag = "_".join([family] * (family != "independent") + [f"{k}{v}" for k, v in sorted(kw.items())])
     path = os.path.join(cache_dir, f"mm3d_synth_{n_maps}x{n_points}{('_' + tag) if tag else ''}.npz") if cache_dir else None
     if path and os.path.exists(path):
         try:
             z = np.load(path)
-            if z["pts"].shape[0] == n_maps:
-                return [z["pts"][i] for i in range(n_maps)], [z["T"][i] for i in range(n_maps)], float(w)
+            if int(z["n_maps"]) == n_maps:
+                return [z[f"pts{i}"] for i in range(n_maps)], [z["T"][i] for i in range(n_maps)], float(w)
         except Exception:
             pass                                           # unreadable cache: regenerate
-    _, maps = synth_maps(n_maps, n_points, **kw)
+    _, maps = (lattice_maps if family == "lattice" else synth_maps)(n_maps, n_points, **kw)
     packed = [pack_points(x, c) for x, c, _ in maps]
     Ts = [T for _, _, T in maps]
     if path:
         try:                                               # several ranks may get here at once: write aside, rename atomically
             tmp = f"{path}.{os.getpid()}.tmp.npz"
-            np.savez(tmp, pts=np.stack(packed), T=np.stack(Ts))
+            np.savez(tmp, n_maps=n_maps, T=np.stack(Ts), **{f"pts{i}": a for i, a in enumerate(packed)})
             os.replace(tmp, path)
         except Exception:
             pass
@@ -260,3 +261,115 @@ def pack_points(xyz: np.ndarray, rgb: np.ndarray) -> np.ndarray:
 def relative_gt(T_i: np.ndarray, T_j: np.ndarray) -> np.ndarray:
     """Ground-truth transform taking map-i coordinates to map-j coordinates."""
     return T_j @ np.linalg.inv(T_i)
+
+
+# ---- a second scene family: the same world seen through a world-anchored sampling lattice ------------------
+# synth_map draws every map's points independently, so two maps never hold the same surface sample: SIFT keypoints
+# (intensity extrema of the sampled cloud) are barely repeatable between them, and FPFH + SAC-IA -- 500 hypotheses,
+# each three random picks among the 10 nearest descriptors -- does not find the basin (tests/test_gpu_baseline_configs.py).
+# Here the WORLD is sampled once, on a jittered lattice over every primitive (spacing `pitch`, jitter and sensor noise
+# hashed from the lattice node), and a map is the part of that sample inside its window, moved into the map's frame:
+# overlapping maps share their surface samples the way two passes of a survey-grade scanner over a static scene nearly
+# do.  Nothing about the registration problem is given away (poses, order and noise are the generator's secret), but
+# keypoints and descriptors repeat, which is what the reference's pipeline needs in order to converge.
+def _hash01(ix, iy, salt):
+    h = (ix.astype(np.int64) * 73856093) ^ (iy.astype(np.int64) * 19349663) ^ (int(salt) * 83492791)
+    h = (h ^ (h >> 13)) * 1274126177
+    h = h ^ (h >> 16)
+    return (h & 0xFFFFFF).astype(np.float64) / float(0x1000000)
+
+
+def _lattice_patch(o, u, v, pitch, salt, lo, hi):
+    """Jittered lattice over the parallelogram o + a u + b v, clipped to the window [lo, hi] (xy)."""
+    lu, lv = np.linalg.norm(u), np.linalg.norm(v)
+    nu, nv = max(int(lu / pitch), 1), max(int(lv / pitch), 1)
+    # only the lattice rows / columns that can reach the window (the ground patch is huge)
+    eu, ev = u / lu, v / lv
+    iu, iv = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    iu, iv = iu.ravel(), iv.ravel()
+    a = (iu + 0.15 + 0.7 * _hash01(iu, iv, salt)) * pitch
+    b = (iv + 0.15 + 0.7 * _hash01(iu, iv, salt + 1)) * pitch
+    p = o + a[:, None] * eu + b[:, None] * ev
+    keep = (p[:, 0] >= lo[0]) & (p[:, 0] <= hi[0]) & (p[:, 1] >= lo[1]) & (p[:, 1] <= hi[1])
+    return p[keep], iu[keep], iv[keep]
+
+
+def lattice_map(world: World, index: int, n_points: int, n_maps: int = 16, window: float | None = None, noise: float = 0.01,
+                overlap_step: float = 0.5, pitch: float | None = None):
+    """One map of the lattice scene family: (xyz float32 [N,3], rgb uint8 [N,3], T_gt) like synth_map.  N is close to
+    n_points (the lattice inside the window, thinned by a hashed threshold to at most n_points)."""
+    rng = np.random.Generator(np.random.PCG64(1000 + index))
+    w = window_for(n_points) if window is None else float(window)
+    loop_r = overlap_step * w * max(n_maps, 2) / (2.0 * np.pi)
+    loop_r = min(loop_r, max(world.extent / 2.0 - w / 2.0 - 1.0, 0.0))
+    ang = 2.0 * np.pi * index / max(n_maps, 1)
+    centre = np.array([loop_r * np.cos(ang), loop_r * np.sin(ang), 0.0])
+    lo, hi = centre[:2] - w / 2.0, centre[:2] + w / 2.0
+    # pitch: the window's ground alone gives n_points / 1.15 samples, the objects the rest (thinned below if more)
+    pitch = float(np.sqrt(w * w * 1.15 / n_points)) if pitch is None else float(pitch)
+    P, C = world.patches, world.cylinders
+    pts, cols, keys = [], [], []
+    for k in range(len(P["o"])):
+        o, u, v = P["o"][k], P["u"][k], P["v"][k]
+        if k == 0:
+            # the ground: lattice anchored at the world's corner, only the nodes near the window are generated
+            i0, i1 = int((lo[0] - o[0]) / pitch) - 1, int((hi[0] - o[0]) / pitch) + 2
+            j0, j1 = int((lo[1] - o[1]) / pitch) - 1, int((hi[1] - o[1]) / pitch) + 2
+            iu, iv = np.meshgrid(np.arange(max(i0, 0), i1), np.arange(max(j0, 0), j1), indexing="ij")
+            iu, iv = iu.ravel(), iv.ravel()
+            x = o[0] + (iu + 0.15 + 0.7 * _hash01(iu, iv, 17)) * pitch
+            y = o[1] + (iv + 0.15 + 0.7 * _hash01(iu, iv, 18)) * pitch
+            keep = (x >= lo[0]) & (x <= hi[0]) & (y >= lo[1]) & (y <= hi[1])
+            p = np.stack([x[keep], y[keep], np.zeros(keep.sum())], axis=1)
+            p[:, 2] = terrain_height(p[:, :2], world.seed)
+            iu, iv = iu[keep], iv[keep]
+        else:
+            c4 = np.stack([o, o + u, o + v, o + u + v])[:, :2]
+            if (c4.max(axis=0) < lo).any() or (c4.min(axis=0) > hi).any():
+                continue
+            p, iu, iv = _lattice_patch(o, u, v, pitch, 100 + 2 * k, lo, hi)
+        if len(p) == 0:
+            continue
+        pts.append(p); cols.append(np.broadcast_to(P["col"][k], (len(p), 3))); keys.append(_hash01(iu, iv, 7000 + k))
+    for k in range(len(C["r"])):
+        c, r, h = C["c"][k], C["r"][k], C["h"][k]
+        if ((c[:2] + r) < lo).any() or ((c[:2] - r) > hi).any():
+            continue
+        nth, nh = max(int(2.0 * np.pi * r / pitch), 3), max(int(h / pitch), 1)
+        it, ih = np.meshgrid(np.arange(nth), np.arange(nh), indexing="ij")
+        it, ih = it.ravel(), ih.ravel()
+        th = 2.0 * np.pi * (it + 0.15 + 0.7 * _hash01(it, ih, 300 + 2 * k)) / nth
+        z = (ih + 0.15 + 0.7 * _hash01(it, ih, 301 + 2 * k)) * (h / nh)
+        p = c + np.stack([r * np.cos(th), r * np.sin(th), z], axis=1)
+        keep = (p[:, 0] >= lo[0]) & (p[:, 0] <= hi[0]) & (p[:, 1] >= lo[1]) & (p[:, 1] <= hi[1])
+        if keep.any():
+            pts.append(p[keep]); cols.append(np.broadcast_to(C["col"][k], (keep.sum(), 3))); keys.append(_hash01(it[keep], ih[keep], 9000 + k))
+    pw = np.concatenate(pts); bc = np.concatenate(cols).astype(np.float64); key = np.concatenate(keys)
+    if len(pw) > n_points:                                 # thin by the nodes' own hash: the same nodes go in every map
+        thr = np.partition(key, n_points - 1)[n_points - 1]
+        sel = key <= thr
+        pw, bc, key = pw[sel][:n_points], bc[sel][:n_points], key[sel][:n_points]
+    rgb = _texture(pw, bc, world.seed)
+    # sensor noise hashed from the (quantised) world position: the same in every map that sees the sample
+    q = np.floor(pw * 1000.0).astype(np.int64)
+    nz = np.stack([_hash01(q[:, 0], q[:, 1] + 7 * q[:, 2], 31 + a) for a in range(3)], axis=1) - 0.5
+    pw = pw + nz * (noise * np.sqrt(12.0))
+    yaw = rng.uniform(-np.pi, np.pi)
+    pitch_a, roll = np.deg2rad(rng.uniform(-5, 5, size=2))
+    R = _rot(yaw, float(pitch_a), float(roll))
+    t = rng.uniform(-10.0, 10.0, size=3) * np.array([1.0, 1.0, 0.1])
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t - R @ centre
+    pm = pw @ R.T + T[:3, 3]
+    perm = rng.permutation(len(pm))
+    return pm[perm].astype(np.float32), rgb[perm], T
+
+
+def lattice_maps(n_maps: int, n_points: int, world_seed: int = 1234, object_density: float = 0.08, **kw):
+    """The lattice scene family: world + maps + T_gt, like synth_maps."""
+    w = kw.get("window") or window_for(n_points)
+    loop_r = kw.get("overlap_step", 0.5) * w * max(n_maps, 2) / (2.0 * np.pi)
+    extent = max(2.0 * (loop_r + w / 2.0 + 2.0), w + 4.0)
+    world = synth_world(world_seed, extent=extent, object_density=object_density)
+    return world, [lattice_map(world, i, n_points, n_maps=n_maps, **kw) for i in range(n_maps)]

@@ -13,10 +13,12 @@ src = lambda n: os.path.join(root, "gpurun_out", f"{tag}_{n}")
 dst = lambda n: os.path.join(root, "profiles", f"{tag}_{n}")
 f = {r["kernel"]: (int(r["dispatches"]), float(r["FETCH_SIZE"])) for r in csv.DictReader(open(src("pmc_FETCH_SIZE.csv")))}
 w = {r["kernel"]: (int(r["dispatches"]), float(r["WRITE_SIZE"])) for r in csv.DictReader(open(src("pmc_WRITE_SIZE.csv")))}
-names = {"k_sift_dog": "sift_dog", "k_spfh": "spfh", "k_sacia_err": "sacia_err", "k_nn_wave": ["icp_corr_reduce", "score_nn_reduce"],
+sys.path.insert(0, root)
+import bench  # noqa: E402  (KERNEL_SOURCES / kernel_source_hash: what makes a committed counter stale)
+names = {"k_sift_dog_lds": "sift_dog", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_spfh": "spfh", "k_sacia_err": "sacia_err", "k_nn_wave": ["icp_corr_reduce", "score_nn_reduce"],
          "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce",
          "k_sift_extrema": "sift_extrema", "k_seq_sum": "sacia_seq_sum", "k_knn_mfma": "desc_knn_mfma", "k_knn_rerank": "desc_knn_rerank",
-         "k_fpfh_weight": "fpfh_weight", "k_fpfh_mark": "fpfh_mark", "k_normals": "normals_radius",
+         "k_fpfh_weight": "fpfh_weight", "k_fpfh_mark": "fpfh_mark", "k_normals": "normals_radius_big",
          "k_radius_count": "radius_outlier_count", "k_voxel_centroid": "voxel_centroid", "trampoline_kernel": "rocprim_radix_sort_pairs"}
 out, rows = {}, []
 for k, (d, fs) in f.items():
@@ -30,7 +32,8 @@ for k, (d, fs) in f.items():
 json.dump({"_note": "HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / dispatches (MI355X_MICROARCH.md: gfx950 FETCH_SIZE "
                     "reads half of a wide coalesced stream; separate --pmc passes; Infinity-Cache hits are counted).  bench.py --steps 1 "
                     "--warmup 1 --streams 1 under rocprofv3 --pmc.  rocprim_radix_sort_pairs is the average over ALL rocPRIM kernels (sort and scan passes).",
-           "bytes_per_launch": out}, open(dst("traffic.json"), "w"), indent=1)
+           "bytes_per_launch": out,
+           "source_sha256": {k: bench.kernel_source_hash(k) for k in out if bench.kernel_source_hash(k)}}, open(dst("traffic.json"), "w"), indent=1)
 with open(dst("pmc_hbm_traffic.csv"), "w") as fo:
     fo.write("kernel,dispatches,FETCH_SIZE_KB_per_launch_raw,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch_corrected\n")
     for r in sorted(rows, key=lambda r: -r[4] * r[1]):
