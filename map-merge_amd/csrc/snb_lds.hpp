@@ -48,12 +48,17 @@ struct SnbStats { long long v[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0
 #define SNB_TOCK(i_, from_) do { snb_st.v[i_] += clock64() - (from_); } while (0)
 #define SNB_COUNT(i_, v_) do { snb_st.v[i_] += (v_); } while (0)
 #define SNB_FLUSH() do { if ((threadIdx.x & 63) == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_snb_stats[i_], (unsigned long long)snb_st.v[i_]); } } while (0)
+// 16 longest item (ticks), 17 items worked in parts, 18 parts of those, 19 bands beyond the first, 20 longest wave total
+#define SNB_MAX(i_, v_) do { if ((threadIdx.x & 63) == 0) atomicMax(&g_snb_stats[i_], (unsigned long long)(v_)); } while (0)
+#define SNB_ADD(i_, v_) do { if (threadIdx.x == 0) atomicAdd(&g_snb_stats[i_], (unsigned long long)(v_)); } while (0)
 #else
 struct SnbStats {};
 #define SNB_TICK(var_)
 #define SNB_TOCK(i_, from_)
 #define SNB_COUNT(i_, v_)
 #define SNB_FLUSH()
+#define SNB_MAX(i_, v_)
+#define SNB_ADD(i_, v_)
 #endif
 
 template <int WAVES_, int TILE_CAP_, int ARENA_, int HIT_CAP_, int NB_, bool PAY_>
@@ -460,6 +465,7 @@ __device__ __forceinline__ int snb_sort_one(SnbLds<Cfg> &S, SnbWave<Cfg> &W, flo
 // of two that doubles until every band fits (the list is the bands one after the other); a list that does not fit
 // the arena even alone sets *overflow (the item goes to the fallback launch) and is left empty.
 constexpr int kSnbMaxBands = 16;
+constexpr int kSnbMaxParts = 4;
 template <class Cfg>
 __device__ __forceinline__ int snb_build(SnbLds<Cfg> &S, SnbWave<Cfg> &W, float qx, float qy, float qz, int n_q, float r2, int n_pad, int lane,
                                          int *overflow, SnbStats &snb_st)
@@ -487,6 +493,7 @@ __device__ __forceinline__ int snb_build(SnbLds<Cfg> &S, SnbWave<Cfg> &W, float 
       if (status != 3) break;
       if (nb == kSnbMaxBands) { status = 2; break; }
       nb *= 2;                                     // (kept for the wave's later queries of this round: they are neighbours)
+
     }
     SNB_COUNT(11, 1);
     if (status == 1 && p > 0) break;               // the arena is full: this query opens the next round
@@ -565,7 +572,10 @@ __device__ __forceinline__ void snb_run(const GridView &g, SnbLds<Cfg> &S, const
       const int n_tile = snb_stage_queries<Cfg>(g, S, q_pts, it.x + lo, hi - lo, ri, load_pay, snb_st);
       SNB_COUNT(13, n_tile);
       if (n_tile > Cfg::kTileCap) {                // block-uniform
-        if (hi - lo == 1) {                        // one query's own box: the fallback launch takes the item
+        // Halving the run of queries shrinks the box only by the patch's share of it (the radius margin stays), and
+        // every part is a staging of its own with fewer queries per wave: beyond kSnbMaxParts the item is a dense
+        // spot for the fallback launch (measured: an item worked down to single queries took 3.5 ms of a 1.8 ms kernel)
+        if (hi - lo == 1 || parts >= kSnbMaxParts) {
           if (threadIdx.x == 0) S.overflow = 1;
           ++part;
         } else {                                   // the same queries again, in two halves
@@ -603,14 +613,21 @@ __device__ __forceinline__ void snb_run(const GridView &g, SnbLds<Cfg> &S, const
     __syncthreads();
     SNB_TOCK(10, t_eb);
     if (threadIdx.x == 0 && S.overflow) ov_items[atomicAdd(&ctl->ov_count, 1)] = item;
+#ifdef MM3D_SNB_STATS
+    SNB_MAX(16, clock64() - t_claim);
+    if (parts > 1) { SNB_ADD(17, 1); SNB_ADD(18, parts); }
+#endif
   }
   SNB_TOCK(15, t_all);
+#ifdef MM3D_SNB_STATS
+  SNB_MAX(20, clock64() - t_all);
+#endif
   SNB_FLUSH();
 }
 
 // host side
 int snb_cu_count(int device);                    // grid.hip
-constexpr unsigned kSnFallbackBlocks = 64;       // grid of the fallback launches (sorted_nb.hpp kernels over the overflow list)
+constexpr unsigned kSnFallbackBlocks = 128;      // grid of the fallback launches (sorted_nb.hpp kernels over the overflow list)
 
 template <class Cfg>
 struct SnbLaunch {
