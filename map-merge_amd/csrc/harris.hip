@@ -8,22 +8,17 @@
 //                         calculateNormalCovar: sums divided by float(count)); response = 0.04 + det C - 0.04 tr(C)^2
 //   detectKeypoints       keep points with response >= threshold that no neighbour within the radius beats
 //   refineCorners         <= 10 steps of  x <- (sum n n^T)^-1 (sum n n^T p)  over the neighbours of x
-// Kernels: one thread per point for the response and the suppression (neighbour normals packed in grid
-// order); one WAVE per corner for the refinement, which sorts the neighbours by (distance, index) and
-// runs the twelve float sums as sequential chains in that order -- the refined positions are bit-equal
-// to the CPU restatement.  The response sums run in grid order instead (sorting 400 k neighbourhoods
-// would cost more than everything else): responses agree to float rounding, see tests.
-#include "device_util.hpp"
+// Kernels: the response sums the neighbours' normal products in radiusSearch's (distance, index) order like the
+// CPU loop does -- sorted neighbour lists in LDS (snb_lds.hpp, the machinery of normals.hip), six chains per point
+// -- so the responses, and with them the set of corners, are the CPU restatement's bit for bit; one thread per
+// point for the suppression; one WAVE per corner for the refinement, which sorts the neighbours by (distance,
+// index) and runs the twelve float sums as sequential chains in that order.
+#include "sorted_nb.hpp"
+#include "snb_lds.hpp"
 
 namespace mm3d {
 
 constexpr int kHarrisCap = 2048;   // neighbour keys of one corner held in LDS (a power of two)
-
-__global__ void k_harris_pack(const float4 *__restrict__ sorted, const float4 *__restrict__ nrm, int n, float4 *__restrict__ out)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) out[j] = nrm[__float_as_int(sorted[j].w)];
-}
 
 template <class F>
 __device__ __forceinline__ void harris_for_each(const GridView &g, float qx, float qy, float qz, float r, F &&f)
@@ -44,29 +39,9 @@ __device__ __forceinline__ void harris_for_each(const GridView &g, float qx, flo
     }
 }
 
-// responseHarris; resp_sorted in grid order (the grid holds the finite points only; the others keep 0)
-__global__ void __launch_bounds__(256)
-k_harris_response(GridView g, const float4 *__restrict__ nrm_sorted, float radius, float r2, float *__restrict__ resp_sorted)
+// what a point's response is once its six sums and the number of finite normals are known
+__device__ __forceinline__ float harris_response_of(float xx, float xy, float xz, float yy, float yz, float zz, unsigned count)
 {
-  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int i = bid * blockDim.x + threadIdx.x;
-  if (i >= g.n) return;
-  const float4 q = g.pts[i];
-  float xx = 0.f, xy = 0.f, xz = 0.f, yy = 0.f, yz = 0.f, zz = 0.f;
-  unsigned count = 0;
-  harris_for_each(g, q.x, q.y, q.z, radius, [&](int j) {
-    const float4 p = g.pts[j];
-    if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) {
-      const float4 n = nrm_sorted[j];
-      if (isfinite(n.x)) {
-        xx += n.x * n.x; xy += n.x * n.y; xz += n.x * n.z;
-        yy += n.y * n.y; yz += n.y * n.z;
-        zz += n.z * n.z;
-        ++count;
-      }
-    }
-    return true;
-  });
   if (count > 0) {
     const float c = (float)count;
     xx /= c; xy /= c; xz /= c; yy /= c; yz /= c; zz /= c;
@@ -77,7 +52,135 @@ k_harris_response(GridView g, const float4 *__restrict__ nrm_sorted, float radiu
     const float det = xx * yy * zz + 2.0f * xy * xz * yz - xz * xz * yy - xy * xy * zz - yz * yz * xx;
     r = 0.04f + det - 0.04f * trace * trace;
   }
-  resp_sorted[i] = r;
+  return r;
+}
+
+// responseHarris, by ORIGINAL index (non-finite points keep 0).  Eight lanes per point: lane sub < 6 owns the sum
+// sub of {xx, xy, xz, yy, yz, zz} and walks the point's sorted list; a neighbour whose normal is not finite is
+// skipped (and not counted), like in the CPU loop.
+using HarrisCfg = SnbCfg<8, 1792, 1024, 256, 128, false>;
+
+__global__ void __launch_bounds__(512)
+k_harris_response_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g, const float4 *__restrict__ nrm,
+                      float radius, float r2, SnbCtl *ctl, int *__restrict__ ov_items, float *__restrict__ resp /* by original index */)
+{
+  using Cfg = HarrisCfg;
+  __shared__ SnbLds<Cfg> S;
+  __shared__ float sums[Cfg::kWaves][Cfg::kQ][6];
+  __shared__ unsigned cnts[Cfg::kWaves][Cfg::kQ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  SnbWave<Cfg> &W = S.w[wave];
+  snb_run<Cfg>(
+      g, S, q_pts, items, n_items, radius, r2, ctl, ov_items, [](const float4 &) { return 0.0f; },
+      [&](int q_first, int fit, const float4 &) {
+        const int p = lane >> 3, sub = lane & 7;
+        if (p < fit) {
+          const int base = W.list_off[p], m = W.list_off[p + 1] - base;
+          float acc = 0.0f;
+          unsigned count = 0;
+          for (int e = 0; e < m; ++e) {
+            const float4 nv = nrm[S.tw[W.arena[base + e]]];
+            if (isfinite(nv.x)) {
+              const float u = sub <= 2 ? nv.x : (sub <= 4 ? nv.y : nv.z);
+              const float v = sub == 0 ? nv.x : ((sub == 1 || sub == 3) ? nv.y : nv.z);
+              acc = __fadd_rn(acc, __fmul_rn(u, v));
+              ++count;
+            }
+          }
+          if (sub < 6) sums[wave][p][sub] = acc;
+          if (sub == 0) cnts[wave][p] = count;
+        }
+        wave_lds_fence();
+        if (lane < fit) {
+          const float *a = sums[wave][lane];
+          resp[__float_as_int(q_pts[q_first + lane].w)] = harris_response_of(a[0], a[1], a[2], a[3], a[4], a[5], cnts[wave][lane]);
+        }
+        wave_lds_fence();
+      });
+}
+
+// the same for the work items the LDS path could not hold (sorted_nb.hpp: lists in global scratch)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_harris_response_big(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g, const float4 *__restrict__ pts,
+                      const float4 *__restrict__ nrm, float radius, float r2, SnScratch sc, float *__restrict__ resp)
+{
+  __shared__ SnLds lds[4];
+  __shared__ float sums[4][kSnG][6];
+  __shared__ unsigned cnts[4][kSnG];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  SnLds &L = lds[wave];
+  const size_t slot = (size_t)blockIdx.x * 4 + wave;
+  unsigned long long *tmp = sc.tmp + slot * kSnEntries;
+  float4 *fin = (float4 *)sc.fin + slot * kSnEntries;
+  const int n_units = sn_unit_count(sc, n_items);
+  for (;;) {
+    const int unit = sn_claim_unit(sc.unit_ctr, n_units, lane);
+    if (unit < 0) break;
+    const int2 it = items[sn_unit_item(sc, unit)];
+    int first = (unit & 3) * kSnG;
+    int left = min(kSnG, it.y - first);
+    while (left > 0) {
+      const int p = lane >> 2, sub = lane & 3;
+      const float4 q = q_pts[it.x + first + (p < left ? p : 0)];
+      const int fit = sn_build_lists<float4>(g, L, q.x, q.y, q.z, left, radius, r2, pts, tmp, fin, sc.error, lane,
+                                             [&](float, unsigned idx, const float4 &) { return nrm[idx]; });
+      if (p < fit) {
+        const int base = L.list_off[p], m = L.list_off[p + 1] - base;
+        // lane sub owns sums sub and sub + 4 (sub < 2) of {xx, xy, xz, yy, yz, zz}
+        float a0 = 0.0f, a1 = 0.0f;
+        unsigned count = 0;
+        for (int e = 0; e < m; ++e) {
+          const float4 nv = fin[base + e];
+          if (isfinite(nv.x)) {
+            const float u0 = sub <= 2 ? nv.x : nv.y, v0 = sub == 0 ? nv.x : ((sub == 1 || sub == 3) ? nv.y : nv.z);
+            a0 = __fadd_rn(a0, __fmul_rn(u0, v0));
+            const float u1 = sub == 0 ? nv.y : nv.z;
+            a1 = __fadd_rn(a1, __fmul_rn(u1, nv.z));
+            ++count;
+          }
+        }
+        sums[wave][p][sub] = a0;
+        if (sub < 2) sums[wave][p][sub + 4] = a1;
+        if (sub == 0) cnts[wave][p] = count;
+      }
+      wave_lds_fence();
+      if (lane < fit) {
+        const float *a = sums[wave][lane];
+        resp[__float_as_int(q_pts[it.x + first + lane].w)] = harris_response_of(a[0], a[1], a[2], a[3], a[4], a[5], cnts[wave][lane]);
+      }
+      wave_lds_fence();
+      first += fit;
+      left -= fit;
+    }
+  }
+}
+
+__global__ void k_harris_to_sorted(const float4 *__restrict__ sorted, const float *__restrict__ resp, int n, float *__restrict__ resp_sorted)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) resp_sorted[j] = resp[__float_as_int(sorted[j].w)];
+}
+
+// the responses of a cloud by original index (zero where the point is not finite): the LDS path, then the
+// (normally empty) launch over the items it could not hold
+static void harris_response_launch(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, const Grid &g, float sr, float r2,
+                                   float *resp /* n floats, zeroed */)
+{
+  cloud_hilbert(c, points);
+  const int n_items = points->n_wave_items;
+  SnbLaunch<HarrisCfg> sl(c, n_items, sizeof(float) * 64 * 7 + 256);
+  SnbCtl *ctl = sl.ctl_dev();
+  MM3D_LAUNCH(c, "harris_response", g.n * 32.0, k_harris_response_lds, dim3(sl.blocks), dim3(64 * HarrisCfg::kWaves), 0,
+              (const float4 *)points->hil_pts.get(), (const int2 *)points->wave_items.get(), n_items, g.view(), (const float4 *)normals->nrm.get(),
+              sr, r2, ctl, sl.ov_items.get(), resp);
+  SnLaunch<float4> sn(c, n_items * 4, points->n, 4, kSnFallbackBlocks);
+  SnScratch sc{sn.tmp.get(), sn.fin.get(), ctl->fb_ctr, &ctl->error, sl.ov_items.get(), &ctl->ov_count};
+  MM3D_LAUNCH(c, "harris_response_big", 0.0, k_harris_response_big, dim3(sn.blocks), dim3(256), 0, (const float4 *)points->hil_pts.get(),
+              (const int2 *)points->wave_items.get(), n_items, g.view(), (const float4 *)points->pts.get(), (const float4 *)normals->nrm.get(), sr, r2,
+              sc, resp);
+  int *h = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(h, &ctl->error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->check_later(h, MM3D_EUNSUPPORTED, "detectKeypoints(HARRIS): a point has more than 16384 neighbours within the radius");
 }
 
 // non-maximum suppression: flag (by ORIGINAL index, so that the compaction emits keypoints in index order)
@@ -97,12 +200,6 @@ k_harris_nonmax(GridView g, const float *__restrict__ resp_sorted, float radius,
     return true;
   });
   if (is_max) flags[__float_as_int(q.w)] = 1;
-}
-
-__global__ void k_harris_unsort(const float4 *__restrict__ sorted, const float *__restrict__ resp_sorted, int n, float *__restrict__ out)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) out[__float_as_int(sorted[j].w)] = resp_sorted[j];
 }
 
 __global__ void k_harris_emit(const float4 *__restrict__ pts, const int *__restrict__ flags, const int *__restrict__ pos, int n,
@@ -249,14 +346,8 @@ void harris_response(Context *c, const mm3d_cloud *points, const mm3d_normals *n
   const float r2 = (float)(sr * sr);
   const Grid &g = cloud_grid(c, points, (float)(sr * 0.5));
   if (g.n == 0) return;
-  DevBuf<float4> ns(c, g.n);
-  DevBuf<float> rs(c, g.n);
-  MM3D_LAUNCH(c, "harris_pack", g.n * 36.0, k_harris_pack, dim3(div_up(g.n, 256)), dim3(256), 0, (const float4 *)g.sorted.get(),
-              (const float4 *)normals->nrm.get(), g.n, ns.get());
-  MM3D_LAUNCH(c, "harris_response", g.n * 32.0, k_harris_response, dim3(div_up(g.n, 256)), dim3(256), 0, g.view(), (const float4 *)ns.get(),
-              (float)sr, r2, rs.get());
-  MM3D_LAUNCH(c, "harris_pack", g.n * 12.0, k_harris_unsort, dim3(div_up(g.n, 256)), dim3(256), 0, (const float4 *)g.sorted.get(),
-              (const float *)rs.get(), g.n, out.get());
+  harris_response_launch(c, points, normals, g, (float)sr, r2, out.get());
+  c->settle();
 }
 
 mm3d_cloud *detect_keypoints_harris(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, double threshold, double radius)
@@ -268,12 +359,11 @@ mm3d_cloud *detect_keypoints_harris(Context *c, const mm3d_cloud *points, const 
   if (n == 0) return cloud_from_device(c, DevBuf<float4>(c, 0), 0);
   const Grid &g = cloud_grid(c, points, (float)(sr * 0.5));
   if (g.n == 0) return cloud_from_device(c, DevBuf<float4>(c, 0), 0);
-  DevBuf<float4> ns(c, g.n);
-  DevBuf<float> rs(c, g.n);
-  MM3D_LAUNCH(c, "harris_pack", g.n * 36.0, k_harris_pack, dim3(div_up(g.n, 256)), dim3(256), 0, (const float4 *)g.sorted.get(),
-              (const float4 *)normals->nrm.get(), g.n, ns.get());
-  MM3D_LAUNCH(c, "harris_response", g.n * 32.0, k_harris_response, dim3(div_up(g.n, 256)), dim3(256), 0, g.view(), (const float4 *)ns.get(),
-              (float)sr, r2, rs.get());
+  DevBuf<float> ro(c, (size_t)n), rs(c, g.n);
+  MM3D_HIP(hipMemsetAsync(ro.get(), 0, (size_t)n * sizeof(float), c->stream));
+  harris_response_launch(c, points, normals, g, (float)sr, r2, ro.get());
+  MM3D_LAUNCH(c, "harris_pack", g.n * 12.0, k_harris_to_sorted, dim3(div_up(g.n, 256)), dim3(256), 0, (const float4 *)g.sorted.get(),
+              (const float *)ro.get(), g.n, rs.get());
   DevBuf<int> flags(c, (size_t)n + 1), pos(c, (size_t)n + 1);
   MM3D_HIP(hipMemsetAsync(flags.get(), 0, ((size_t)n + 1) * sizeof(int), c->stream));
   MM3D_LAUNCH(c, "harris_nonmax", g.n * 20.0, k_harris_nonmax, dim3(div_up(g.n, 256)), dim3(256), 0, g.view(), (const float *)rs.get(),

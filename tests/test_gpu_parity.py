@@ -630,8 +630,9 @@ def test_shot_configuration_end_to_end(ctx, po, mm, scene, synth):
         ref_T, ref_pairs = po.estimate_maps_transforms([a["raw"], b["raw"]], op)
         T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
         assert len(T) == len(ref_T) == 2 and len(pairs) == len(ref_pairs) == 1
-        assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= 0.15, method
-        assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=0.2)
+        assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= 1e-3, method
+        assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=1e-3)
+        assert pairs[0]["n_correspondences"] == len(po.last_pair_trace()["correspondences"]) if method == 0 and "correspondences" in (po.last_pair_trace() or {}) else True
         # and the right basin: the generator's ground truth (ICP stops at transform_epsilon = 1e-2 on
         # this sparse 12 k-point scene, a few decimetres short -- the CPU path stops at the same place)
         gt = synth.relative_gt(a["T"], b["T"])
@@ -674,26 +675,24 @@ def test_pfhrgb(ctx, po, mm, scene):
     ref_T, ref_pairs = po.estimate_maps_transforms([a["raw"], b["raw"]], op)
     T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
     assert len(pairs) == len(ref_pairs) == 1
-    assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= 1e-3
+    # (the two maps lie 25 m apart: the CPU path's ICP sums are sequential float sums over coordinates of that
+    # size, the device's run in double -- 1e-3 per 10 m of translation)
+    tol = 1e-3 * max(1.0, float(np.linalg.norm(ref_pairs[0]["transform"][12:15])) / 10.0)
+    assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= tol
     assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=1e-3)
 
 
 def test_harris_keypoints(ctx, po, mm, scene):
-    """detectKeypoints(HARRIS) (features.cpp:64-83): response within float rounding of the oracle (the sums
-    run in grid order instead of the oracle's neighbour order), the same corners, refined positions
-    bit-equal (the refinement keeps the oracle's order)."""
+    """detectKeypoints(HARRIS) (features.cpp:64-83): the responses (their sums run in radiusSearch's order, like the
+    oracle's), the set of corners and the refined positions are the oracle's bit for bit."""
     for m in scene:
         pts, nrm = ctx.cloud(m["filt"]), ctx.normals(m["nrm"])
         kp_ref, idx_ref, resp_ref = po.keypoints_harris(m["filt"], m["nrm"], 0.002, R_NRM)
         resp = ctx.harrisResponse(pts, nrm, R_NRM)
-        assert np.abs(resp - resp_ref).max() <= 2e-6, np.abs(resp - resp_ref).max()
+        assert np.array_equal(resp.view(np.uint32), resp_ref.view(np.uint32)), np.abs(resp - resp_ref).max()
         kp = ctx.detectKeypoints(pts, nrm, 1, 0.002, R_NRM, RES).numpy()
         assert len(kp_ref) >= 10
-        # a response 1e-7 away from the oracle's can flip a comparison against the threshold or a neighbour:
-        # allow one corner of difference, the common ones must agree bit for bit
-        a = {tuple(r) for r in xyz(kp).view(np.uint32).tolist()}
-        b = {tuple(r) for r in xyz(kp_ref).view(np.uint32).tolist()}
-        assert len(a ^ b) <= 1 and len(a & b) >= len(b) - 1, (len(a), len(b), len(a & b))
+        assert np.array_equal(xyz(kp).view(np.uint32), xyz(kp_ref).view(np.uint32))
         assert (kp["rgba"] == 0).all()
     # through the pipeline: keypoint_type = HARRIS with FPFH + SAC-IA on the two maps
     a, b = scene
@@ -702,7 +701,10 @@ def test_harris_keypoints(ctx, po, mm, scene):
     po.srand(1); ctx.srand(1)
     ref_T, ref_pairs = po.estimate_maps_transforms([a["raw"], b["raw"]], op)
     T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
-    assert len(pairs) == len(ref_pairs) == 1 and np.isfinite(pairs[0]["transform"]).all()
+    assert len(pairs) == len(ref_pairs) == 1
+    # corners, descriptors and the SAC-IA winner are the oracle's bits; ICP and the score reduce in double on the device
+    assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= 1e-3
+    assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=1e-3)
     f = ctx.mapFeatures(ctx.cloud(a["raw"]), params)
     nk = len(f.keypoints)
     f.free()
@@ -753,9 +755,16 @@ def test_rsd(ctx, po, mm, scene):
             assert np.array_equal(a["index_match"], b["index_match"]) and np.array_equal(a["distance"].view(np.uint32), b["distance"].view(np.uint32))
     a, b = scene
     params = mm.MapMergingParams(descriptor_type=3, estimation_method=1)
-    ctx.srand(1)
+    op = po.params_default(); op.descriptor_type = 3; op.estimation_method = 1
+    po.srand(1); ctx.srand(1)
+    ref_T, ref_pairs = po.estimate_maps_transforms([a["raw"], b["raw"]], op)
     T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
-    assert len(pairs) == 1 and np.isfinite(pairs[0]["transform"]).all()
+    assert len(pairs) == len(ref_pairs) == 1
+    # (the two maps lie 25 m apart: the CPU path's ICP sums are sequential float sums over coordinates of that
+    # size, the device's run in double -- 1e-3 per 10 m of translation)
+    tol = 1e-3 * max(1.0, float(np.linalg.norm(ref_pairs[0]["transform"][12:15])) / 10.0)
+    assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= tol
+    assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=1e-3)
 
 
 def test_sc3d(ctx, po, mm, scene):
@@ -788,9 +797,16 @@ def test_sc3d(ctx, po, mm, scene):
     assert np.array_equal(a["index_match"], b["index_match"]) and np.array_equal(a["distance"].view(np.uint32), b["distance"].view(np.uint32))
     a, b = scene
     params = mm.MapMergingParams(descriptor_type=5, estimation_method=1)
-    ctx.srand(1)
+    op = po.params_default(); op.descriptor_type = 5; op.estimation_method = 1
+    po.srand(1); ctx.srand(1)
+    ref_T, ref_pairs = po.estimate_maps_transforms([a["raw"], b["raw"]], op)
     T, pairs = ctx.estimateMapsTransforms([a["raw"], b["raw"]], params, return_pairs=True)
-    assert len(pairs) == 1 and np.isfinite(pairs[0]["transform"]).all()
+    assert len(pairs) == len(ref_pairs) == 1
+    # (the two maps lie 25 m apart: the CPU path's ICP sums are sequential float sums over coordinates of that
+    # size, the device's run in double -- 1e-3 per 10 m of translation)
+    tol = 1e-3 * max(1.0, float(np.linalg.norm(ref_pairs[0]["transform"][12:15])) / 10.0)
+    assert np.linalg.norm(pairs[0]["transform"] - ref_pairs[0]["transform"]) <= tol
+    assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=1e-3)
 
 
 def test_float_chain_replay_is_exact(ctx, mm):
