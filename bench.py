@@ -116,12 +116,14 @@ def cgroup_throttle():
     return 0
 
 
-def make_workload_gt(n_maps, n_points, cache=True, scenes="independent", overlap_step=0.5):
+def make_workload_gt(n_maps, n_points, cache=True, scenes="independent", overlap_step=0.5, window=0.0):
     """The synthetic maps as packed records plus their ground-truth poses.  scenes: 'independent' = every map draws its
     own surface samples (synth.synth_map; the headline workload), 'lattice' = the maps share the samples of one
     world-anchored lattice (synth.lattice_map)."""
     from map_merge_amd import synth
     kw = {} if overlap_step == 0.5 else {"overlap_step": overlap_step}
+    if window > 0:
+        kw["window"] = window
     return synth.cached_maps(n_maps, n_points, cache_dir="/tmp" if cache else None, family=scenes, **kw)
 
 
@@ -178,6 +180,9 @@ def main():
     ap.add_argument("--overlap-step", type=float, default=0.5,
                     help="distance between consecutive map windows in window sides (0.5 = about half of a window shared)")
     ap.add_argument("--sac-iterations", type=int, default=0, help="MapMergingParams.max_iterations (0 = the reference's default, 500)")
+    ap.add_argument("--window", type=float, default=0.0, help="side of a map's window in metres (0 = 60 m at 500 k points, constant raw density)")
+    ap.add_argument("--resolution", type=float, default=0.0, help="MapMergingParams.resolution (0 = the reference's default 0.1; the radii keep their defaults, "
+                    "as with the reference's --resolution option)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the extra PCIe-inclusive step (host pcl::PointXYZRGB input) at N = 1")
     args = ap.parse_args()
 
@@ -213,10 +218,12 @@ def main():
                                  refine_transform=1)
     if args.sac_iterations > 0:
         params.max_iterations = args.sac_iterations
+    if args.resolution > 0:
+        params.resolution = args.resolution
 
     # ---- synthetic workload, resident in HBM before timing ---------------------------------
     n_maps, n_pts = args.maps, args.points
-    host, T_gt, _ = make_workload_gt(n_maps, n_pts, cache=not args.no_cache, scenes=args.scenes, overlap_step=args.overlap_step)
+    host, T_gt, _ = make_workload_gt(n_maps, n_pts, cache=not args.no_cache, scenes=args.scenes, overlap_step=args.overlap_step, window=args.window)
     dev_raw = [torch.from_numpy(h.view(np.uint8).reshape(-1, 16)).to(dev) for h in host]
     torch.cuda.synchronize()
     pairs_idx = [(i, j) for i in range(n_maps - 1) for j in range(i + 1, n_maps)]
@@ -579,6 +586,9 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n_maps} maps x {n_pts} raw pts, {args.descriptor} + {args.method} + ICP refine, {n_pairs} pairs"
+                                   + (f", {args.window:g} m windows" if args.window > 0 else "") + (f", resolution {args.resolution:g}" if args.resolution > 0 else "")
+                                   + (f", '{args.scenes}' scenes, windows {args.overlap_step:g} of a side apart" if args.scenes != "independent" or args.overlap_step != 0.5 else "")
+                                   + (f", {args.sac_iterations} SAC-IA hypotheses" if args.sac_iterations > 0 else "")
                                    + (" [DIAGNOSTIC: host pcl::PointXYZRGB input, upload inside the step]" if args.host_input != "none" else ""),
                        "parallelism": (f"one mm3d_estimate_maps_transforms call, {S} streams inside the library"
                                        if world == 1 and args.engine == "library" else
@@ -617,7 +627,7 @@ def main():
         errs = []
         for rec in stats.get("records", []):
             i, j = int(rec["source_idx"]), int(rec["target_idx"])
-            if synth.window_overlap(n_maps, n_pts, i, j, overlap_step=args.overlap_step) >= 0.3:
+            if synth.window_overlap(n_maps, n_pts, i, j, overlap_step=args.overlap_step, window=args.window or None) >= 0.3:
                 errs.append(float(np.linalg.norm(np.asarray(rec["transform"], dtype=np.float64).reshape(4, 4).T - synth.relative_gt(T_gt[i], T_gt[j]))))
         out["gt_error"] = {"pairs_with_overlap_ge_0.3": len(errs),
                            "median_frobenius": round(float(np.median(errs)), 4) if errs else None,

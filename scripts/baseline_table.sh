@@ -19,3 +19,7 @@ run 2 --maps 4 --points 200000 --steps 5 --warmup 1
 run 3
 run 5 --maps 64 --points 50000 --steps 2 --warmup 1
 run 4 --maps 8 --points 2000000 --descriptor SHOT --steps 2 --warmup 1
+# configs[3] as SURVEY 8d words it: dense indoor -- 30 m windows, resolution 0.05 (the radii keep the reference's defaults)
+run 4indoor --maps 8 --points 2000000 --descriptor SHOT --window 30 --resolution 0.05 --steps 1 --warmup 1
+# the 'lattice' scene family with enough SAC-IA hypotheses for the algorithm to find the basin: ICP iterates, gt_error is small
+run 2lattice --maps 4 --points 200000 --scenes lattice --overlap-step 0.25 --sac-iterations 20000 --steps 3 --warmup 1

@@ -622,25 +622,33 @@ def test_threads_do_not_change_a_bit(po, synth):
     assert a == b
 
 
+PCL_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pcl_pair_12k.bin")
+
+
 def test_oracle_against_real_pcl(po, synth, tmp_path):
-    """Baseline B3: where a real PCL is installed, oracle/pcl_harness/build.sh builds
-    oracle/_ref/pcl_oracle -- the reference's own PCL calls -- and every stage of the restatement is held against it.
-    This image has no PCL: the test then reports exactly that and the oracle stays unpinned."""
+    """Baseline B3: every stage of the restatement held against the reference's own PCL calls
+    (oracle/pcl_harness/pcl_oracle.cpp).  The PCL side comes from tests/golden/pcl_pair_12k.bin when that file is
+    committed (scripts/pin_from_pcl.sh writes it on any machine with PCL >= 1.8: one command pins the oracle for good),
+    else from the harness built here; this image has no PCL, so without the file the test reports
+    exactly that and the oracle stays unpinned."""
     import struct
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.run([os.path.join(root, "oracle", "pcl_harness", "build.sh")], capture_output=True)
-    exe = os.path.join(root, "oracle", "_ref", "pcl_oracle")
-    if not os.path.exists(exe):
-        pytest.skip("PCL absent -- oracle = restatement (parity unpinned)")
     _, maps = synth.synth_maps(2, 12000)
     raws = [synth.pack_points(x, c) for x, c, _ in maps]
-    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
-    with open(inp, "wb") as f:
-        f.write(struct.pack("<Q", len(raws)))
-        for r in raws:
-            f.write(struct.pack("<Q", len(r)) + r.tobytes())
-    assert subprocess.run([exe, inp, outp], timeout=1800).returncode == 0
+    if os.path.exists(PCL_GOLDEN):
+        outp = PCL_GOLDEN
+    else:
+        subprocess.run([os.path.join(root, "oracle", "pcl_harness", "build.sh")], capture_output=True)
+        exe = os.path.join(root, "oracle", "_ref", "pcl_oracle")
+        if not os.path.exists(exe):
+            pytest.skip("PCL absent -- oracle = restatement (parity unpinned)")
+        inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+        with open(inp, "wb") as f:
+            f.write(struct.pack("<Q", len(raws)))
+            for r in raws:
+                f.write(struct.pack("<Q", len(r)) + r.tobytes())
+        assert subprocess.run([exe, inp, outp], timeout=1800).returncode == 0
     data = open(outp, "rb").read()
     off = [0]
 
