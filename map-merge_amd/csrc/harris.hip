@@ -72,7 +72,7 @@ k_harris_response_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__
   SnbWave<Cfg> &W = S.w[wave];
   snb_run<Cfg>(
       g, S, q_pts, items, n_items, radius, r2, ctl, ov_items, [](const float4 &) { return 0.0f; },
-      [&](int q_first, int fit, const float4 &) {
+      [&](int fit, const float4 &, const float4 &qw) {
         const int p = lane >> 3, sub = lane & 7;
         if (p < fit) {
           const int base = W.list_off[p], m = W.list_off[p + 1] - base;
@@ -93,7 +93,7 @@ k_harris_response_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__
         wave_lds_fence();
         if (lane < fit) {
           const float *a = sums[wave][lane];
-          resp[__float_as_int(q_pts[q_first + lane].w)] = harris_response_of(a[0], a[1], a[2], a[3], a[4], a[5], cnts[wave][lane]);
+          resp[__float_as_int(qw.w)] = harris_response_of(a[0], a[1], a[2], a[3], a[4], a[5], cnts[wave][lane]);
         }
         wave_lds_fence();
       });

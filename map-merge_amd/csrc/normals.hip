@@ -124,7 +124,7 @@ k_normals_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, 
   SnbWave<Cfg> &W = S.w[wave];
   snb_run<Cfg>(
       g, S, q_pts, items, n_items, radius, r2, ctl, ov_items, [](const float4 &) { return 0.0f; },
-      [&](int q_first, int fit, const float4 &) {
+      [&](int fit, const float4 &, const float4 &pq) {
         const int p = lane >> 3, sub = lane & 7;
         if (p < fit) {
           const int base = W.list_off[p], m = W.list_off[p + 1] - base;
@@ -159,7 +159,6 @@ k_normals_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, 
         wave_lds_fence();
         // one lane per point: covariance, eigen33, flip (features/normal_3d.h computePointNormal)
         if (lane < fit) {
-          const float4 pq = q_pts[q_first + lane];
           const int cnt = cnts[wave][lane];
           float4 o;
           if (cnt < 3) {

@@ -167,7 +167,7 @@ __device__ __forceinline__ float quad_bcast(float v)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J * 0x55, 0xf, 0xf, false));
 }
 
-using SiftCfgSmall = SnbCfg<8, 1792, 1280, 384, 128, true>;     // first octave: lists of ~100, 2 blocks of 8 waves per CU
+using SiftCfgSmall = SnbCfg<8, 1792, 1024, 384, 128, true>;     // first octave: lists of ~100, 2 blocks of 8 waves per CU
 using SiftCfgLarge = SnbCfg<8, 3584, 2560, 768, 256, true>;     // later octaves: lists of 300-900 (longer ones in bands), 1 block of 8 waves per CU
 
 template <class Cfg>
@@ -200,7 +200,7 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
   snb_run<Cfg>(
       g, S, q_pts, items, n_items, radius, r2, ctl, ov_items,
       [&](const float4 &c) { return intensity_of(pts[__float_as_int(c.w)].w); },
-      [&](int q_first, int fit, const float4 &q) {
+      [&](int fit, const float4 &q, const float4 &pq) {
         const int p = lane / LPQ;
         const bool mine = p < fit;
         const int base = mine ? W.list_off[p] : 0, m = mine ? W.list_off[p + 1] - base : 0;
@@ -254,7 +254,6 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
         }
         wave_lds_fence();
         if (lane < fit) {
-          const float4 pq = q_pts[q_first + lane];
           float *o = dog + (size_t)__float_as_int(pq.w) * kDog;
           float prev = resp[wave][lane][0];
 #pragma unroll

@@ -86,6 +86,7 @@ struct alignas(16) SnbWave {
   unsigned short sbuf[Cfg::kHitCap + 8];         // their tile slots, same order (the last entry of both: a dump for masked stores)
   unsigned hist[Cfg::kNB + 4];                   // bucket counts, then bucket starts; [kNB] = total
   int list_off[Cfg::kQ + 1];
+  int qidx[Cfg::kQ];                             // which of the part's queries the lists belong to
   // staging (before any list is built): the row offsets / first points of the current 64 rows live in d2buf
   __device__ __forceinline__ int *off() { return reinterpret_cast<int *>(d2buf); }
   __device__ __forceinline__ int *beg() { return reinterpret_cast<int *>(d2buf) + 64; }
@@ -97,7 +98,10 @@ struct alignas(16) SnbLds {
   unsigned tw[Cfg::kTileCap];                                       // their original indices
   float pay[Cfg::kPay ? Cfg::kTileCap : 4];
   SnbWave<Cfg> w[Cfg::kWaves];
+  float4 qpts[64];                               // the queries of the part in work (.w = original index)
   int n_tile, item, overflow, pad;
+  int next_q[2];                                 // the waves take the part's queries one at a time; two counters in turn:
+                                                 // a wave may still be claiming from one part's when the next part's is reset
 };
 
 // device control block of one launch (zeroed before it)
@@ -457,25 +461,39 @@ __device__ __forceinline__ int snb_sort_one(SnbLds<Cfg> &S, SnbWave<Cfg> &W, flo
   return nh;
 }
 
-// Builds the sorted lists of the wave's next queries.  Lane l carries query l / kLpq of the n_q (<= kQ) that
-// are left, in (qx, qy, qz).  Returns how many lists were built (>= 1): W.list_off[p] .. W.list_off[p + 1] is
-// query p's range of W.arena (tile slots in (d2, original index) order).  n_pad = n_tile rounded up to 128: the
-// tile is padded with candidates at kSnbFar.
+// Builds the sorted lists of up to kQ more of the part's n_queries queries (S.qpts), taken from the block's counter.
+// Returns how many lists were built (0: the part is done): list p belongs to query W.qidx[p] and is
+// W.list_off[p] .. W.list_off[p + 1] of W.arena (tile slots in (d2, original index) order).  n_pad = n_tile rounded
+// up to 256: the tile is padded with candidates at kSnbFar.
 // A ball with more than kHitCap neighbours is sorted in nb distance bands [r2 b / nb, r2 (b + 1) / nb), nb a power
 // of two that doubles until every band fits (the list is the bands one after the other); a list that does not fit
 // the arena even alone sets *overflow (the item goes to the fallback launch) and is left empty.
 constexpr int kSnbMaxBands = 16;
 constexpr int kSnbMaxParts = 4;
 template <class Cfg>
-__device__ __forceinline__ int snb_build(SnbLds<Cfg> &S, SnbWave<Cfg> &W, float qx, float qy, float qz, int n_q, float r2, int n_pad, int lane,
-                                         int *overflow, SnbStats &snb_st)
+__device__ __forceinline__ int snb_build(SnbLds<Cfg> &S, SnbWave<Cfg> &W, int n_queries, int *next_q, float r2, int n_pad, int lane, int *pending,
+                                         int *budget, int *overflow, SnbStats &snb_st)
 {
   int total = 0, fit = 0, nb = 1;
   if (lane == 0) W.list_off[0] = 0;
-  for (int p = 0; p < n_q; ++p) {
-    const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), p * Cfg::kLpq));
-    const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), p * Cfg::kLpq));
-    const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), p * Cfg::kLpq));
+  for (int p = 0; p < Cfg::kQ; ++p) {
+    // the next query of the part: the one this wave could not fit last round, else the block's counter.  The waves
+    // take queries one at a time, so a wave whose lists are long simply takes fewer; a wave takes at most kQ of a
+    // part (its budget): the consumer's pass costs the same for one list as for kQ, a ninth query would buy a
+    // whole pass for itself.
+    int qi = *pending;
+    *pending = -1;
+    if (qi < 0) {
+      if (*budget <= 0) break;
+      --*budget;
+      if (lane == 0) qi = atomicAdd(next_q, 1);
+      qi = __builtin_amdgcn_readfirstlane(qi);
+    }
+    if (qi >= n_queries) break;
+    const float4 qp = S.qpts[qi];
+    const float px = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qp.x)));
+    const float py = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qp.y)));
+    const float pz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qp.z)));
     // (a band's length is known after its distance tests; one that finds too little room left in the arena is not
     // sorted: the query then opens the next round)
     int len = 0, status = 0;                       // 0 sorted, 1 no room in the arena, 2 too dense even in kSnbMaxBands bands
@@ -496,7 +514,8 @@ __device__ __forceinline__ int snb_build(SnbLds<Cfg> &S, SnbWave<Cfg> &W, float 
 
     }
     SNB_COUNT(11, 1);
-    if (status == 1 && p > 0) break;               // the arena is full: this query opens the next round
+    if (status == 1 && p > 0) { *pending = qi; break; }   // the arena is full: this query opens the next round
+    if (lane == 0) W.qidx[p] = qi;
     if (status != 0) {                             // alone and still too long, or a dense spot: left to the fallback launch
       if (lane == 0) { *overflow = 1; W.list_off[p + 1] = total; }
       fit = p + 1;
@@ -516,15 +535,16 @@ __device__ __forceinline__ int snb_build(SnbLds<Cfg> &S, SnbWave<Cfg> &W, float 
 // Returns the number of staged candidates (block-uniform); more than kTileCap means "does not fit".
 template <class Cfg, class LoadPay>
 __device__ __forceinline__ int snb_stage_queries(const GridView &g, SnbLds<Cfg> &S, const float4 *__restrict__ q_pts, int first, int count, float ri,
-                                                 LoadPay &&load_pay, SnbStats &snb_st)
+                                                 int epoch, LoadPay &&load_pay, SnbStats &snb_st)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) S.n_tile = 0;
+  if (threadIdx.x == 0) { S.n_tile = 0; S.next_q[epoch & 1] = 0; }
   __syncthreads();
   SNB_TICK(t_stage);
   // the box (every wave computes it from the same queries)
   const bool live = lane < count;
   const float4 qa = q_pts[first + (live ? lane : 0)];
+  if (wave == 0 && live) S.qpts[lane] = qa;
   const float lx = snb_min_f_dpp(live ? qa.x : INFINITY), hx = snb_max_f_dpp(live ? qa.x : -INFINITY);
   const float ly = snb_min_f_dpp(live ? qa.y : INFINITY), hy = snb_max_f_dpp(live ? qa.y : -INFINITY);
   const float lz = snb_min_f_dpp(live ? qa.z : INFINITY), hz = snb_max_f_dpp(live ? qa.z : -INFINITY);
@@ -539,9 +559,10 @@ __device__ __forceinline__ int snb_stage_queries(const GridView &g, SnbLds<Cfg> 
   return S.n_tile;
 }
 
-// Per-item driver: claims items, stages their boxes and hands each wave's lists to consume(q_first, fit, q) --
-// q_first = index into q_pts of the round's first query, lane l carries query q_first + l / kLpq in q (its list is
-// W.list_off[l / kLpq] .. [l / kLpq + 1] when l / kLpq < fit).  An item whose box holds more candidates than the
+// Per-item driver: claims items, stages their boxes and hands each wave's lists to consume(fit, q, qw) -- fit lists;
+// lane l is given the query of list l / kLpq in q (its list is W.list_off[l / kLpq] .. [l / kLpq + 1] when
+// l / kLpq < fit) and, for the lanes l < fit that write a result per query, the query of list l in qw (.w = the
+// query's original index).  An item whose box holds more candidates than the
 // tile is worked in 2, 4, ... parts (runs of its queries: smaller boxes); what still does not fit -- one query's
 // box alone, or a list of more than kSnbMaxBands * kHitCap neighbours -- sends the item to ov_items / ctl->ov_count.
 template <class Cfg, class LoadPay, class Consume>
@@ -553,6 +574,7 @@ __device__ __forceinline__ void snb_run(const GridView &g, SnbLds<Cfg> &S, const
   const float ri = radius * 1.0001f + 1e-4f;
   SnbStats snb_st;
   SNB_TICK(t_all);
+  int epoch = 0;                                 // stagings so far (block-uniform)
   for (;;) {
     SNB_TICK(t_claim);
     if (threadIdx.x == 0) {
@@ -566,10 +588,10 @@ __device__ __forceinline__ void snb_run(const GridView &g, SnbLds<Cfg> &S, const
     SNB_TOCK(1, t_claim);
     SNB_COUNT(0, 1);
     int parts = 1;
-    for (int part = 0; part < parts;) {
+    for (int part = 0; part < parts; ++epoch) {
       const int lo = (int)((long long)it.y * part / parts), hi = (int)((long long)it.y * (part + 1) / parts);
       if (hi == lo) { ++part; continue; }
-      const int n_tile = snb_stage_queries<Cfg>(g, S, q_pts, it.x + lo, hi - lo, ri, load_pay, snb_st);
+      const int n_tile = snb_stage_queries<Cfg>(g, S, q_pts, it.x + lo, hi - lo, ri, epoch, load_pay, snb_st);
       SNB_COUNT(13, n_tile);
       if (n_tile > Cfg::kTileCap) {                // block-uniform
         // Halving the run of queries shrinks the box only by the patch's share of it (the radius margin stays), and
@@ -589,23 +611,16 @@ __device__ __forceinline__ void snb_run(const GridView &g, SnbLds<Cfg> &S, const
       const int n_pad = (n_tile + 255) & ~255;
       for (int s = n_tile + lane; s < n_pad; s += kWave) { S.tx[s] = kSnbFar; S.ty[s] = kSnbFar; S.tz[s] = kSnbFar; }
       wave_lds_fence();
-      // the part's queries in equal shares (a part of 40 points is five per wave, not 8 + ... + 0)
-      const int share = (hi - lo + Cfg::kWaves - 1) / Cfg::kWaves;
-      const int wq0 = lo + wave * share;
-      const int nq_w = min(share, hi - wq0);
-      int done = 0;
-      while (done < nq_w) {
-        const int left = nq_w - done;
-        const int pl = lane / Cfg::kLpq;
-        const int q_first = it.x + wq0 + done;
-        const float4 q = q_pts[q_first + (pl < left ? pl : 0)];
-        const int fit = snb_build<Cfg>(S, W, q.x, q.y, q.z, left, r2, n_pad, lane, &S.overflow, snb_st);
+      int pending = -1, budget = Cfg::kQ;
+      for (;;) {
+        const int fit = snb_build<Cfg>(S, W, hi - lo, &S.next_q[epoch & 1], r2, n_pad, lane, &pending, &budget, &S.overflow, snb_st);
+        if (fit == 0) break;
         SNB_COUNT(14, 1);
         SNB_TICK(t_cons);
-        consume(q_first, fit, q);
+        const int pl = lane / Cfg::kLpq;
+        consume(fit, S.qpts[W.qidx[pl < fit ? pl : 0]], S.qpts[W.qidx[lane < fit ? lane : 0]]);
         wave_lds_fence();
         SNB_TOCK(9, t_cons);
-        done += fit;
       }
       ++part;
     }
