@@ -128,25 +128,8 @@ def make_workload_gt(n_maps, n_points, cache=True, scenes="independent", overlap
 
 
 def make_workload(n_maps, n_points, cache=True):
-    from map_merge_amd import synth
-    path = f"/tmp/mm3d_bench_{n_maps}x{n_points}.npy"
-    if cache and os.path.exists(path):
-        try:
-            arr = np.load(path)
-            if arr.shape[0] == n_maps:
-                return [arr[i] for i in range(n_maps)]
-        except Exception:
-            pass                                           # unreadable cache: regenerate
-    _, maps = synth.synth_maps(n_maps, n_points)
-    packed = [synth.pack_points(x, c) for x, c, _ in maps]
-    if cache:
-        try:                                               # several ranks may get here at once: write aside, rename atomically
-            tmp = f"{path}.{os.getpid()}.tmp.npy"
-            np.save(tmp, np.stack(packed))
-            os.replace(tmp, path)
-        except Exception:
-            pass
-    return packed
+    """The maps of the headline scene family as packed records (the scripts under scripts/ use this)."""
+    return make_workload_gt(n_maps, n_points, cache=cache)[0]
 
 
 def main():

@@ -19,7 +19,7 @@ from map_merge_amd import sharding  # noqa: E402
 
 n_maps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 n_pts = int(sys.argv[2]) if len(sys.argv) > 2 else 500000
-host = bench.make_workload(n_maps, n_pts)
+host, _, _ = bench.make_workload_gt(n_maps, n_pts)
 dev = torch.device("cuda", 0)
 dev_raw = [torch.from_numpy(h.view(np.uint8).reshape(-1, 16)).to(dev) for h in host]
 views = [(dev_raw[i].data_ptr(), len(host[i])) for i in range(n_maps)]
