@@ -129,6 +129,20 @@ __device__ __forceinline__ float float_chain_sum(float incr, unsigned hits)
   return v;
 }
 
+// acos(fabs(a1)) > acos(fabs(a2)) as the CPU path evaluates it (pcl::computePairFeatures: the arguments are floats, the
+// arc cosines glibc's double ones).  acos is decreasing, so this is |a1| < |a2| -- except where it is not: an argument
+// above 1 (a rounded-up cosine) gives NaN and the comparison is false; and below 2^-28 two different floats can have
+// the same double arc cosine (acos(x) = RN(pi/2 - x) there, and the double nearest pi/2 has an ulp of 2.2e-16), in which
+// case the CPU path sees a tie.  Checked against this image's libm on 14 M pairs incl. adjacent floats down to 2^-70.
+__device__ __forceinline__ bool acos_abs_greater(float a1, float a2)
+{
+  const float x1 = fabsf(a1), x2 = fabsf(a2);
+  if (!(x1 <= 1.0f) || !(x2 <= 1.0f)) return false;
+  if (x1 >= 0x1p-28f || x2 >= 0x1p-28f) return x1 < x2;
+  const double hi = 0x1.921fb54442d18p+0, lo = 0x1.1a62633145c07p-54;   // pi/2 = hi + lo
+  return (hi + (lo - (double)x1)) > (hi + (lo - (double)x2));
+}
+
 // ---- wave / block reductions -------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v)
 {

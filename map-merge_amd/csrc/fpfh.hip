@@ -65,9 +65,8 @@ __device__ __forceinline__ void pair_features(const float4 &p1, const float4 &n1
   float ax = n1.x, ay = n1.y, az = n1.z, bx = n2.x, by = n2.y, bz = n2.z;
   const float angle1 = (ax * dx + ay * dy + az * dz) / f4;
   const float angle2 = (bx * dx + by * dy + bz * dz) / f4;
-  // acos(fabs(angle1)) > acos(fabs(angle2)) evaluated in double on the CPU; acos is strictly
-  // decreasing there, so the test is |angle1| < |angle2| (NaN -> false on both sides)
-  if (fabsf(angle1) < fabsf(angle2)) {
+  // acos(fabs(angle1)) > acos(fabs(angle2)) evaluated in double on the CPU: device_util.hpp::acos_abs_greater
+  if (acos_abs_greater(angle1, angle2)) {
     float t;
     t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; t = az; az = bz; bz = t;
     dx *= -1.0f; dy *= -1.0f; dz *= -1.0f;

@@ -39,8 +39,8 @@ __device__ __forceinline__ void pfh_pair_features(const PfhNb &p1, const PfhNb &
   float ax = p1.nx, ay = p1.ny, az = p1.nz, bx = p2.nx, by = p2.ny, bz = p2.nz;
   const float angle1 = (ax * dx + ay * dy + az * dz) / f4;
   const float angle2 = (bx * dx + by * dy + bz * dz) / f4;
-  // acos(fabs(angle1)) > acos(fabs(angle2)) in double == |angle1| < |angle2| (acos strictly decreasing)
-  if (fabsf(angle1) < fabsf(angle2)) {
+  // acos(fabs(angle1)) > acos(fabs(angle2)) in double: device_util.hpp::acos_abs_greater
+  if (acos_abs_greater(angle1, angle2)) {
     float t;
     t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; t = az; az = bz; bz = t;
     dx *= -1.0f; dy *= -1.0f; dz *= -1.0f;

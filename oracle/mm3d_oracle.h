@@ -168,6 +168,10 @@ void mo_icp(const mo_point *src, int ns, const mo_point *tgt, int nt,
             const float guess[16], double max_correspondence_distance,
             double outlier_rejection_threshold, int max_iterations,
             double transformation_epsilon, float T[16], int *iters_out);
+/* the same ICP with double sums over the original points (NOT the reference's arithmetic; see o_matching.c) */
+void mo_icp_double_sums(const mo_point *src, int ns, const mo_point *tgt, int nt, const float guess[16],
+                        double max_correspondence_distance, int max_iterations, double transformation_epsilon,
+                        float T[16], int *iters_out);
 /* estimateTransform: R/src/matching.cpp:223-257. */
 void mo_estimate_transform(const mo_point *src, int ns, const mo_point *src_kp,
                            const float *src_desc, int nsk, const mo_point *tgt,

@@ -432,6 +432,78 @@ void mo_icp(const mo_point *src, int ns, const mo_point *tgt, int nt, const floa
   mo_mat4_mul(final_T, guess, T);   /* icp.getFinalTransformation() * initial_guess */
 }
 
+/* The same ICP with its sums in double and ONE cumulative transform applied to the original source points --
+ * what exact arithmetic gives, and how the device formulates it (documented deviation).
+ * NOT the reference's arithmetic: pcl::IterativeClosestPoint re-transforms the float cloud every iteration and
+ * TransformationEstimationSVD sums in float, sequentially; beyond ~1 M points those float sums carry millimetres of
+ * their own rounding noise (a sum of a million coordinates of ~15 m passes 2^24, where a float's ulp is 1).  This
+ * variant lets a check tell "the device differs from the CPU path" from "the CPU path's float sums are noisy". */
+void mo_icp_double_sums(const mo_point *src, int ns, const mo_point *tgt, int nt, const float guess[16],
+                        double max_correspondence_distance, int max_iterations, double transformation_epsilon,
+                        float T[16], int *iters_out)
+{
+  double Tc[16];
+  for (int i = 0; i < 16; ++i) Tc[i] = (double)guess[i];
+  int iters = 0;
+  if (ns > 0 && nt > 0) {
+    const double max_dist_sqr = max_correspondence_distance * max_correspondence_distance;
+    float bound = (float)(max_dist_sqr * (1.0 + 1e-6));
+    float cell = (float)(max_correspondence_distance * 0.25);
+    if (!(cell > 0.0f)) cell = 0.25f;
+    mo_grid *g = mo_grid_build(tgt, nt, cell);
+    float *cur = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
+    double *cs = (double *)malloc(sizeof(double) * 3 * (size_t)ns), *cd = (double *)malloc(sizeof(double) * 3 * (size_t)ns);
+    int *nn_of = (int *)malloc(sizeof(int) * (size_t)ns);
+    float *nd_of = (float *)malloc(sizeof(float) * (size_t)ns);
+    double prev_mse = DBL_MAX;
+    const double rot_thresh = 1.0 - transformation_epsilon, trans_thresh = transformation_epsilon;
+    int converged = 0;
+    do {
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(mo_get_threads())
+      for (int i = 0; i < ns; ++i) {
+        const double x = src[i].x, y = src[i].y, z = src[i].z;
+        for (int r = 0; r < 3; ++r) cur[i * 3 + r] = (float)(Tc[r] * x + Tc[4 + r] * y + Tc[8 + r] * z + Tc[12 + r]);
+        int ni; float d2;
+        int found = mo_knn_search(g, cur[i * 3], cur[i * 3 + 1], cur[i * 3 + 2], 1, bound, &ni, &d2);
+        nn_of[i] = (!found || (double)d2 > max_dist_sqr) ? -1 : ni;
+        nd_of[i] = d2;
+      }
+      int cnt = 0;
+      double mse = 0.0;
+      for (int i = 0; i < ns; ++i) {
+        const int ni = nn_of[i];
+        if (ni < 0) continue;
+        cs[cnt * 3] = cur[i * 3]; cs[cnt * 3 + 1] = cur[i * 3 + 1]; cs[cnt * 3 + 2] = cur[i * 3 + 2];
+        cd[cnt * 3] = tgt[ni].x; cd[cnt * 3 + 1] = tgt[ni].y; cd[cnt * 3 + 2] = tgt[ni].z;
+        mse += nd_of[i];
+        ++cnt;
+      }
+      if (cnt < 3) break;
+      double Tinc[16], Tn[16];
+      mo_umeyama_f64(cs, cd, cnt, Tinc);
+      for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+          double a = 0.0;
+          for (int k = 0; k < 4; ++k) a += Tinc[k * 4 + r] * Tc[c * 4 + k];
+          Tn[c * 4 + r] = a;
+        }
+      memcpy(Tc, Tn, sizeof(Tc));
+      ++iters;
+      if (iters >= max_iterations) break;
+      const double cos_angle = 0.5 * (Tinc[0] + Tinc[5] + Tinc[10] - 1.0);
+      const double translation_sqr = Tinc[12] * Tinc[12] + Tinc[13] * Tinc[13] + Tinc[14] * Tinc[14];
+      if (cos_angle >= rot_thresh && translation_sqr <= trans_thresh) converged = 1;
+      mse /= (double)cnt;
+      if (fabs(mse - prev_mse) < 1e-12) converged = 1;
+      prev_mse = mse;
+    } while (!converged);
+    free(cur); free(cs); free(cd); free(nn_of); free(nd_of);
+    mo_grid_free(g);
+  }
+  if (iters_out) *iters_out = iters;
+  for (int i = 0; i < 16; ++i) T[i] = (float)Tc[i];
+}
+
 /* ------------------------------------------------------------------------------------------ */
 double mo_transform_score(const mo_point *src, int ns, const mo_point *tgt, int nt,
                           const float T[16], double max_distance)

@@ -296,6 +296,17 @@ def icp(src, tgt, guess, max_corr_dist, outlier_thr, max_iterations, eps):
     return T.reshape(4, 4).T.copy(), it.value
 
 
+def icp_double_sums(src, tgt, guess, max_corr_dist, max_iterations, eps):
+    """ICP with double sums over the original points: exact-arithmetic yardstick, not the reference's arithmetic."""
+    src, tgt = _pts(src), _pts(tgt)
+    g = np.ascontiguousarray(np.asarray(guess, dtype=np.float32).T.reshape(16))
+    T = np.zeros(16, dtype=np.float32)
+    it = C.c_int()
+    lib().mo_icp_double_sums(_p(src), len(src), _p(tgt), len(tgt), _p(g), C.c_double(max_corr_dist), int(max_iterations),
+                             C.c_double(eps), _p(T), C.byref(it))
+    return T.reshape(4, 4).T.copy(), it.value
+
+
 def transform_score(src, tgt, T, max_distance):
     src, tgt = _pts(src), _pts(tgt)
     t = np.ascontiguousarray(np.asarray(T, dtype=np.float32).T.reshape(16))

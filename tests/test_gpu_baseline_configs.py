@@ -188,7 +188,7 @@ def test_config0_two_clouds_of_10000_points_against_the_oracle(ctx, po, mm, synt
         m.free()
 
 
-def test_lattice_scenes_fpfh_sac_ia_recovers_the_ground_truth(ctx, mm, synth):
+def test_lattice_scenes_fpfh_sac_ia_recovers_the_ground_truth(ctx, po, mm, synth):
     """4 x 200 000 points of the 'lattice' scene family (overlapping maps share their surface samples, synth.lattice_map),
     windows three quarters of a side apart in the loop (every pair shares >= 2/3 of a window), FPFH + SAC-IA + ICP with
     20 000 hypotheses instead of the reference's default 500.  With the default the algorithm does not find the basin on
@@ -217,3 +217,18 @@ def test_lattice_scenes_fpfh_sac_ia_recovers_the_ground_truth(ctx, mm, synth):
     # the pair that failed, if any, is the one the pose graph trusts least
     if sum(good) < 6:
         assert np.argmin(conf) == good.index(False), (errs, conf)
+    # and the features are still the oracle's bits on this scene family.  (They were not when it was first run: map 1
+    # has pairs of points whose Darboux source / target choice -- acos(|angle1|) > acos(|angle2|) in double -- is decided
+    # by a cosine rounded above 1 or by two angles below 2^-28, where "acos is decreasing" is not the whole truth;
+    # device_util.hpp::acos_abs_greater.)
+    po.set_threads(16)
+    r = raws[1].view(po.POINT)
+    f = po.remove_outliers(po.downsample(r, 0.1), 0.8, 50)
+    n = po.normals(f, 0.6)
+    kp, _ = po.keypoints_sift(f, 0.1, 3, 3, 5.0)
+    kp, d = po.descriptors_fpfh(f, n, kp, 0.8)
+    po.set_threads(1)
+    m = ctx.mapFeatures(ctx.cloud(raws[1]), params)
+    assert np.array_equal(xyz(m.keypoints.numpy()).view(np.uint32), xyz(kp).view(np.uint32))
+    assert np.array_equal(m.descriptors.numpy().view(np.uint32), d.view(np.uint32))
+    m.free()
