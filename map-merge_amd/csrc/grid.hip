@@ -680,7 +680,7 @@ __global__ void k_nb_count(const int *__restrict__ cell_start, int dx, int dy, i
 }
 
 __global__ void k_nb_fill(const int *__restrict__ cell_start, const float4 *__restrict__ sorted, int dx, int dy, int dz, int R,
-                          const int *__restrict__ nb_start, float *__restrict__ nb_pts)
+                          const int *__restrict__ nb_start, float4 *__restrict__ nb_pts)
 {
   // one wave per cell: lanes stride over each row span
   const size_t c = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -697,11 +697,45 @@ __global__ void k_nb_fill(const int *__restrict__ cell_start, const float4 *__re
       const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
       for (int j = b + lane; j < e; j += 64) {
         const float4 p = sorted[j];
-        float *o = nb_pts + (size_t)(out + (j - b)) * 3;
-        o[0] = p.x; o[1] = p.y; o[2] = p.z;
+        nb_pts[(size_t)(out + (j - b))] = make_float4(p.x, p.y, p.z, 0.0f);
       }
       out += e - b;
     }
+}
+
+// Lists of up to kNbSortCap entries: .w = distance from the cell centre, entries reordered to ascend in it
+// (rank by counting in LDS; ties by stencil position, so the order is a function of the input alone).
+constexpr int kNbSortCap = 1024;
+__global__ void __launch_bounds__(256)
+k_nb_sort(float minx, float miny, float minz, float cell, int dx, int dy, int dz, const int *__restrict__ nb_start,
+          float4 *__restrict__ nb_pts)
+{
+  __shared__ float4 ent[4][kNbSortCap];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t c = (size_t)blockIdx.x * 4 + w;
+  const size_t nc = (size_t)dx * dy * dz;
+  if (c >= nc) return;
+  const int b = nb_start[c], n = nb_start[c + 1] - b;
+  if (n == 0) return;
+  if (n > kNbSortCap) return;
+  const int x = (int)(c % dx), y = (int)((c / dx) % dy), z = (int)(c / ((size_t)dx * dy));
+  const float ox = minx + ((float)x + 0.5f) * cell, oy = miny + ((float)y + 0.5f) * cell, oz = minz + ((float)z + 0.5f) * cell;
+  for (int j = lane; j < n; j += 64) {
+    float4 p = nb_pts[(size_t)b + j];
+    const float ax = p.x - ox, ay = p.y - oy, az = p.z - oz;
+    p.w = sqrtf(ax * ax + ay * ay + az * az);
+    ent[w][j] = p;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int j = lane; j < n; j += 64) {
+    const float4 p = ent[w][j];
+    int rank = 0;
+    for (int k = 0; k < n; ++k) {
+      const float o = ent[w][k].w;
+      rank += (o < p.w || (o == p.w && k < j)) ? 1 : 0;
+    }
+    nb_pts[(size_t)b + rank] = p;
+  }
 }
 
 void grid_ensure_nblists(Context *c, const Grid &g_, int R)
@@ -719,10 +753,13 @@ void grid_ensure_nblists(Context *c, const Grid &g_, int R)
   MM3D_HIP(hipMemcpyAsync(h, g.nb_start.get() + nc, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   c->sync();
   const size_t total = (size_t)h[0];
-  g.nb_pts = DevBuf<float>(c, total ? total * 3 : 1);
-  if (total)
+  g.nb_pts = DevBuf<float4>(c, total ? total : 1);
+  if (total) {
     MM3D_LAUNCH(c, "grid_nblists", total * 32.0, k_nb_fill, dim3(div_up(nc, 4)), dim3(256), 0, (const int *)g.cell_start.get(),
                 (const float4 *)g.sorted.get(), g.dims[0], g.dims[1], g.dims[2], R, (const int *)g.nb_start.get(), g.nb_pts.get());
+    MM3D_LAUNCH(c, "grid_nblists", total * 32.0, k_nb_sort, dim3(div_up(nc, 4)), dim3(256), 0, g.mn[0], g.mn[1], g.mn[2], g.cell,
+                g.dims[0], g.dims[1], g.dims[2], (const int *)g.nb_start.get(), g.nb_pts.get());
+  }
   g.nb_R = R;
   c->settle();
 }

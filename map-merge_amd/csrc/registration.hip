@@ -93,6 +93,10 @@ __global__ void k_sacia_models(const SacJob *__restrict__ jobs, int H)
 // ---------------------------------------------------------------- SAC-IA hypothesis scoring
 // E[h][i] = TruncatedError(d2 of (T_h * src_i) to its nearest target keypoint); rows padded to a
 // multiple of 4 floats so the summation kernel can stream them with 16-byte loads.
+#ifndef MM3D_SAC_SUB
+#define MM3D_SAC_SUB 1
+#endif
+constexpr int kSacSub = MM3D_SAC_SUB;
 __global__ void __launch_bounds__(256)
 k_sacia_err(const SacJob *__restrict__ jobs, int h_first, float thresh, float radius)
 {
@@ -113,26 +117,35 @@ k_sacia_err(const SacJob *__restrict__ jobs, int h_first, float thresh, float ra
   const float3 p = xform(Tl, s.x, s.y, s.z);
   float best = INFINITY;
   // 500 x K_s queries per pair against the same K_t targets: the stencil walk is taken out of the
-  // query.  The target grid carries, per cell, the merged list of its 3x3x3 block (cell = radius,
-  // grid_ensure_nblists), and a query scans ONE contiguous span; an empty span is the "nothing in
-  // range" answer most wrong hypotheses get.  (5x5x5 blocks of half-size cells have 30 % fewer
-  // candidates per query but a 5x larger table that no longer stays in L2: measured equal, 35x the
-  // HBM-side traffic.)
+  // query.  The target grid (cell = radius / kSacSub) carries, per cell, the merged list of the block
+  // of cells the radius can reach (grid_ensure_nblists), ascending in distance from the cell centre.
+  // A query scans ONE contiguous span and stops at the first entry whose centre distance, less the
+  // query's own, exceeds min(best so far, radius): nothing later can be nearer.  An empty
+  // span is the "nothing in range" answer most wrong hypotheses get.  The minimum itself is taken
+  // over exact float distances, so the order of the scan does not show in the result.
   const int cx = cell_floor(p.x, g.minx, g.inv), cy = cell_floor(p.y, g.miny, g.inv), cz = cell_floor(p.z, g.minz, g.inv);
   const bool inside = cx >= 0 && cx < g.dx && cy >= 0 && cy < g.dy && cz >= 0 && cz < g.dz;
   if (inside) {
     const size_t c = ((size_t)cz * g.dy + cy) * g.dx + cx;
     const int b = g.nb_start[c], e = g.nb_start[c + 1];
+    // |q - e| >= |e - centre| - |q - centre| for every entry e; 1e-3 cell covers the rounding of both terms
+    const float ox = p.x - (g.minx + ((float)cx + 0.5f) * g.cell), oy = p.y - (g.miny + ((float)cy + 0.5f) * g.cell);
+    const float oz = p.z - (g.minz + ((float)cz + 0.5f) * g.cell);
+    const float slack = sqrtf(ox * ox + oy * oy + oz * oz) + 1e-3f * g.cell;
+    float want = thresh;                              // squared distance still worth finding
     // four loads in flight per step; min is idempotent, so the tail just re-reads the last point
     for (int j = b; j < e; j += 4) {
       const int last = e - 1;
-      const float3 q0 = *reinterpret_cast<const float3 *>(g.nb_pts + (size_t)j * 3);
-      const float3 q1 = *reinterpret_cast<const float3 *>(g.nb_pts + (size_t)min(j + 1, last) * 3);
-      const float3 q2 = *reinterpret_cast<const float3 *>(g.nb_pts + (size_t)min(j + 2, last) * 3);
-      const float3 q3 = *reinterpret_cast<const float3 *>(g.nb_pts + (size_t)min(j + 3, last) * 3);
+      const float4 q0 = g.nb_pts[j];
+      const float4 q1 = g.nb_pts[min(j + 1, last)];
+      const float4 q2 = g.nb_pts[min(j + 2, last)];
+      const float4 q3 = g.nb_pts[min(j + 3, last)];
       const float d0 = dist2(p.x, p.y, p.z, q0.x, q0.y, q0.z), d1 = dist2(p.x, p.y, p.z, q1.x, q1.y, q1.z);
       const float d2 = dist2(p.x, p.y, p.z, q2.x, q2.y, q2.z), d3 = dist2(p.x, p.y, p.z, q3.x, q3.y, q3.z);
       best = fminf(best, fminf(fminf(d0, d1), fminf(d2, d3)));
+      want = fminf(want, best);
+      const float lb = q3.w - slack;
+      if (lb > 0.0f && lb * lb > want) break;
     }
   } else {
     // outside the grid: clipped stencil walk
@@ -223,11 +236,12 @@ __global__ void __launch_bounds__(256) k_seq_sum(const SacJob *__restrict__ jobs
 static const Grid &sacia_target_grid(Context *c, const mm3d_cloud *tgt_kp, float corr_thresh)
 {
   const float radius = std::sqrt(corr_thresh > 0.f ? corr_thresh : 0.f);
-  // cell a hair larger than the search radius: everything within the radius of a point of cell c
-  // lies in c's 3x3x3 block (cloud_grid may only ever ENLARGE the cell, which keeps that true)
-  const float cell = radius * 1.001f > 0.25f ? radius * 1.001f : 0.25f;
+  // kSacSub cells a hair longer than the search radius: everything within the radius of a point of cell c
+  // lies in c's (2 kSacSub + 1)^3 block (cloud_grid may only ever ENLARGE the cell, which keeps that true)
+  const float want = radius * 1.001f / (float)kSacSub;
+  const float cell = want > 0.125f ? want : 0.125f;
   const Grid &g = cloud_grid(c, tgt_kp, cell);
-  grid_ensure_nblists(c, g, 1);
+  grid_ensure_nblists(c, g, kSacSub);
   return g;
 }
 

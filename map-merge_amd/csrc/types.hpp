@@ -37,7 +37,10 @@ struct GridView {
   // optional merged neighbourhood lists: nb_pts[nb_start[c] .. nb_start[c+1]) = every point of the
   // (2 nb_R + 1)^3 block of cells around cell c, so a fixed-radius query reads ONE contiguous span
   const int *nb_start;
-  const float *nb_pts;       // packed x, y, z triples (12 B per entry)
+  // .w = distance of the entry from the centre of cell c, and the list ascends in it: a nearest-point scan
+  // stops once .w minus the cell's half diagonal exceeds what it still looks for.  (A list too long to
+  // sort in LDS keeps stencil order and .w = 0: it is scanned to the end.)
+  const float4 *nb_pts;
   int nb_R;
 };
 
@@ -51,7 +54,7 @@ struct Grid {
   DevBuf<unsigned char> dt;   // built on demand by grid_ensure_dt
   int dt_cap = 0;
   DevBuf<int> nb_start;       // built on demand by grid_ensure_nblists
-  DevBuf<float> nb_pts;       // packed x, y, z triples
+  DevBuf<float4> nb_pts;      // x, y, z, distance from the list's cell centre
   int nb_R = 0;
   std::mutex cache_mu;        // grid_ensure_dt / grid_ensure_nblists
   GridView view() const
