@@ -174,7 +174,8 @@ template <class Cfg>
 __global__ void __launch_bounds__(64 * Cfg::kWaves)
 k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* .w = original index */,
                const float4 *__restrict__ pts /* original order: rgba */, float radius, float r2, SiftScales sc, SnbCtl *ctl,
-               int *__restrict__ ov_items, float *__restrict__ dog /* [n][5] by original index */)
+               int *__restrict__ ov_items, float *__restrict__ dog /* [n][5] by original index */,
+               int *__restrict__ knn /* [n][kKnn] by original index */, unsigned char *__restrict__ knn_ok /* [n], zeroed */)
 {
   __shared__ SnbLds<Cfg> S;
   __shared__ float resp[Cfg::kWaves][Cfg::kQ][kScales];
@@ -252,6 +253,15 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
 #pragma unroll
           for (int k = 0; k < NS; ++k) resp[wave][p][ss[k]] = num[k] / den[k];
         }
+        // The list's first 25 entries ARE the point's 25 nearest neighbours in nearestKSearch's (distance, index)
+        // order whenever the ball holds that many: findScaleSpaceExtrema (k_sift_extrema_knn) reads them back
+        // instead of searching again.  A shorter list leaves knn_ok at 0: that point takes the searching kernel.
+        if (mine && m >= kKnn) {
+          const int self_q = __float_as_int(q.w);
+          int *row = knn + (size_t)self_q * kKnn;
+          for (int e = lane & (LPQ - 1); e < kKnn; e += LPQ) row[e] = (int)S.tw[W.arena[base + e]];
+          if ((lane & (LPQ - 1)) == 0) knn_ok[self_q] = 1;
+        }
         wave_lds_fence();
         if (lane < fit) {
           float *o = dog + (size_t)__float_as_int(pq.w) * kDog;
@@ -270,12 +280,12 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
 // one octave's scale space: the LDS path, then the (normally empty) launch over the items it could not hold
 template <class Cfg>
 static void sift_dog_octave(Context *c, const mm3d_cloud *cur, const Grid &gr, int n_items, float max_radius, float r2, const SiftScales &sc,
-                            float *dog)
+                            float *dog, int *knn, unsigned char *knn_ok)
 {
   SnbLaunch<Cfg> sl(c, n_items, sizeof(float) * 64 * kScales + 256);
   MM3D_LAUNCH(c, getenv("MM3D_SNB_DEBUG") ? (gr.n > 300000 ? "sift_dog_oct0" : (gr.n > 150000 ? "sift_dog_oct1" : "sift_dog_oct2")) : "sift_dog", gr.n * 36.0, k_sift_dog_lds<Cfg>, dim3(sl.blocks), dim3(64 * Cfg::kWaves), 0, (const float4 *)cur->hil_pts.get(),
               (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, sl.ctl_dev(),
-              sl.ov_items.get(), dog);
+              sl.ov_items.get(), dog, knn, knn_ok);
   SnbCtl *ctl = sl.ctl_dev();
   SnLaunch<float2> sn(c, n_items * 4, cur->n, 4, kSnFallbackBlocks);
   SnScratch scr{sn.tmp.get(), sn.fin.get(), ctl->fb_ctr, &ctl->error, sl.ov_items.get(), &ctl->ov_count};
@@ -301,17 +311,55 @@ extern "C" void mm3d_debug_sn_stats_sift(unsigned long long *out, int reset)
 }
 #endif
 
-// per point, in the grid's sorted order, two float4: (mn1, mn2, mn3, mx1) and (mx2, mx3, -, -)
-__global__ void k_sift_dogx(const float4 *__restrict__ sorted, const float *__restrict__ dog, int n, float4 *__restrict__ dogx)
+// per point, by original index, two float4: (mn1, mn2, mn3, mx1) and (mx2, mx3, -, -)
+__global__ void k_sift_dogx(const float *__restrict__ dog, int n, float4 *__restrict__ dogx)
 {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const float *d = dog + (size_t)__float_as_int(sorted[j].w) * kDog;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *d = dog + (size_t)i * kDog;
   // what a neighbour contributes to the extremum tests of scale s = 1, 2, 3: the min and the max of its
   // own DoG over s-1, s, s+1 (computed once per point instead of once per (query, neighbour))
-  dogx[j] = make_float4(fminf(fminf(d[0], d[1]), d[2]), fminf(fminf(d[1], d[2]), d[3]), fminf(fminf(d[2], d[3]), d[4]),
+  dogx[i] = make_float4(fminf(fminf(d[0], d[1]), d[2]), fminf(fminf(d[1], d[2]), d[3]), fminf(fminf(d[2], d[3]), d[4]),
                         fmaxf(fmaxf(d[0], d[1]), d[2]));
-  dogx[n + j] = make_float4(fmaxf(fmaxf(d[1], d[2]), d[3]), fmaxf(fmaxf(d[2], d[3]), d[4]), 0.f, 0.f);
+  dogx[n + i] = make_float4(fmaxf(fmaxf(d[1], d[2]), d[3]), fmaxf(fmaxf(d[2], d[3]), d[4]), 0.f, 0.f);
+}
+
+// findScaleSpaceExtrema for the points whose 25 nearest neighbours the scale-space kernel left behind (knn_ok):
+// one thread per point of the octave, in Hilbert order.  A point is a minimum at scale s iff none of its 25
+// nearest (itself included) has a DoG below its own at s-1, s or s+1; a maximum likewise.
+__global__ void __launch_bounds__(256)
+k_sift_extrema_knn(const float4 *__restrict__ hil, int nh, int n, const float *__restrict__ dog, const float4 *__restrict__ dogx,
+                   const int *__restrict__ knn, const unsigned char *__restrict__ knn_ok, float min_contrast, int *__restrict__ flags /* [n*3] */)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nh) return;
+  const int self = __float_as_int(hil[j].w);
+  if (!knn_ok[self]) return;
+  float v[3];
+  unsigned live = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    v[s] = dog[(size_t)self * kDog + s + 1];
+    if (fabsf(v[s]) >= min_contrast) live |= 1u << s;
+  }
+  if (!live) return;
+  bool is_min[3] = {true, true, true}, is_max[3] = {true, true, true};
+  const int *row = knn + (size_t)self * kKnn;
+#pragma unroll 5
+  for (int e = 0; e < kKnn; ++e) {
+    const int nb = row[e];
+    const float4 a = dogx[nb], b = dogx[n + nb];
+    const float mn[3] = {a.x, a.y, a.z};
+    const float mx[3] = {a.w, b.x, b.y};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      is_min[s] = is_min[s] && !(mn[s] < v[s]);
+      is_max[s] = is_max[s] && !(mx[s] > v[s]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+    if (live & (1u << s)) flags[(size_t)self * 3 + s] = (is_min[s] || is_max[s]) ? 1 : 0;
 }
 
 // The extremum test only concerns points whose DoG passes the contrast test at some scale (about a
@@ -319,7 +367,7 @@ __global__ void k_sift_dogx(const float4 *__restrict__ sorted, const float *__re
 // lanes all have work (k_sift_live + scan + k_sift_live_compact), instead of idling through the box
 // scans of their item's few live points.
 __global__ void k_sift_live(const float4 *__restrict__ hil, int n, const float *__restrict__ dog, float min_contrast,
-                            int *__restrict__ flag /* [n + 1] */)
+                            const unsigned char *__restrict__ knn_ok, int *__restrict__ flag /* [n + 1] */)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j > n) return;
@@ -328,6 +376,7 @@ __global__ void k_sift_live(const float4 *__restrict__ hil, int n, const float *
     const int self = __float_as_int(hil[j].w);
 #pragma unroll
     for (int s = 0; s < 3; ++s) f |= fabsf(dog[(size_t)self * kDog + s + 1]) >= min_contrast ? 1 : 0;
+    if (knn_ok[self]) f = 0;                   // k_sift_extrema_knn's
   }
   flag[j] = f;
 }
@@ -373,7 +422,8 @@ template <int SPLIT>
 __global__ void __launch_bounds__(256) MM3D_EXT_ATTR
 k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, const int *__restrict__ n_items_dev,
                GridView g /* .w = original index */,
-               const float4 *__restrict__ dogx, const float *__restrict__ dog, float min_contrast, int *__restrict__ flags /* [n*3] */)
+               const float4 *__restrict__ dogx /* by original index, [2][n_pts] */, int n_pts, const float *__restrict__ dog, float min_contrast,
+               int *__restrict__ flags /* [n*3] */)
 {
   __shared__ float4 s_pts[4][kSiftTile];
   __shared__ float4 s_x[4][2 * kSiftTile];
@@ -404,7 +454,6 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
   const int max_e = max(max(g.dx, g.dy), g.dz) + 1;
   const float4 *sp = s_pts[wave];
   const float4 *sx = s_x[wave];
-  const int ngrid = g.n;
   // a run of live points is normally one compact patch; where the Hilbert curve leaves the occupied
   // area and re-enters far away it is worked group by group (lanes near the first open lane)
   for (int grp = 0; grp < 64; ++grp) {
@@ -483,7 +532,7 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
     bool counted = false;                       // wave-uniform
     wave_stream_box<kSiftTile, 2>(
         g, x0, x1, y0, y1, z0, z1, s_pts[wave], s_x[wave], s_off[wave], s_beg[wave], lane,
-        [&](int j, float4 (&out)[2]) { out[0] = dogx[j]; out[1] = dogx[ngrid + j]; },
+        [&](int j, float4 (&out)[2]) { const int o = __float_as_int(g.pts[j].w); out[0] = dogx[o]; out[1] = dogx[n_pts + o]; },
         [&](int cnt, bool whole_box) {
           int k0, k1;
           my_range(cnt, k0, k1);
@@ -602,17 +651,23 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     // scale space on a grid with cell = r/2
     const Grid &gr = cloud_grid(c, cur.get(), max_radius * 0.5f);
     DevBuf<float> dog(c, (size_t)n * kDog);
-    if (oct == 0) sift_dog_octave<SiftCfgSmall>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get());
-    else sift_dog_octave<SiftCfgLarge>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get());
-    // the extremum test walks the same grid (25 neighbours lie within ~3 leaf sizes on a surface, i.e.
-    // within one of these cells): one radix sort per octave instead of two
+    DevBuf<int> knn(c, (size_t)n * kKnn);
+    DevBuf<unsigned char> knn_ok(c, (size_t)n);
+    MM3D_HIP(hipMemsetAsync(knn_ok.get(), 0, (size_t)n, c->stream));
+    if (oct == 0) sift_dog_octave<SiftCfgSmall>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get());
+    else sift_dog_octave<SiftCfgLarge>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get());
+    // The extremum test: the points whose list held 25 neighbours read them back (k_sift_extrema_knn, nearly all
+    // of them); the others -- borders and sparse places, where the 25 nearest reach beyond 3 sigma_max -- search the
+    // same grid (k_sift_extrema over their compacted runs, normally a handful of items).
     const Grid &gk = gr;
-    DevBuf<float4> dogx(c, (size_t)gk.n * 2);
-    MM3D_LAUNCH(c, "sift_pack", gk.n * 48.0, k_sift_dogx, dim3(div_up(gk.n, 256)), dim3(256), 0, (const float4 *)gk.sorted.get(),
-                (const float *)dog.get(), gk.n, dogx.get());
+    DevBuf<float4> dogx(c, (size_t)n * 2);
+    MM3D_LAUNCH(c, "sift_pack", n * 52.0, k_sift_dogx, dim3(div_up(n, 256)), dim3(256), 0, (const float *)dog.get(), n, dogx.get());
     DevBuf<int> flags(c, (size_t)n * 3 + 1);
     MM3D_HIP(hipMemsetAsync(flags.get(), 0, ((size_t)n * 3 + 1) * sizeof(int), c->stream));
     const int nh = (int)cur->n_finite;
+    MM3D_LAUNCH(c, "sift_extrema_knn", nh * 16.0 + n * 0.25 * (kKnn * 36.0 + 20.0), k_sift_extrema_knn, dim3(div_up(nh, 256)), dim3(256), 0,
+                (const float4 *)cur->hil_pts.get(), nh, n, (const float *)dog.get(), (const float4 *)dogx.get(), (const int *)knn.get(),
+                (const unsigned char *)knn_ok.get(), (float)min_contrast, flags.get());
     DevBuf<int> lflag(c, (size_t)nh + 1), lpos(c, (size_t)nh + 1);
     DevBuf<float4> lpts(c, (size_t)nh);
     DevBuf<uint32_t> lkeys(c, (size_t)nh);
@@ -620,7 +675,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     const int max_items = 2 * n_items + 4;                // a block's live run splits at most once more than its full run
     DevBuf<int2> litems(c, (size_t)max_items);
     MM3D_LAUNCH(c, "sift_live", nh * 28.0, k_sift_live, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(), nh,
-                (const float *)dog.get(), (float)min_contrast, lflag.get());
+                (const float *)dog.get(), (float)min_contrast, (const unsigned char *)knn_ok.get(), lflag.get());
     exclusive_scan_int(c, lflag.get(), lpos.get(), (size_t)nh + 1);
     MM3D_LAUNCH(c, "sift_live", nh * 32.0, k_sift_live_compact, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
                 (const uint32_t *)cur->hil_keys.get(), nh, (const int *)lflag.get(), (const int *)lpos.get(), lpts.get(), lkeys.get());
@@ -632,7 +687,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     // one item per block (measured on MI355X, three octaves of one map: 1.69 -> 1.05 ms at 500 k points, 1.28 -> 0.45 ms
     // at 50 k; four items per block, k_sift_extrema<1>, is the same code with one wave per item)
     MM3D_LAUNCH(c, "sift_extrema", gk.n * 48.0, k_sift_extrema<4>, dim3((unsigned)max_items), dim3(256), 0,
-                (const float4 *)lpts.get(), (const int2 *)litems.get(), (const int *)(lipos.get() + nh), gk.view(), (const float4 *)dogx.get(),
+                (const float4 *)lpts.get(), (const int2 *)litems.get(), (const int *)(lipos.get() + nh), gk.view(), (const float4 *)dogx.get(), n,
                 (const float *)dog.get(), (float)min_contrast, flags.get());
     DevBuf<int> pos(c, (size_t)n * 3 + 1);
     exclusive_scan_int(c, flags.get(), pos.get(), (size_t)n * 3 + 1);
