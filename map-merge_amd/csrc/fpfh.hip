@@ -109,17 +109,23 @@ __device__ __forceinline__ int bin_of(double x)
 // per-lane hit count.
 constexpr int kSpfhTile = 64;
 constexpr int kSpfhPool = 2048;
-constexpr int kSpfhWaves = 2;
+#ifndef MM3D_SPFH_WAVES
+#define MM3D_SPFH_WAVES 2
+#endif
+constexpr int kSpfhWaves = MM3D_SPFH_WAVES;
 __global__ void __launch_bounds__(64 * kSpfhWaves)
 k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g,
        const float4 *__restrict__ nrm /* original order */, const float4 *__restrict__ nrm_sorted,
-       const int *__restrict__ in_set, const int *__restrict__ pos, float radius, float r2, float *__restrict__ spfh /* [ns][33] */)
+       const int *__restrict__ in_set, const int *__restrict__ pos, float radius, float r2, float *__restrict__ spfh /* [ns][33] */,
+       int *__restrict__ error)
 {
   __shared__ float4 s_pts[kSpfhWaves][kSpfhTile];
   __shared__ float4 s_nrm[kSpfhWaves][kSpfhTile];
   __shared__ int s_off[kSpfhWaves][64];
   __shared__ int s_beg[kSpfhWaves][64];
-  __shared__ unsigned hist[kSpfhWaves][kDim][64];
+  // hit counters, two 16-bit counts to a word (lanes 2w and 2w + 1): half the LDS of one word per lane, which is
+  // what bounds the blocks per CU; a point with more than 65535 neighbours is reported, not miscounted
+  __shared__ unsigned hist[kSpfhWaves][kDim][32];
   __shared__ unsigned short s_pool[kSpfhWaves][kSpfhPool];
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -133,7 +139,7 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
   if (!__ballot(live)) return;                // wave-uniform: no support point in this patch
   const float4 nq = nrm[self];
 #pragma unroll
-  for (int b = 0; b < kDim; ++b) hist[wave][b][lane] = 0u;
+  for (int b = 0; b < kDim; ++b) hist[wave][b][lane >> 1] = 0u;
   const float ri = radius * 1.0001f + 1e-4f;
   const float lx = wave_min_f(live ? q.x : INFINITY), hx = wave_max_f(live ? q.x : -INFINITY);
   const float ly = wave_min_f(live ? q.y : INFINITY), hy = wave_max_f(live ? q.y : -INFINITY);
@@ -145,7 +151,7 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
   int cnt = 0;
   const float4 *sp = s_pts[wave];
   const float4 *sn = s_nrm[wave];
-  unsigned(*hw)[64] = hist[wave];
+  unsigned(*hw)[32] = hist[wave];
   unsigned short *pool = s_pool[wave];
   wave_stream_box<kSpfhTile, 1>(
       g, x0, x1, y0, y1, z0, z1, s_pts[wave], s_nrm[wave], s_off[wave], s_beg[wave], lane,
@@ -194,9 +200,10 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
                 const int h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
                 const int h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
                 const int h3 = bin_of(kBins * (((double)f3 + 1.0) * 0.5));
-                atomicAdd(&hw[h1][o], 1u);
-                atomicAdd(&hw[kBins + h2][o], 1u);
-                atomicAdd(&hw[2 * kBins + h3][o], 1u);
+                const unsigned one = 1u << ((o & 1) << 4);
+                atomicAdd(&hw[h1][o >> 1], one);
+                atomicAdd(&hw[kBins + h2][o >> 1], one);
+                atomicAdd(&hw[2 * kBins + h3][o >> 1], one);
               }
             }
           }
@@ -206,10 +213,11 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
       // only points inside the patch's bounding box grown by the radius can be in range
       KeepInBox{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri});
   if (!live) return;
+  if (cnt > 65535) { atomicExch(error, 1); return; }
   const float hist_incr = 100.0f / (float)(cnt - 1);
   float *o = spfh + (size_t)pos[self] * kDim;
   for (int b = 0; b < kDim; ++b) {
-    const unsigned hits = hw[b][lane];
+    const unsigned hits = (hw[b][lane >> 1] >> ((lane & 1) << 4)) & 0xffffu;
     float v = 0.0f;
     for (unsigned i = 0; i < hits; ++i) v += hist_incr;
     o[b] = v;
@@ -346,9 +354,14 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
   if (ns > 0) {
     cloud_hilbert(c, points);                            // query order + wave work items (shared with ICP / score)
     const int n_items = points->n_wave_items;
+    DevBuf<int> spfh_err(c, 1);
+    MM3D_HIP(hipMemsetAsync(spfh_err.get(), 0, sizeof(int), c->stream));
     MM3D_LAUNCH(c, "spfh", ns * 156.0, k_spfh, dim3(div_up(n_items, kSpfhWaves)), dim3(64 * kSpfhWaves), 0, (const float4 *)points->hil_pts.get(),
                 (const int2 *)points->wave_items.get(), n_items, g.view(), (const float4 *)normals->nrm.get(),
-                (const float4 *)nrm_sorted.get(), (const int *)in_set.get(), (const int *)pos.get(), (float)radius, r2, spfh.get());
+                (const float4 *)nrm_sorted.get(), (const int *)in_set.get(), (const int *)pos.get(), (float)radius, r2, spfh.get(), spfh_err.get());
+    int *hse = (int *)c->pin(64);
+    MM3D_HIP(hipMemcpyAsync(hse, spfh_err.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->check_later(hse, MM3D_EUNSUPPORTED, "computeLocalDescriptors(FPFH): a point has more than 65535 neighbours within the radius");
   }
   {
     // row of the support set by ORIGINAL point index (what a sorted list entry carries)

@@ -431,13 +431,14 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
   __shared__ int s_beg[4][64];
   const int n_items = *n_items_dev;
   const int n_blocks = SPLIT == 4 ? n_items : (n_items + 3) >> 2;
-  if ((int)blockIdx.x >= n_blocks) return;                 // the grid is sized for the worst case
-  const unsigned bid = xcd_remap(blockIdx.x, (unsigned)n_blocks);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = SPLIT == 4 ? (int)bid : (int)bid * 4 + wave;
+  // the number of items is only known on the device (normally a handful: the points k_sift_extrema_knn could not
+  // take): a modest grid walks them, instead of a worst-case grid of blocks that find nothing to do
+  for (int vb = (int)blockIdx.x; vb < n_blocks; vb += (int)gridDim.x) {
+  const int item = SPLIT == 4 ? vb : vb * 4 + wave;
   const int2 it = item < n_items ? items[item] : make_int2(0, 0);
   const bool valid = lane < it.y;
-  if (it.y == 0) return;                      // wave-uniform
+  if (it.y == 0) continue;                    // wave-uniform (SPLIT 4: block-uniform)
   const float4 q = q_pts[it.x + (valid ? lane : 0)];
   const int self = __float_as_int(q.w);
   float v[3];
@@ -603,10 +604,13 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
     }
   }
   }
-  if (!valid || (SPLIT == 4 && wave != 0)) return;
+  if (valid && !(SPLIT == 4 && wave != 0)) {
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
-    if (live & (1u << s)) flags[(size_t)self * 3 + s] = (is_min[s] || is_max[s]) ? 1 : 0;
+    for (int s = 0; s < 3; ++s)
+      if (live & (1u << s)) flags[(size_t)self * 3 + s] = (is_min[s] || is_max[s]) ? 1 : 0;
+  }
+  if (SPLIT == 4) __syncthreads();            // the next item reuses the tiles
+  }
 }
 
 __global__ void k_sift_emit(const float4 *__restrict__ pts, const int *__restrict__ flags, const int *__restrict__ pos,
@@ -686,7 +690,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
                 (const int *)lipos.get(), (const int *)(lpos.get() + nh), litems.get());
     // one item per block (measured on MI355X, three octaves of one map: 1.69 -> 1.05 ms at 500 k points, 1.28 -> 0.45 ms
     // at 50 k; four items per block, k_sift_extrema<1>, is the same code with one wave per item)
-    MM3D_LAUNCH(c, "sift_extrema", gk.n * 48.0, k_sift_extrema<4>, dim3((unsigned)max_items), dim3(256), 0,
+    MM3D_LAUNCH(c, "sift_extrema", 0.0, k_sift_extrema<4>, dim3((unsigned)std::min(max_items, 1024)), dim3(256), 0,
                 (const float4 *)lpts.get(), (const int2 *)litems.get(), (const int *)(lipos.get() + nh), gk.view(), (const float4 *)dogx.get(), n,
                 (const float *)dog.get(), (float)min_contrast, flags.get());
     DevBuf<int> pos(c, (size_t)n * 3 + 1);
