@@ -108,7 +108,10 @@ __device__ __forceinline__ int bin_of(double x)
 // bumps the owner's counters with LDS atomics.  Trip count = total hits / 64 instead of the largest
 // per-lane hit count.
 constexpr int kSpfhTile = 64;
-constexpr int kSpfhPool = 2048;
+#ifndef MM3D_SPFH_POOL
+#define MM3D_SPFH_POOL 1536
+#endif
+constexpr int kSpfhPool = MM3D_SPFH_POOL;
 #ifndef MM3D_SPFH_WAVES
 #define MM3D_SPFH_WAVES 2
 #endif

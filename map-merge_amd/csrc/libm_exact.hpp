@@ -193,43 +193,40 @@ MM3D_HD float cosf_glibc(float y)
 MM3D_HD float atanf_glibc(float x)
 {
   // the decimal literals of s_atanf.c (its hex comments are not all exact)
-  const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
-  const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
   const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
                         6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
   const int32_t hx = (int32_t)f2u(x);
   const int32_t ix = hx & 0x7fffffff;
-  int id;
   if (ix >= 0x4c000000) {                          // |x| >= 2^25
     if (ix > 0x7f800000) return x + x;             // NaN
-    return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    return hx > 0 ? 1.5707962513e+00f + 7.5497894159e-08f : -1.5707962513e+00f - 7.5497894159e-08f;
   }
-  if (ix < 0x3ee00000) {                           // |x| < 0.4375
-    if (ix < 0x31000000) return x;                 // |x| < 2^-29
-    id = -1;
-  } else {
-    x = fabsf_(x);
-    if (ix < 0x3f980000) {                         // |x| < 1.1875
-      if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
-      else { id = 1; x = (x - 1.0f) / (x + 1.0f); }
-    } else {
-      if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
-      else { id = 3; x = -1.0f / x; }
-    }
-  }
-  float z = x * x;
+  if (ix < 0x31000000) return x;                   // |x| < 2^-29
+  // s_atanf.c reduces by range -- (2x-1)/(2+x), (x-1)/(x+1), (x-1.5)/(1+1.5x), -1/x, or x itself below 0.4375 --
+  // in four branches; here the numerator and the denominator are picked by range and divided ONCE (a wave's lanes
+  // fall into all the ranges: every branch would run, each with a division of its own).  x / 1 is x, and the
+  // function is odd in every step (rounding is symmetric), so the work is done on |x| and the sign put back.
+  const float ax = fabsf_(x);
+  const bool r_lo = ix < 0x3ee00000, r0 = ix < 0x3f300000, r1 = ix < 0x3f980000, r2 = ix < 0x401c0000;
+  const float num = r_lo ? ax : (r0 ? 2.0f * ax - 1.0f : (r1 ? ax - 1.0f : (r2 ? ax - 1.5f : -1.0f)));
+  const float den = r_lo ? 1.0f : (r0 ? 2.0f + ax : (r1 ? ax + 1.0f : (r2 ? 1.0f + 1.5f * ax : ax)));
+  const float hi = r0 ? 4.6364760399e-01f : (r1 ? 7.8539812565e-01f : (r2 ? 9.8279368877e-01f : 1.5707962513e+00f));
+  const float lo = r0 ? 5.0121582440e-09f : (r1 ? 3.7748947079e-08f : (r2 ? 3.4473217170e-08f : 7.5497894159e-08f));
+  const float t = num / den;
+  const float z = t * t;
   const float w = z * z;
   const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
   const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
-  if (id < 0) return x - x * (s1 + s2);
-  z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
-  return hx < 0 ? -z : z;
+  const float ts = t * (s1 + s2);
+  const float r = r_lo ? t - ts : hi - ((ts - lo) - t);
+  return hx < 0 ? -r : r;
 }
 
-MM3D_HD float atan2f_glibc(float y, float x)
+// the zeros, infinities, NaNs and x == 1 of e_atan2f.c, in its own order
+MM3D_HD float atan2f_glibc_special(float y, float x)
 {
   const float tiny = 1.0e-30f;
-  const float pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const float pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f;
   const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
   const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
   if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;          // NaN
@@ -259,18 +256,23 @@ MM3D_HD float atan2f_glibc(float y, float x)
       default: return -pi - tiny;
     }
   }
-  if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;               // y = +-inf, x finite
+}
+
+MM3D_HD float atan2f_glibc(float y, float x)
+{
+  const float pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
+  const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+  // one test for every special operand (zero, infinity, NaN on either side, x == 1): ix - 1 wraps for zero
+  if ((uint32_t)(ix - 1) >= 0x7f7fffffu || (uint32_t)(iy - 1) >= 0x7f7fffffu || hx == 0x3f800000) return atan2f_glibc_special(y, x);
   const int32_t k = (iy - ix) >> 23;
-  float z;
+  float z = atanf_glibc(fabsf_(y / x));
   if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                          // |y / x| > 2^60
   else if (hx < 0 && k < -60) z = 0.0f;                           // |y| / x < -2^60
-  else z = atanf_glibc(fabsf_(y / x));
-  switch (m) {
-    case 0: return z;
-    case 1: return u2f(f2u(z) ^ 0x80000000u);
-    case 2: return pi - (z - pi_lo);
-    default: return (z - pi_lo) - pi;
-  }
+  // quadrants: z | -z | pi - (z - pi_lo) | (z - pi_lo) - pi; the last is the third negated (z - pi_lo never equals pi)
+  const float q = hx < 0 ? pi - (z - pi_lo) : z;
+  return u2f(f2u(q) ^ ((uint32_t)hy & 0x80000000u));
 }
 
 }  // namespace lm
