@@ -191,7 +191,7 @@ __global__ void k_knn_prep(const float *__restrict__ X, int n, int ntiles, int i
 // block = one tile of 32 queries; its 4 waves scan disjoint quarters of the target tiles.
 template <int kD>
 __global__ void __launch_bounds__(256)
-k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, int nb, int nb_tiles,
+k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, int nb, int nb_tiles, int tile_step,
            float *__restrict__ cand_d, int *__restrict__ cand_i)
 {
   constexpr int kSteps = knn_kp(kD) / 2;   // 32x32x2 MFMA steps: 18 (FPFH) / 64 (PFH)
@@ -210,8 +210,9 @@ k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, i
   // interleaving spreads a query's true neighbours evenly over the lists, which is what keeps short
   // lists certifiable.  gridDim.y = parts > 1 when there are few query tiles (SAC-IA only looks up
   // its sampled rows): the targets are then split over more blocks so the launch still fills the chip.
-  const int part = blockIdx.y, stride = kSlices * (int)gridDim.y;
-  const int c0 = part * kSlices + slice, c1 = nb_tiles;
+  // tile_step > 1: only every tile_step-th target tile is visited (the sample that sets the filter's thresholds)
+  const int part = blockIdx.y, stride = kSlices * (int)gridDim.y * tile_step;
+  const int c0 = (part * kSlices + slice) * tile_step, c1 = nb_tiles;
   float bf[kSteps], bn[kSteps];
   if (c0 < c1) {
 #pragma unroll
@@ -266,6 +267,225 @@ k_knn_mfma(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, i
     od[s] = real ? ld[s] : INFINITY;
     oi[s] = real ? li[s] : -1;
   }
+}
+
+// ---------------------------------------------------------------- stage 2': threshold filter (short rows, many targets)
+// Keeping sorted lists in the MFMA loop costs five times the matrix work (every tile finds SOME lane with a new
+// entry, and a wave's lists never mature when the targets are split over many blocks).  Instead:
+//   a. k_knn_mfma over every kSampleStep-th target tile (lists as above, a small job), and per query
+//      theta = the (k + kThetaExtra)-th smallest approximate distance of that sample (k_knn_theta) -- an upper
+//      bound of the k-th smallest over all targets, with room for the certificate;
+//   b. k_knn_filter: the full product; a lane only compares its 16 values with its query's theta and appends
+//      the few that pass (about (k + kThetaExtra) * kSampleStep per query) to the query's candidate buffer;
+//   c. k_knn_rerank_filter: exact distances of those candidates; a target that is NOT a candidate has an
+//      approximate distance >= theta, which is what the certificate needs (tau = theta).  A buffer that
+//      overflows leaves its row to the exact fallback.
+constexpr int kSampleStep = 8;
+constexpr int kThetaExtra = 6;
+constexpr int kFilterCap = 512;
+
+__device__ __forceinline__ unsigned knn_ordered_bits(float v);
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v);
+
+// wave-wide minimum / sum through the DPP network (row shifts, then row broadcasts; the last lane holds the result)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned knn_dpp_keep(unsigned v)           // lanes without a source keep their own value
+{
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned knn_wave_min_u32(unsigned v)
+{
+  v = min(v, knn_dpp_keep<0x111, 0xf>(v));
+  v = min(v, knn_dpp_keep<0x112, 0xf>(v));
+  v = min(v, knn_dpp_keep<0x114, 0xf>(v));
+  v = min(v, knn_dpp_keep<0x118, 0xf>(v));
+  v = min(v, knn_dpp_keep<0x142, 0xa>(v));
+  v = min(v, knn_dpp_keep<0x143, 0xc>(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int knn_wave_sum_i32(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// one wave per query row: theta[a] = the kq-th smallest approximate distance among the row's sample candidates,
+// counted with multiplicity (n_cand <= 64 * kThetaPerLane: a lane keeps its share in registers as order-preserving
+// 32-bit keys and the wave draws distinct minima until kq values are covered)
+constexpr int kThetaPerLane = 8;
+__global__ void __launch_bounds__(256)
+k_knn_theta(const float *__restrict__ cand_d, const int *__restrict__ cand_i, int na, int n_cand, int kq, float *__restrict__ theta)
+{
+  const int lane = threadIdx.x & 63;
+  const int a = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (a >= na) return;               // wave-uniform
+  const float *cd_ = cand_d + (size_t)a * n_cand;
+  const int *ci_ = cand_i + (size_t)a * n_cand;
+  unsigned key[kThetaPerLane];       // 0xffffffff = none (an ordered key of a finite distance is never all ones)
+#pragma unroll
+  for (int u = 0; u < kThetaPerLane; ++u) {
+    const int e = lane + u * kWave;
+    key[u] = 0xffffffffu;
+    if (e < n_cand && ci_[e] >= 0) key[u] = knn_ordered_bits(cd_[e]);
+  }
+  unsigned best = 0xffffffffu;
+  int covered = 0;
+  while (covered < kq) {
+    unsigned cur = key[0];
+#pragma unroll
+    for (int u = 1; u < kThetaPerLane; ++u) cur = min(cur, key[u]);
+    best = knn_wave_min_u32(cur);
+    if (best == 0xffffffffu) break;                   // fewer than kq candidates: no bound
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < kThetaPerLane; ++u) {
+      mine += key[u] == best ? 1 : 0;
+      key[u] = key[u] == best ? 0xffffffffu : key[u];
+    }
+    covered += knn_wave_sum_i32(mine);
+  }
+  // back from the ordered key to the float
+  const unsigned bits = (best & 0x80000000u) ? (best & 0x7fffffffu) : ~best;
+  if (lane == 0) theta[a] = best == 0xffffffffu ? INFINITY : __uint_as_float(bits);
+}
+
+template <int kD>
+__global__ void __launch_bounds__(256)
+k_knn_filter(const float *__restrict__ Ap, int na, const float *__restrict__ Bp, int nb, int nb_tiles, const float *__restrict__ theta,
+             int *__restrict__ cand_n /* [na], zeroed */, int *__restrict__ cand_i /* [na][kFilterCap] */)
+{
+  constexpr int kSteps = knn_kp(kD) / 2;
+  const int lane = threadIdx.x & 63;
+  const int slice = threadIdx.x >> 6;
+  const int tile_a = blockIdx.x;
+  float af[kSteps];
+#pragma unroll
+  for (int s = 0; s < kSteps; ++s) af[s] = Ap[((size_t)tile_a * kSteps + s) * 64 + lane];
+  const int a = tile_a * 32 + (lane & 31);
+  const float th = a < na ? theta[a] : -INFINITY;      // rows past the end take nothing
+  int *cnt = cand_n + (a < na ? a : 0);
+  int *out = cand_i + (size_t)(a < na ? a : 0) * kFilterCap;
+  const int part = blockIdx.y, stride = kSlices * (int)gridDim.y;
+  const int c0 = part * kSlices + slice, c1 = nb_tiles;
+  float bf[kSteps], bn[kSteps];
+  if (c0 < c1) {
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) bf[s] = Bp[((size_t)c0 * kSteps + s) * 64 + lane];
+  }
+  // A tile's passing values are claimed with ONE atomic per lane (their count) and written out an iteration later,
+  // after the next tile's MFMA chain: the atomic's round trip is never waited for.
+  unsigned pend_mask = 0u;
+  int pend_pos = 0, pend_base = 0;
+  auto flush = [&]() {
+    unsigned m = pend_mask;
+    int pos = pend_pos;
+    while (m) {
+      const int r = __ffs((int)m) - 1;
+      m &= m - 1u;
+      if (pos < kFilterCap) out[pos] = pend_base + (r & 3) + 8 * (r >> 2);
+      ++pos;
+    }
+  };
+  for (int c = c0; c < c1; c += stride) {
+    const int cn = (c + stride < c1) ? c + stride : c;
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) bn[s] = Bp[((size_t)cn * kSteps + s) * 64 + lane];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc, 0, 0, 0);
+    if (__any(pend_mask != 0u)) flush();
+    const int rbase = c * 32 + 4 * (lane >> 5);
+    unsigned mask = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mask |= (acc[r] < th && rbase + (r & 3) + 8 * (r >> 2) < nb) ? (1u << r) : 0u;
+    pend_mask = mask;
+    pend_base = rbase;
+    if (mask) pend_pos = atomicAdd(cnt, (int)__popc(mask));
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) bf[s] = bn[s];
+  }
+  flush();
+}
+
+// One wave per query row: exact distances of the filter's candidates, the k best by (distance, index), and the
+// certificate against theta (see k_knn_rerank for the bound).
+template <int kD>
+__global__ void __launch_bounds__(256)
+k_knn_rerank_filter(const float *__restrict__ A, int na, const float *__restrict__ B, int nb, int k, const int *__restrict__ cand_n,
+                    const int *__restrict__ cand_i, const float *__restrict__ theta, const float *__restrict__ colsum, float inv_nb,
+                    int *__restrict__ idx, float *__restrict__ d2out, int *__restrict__ fb_rows, int *__restrict__ fb_count)
+{
+  const int lane = threadIdx.x & 63;
+  const int a = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (a >= na) return;               // wave-uniform
+  float x[kD];
+  float na2 = 0.0f;
+#pragma unroll
+  for (int d = 0; d < kD; ++d) {
+    x[d] = A[(size_t)a * kD + d];
+    const float xc = x[d] - colsum[d] * inv_nb;
+    na2 = fmaf(xc, xc, na2);         // |a - mu|^2
+  }
+  float bd[kMaxK];
+  int bi[kMaxK];
+#pragma unroll
+  for (int s = 0; s < kMaxK; ++s) { bd[s] = INFINITY; bi[s] = 0x7fffffff; }
+  const int found = cand_n[a];
+  const int n_cand = found < kFilterCap ? found : kFilterCap;
+  const int *ci_ = cand_i + (size_t)a * kFilterCap;
+  for (int e = lane; e < n_cand; e += kWave) {
+    const int j = ci_[e];
+    const float *b = B + (size_t)j * kD;
+    float r = 0.0f;
+#pragma unroll
+    for (int d = 0; d < kD; ++d) {
+      const float df = x[d] - b[d];
+      r = __fadd_rn(r, __fmul_rn(df, df));
+    }
+    if (r < bd[kMaxK - 1] || (r == bd[kMaxK - 1] && j < bi[kMaxK - 1])) {
+      float cd = r;
+      int ci = j;
+      bool carrying = false;
+#pragma unroll
+      for (int t = 0; t < kMaxK; ++t) {
+        const bool sw = carrying || cd < bd[t] || (cd == bd[t] && ci < bi[t]);
+        carrying = sw;
+        const float td = bd[t];
+        const int ti = bi[t];
+        bd[t] = sw ? cd : td; bi[t] = sw ? ci : ti;
+        cd = sw ? td : cd; ci = sw ? ti : ci;
+      }
+    }
+  }
+  float kth = INFINITY;
+  for (int o = 0; o < k; ++o) {
+    const unsigned long long key = ((unsigned long long)__float_as_uint(bd[0]) << 32) | (unsigned)bi[0];
+    const unsigned long long best = wave_min_u64(key);
+    const float d = __uint_as_float((unsigned)(best >> 32));
+    if (lane == 0) {
+      idx[(size_t)a * k + o] = d < INFINITY ? (int)(unsigned)(best & 0xffffffffull) : -1;
+      d2out[(size_t)a * k + o] = d;
+    }
+    if (o == k - 1) kth = d;
+    if (key == best && bd[0] < INFINITY) {
+#pragma unroll
+      for (int s = 0; s + 1 < kMaxK; ++s) { bd[s] = bd[s + 1]; bi[s] = bi[s + 1]; }
+      bd[kMaxK - 1] = INFINITY; bi[kMaxK - 1] = 0x7fffffff;
+    }
+  }
+  // every target outside the candidates has approx >= theta: k_knn_rerank's certificate with tau = theta
+  const float tau = theta[a];
+  const float rho = (sqrtf(na2) + sqrtf(kth)) * 1.001f + 1e-3f;
+  const float eps = (2e-5f * (na2 + rho * rho) + 1e-5f * kth) * ((float)knn_kp(kD) / 36.0f);
+  const bool certified = found <= kFilterCap && (!(tau < INFINITY) ? found >= nb : (kth < tau - eps));
+  if (!certified && lane == 0) fb_rows[atomicAdd(fb_count, 1)] = a;
 }
 
 // ---------------------------------------------------------------- stage 3: exact re-rank + certificate
@@ -926,27 +1146,59 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
   const float inv_nb = 1.0f / (float)nb;
   MM3D_LAUNCH(c, "desc_knn_prep", na * (kD + kKP) * 4.0, (k_knn_prep<kD>), dim3(div_up((size_t)na_tiles * kSteps * 64, 256)), dim3(256), 0, Ad, na,
               na_tiles, 0, colsum, inv_nb, Ap.get());
+  DevBuf<int> fb_rows(c, na);
   // few query tiles (SAC-IA's sampled rows): split the targets over `parts` blocks per query tile so
-  // that the launch still has >= 2 blocks per CU; each part keeps its own 8 lists per query
+  // that the launch still has >= 2 blocks per CU
   int parts = 1;
   while (parts < 16 && na_tiles * parts < 512 && nb_tiles / (kSlices * parts * 2) >= 4) parts *= 2;
-  const int n_lists = kLists * parts;
-  DevBuf<float> cand_d(c, (size_t)na * n_lists * kListLen);
-  DevBuf<int> cand_i(c, (size_t)na * n_lists * kListLen);
-  // roofline unit for this kernel is FLOPs (2 * na * nb * kKP per launch), reported as such by bench.py
-  MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, (k_knn_mfma<kD>), dim3(na_tiles, parts),
-              dim3(256), 0, (const float *)Ap.get(), na, Bp, nb, nb_tiles, cand_d.get(), cand_i.get());
-  DevBuf<int> fb_rows(c, na);
-  // short rows (RSD, FPFH): every candidate is re-ranked, a 33-term chain is cheaper than choosing; long rows (PFH):
-  // the pruned re-rank of the wide path (k best approximate candidates first, then only what can still matter)
-  if constexpr (kD >= 64)
-    MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * 8 + 32 * kD * 4), (k_knn_rerank_wide<kD>), dim3(div_up(na, 4)), dim3(256), 0,
-                Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
+  static const bool no_filter = getenv("MM3D_KNN_NO_FILTER") != nullptr;     // A/B: the list path for every shape
+  if (kD < 64 && nb_tiles >= 64 && k + kThetaExtra <= 32 && !no_filter) {
+   if constexpr (kD < 64) {
+    // short rows against many targets: thresholds from a sample of the target tiles, then the filtered product
+    const int ns_tiles = div_up(nb_tiles, kSampleStep);
+    int sparts = 1;
+    while (sparts < 4 && na_tiles * sparts < 512 && ns_tiles / (kSlices * sparts * 2) >= 2) sparts *= 2;
+    const int s_lists = kLists * sparts;
+    DevBuf<float> samp_d(c, (size_t)na * s_lists * kListLen);
+    DevBuf<int> samp_i(c, (size_t)na * s_lists * kListLen);
+    DevBuf<float> theta(c, (size_t)na);
+    DevBuf<int> cand_n(c, (size_t)na);
+    DevBuf<int> cand_i(c, (size_t)na * kFilterCap);
+    MM3D_HIP(hipMemsetAsync(cand_n.get(), 0, (size_t)na * sizeof(int), c->stream));
+    MM3D_LAUNCH(c, "desc_knn_sample", 2.0 * (double)na_tiles * 32 * (double)ns_tiles * 32 * kKP, (k_knn_mfma<kD>), dim3(na_tiles, sparts), dim3(256), 0,
+                (const float *)Ap.get(), na, Bp, nb, nb_tiles, kSampleStep, samp_d.get(), samp_i.get());
+    static_assert(kLists * 4 * kListLen <= 64 * kThetaPerLane, "k_knn_theta keeps a row's sample candidates in registers");
+    MM3D_LAUNCH(c, "desc_knn_theta", na * (double)(s_lists * kListLen * 8), k_knn_theta, dim3(div_up(na, 4)), dim3(256), 0, (const float *)samp_d.get(),
+                (const int *)samp_i.get(), na, s_lists * kListLen, k + kThetaExtra, theta.get());
+    // roofline unit for this kernel is FLOPs (2 * na * nb * kKP per launch), reported as such by bench.py
+    // (no lists to keep: the targets are split until the launch has eight waves per SIMD or a wave is down to four tiles)
+    int fparts = 1;
+    while (fparts < 64 && na_tiles * fparts < 2048 && nb_tiles / (kSlices * fparts * 2) >= 4) fparts *= 2;
+    if (const char *e = getenv("MM3D_KNN_PARTS")) fparts = std::max(1, atoi(e));   // experiment
+    MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, (k_knn_filter<kD>), dim3(na_tiles, fparts), dim3(256), 0,
+                (const float *)Ap.get(), na, Bp, nb, nb_tiles, (const float *)theta.get(), cand_n.get(), cand_i.get());
+    MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)((k + kThetaExtra) * kSampleStep * (kD * 4 + 4) + kD * 4), (k_knn_rerank_filter<kD>), dim3(div_up(na, 4)),
+                dim3(256), 0, Ad, na, Bd, nb, k, (const int *)cand_n.get(), (const int *)cand_i.get(), (const float *)theta.get(), colsum, inv_nb,
                 idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
-  else
-    MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * (kD * 4 + 8) + kD * 4), (k_knn_rerank<kD>), dim3(div_up(na, 4)), dim3(256), 0,
-                Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
-                idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
+   }
+  } else {
+    // each part keeps its own 8 lists per query
+    const int n_lists = kLists * parts;
+    DevBuf<float> cand_d(c, (size_t)na * n_lists * kListLen);
+    DevBuf<int> cand_i(c, (size_t)na * n_lists * kListLen);
+    MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, (k_knn_mfma<kD>), dim3(na_tiles, parts),
+                dim3(256), 0, (const float *)Ap.get(), na, Bp, nb, nb_tiles, 1, cand_d.get(), cand_i.get());
+    // short rows (RSD, FPFH): every candidate is re-ranked, a 33-term chain is cheaper than choosing; long rows (PFH):
+    // the pruned re-rank of the wide path (k best approximate candidates first, then only what can still matter)
+    if constexpr (kD >= 64)
+      MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * 8 + 32 * kD * 4), (k_knn_rerank_wide<kD>), dim3(div_up(na, 4)), dim3(256), 0,
+                  Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
+                  idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
+    else
+      MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * (kD * 4 + 8) + kD * 4), (k_knn_rerank<kD>), dim3(div_up(na, 4)), dim3(256), 0,
+                  Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
+                  idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
+  }
   // rows without a certificate: exact search over the targets whose norm is within the row's current k-th
   // distance of its own (the grid is sized for the worst case; waves beyond the device-side count exit at once)
   DevBuf<uint32_t> nsort_tmp, nperm_tmp;

@@ -168,7 +168,10 @@ __device__ __forceinline__ float quad_bcast(float v)
 }
 
 using SiftCfgSmall = SnbCfg<8, 1792, 1024, 384, 128, true>;     // first octave: lists of ~100, 2 blocks of 8 waves per CU
-using SiftCfgLarge = SnbCfg<8, 3584, 2560, 768, 256, true>;     // later octaves: lists of 300-900 (longer ones in bands), 1 block of 8 waves per CU
+#ifndef MM3D_SIFT_LARGE
+#define MM3D_SIFT_LARGE 8, 3584, 2560, 768, 256
+#endif
+using SiftCfgLarge = SnbCfg<MM3D_SIFT_LARGE, true>;     // later octaves: lists of 300-900 (longer ones in bands), 1 block of 8 waves per CU
 
 template <class Cfg>
 __global__ void __launch_bounds__(64 * Cfg::kWaves)

@@ -196,6 +196,34 @@ def test_desc_knn_mfma_path_exact(ctx, po, mm, scene):
     assert rows > 0 and fb <= 0.05 * rows, (rows, fb)   # the certificate holds for nearly every row
 
 
+def test_desc_knn_filter_path_exact(ctx, po, mm, scene):
+    """Short rows against many targets take the threshold filter (thresholds from a sample of the target tiles,
+    candidates = every target under its query's threshold): the same exact FLANN-order k-NN, the SAC-IA shape
+    (few queries, targets split over parts) and the matching shape (both directions), ties and zero distances
+    included; almost no row may need the exact fallback."""
+    rng = np.random.default_rng(17)
+    base = np.concatenate([scene[0]["desc"], scene[1]["desc"]])
+    L = mm.lib()
+    L.mm3d_debug_knn_fallback_rows.restype = L.mm3d_debug_knn_rows.restype = __import__("ctypes").c_longlong
+    for na, nb in ((700, 9000), (5000, 6000)):
+        A = (base[rng.integers(0, len(base), na)] + rng.normal(0, 0.3, (na, 33))).astype(np.float32)
+        B = (base[rng.integers(0, len(base), nb)] + rng.normal(0, 0.3, (nb, 33))).astype(np.float32)
+        B[100:140] = B[200:240]
+        A[:20] = B[300:320]
+        L.mm3d_set_debug(ctx._h, 1)
+        r0, f0 = L.mm3d_debug_knn_rows(ctx._h), L.mm3d_debug_knn_fallback_rows(ctx._h)
+        da, db = ctx.descriptors(A), ctx.descriptors(B)
+        for k in (1, 5, 10):
+            got = ctx.findFeatureCorrespondences(da, db, k)
+            ref = po.find_correspondences(A, B, k)
+            assert np.array_equal(got["index_query"], ref["index_query"]), (na, nb, k)
+            assert np.array_equal(got["index_match"], ref["index_match"]), (na, nb, k)
+            assert np.array_equal(got["distance"].view(np.uint32), ref["distance"].view(np.uint32)), (na, nb, k)
+        rows, fb = L.mm3d_debug_knn_rows(ctx._h) - r0, L.mm3d_debug_knn_fallback_rows(ctx._h) - f0
+        L.mm3d_set_debug(ctx._h, 0)
+        assert rows > 0 and fb <= 0.05 * rows, (na, nb, rows, fb)
+
+
 def test_matching_k_is_any_positive_number(ctx, po, mm, scene):
     """matching_k is an arbitrary size_t in the reference (R/src/map_merging.cpp:43-47 -> FLANN nearestKSearch):
     beyond the 16 neighbours the register kernels keep, the plain exact kernel takes over; more neighbours than
