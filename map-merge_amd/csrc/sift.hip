@@ -167,7 +167,10 @@ __device__ __forceinline__ float quad_bcast(float v)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J * 0x55, 0xf, 0xf, false));
 }
 
-using SiftCfgSmall = SnbCfg<8, 1792, 1024, 384, 128, true>;     // first octave: lists of ~100, 2 blocks of 8 waves per CU
+#ifndef MM3D_SIFT_SMALL
+#define MM3D_SIFT_SMALL 8, 1792, 1024, 384, 128
+#endif
+using SiftCfgSmall = SnbCfg<MM3D_SIFT_SMALL, true>;     // first octave: lists of ~100, 2 blocks of 8 waves per CU
 #ifndef MM3D_SIFT_LARGE
 #define MM3D_SIFT_LARGE 8, 3584, 2560, 768, 256
 #endif
