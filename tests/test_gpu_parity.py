@@ -132,6 +132,20 @@ def test_sift_keypoints(ctx, scene):
         assert (got["rgba"] == 0).all()
 
 
+def test_sift_keypoints_where_the_25_nearest_reach_beyond_the_scale_space_ball(ctx, po, scene):
+    """The extremum test reads a point's 25 nearest neighbours from the scale-space kernel's sorted list when the
+    3 sigma_max ball holds that many, and searches for them otherwise.  A cloud thinned to a fifth (most balls hold
+    fewer than 25 points in the first octave, more in the later ones) takes both routes; the keypoints must be the
+    oracle's either way."""
+    rng = np.random.default_rng(5)
+    filt = scene[0]["filt"]
+    thin = filt[np.sort(rng.choice(len(filt), len(filt) // 5, replace=False))].copy()
+    ref, _ = po.keypoints_sift(thin, RES, 3, 3, 1.0)
+    got = ctx.detectKeypoints(ctx.cloud(thin), None, 0, 1.0, R_NRM, RES).numpy()
+    assert len(got) == len(ref) > 20
+    assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
+
+
 def test_fpfh(ctx, scene):
     for m in scene:
         pts, nrm = ctx.cloud(m["filt"]), ctx.normals(m["nrm"])
