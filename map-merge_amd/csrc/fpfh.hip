@@ -354,6 +354,7 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
   MM3D_LAUNCH(c, "fpfh_support", g.n * 44.0, k_fpfh_support, dim3(div_up(g.n, 256)), dim3(256), 0, g.sorted.get(), g.n,
               in_set.get(), pos.get(), row_of.get(), normals->nrm.get(), nrm_sorted.get());
   DevBuf<float> spfh(c, (size_t)(ns > 0 ? ns : 1) * kDim);
+  int *hse = nullptr;                                   // the SPFH kernel's error word, looked at with the weighting's below
   if (ns > 0) {
     cloud_hilbert(c, points);                            // query order + wave work items (shared with ICP / score)
     const int n_items = points->n_wave_items;
@@ -362,9 +363,8 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
     MM3D_LAUNCH(c, "spfh", ns * 156.0, k_spfh, dim3(div_up(n_items, kSpfhWaves)), dim3(64 * kSpfhWaves), 0, (const float4 *)points->hil_pts.get(),
                 (const int2 *)points->wave_items.get(), n_items, g.view(), (const float4 *)normals->nrm.get(),
                 (const float4 *)nrm_sorted.get(), (const int *)in_set.get(), (const int *)pos.get(), (float)radius, r2, spfh.get(), spfh_err.get());
-    int *hse = (int *)c->pin(64);
+    hse = (int *)c->pin(64);
     MM3D_HIP(hipMemcpyAsync(hse, spfh_err.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    c->check_later(hse, MM3D_EUNSUPPORTED, "computeLocalDescriptors(FPFH): a point has more than 65535 neighbours within the radius");
   }
   {
     // row of the support set by ORIGINAL point index (what a sorted list entry carries)
@@ -378,6 +378,7 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
                   (const float4 *)points->pts.get(), (const int *)pos.get(), (const float *)spfh.get(), (float)radius, r2, scr, raw.get(), valid.get());
     int *he = (int *)c->pin(64);
     MM3D_HIP(hipMemcpyAsync(he, sn.error(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (hse) c->check_later(hse, MM3D_EUNSUPPORTED, "computeLocalDescriptors(FPFH): a point has more than 65535 neighbours within the radius");
     c->check_later(he, MM3D_EUNSUPPORTED, "computeLocalDescriptors(FPFH): a keypoint has more than 16384 neighbours within the radius");
   }
   // prune invalid descriptors and the same keypoints (features.cpp:118-143)
