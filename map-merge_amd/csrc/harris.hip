@@ -161,8 +161,8 @@ __global__ void k_harris_to_sorted(const float4 *__restrict__ sorted, const floa
   if (j < n) resp_sorted[j] = resp[__float_as_int(sorted[j].w)];
 }
 
-// the responses of a cloud by original index (zero where the point is not finite): the LDS path, then the
-// (normally empty) launch over the items it could not hold
+// the responses of a cloud by original index (zero where the point is not finite): the LDS path, then -- if it
+// counted any -- the launch over the items it could not hold
 static void harris_response_launch(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, const Grid &g, float sr, float r2,
                                    float *resp /* n floats, zeroed */)
 {
@@ -173,6 +173,11 @@ static void harris_response_launch(Context *c, const mm3d_cloud *points, const m
   MM3D_LAUNCH(c, "harris_response", g.n * 32.0, k_harris_response_lds, dim3(sl.blocks), dim3(64 * HarrisCfg::kWaves), 0,
               (const float4 *)points->hil_pts.get(), (const int2 *)points->wave_items.get(), n_items, g.view(), (const float4 *)normals->nrm.get(),
               sr, r2, ctl, sl.ov_items.get(), resp);
+  // (the fallback launch only when the LDS path counted items it could not hold: normals.hip has the reason)
+  int *ho = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(ho, &ctl->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  if (ho[0] == 0) return;
   SnLaunch<float4> sn(c, n_items * 4, points->n, 4, kSnFallbackBlocks);
   SnScratch sc{sn.tmp.get(), sn.fin.get(), ctl->fb_ctr, &ctl->error, sl.ov_items.get(), &ctl->ov_count};
   MM3D_LAUNCH(c, "harris_response_big", 0.0, k_harris_response_big, dim3(sn.blocks), dim3(256), 0, (const float4 *)points->hil_pts.get(),

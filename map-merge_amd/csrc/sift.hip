@@ -16,6 +16,9 @@
 // the NEAREST such violator (one min-reduction over (distance, index) keys) and count how many
 // points are closer than it (>= 25 <=> the violator is not among the 25 nearest).
 #include <cfloat>
+#include <functional>
+#include <type_traits>
+#include <memory>
 
 #include "sorted_nb.hpp"
 #include "snb_lds.hpp"
@@ -181,7 +184,8 @@ __global__ void __launch_bounds__(64 * Cfg::kWaves)
 k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* .w = original index */,
                const float4 *__restrict__ pts /* original order: rgba */, float radius, float r2, SiftScales sc, SnbCtl *ctl,
                int *__restrict__ ov_items, float *__restrict__ dog /* [n][5] by original index */,
-               int *__restrict__ knn /* [n][kKnn] by original index */, unsigned char *__restrict__ knn_ok /* [n], zeroed */)
+               int *__restrict__ knn /* [n][kKnn] by original index */, unsigned char *__restrict__ knn_ok /* [n], zeroed */,
+               const int *__restrict__ sub_items, const int *__restrict__ sub_count)
 {
   __shared__ SnbLds<Cfg> S;
   __shared__ float resp[Cfg::kWaves][Cfg::kQ][kScales];
@@ -280,32 +284,58 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
           }
         }
         wave_lds_fence();
-      });
+      },
+      sub_items, sub_count);
 }
 
-// one octave's scale space: the LDS path, then the (normally empty) launch over the items it could not hold
+// one octave's scale space on the LDS path.  What it could not hold (a dense spot: normally nothing) is counted in
+// *h_overflow -- pinned host memory, valid after the stream's next sync -- and worked by fallback(), the launch over
+// those items with the lists in global memory (sorted_nb.hpp).  The caller only launches it when the count says so:
+// an empty launch of that kernel still waits for LDS the scale-space kernels of other streams hold (0.7 ms of stream
+// time per octave on the 16-stream bench), and the hardware queue behind it waits with it.
+struct SiftDogPending {
+  int *h_overflow = nullptr;
+  std::function<void(int)> fallback;       // argument: *h_overflow
+};
+
 template <class Cfg>
-static void sift_dog_octave(Context *c, const mm3d_cloud *cur, const Grid &gr, int n_items, float max_radius, float r2, const SiftScales &sc,
-                            float *dog, int *knn, unsigned char *knn_ok)
+static SiftDogPending sift_dog_octave(Context *c, const mm3d_cloud *cur, const Grid &gr, int n_items, float max_radius, float r2,
+                                      const SiftScales &sc, float *dog, int *knn, unsigned char *knn_ok)
 {
-  SnbLaunch<Cfg> sl(c, n_items, sizeof(float) * 64 * kScales + 256);
-  MM3D_LAUNCH(c, getenv("MM3D_SNB_DEBUG") ? (gr.n > 300000 ? "sift_dog_oct0" : (gr.n > 150000 ? "sift_dog_oct1" : "sift_dog_oct2")) : "sift_dog", gr.n * 36.0, k_sift_dog_lds<Cfg>, dim3(sl.blocks), dim3(64 * Cfg::kWaves), 0, (const float4 *)cur->hil_pts.get(),
-              (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, sl.ctl_dev(),
-              sl.ov_items.get(), dog, knn, knn_ok);
-  SnbCtl *ctl = sl.ctl_dev();
-  SnLaunch<float2> sn(c, n_items * 4, cur->n, 4, kSnFallbackBlocks);
-  SnScratch scr{sn.tmp.get(), sn.fin.get(), ctl->fb_ctr, &ctl->error, sl.ov_items.get(), &ctl->ov_count};
-  MM3D_LAUNCH(c, "sift_dog_big", 0.0, k_sift_dog, dim3(sn.blocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
-              (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, scr, dog);
-  int *he = (int *)c->pin(64);
-  MM3D_HIP(hipMemcpyAsync(he, &ctl->error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  if (getenv("MM3D_SNB_DEBUG")) {
-    int *ho = (int *)c->pin(64);
-    MM3D_HIP(hipMemcpyAsync(ho, &ctl->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    c->sync();
-    fprintf(stderr, "sift_dog: n=%d items=%d blocks=%u overflow items=%d\n", gr.n, n_items, sl.blocks, ho[0]);
-  }
-  c->check_later(he, MM3D_EUNSUPPORTED, "detectKeypoints(SIFT): a point has more than 16384 neighbours within 3 sigma");
+  auto sl = std::make_shared<SnbLaunch<Cfg>>(c, n_items, sizeof(float) * 64 * kScales + 256);
+  MM3D_LAUNCH(c, getenv("MM3D_SNB_DEBUG") ? (gr.n > 300000 ? "sift_dog_oct0" : (gr.n > 150000 ? "sift_dog_oct1" : "sift_dog_oct2")) : "sift_dog", gr.n * 36.0, k_sift_dog_lds<Cfg>, dim3(sl->blocks), dim3(64 * Cfg::kWaves), 0, (const float4 *)cur->hil_pts.get(),
+              (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, sl->ctl_dev(),
+              sl->ov_items.get(), dog, knn, knn_ok, (const int *)nullptr, (const int *)nullptr);
+  SiftDogPending pend;
+  pend.h_overflow = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(pend.h_overflow, &sl->ctl_dev()->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  const Grid *grp = &gr;
+  pend.fallback = [c, cur, grp, n_items, max_radius, r2, sc, dog, knn, knn_ok, sl](int n_overflow) {
+    SnbCtl *ctl = sl->ctl_dev();
+    int *ov = sl->ov_items.get();
+    // the first octave's configuration has the small tile: a few overflow items (dense spots of an outdoor map) go
+    // through the large one -- one block per item, a tile and lists twice as long -- before anything is left to the
+    // global-memory lists; a cloud that is dense everywhere (thousands of items) goes to those directly (measured on
+    // 8 x 2 M indoor points: the large configuration is no faster per neighbour there, and it runs one block per CU)
+    std::shared_ptr<SnbLaunch<SiftCfgLarge>> sl2;
+    if (!std::is_same<Cfg, SiftCfgLarge>::value && n_overflow <= 256) {
+      sl2 = std::make_shared<SnbLaunch<SiftCfgLarge>>(c, n_items, sizeof(float) * 64 * kScales + 256);
+      MM3D_LAUNCH(c, "sift_dog_dense", 0.0, k_sift_dog_lds<SiftCfgLarge>, dim3(std::min(sl2->blocks, (unsigned)n_overflow)), dim3(64 * SiftCfgLarge::kWaves), 0,
+                  (const float4 *)cur->hil_pts.get(), (const int2 *)cur->wave_items.get(), n_items, grp->view(), (const float4 *)cur->pts.get(),
+                  max_radius, r2, sc, sl2->ctl_dev(), sl2->ov_items.get(), dog, knn, knn_ok, (const int *)sl->ov_items.get(),
+                  (const int *)&sl->ctl_dev()->ov_count);
+      ctl = sl2->ctl_dev();
+      ov = sl2->ov_items.get();
+    }
+    SnLaunch<float2> sn(c, n_items * 4, cur->n, 4, kSnFallbackBlocks);
+    SnScratch scr{sn.tmp.get(), sn.fin.get(), ctl->fb_ctr, &ctl->error, ov, &ctl->ov_count};
+    MM3D_LAUNCH(c, "sift_dog_big", 0.0, k_sift_dog, dim3(sn.blocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
+                (const int2 *)cur->wave_items.get(), n_items, grp->view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, scr, dog);
+    int *he = (int *)c->pin(64);
+    MM3D_HIP(hipMemcpyAsync(he, &ctl->error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->check_later(he, MM3D_EUNSUPPORTED, "detectKeypoints(SIFT): a point has more than 16384 neighbours within 3 sigma");
+  };
+  return pend;
 }
 
 #ifdef MM3D_SN_STATS
@@ -335,12 +365,12 @@ __global__ void k_sift_dogx(const float *__restrict__ dog, int n, float4 *__rest
 // nearest (itself included) has a DoG below its own at s-1, s or s+1; a maximum likewise.
 __global__ void __launch_bounds__(256)
 k_sift_extrema_knn(const float4 *__restrict__ hil, int nh, int n, const float *__restrict__ dog, const float4 *__restrict__ dogx,
-                   const int *__restrict__ knn, const unsigned char *__restrict__ knn_ok, float min_contrast, int *__restrict__ flags /* [n*3] */)
+                   const int *__restrict__ knn, const unsigned char *__restrict__ knn_ok, float min_contrast, int *__restrict__ flags /* [n*3] */,
+                   int *__restrict__ n_search /* points that pass the contrast test but have no list of 25: the searching kernel's */)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nh) return;
   const int self = __float_as_int(hil[j].w);
-  if (!knn_ok[self]) return;
   float v[3];
   unsigned live = 0;
 #pragma unroll
@@ -349,6 +379,7 @@ k_sift_extrema_knn(const float4 *__restrict__ hil, int nh, int n, const float *_
     if (fabsf(v[s]) >= min_contrast) live |= 1u << s;
   }
   if (!live) return;
+  if (!knn_ok[self]) { atomicAdd(n_search, 1); return; }
   bool is_min[3] = {true, true, true}, is_max[3] = {true, true, true};
   const int *row = knn + (size_t)self * kKnn;
 #pragma unroll 5
@@ -664,46 +695,66 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     DevBuf<int> knn(c, (size_t)n * kKnn);
     DevBuf<unsigned char> knn_ok(c, (size_t)n);
     MM3D_HIP(hipMemsetAsync(knn_ok.get(), 0, (size_t)n, c->stream));
-    if (oct == 0) sift_dog_octave<SiftCfgSmall>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get());
-    else sift_dog_octave<SiftCfgLarge>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get());
+    SiftDogPending pend = oct == 0 ? sift_dog_octave<SiftCfgSmall>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get())
+                                   : sift_dog_octave<SiftCfgLarge>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get());
     // The extremum test: the points whose list held 25 neighbours read them back (k_sift_extrema_knn, nearly all
     // of them); the others -- borders and sparse places, where the 25 nearest reach beyond 3 sigma_max -- search the
-    // same grid (k_sift_extrema over their compacted runs, normally a handful of items).
+    // same grid (k_sift_extrema over their compacted runs).  Both rare cases -- scale-space items left to the
+    // global-memory lists, points for the searching kernel -- are COUNTED by the kernels of the first pass; the octave
+    // ends with a host look at the keypoint count anyway, and only if one of the two counts is not zero the launches
+    // that serve them run and the test is taken again (a launch that finds nothing to do is not free here: it queues
+    // for LDS behind the other streams' kernels).
     const Grid &gk = gr;
     DevBuf<float4> dogx(c, (size_t)n * 2);
-    MM3D_LAUNCH(c, "sift_pack", n * 52.0, k_sift_dogx, dim3(div_up(n, 256)), dim3(256), 0, (const float *)dog.get(), n, dogx.get());
     DevBuf<int> flags(c, (size_t)n * 3 + 1);
-    MM3D_HIP(hipMemsetAsync(flags.get(), 0, ((size_t)n * 3 + 1) * sizeof(int), c->stream));
-    const int nh = (int)cur->n_finite;
-    MM3D_LAUNCH(c, "sift_extrema_knn", nh * 16.0 + n * 0.25 * (kKnn * 36.0 + 20.0), k_sift_extrema_knn, dim3(div_up(nh, 256)), dim3(256), 0,
-                (const float4 *)cur->hil_pts.get(), nh, n, (const float *)dog.get(), (const float4 *)dogx.get(), (const int *)knn.get(),
-                (const unsigned char *)knn_ok.get(), (float)min_contrast, flags.get());
-    DevBuf<int> lflag(c, (size_t)nh + 1), lpos(c, (size_t)nh + 1);
-    DevBuf<float4> lpts(c, (size_t)nh);
-    DevBuf<uint32_t> lkeys(c, (size_t)nh);
-    DevBuf<int> lheads(c, (size_t)nh + 1), lipos(c, (size_t)nh + 1);
-    const int max_items = 2 * n_items + 4;                // a block's live run splits at most once more than its full run
-    DevBuf<int2> litems(c, (size_t)max_items);
-    MM3D_LAUNCH(c, "sift_live", nh * 28.0, k_sift_live, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(), nh,
-                (const float *)dog.get(), (float)min_contrast, (const unsigned char *)knn_ok.get(), lflag.get());
-    exclusive_scan_int(c, lflag.get(), lpos.get(), (size_t)nh + 1);
-    MM3D_LAUNCH(c, "sift_live", nh * 32.0, k_sift_live_compact, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
-                (const uint32_t *)cur->hil_keys.get(), nh, (const int *)lflag.get(), (const int *)lpos.get(), lpts.get(), lkeys.get());
-    MM3D_LAUNCH(c, "sift_live", nh * 8.0, k_sift_live_heads, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const uint32_t *)lkeys.get(),
-                (const int *)(lpos.get() + nh), nh, lheads.get());
-    exclusive_scan_int(c, lheads.get(), lipos.get(), (size_t)nh + 1);
-    MM3D_LAUNCH(c, "sift_live", nh * 12.0, k_sift_live_items, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const int *)lheads.get(),
-                (const int *)lipos.get(), (const int *)(lpos.get() + nh), litems.get());
-    // one item per block (measured on MI355X, three octaves of one map: 1.69 -> 1.05 ms at 500 k points, 1.28 -> 0.45 ms
-    // at 50 k; four items per block, k_sift_extrema<1>, is the same code with one wave per item)
-    MM3D_LAUNCH(c, "sift_extrema", 0.0, k_sift_extrema<4>, dim3((unsigned)std::min(max_items, 1024)), dim3(256), 0,
-                (const float4 *)lpts.get(), (const int2 *)litems.get(), (const int *)(lipos.get() + nh), gk.view(), (const float4 *)dogx.get(), n,
-                (const float *)dog.get(), (float)min_contrast, flags.get());
     DevBuf<int> pos(c, (size_t)n * 3 + 1);
-    exclusive_scan_int(c, flags.get(), pos.get(), (size_t)n * 3 + 1);
-    int *h = (int *)c->pin(64);
-    MM3D_HIP(hipMemcpyAsync(h, pos.get() + (size_t)n * 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    c->sync();
+    DevBuf<int> n_search(c, 1);
+    const int nh = (int)cur->n_finite;
+    int *h = (int *)c->pin(64);                          // [0] keypoints, [1] points for the searching kernel
+    auto extremum_test = [&](bool search) {
+      MM3D_LAUNCH(c, "sift_pack", n * 52.0, k_sift_dogx, dim3(div_up(n, 256)), dim3(256), 0, (const float *)dog.get(), n, dogx.get());
+      MM3D_HIP(hipMemsetAsync(flags.get(), 0, ((size_t)n * 3 + 1) * sizeof(int), c->stream));
+      MM3D_HIP(hipMemsetAsync(n_search.get(), 0, sizeof(int), c->stream));
+      MM3D_LAUNCH(c, "sift_extrema_knn", nh * 16.0 + n * 0.25 * (kKnn * 36.0 + 20.0), k_sift_extrema_knn, dim3(div_up(nh, 256)), dim3(256), 0,
+                  (const float4 *)cur->hil_pts.get(), nh, n, (const float *)dog.get(), (const float4 *)dogx.get(), (const int *)knn.get(),
+                  (const unsigned char *)knn_ok.get(), (float)min_contrast, flags.get(), n_search.get());
+      if (search) {
+        DevBuf<int> lflag(c, (size_t)nh + 1), lpos(c, (size_t)nh + 1);
+        DevBuf<float4> lpts(c, (size_t)nh);
+        DevBuf<uint32_t> lkeys(c, (size_t)nh);
+        DevBuf<int> lheads(c, (size_t)nh + 1), lipos(c, (size_t)nh + 1);
+        const int max_items = 2 * n_items + 4;                // a block's live run splits at most once more than its full run
+        DevBuf<int2> litems(c, (size_t)max_items);
+        MM3D_LAUNCH(c, "sift_live", nh * 28.0, k_sift_live, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(), nh,
+                    (const float *)dog.get(), (float)min_contrast, (const unsigned char *)knn_ok.get(), lflag.get());
+        exclusive_scan_int(c, lflag.get(), lpos.get(), (size_t)nh + 1);
+        MM3D_LAUNCH(c, "sift_live", nh * 32.0, k_sift_live_compact, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
+                    (const uint32_t *)cur->hil_keys.get(), nh, (const int *)lflag.get(), (const int *)lpos.get(), lpts.get(), lkeys.get());
+        MM3D_LAUNCH(c, "sift_live", nh * 8.0, k_sift_live_heads, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const uint32_t *)lkeys.get(),
+                    (const int *)(lpos.get() + nh), nh, lheads.get());
+        exclusive_scan_int(c, lheads.get(), lipos.get(), (size_t)nh + 1);
+        MM3D_LAUNCH(c, "sift_live", nh * 12.0, k_sift_live_items, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const int *)lheads.get(),
+                    (const int *)lipos.get(), (const int *)(lpos.get() + nh), litems.get());
+        // one item per block (measured on MI355X, three octaves of one map: 1.69 -> 1.05 ms at 500 k points, 1.28 -> 0.45 ms
+        // at 50 k; four items per block, k_sift_extrema<1>, is the same code with one wave per item)
+        MM3D_LAUNCH(c, "sift_extrema", 0.0, k_sift_extrema<4>, dim3((unsigned)std::min(max_items, 1024)), dim3(256), 0,
+                    (const float4 *)lpts.get(), (const int2 *)litems.get(), (const int *)(lipos.get() + nh), gk.view(), (const float4 *)dogx.get(), n,
+                    (const float *)dog.get(), (float)min_contrast, flags.get());
+      }
+      exclusive_scan_int(c, flags.get(), pos.get(), (size_t)n * 3 + 1);
+      MM3D_HIP(hipMemcpyAsync(h, pos.get() + (size_t)n * 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      MM3D_HIP(hipMemcpyAsync(h + 1, n_search.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      c->sync();
+    };
+    extremum_test(false);
+    if (getenv("MM3D_SNB_DEBUG"))
+      fprintf(stderr, "sift_dog: n=%d items=%d overflow items=%d, points for the searching extremum kernel %d\n", gr.n, n_items, *pend.h_overflow, h[1]);
+    if (*pend.h_overflow > 0 || h[1] > 0) {
+      // (the points of an item the fallback works have no list of 25 either, and the first pass counted them on
+      // scale-space values that are only now being computed: the second pass always searches)
+      if (*pend.h_overflow > 0) pend.fallback(*pend.h_overflow);
+      extremum_test(true);
+    }
     const size_t nk = (size_t)h[0];
     DevBuf<float4> kp(c, nk);
     if (nk)

@@ -567,8 +567,12 @@ __device__ __forceinline__ int snb_stage_queries(const GridView &g, SnbLds<Cfg> 
 // box alone, or a list of more than kSnbMaxBands * kHitCap neighbours -- sends the item to ov_items / ctl->ov_count.
 template <class Cfg, class LoadPay, class Consume>
 __device__ __forceinline__ void snb_run(const GridView &g, SnbLds<Cfg> &S, const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items,
-                                        float radius, float r2, SnbCtl *ctl, int *__restrict__ ov_items, LoadPay &&load_pay, Consume &&consume)
+                                        float radius, float r2, SnbCtl *ctl, int *__restrict__ ov_items, LoadPay &&load_pay, Consume &&consume,
+                                        const int *__restrict__ sub_items = nullptr, const int *__restrict__ sub_count = nullptr)
 {
+  // sub_items: this launch works the *sub_count items an earlier launch (a configuration with a smaller tile) could
+  // not hold -- its overflow list -- instead of all n_items
+  if (sub_items) n_items = *sub_count;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   SnbWave<Cfg> &W = S.w[wave];
   const float ri = radius * 1.0001f + 1e-4f;
@@ -582,8 +586,8 @@ __device__ __forceinline__ void snb_run(const GridView &g, SnbLds<Cfg> &S, const
       S.overflow = 0;
     }
     __syncthreads();
-    const int item = S.item;
-    if (item < 0) break;
+    if (S.item < 0) break;
+    const int item = sub_items ? sub_items[S.item] : S.item;
     const int2 it = items[item];
     SNB_TOCK(1, t_claim);
     SNB_COUNT(0, 1);
