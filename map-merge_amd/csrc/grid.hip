@@ -705,7 +705,7 @@ __global__ void k_nb_fill(const int *__restrict__ cell_start, const float4 *__re
 
 // Lists of up to kNbSortCap entries: .w = distance from the cell centre, entries reordered to ascend in it
 // (rank by counting in LDS; ties by stencil position, so the order is a function of the input alone).
-constexpr int kNbSortCap = 1024;
+constexpr int kNbSortCap = 256;       // 16 KB of LDS per block: a launch that asks for more waits for the neighbourhood kernels of other streams
 __global__ void __launch_bounds__(256)
 k_nb_sort(float minx, float miny, float minz, float cell, int dx, int dy, int dz, const int *__restrict__ nb_start,
           float4 *__restrict__ nb_pts)
