@@ -265,12 +265,16 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
         }
         // The list's first 25 entries ARE the point's 25 nearest neighbours in nearestKSearch's (distance, index)
         // order whenever the ball holds that many: findScaleSpaceExtrema (k_sift_extrema_knn) reads them back
-        // instead of searching again.  A shorter list leaves knn_ok at 0: that point takes the searching kernel.
-        if (mine && m >= kKnn) {
+        // instead of searching again.
+        // A shorter list is left behind as well, with its length: its entries are the point's m nearest, and a
+        // violator among them already decides the test (only a point that is still an extremum candidate after
+        // its m < 25 nearest has to search for the others).  0 stays for a point whose list was not built here.
+        if (mine && m > 0) {
           const int self_q = __float_as_int(q.w);
+          const int keep = m < kKnn ? m : kKnn;
           int *row = knn + (size_t)self_q * kKnn;
-          for (int e = lane & (LPQ - 1); e < kKnn; e += LPQ) row[e] = (int)S.tw[W.arena[base + e]];
-          if ((lane & (LPQ - 1)) == 0) knn_ok[self_q] = 1;
+          for (int e = lane & (LPQ - 1); e < keep; e += LPQ) row[e] = (int)S.tw[W.arena[base + e]];
+          if ((lane & (LPQ - 1)) == 0) knn_ok[self_q] = (unsigned char)keep;
         }
         wave_lds_fence();
         if (lane < fit) {
@@ -360,13 +364,15 @@ __global__ void k_sift_dogx(const float *__restrict__ dog, int n, float4 *__rest
   dogx[n + i] = make_float4(fmaxf(fmaxf(d[1], d[2]), d[3]), fmaxf(fmaxf(d[2], d[3]), d[4]), 0.f, 0.f);
 }
 
-// findScaleSpaceExtrema for the points whose 25 nearest neighbours the scale-space kernel left behind (knn_ok):
-// one thread per point of the octave, in Hilbert order.  A point is a minimum at scale s iff none of its 25
-// nearest (itself included) has a DoG below its own at s-1, s or s+1; a maximum likewise.
+// findScaleSpaceExtrema from the neighbours the scale-space kernel left behind (knn, knn_ok = how many: 25, or
+// fewer when the 3 sigma_max ball holds fewer, or 0 when the point's list was not built there): one thread per point
+// of the octave, in Hilbert order.  A point is a minimum at scale s iff none of its 25 nearest (itself included)
+// has a DoG below its own at s-1, s or s+1; a maximum likewise.  With fewer than 25 neighbours at hand a violator
+// among them still decides "no"; a point they leave undecided is marked for the searching kernel and counted.
 __global__ void __launch_bounds__(256)
 k_sift_extrema_knn(const float4 *__restrict__ hil, int nh, int n, const float *__restrict__ dog, const float4 *__restrict__ dogx,
                    const int *__restrict__ knn, const unsigned char *__restrict__ knn_ok, float min_contrast, int *__restrict__ flags /* [n*3] */,
-                   int *__restrict__ n_search /* points that pass the contrast test but have no list of 25: the searching kernel's */)
+                   unsigned char *__restrict__ need_search /* [n], zeroed */, int *__restrict__ n_search)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nh) return;
@@ -379,11 +385,10 @@ k_sift_extrema_knn(const float4 *__restrict__ hil, int nh, int n, const float *_
     if (fabsf(v[s]) >= min_contrast) live |= 1u << s;
   }
   if (!live) return;
-  if (!knn_ok[self]) { atomicAdd(n_search, 1); return; }
+  const int cnt = knn_ok[self];
   bool is_min[3] = {true, true, true}, is_max[3] = {true, true, true};
   const int *row = knn + (size_t)self * kKnn;
-#pragma unroll 5
-  for (int e = 0; e < kKnn; ++e) {
+  for (int e = 0; e < cnt; ++e) {
     const int nb = row[e];
     const float4 a = dogx[nb], b = dogx[n + nb];
     const float mn[3] = {a.x, a.y, a.z};
@@ -393,6 +398,12 @@ k_sift_extrema_knn(const float4 *__restrict__ hil, int nh, int n, const float *_
       is_min[s] = is_min[s] && !(mn[s] < v[s]);
       is_max[s] = is_max[s] && !(mx[s] > v[s]);
     }
+  }
+  if (cnt < kKnn) {
+    bool open = false;                         // still a candidate at some scale that passes the contrast test
+#pragma unroll
+    for (int s = 0; s < 3; ++s) open = open || ((live & (1u << s)) && (is_min[s] || is_max[s]));
+    if (open) { need_search[self] = 1; atomicAdd(n_search, 1); return; }
   }
 #pragma unroll
   for (int s = 0; s < 3; ++s)
@@ -404,7 +415,7 @@ k_sift_extrema_knn(const float4 *__restrict__ hil, int nh, int n, const float *_
 // lanes all have work (k_sift_live + scan + k_sift_live_compact), instead of idling through the box
 // scans of their item's few live points.
 __global__ void k_sift_live(const float4 *__restrict__ hil, int n, const float *__restrict__ dog, float min_contrast,
-                            const unsigned char *__restrict__ knn_ok, int *__restrict__ flag /* [n + 1] */)
+                            const unsigned char *__restrict__ need_search, int *__restrict__ flag /* [n + 1] */)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j > n) return;
@@ -413,7 +424,7 @@ __global__ void k_sift_live(const float4 *__restrict__ hil, int n, const float *
     const int self = __float_as_int(hil[j].w);
 #pragma unroll
     for (int s = 0; s < 3; ++s) f |= fabsf(dog[(size_t)self * kDog + s + 1]) >= min_contrast ? 1 : 0;
-    if (knn_ok[self]) f = 0;                   // k_sift_extrema_knn's
+    if (!need_search[self]) f = 0;             // k_sift_extrema_knn has decided it
   }
   flag[j] = f;
 }
@@ -709,15 +720,17 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     DevBuf<int> flags(c, (size_t)n * 3 + 1);
     DevBuf<int> pos(c, (size_t)n * 3 + 1);
     DevBuf<int> n_search(c, 1);
+    DevBuf<unsigned char> need_search(c, (size_t)n);
     const int nh = (int)cur->n_finite;
     int *h = (int *)c->pin(64);                          // [0] keypoints, [1] points for the searching kernel
     auto extremum_test = [&](bool search) {
       MM3D_LAUNCH(c, "sift_pack", n * 52.0, k_sift_dogx, dim3(div_up(n, 256)), dim3(256), 0, (const float *)dog.get(), n, dogx.get());
       MM3D_HIP(hipMemsetAsync(flags.get(), 0, ((size_t)n * 3 + 1) * sizeof(int), c->stream));
       MM3D_HIP(hipMemsetAsync(n_search.get(), 0, sizeof(int), c->stream));
+      MM3D_HIP(hipMemsetAsync(need_search.get(), 0, (size_t)n, c->stream));
       MM3D_LAUNCH(c, "sift_extrema_knn", nh * 16.0 + n * 0.25 * (kKnn * 36.0 + 20.0), k_sift_extrema_knn, dim3(div_up(nh, 256)), dim3(256), 0,
                   (const float4 *)cur->hil_pts.get(), nh, n, (const float *)dog.get(), (const float4 *)dogx.get(), (const int *)knn.get(),
-                  (const unsigned char *)knn_ok.get(), (float)min_contrast, flags.get(), n_search.get());
+                  (const unsigned char *)knn_ok.get(), (float)min_contrast, flags.get(), need_search.get(), n_search.get());
       if (search) {
         DevBuf<int> lflag(c, (size_t)nh + 1), lpos(c, (size_t)nh + 1);
         DevBuf<float4> lpts(c, (size_t)nh);
@@ -726,7 +739,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
         const int max_items = 2 * n_items + 4;                // a block's live run splits at most once more than its full run
         DevBuf<int2> litems(c, (size_t)max_items);
         MM3D_LAUNCH(c, "sift_live", nh * 28.0, k_sift_live, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(), nh,
-                    (const float *)dog.get(), (float)min_contrast, (const unsigned char *)knn_ok.get(), lflag.get());
+                    (const float *)dog.get(), (float)min_contrast, (const unsigned char *)need_search.get(), lflag.get());
         exclusive_scan_int(c, lflag.get(), lpos.get(), (size_t)nh + 1);
         MM3D_LAUNCH(c, "sift_live", nh * 32.0, k_sift_live_compact, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
                     (const uint32_t *)cur->hil_keys.get(), nh, (const int *)lflag.get(), (const int *)lpos.get(), lpts.get(), lkeys.get());
@@ -749,12 +762,13 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     extremum_test(false);
     if (getenv("MM3D_SNB_DEBUG"))
       fprintf(stderr, "sift_dog: n=%d items=%d overflow items=%d, points for the searching extremum kernel %d\n", gr.n, n_items, *pend.h_overflow, h[1]);
-    if (*pend.h_overflow > 0 || h[1] > 0) {
-      // (the points of an item the fallback works have no list of 25 either, and the first pass counted them on
-      // scale-space values that are only now being computed: the second pass always searches)
-      if (*pend.h_overflow > 0) pend.fallback(*pend.h_overflow);
-      extremum_test(true);
+    if (*pend.h_overflow > 0) {
+      // the items the first pass left out get their scale space now (and, from the large LDS configuration, their
+      // neighbour lists): the test is taken again on the complete values
+      pend.fallback(*pend.h_overflow);
+      extremum_test(false);
     }
+    if (h[1] > 0) extremum_test(true);                    // some point's short list left it undecided: search for its 25 nearest
     const size_t nk = (size_t)h[0];
     DevBuf<float4> kp(c, nk);
     if (nk)
