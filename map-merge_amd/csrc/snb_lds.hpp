@@ -469,7 +469,10 @@ __device__ __forceinline__ int snb_sort_one(SnbLds<Cfg> &S, SnbWave<Cfg> &W, flo
 // of two that doubles until every band fits (the list is the bands one after the other); a list that does not fit
 // the arena even alone sets *overflow (the item goes to the fallback launch) and is left empty.
 constexpr int kSnbMaxBands = 16;
-constexpr int kSnbMaxParts = 4;
+#ifndef MM3D_SNB_MAX_PARTS
+#define MM3D_SNB_MAX_PARTS 8
+#endif
+constexpr int kSnbMaxParts = MM3D_SNB_MAX_PARTS;
 template <class Cfg>
 __device__ __forceinline__ int snb_build(SnbLds<Cfg> &S, SnbWave<Cfg> &W, int n_queries, int *next_q, float r2, int n_pad, int lane, int *pending,
                                          int *budget, int *overflow, SnbStats &snb_st)
