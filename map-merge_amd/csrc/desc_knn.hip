@@ -286,6 +286,10 @@ constexpr int kFilterCap = 512;
 
 __device__ __forceinline__ unsigned knn_ordered_bits(float v);
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v);
+template <int kD>
+__device__ __forceinline__ void knn_exact_range_row(const float (&x)[kD], float U, int row, const float *__restrict__ B, int nb, int k,
+                                                    const uint32_t *__restrict__ nsort, const uint32_t *__restrict__ nperm, int lane,
+                                                    int *__restrict__ idx, float *__restrict__ d2out);
 
 // wave-wide minimum / sum through the DPP network (row shifts, then row broadcasts; the last lane holds the result)
 template <int CTRL, int ROWMASK>
@@ -420,7 +424,8 @@ template <int kD>
 __global__ void __launch_bounds__(256)
 k_knn_rerank_filter(const float *__restrict__ A, int na, const float *__restrict__ B, int nb, int k, const int *__restrict__ cand_n,
                     const int *__restrict__ cand_i, const float *__restrict__ theta, const float *__restrict__ colsum, float inv_nb,
-                    int *__restrict__ idx, float *__restrict__ d2out, int *__restrict__ fb_rows, int *__restrict__ fb_count)
+                    const uint32_t *__restrict__ nsort, const uint32_t *__restrict__ nperm, int *__restrict__ idx, float *__restrict__ d2out,
+                    int *__restrict__ fb_count)
 {
   const int lane = threadIdx.x & 63;
   const int a = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -485,7 +490,14 @@ k_knn_rerank_filter(const float *__restrict__ A, int na, const float *__restrict
   const float rho = (sqrtf(na2) + sqrtf(kth)) * 1.001f + 1e-3f;
   const float eps = (2e-5f * (na2 + rho * rho) + 1e-5f * kth) * ((float)knn_kp(kD) / 36.0f);
   const bool certified = found <= kFilterCap && (!(tau < INFINITY) ? found >= nb : (kth < tau - eps));
-  if (!certified && lane == 0) fb_rows[atomicAdd(fb_count, 1)] = a;
+  // A row without a certificate (wave-uniform, rare) is searched exactly right here -- the targets whose norm lies within
+  // sqrt(kth) of the row's own, k_knn_exact_range's argument -- instead of being listed for a launch of its own: that
+  // launch would follow EVERY search and, with nothing to do, still queue for registers behind the other streams'
+  // kernels (68 us of stream time per pair on the 16-stream bench).
+  if (!certified) {
+    if (lane == 0) atomicAdd(fb_count, 1);           // (statistics: mm3d_debug_knn_fallback_rows)
+    knn_exact_range_row<kD>(x, kth, a, B, nb, k, nsort, nperm, lane, idx, d2out);
+  }
 }
 
 // ---------------------------------------------------------------- stage 3: exact re-rank + certificate
@@ -599,6 +611,78 @@ __global__ void k_knn_norms(const float *__restrict__ X, int n, uint32_t *__rest
   vals[i] = (uint32_t)i;
 }
 
+// one row, one wave: x = the row (in every lane's registers), U = an upper bound of its k-th distance
+template <int kD>
+__device__ __forceinline__ void knn_exact_range_row(const float (&x)[kD], float U, int row, const float *__restrict__ B, int nb, int k,
+                                                    const uint32_t *__restrict__ nsort, const uint32_t *__restrict__ nperm, int lane,
+                                                    int *__restrict__ idx, float *__restrict__ d2out)
+{
+  float s = 0.0f;
+#pragma unroll
+  for (int d = 0; d < kD; ++d) s = fmaf(x[d], x[d], s);
+  const float na = sqrtf(s);
+  int lo = 0, hi = nb;
+  if (U < INFINITY && na == na) {
+    const float reach = sqrtf(U);
+    const float slack = 1e-4f * (na + reach) + 1e-6f;
+    const float lo_v = na - reach - slack, hi_v = na + reach + slack;
+    // first index with norm >= lo_v / first index with norm > hi_v (NaN norms sit at the end and compare false)
+    int a = 0, b = nb;
+    while (a < b) { const int m = (a + b) >> 1; if (__uint_as_float(nsort[m]) >= lo_v) b = m; else a = m + 1; }
+    lo = a;
+    a = lo; b = nb;
+    while (a < b) { const int m = (a + b) >> 1; if (__uint_as_float(nsort[m]) > hi_v) b = m; else a = m + 1; }
+    hi = a;
+  }
+  float bd[kMaxK];
+  int bi[kMaxK];
+#pragma unroll
+  for (int t = 0; t < kMaxK; ++t) { bd[t] = INFINITY; bi[t] = 0x7fffffff; }
+  for (int t = lo + lane; t < hi; t += kWave) {
+    const int j = (int)nperm[t];
+    const float *bp = B + (size_t)j * kD;
+    float r = 0.0f;
+#pragma unroll
+    for (int d = 0; d < kD; ++d) {
+      const float df = x[d] - bp[d];
+      r = __fadd_rn(r, __fmul_rn(df, df));
+    }
+    if (r < bd[kMaxK - 1] || (r == bd[kMaxK - 1] && j < bi[kMaxK - 1])) {
+      float cd = r;
+      int ci = j;
+      bool carrying = false;
+#pragma unroll
+      for (int t2 = 0; t2 < kMaxK; ++t2) {
+        const bool sw = carrying || cd < bd[t2] || (cd == bd[t2] && ci < bi[t2]);
+        carrying = sw;
+        const float td = bd[t2];
+        const int ti = bi[t2];
+        bd[t2] = sw ? cd : td; bi[t2] = sw ? ci : ti;
+        cd = sw ? td : cd; ci = sw ? ti : ci;
+      }
+    }
+  }
+  for (int o = 0; o < k; ++o) {
+    const unsigned long long key = ((unsigned long long)__float_as_uint(bd[0]) << 32) | (unsigned)bi[0];
+    unsigned long long best = key;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      const unsigned long long other = __shfl_xor(best, sft, kWave);
+      best = other < best ? other : best;
+    }
+    const float d = __uint_as_float((unsigned)(best >> 32));
+    if (lane == 0) {
+      idx[(size_t)row * k + o] = d < INFINITY ? (int)(unsigned)(best & 0xffffffffull) : -1;
+      d2out[(size_t)row * k + o] = d;
+    }
+    if (key == best && bd[0] < INFINITY) {
+#pragma unroll
+      for (int t = 0; t + 1 < kMaxK; ++t) { bd[t] = bd[t + 1]; bi[t] = bi[t + 1]; }
+      bd[kMaxK - 1] = INFINITY; bi[kMaxK - 1] = 0x7fffffff;
+    }
+  }
+}
+
 template <int kD>
 __global__ void __launch_bounds__(256)
 k_knn_exact_range(const float *__restrict__ A, const float *__restrict__ B, int nb, int k, const int *__restrict__ rows,
@@ -611,71 +695,10 @@ k_knn_exact_range(const float *__restrict__ A, const float *__restrict__ B, int 
   for (int slot = wave0; slot < nrows; slot += nwaves) {          // wave-uniform
     const int row = rows[slot];
     float x[kD];
-    float s = 0.0f;
 #pragma unroll
-    for (int d = 0; d < kD; ++d) { x[d] = A[(size_t)row * kD + d]; s = fmaf(x[d], x[d], s); }
-    const float na = sqrtf(s);
+    for (int d = 0; d < kD; ++d) x[d] = A[(size_t)row * kD + d];
     const float U = d2out[(size_t)row * k + k - 1];
-    int lo = 0, hi = nb;
-    if (U < INFINITY && na == na) {
-      const float reach = sqrtf(U);
-      const float slack = 1e-4f * (na + reach) + 1e-6f;
-      const float lo_v = na - reach - slack, hi_v = na + reach + slack;
-      // first index with norm >= lo_v / first index with norm > hi_v (NaN norms sit at the end and compare false)
-      int a = 0, b = nb;
-      while (a < b) { const int m = (a + b) >> 1; if (__uint_as_float(nsort[m]) >= lo_v) b = m; else a = m + 1; }
-      lo = a;
-      a = lo; b = nb;
-      while (a < b) { const int m = (a + b) >> 1; if (__uint_as_float(nsort[m]) > hi_v) b = m; else a = m + 1; }
-      hi = a;
-    }
-    float bd[kMaxK];
-    int bi[kMaxK];
-#pragma unroll
-    for (int t = 0; t < kMaxK; ++t) { bd[t] = INFINITY; bi[t] = 0x7fffffff; }
-    for (int t = lo + lane; t < hi; t += kWave) {
-      const int j = (int)nperm[t];
-      const float *bp = B + (size_t)j * kD;
-      float r = 0.0f;
-#pragma unroll
-      for (int d = 0; d < kD; ++d) {
-        const float df = x[d] - bp[d];
-        r = __fadd_rn(r, __fmul_rn(df, df));
-      }
-      if (r < bd[kMaxK - 1] || (r == bd[kMaxK - 1] && j < bi[kMaxK - 1])) {
-        float cd = r;
-        int ci = j;
-        bool carrying = false;
-#pragma unroll
-        for (int t2 = 0; t2 < kMaxK; ++t2) {
-          const bool sw = carrying || cd < bd[t2] || (cd == bd[t2] && ci < bi[t2]);
-          carrying = sw;
-          const float td = bd[t2];
-          const int ti = bi[t2];
-          bd[t2] = sw ? cd : td; bi[t2] = sw ? ci : ti;
-          cd = sw ? td : cd; ci = sw ? ti : ci;
-        }
-      }
-    }
-    for (int o = 0; o < k; ++o) {
-      const unsigned long long key = ((unsigned long long)__float_as_uint(bd[0]) << 32) | (unsigned)bi[0];
-      unsigned long long best = key;
-#pragma unroll
-      for (int sft = 32; sft > 0; sft >>= 1) {
-        const unsigned long long other = __shfl_xor(best, sft, kWave);
-        best = other < best ? other : best;
-      }
-      const float d = __uint_as_float((unsigned)(best >> 32));
-      if (lane == 0) {
-        idx[(size_t)row * k + o] = d < INFINITY ? (int)(unsigned)(best & 0xffffffffull) : -1;
-        d2out[(size_t)row * k + o] = d;
-      }
-      if (key == best && bd[0] < INFINITY) {
-#pragma unroll
-        for (int t = 0; t + 1 < kMaxK; ++t) { bd[t] = bd[t + 1]; bi[t] = bi[t + 1]; }
-        bd[kMaxK - 1] = INFINITY; bi[kMaxK - 1] = 0x7fffffff;
-      }
-    }
+    knn_exact_range_row<kD>(x, U, row, B, nb, k, nsort, nperm, lane, idx, d2out);
   }
 }
 
@@ -1147,6 +1170,16 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
   MM3D_LAUNCH(c, "desc_knn_prep", na * (kD + kKP) * 4.0, (k_knn_prep<kD>), dim3(div_up((size_t)na_tiles * kSteps * 64, 256)), dim3(256), 0, Ad, na,
               na_tiles, 0, colsum, inv_nb, Ap.get());
   DevBuf<int> fb_rows(c, na);
+  // the targets' norms in sorted order (rows without a certificate: exact search over the targets whose norm is within
+  // the row's current k-th distance of its own)
+  DevBuf<uint32_t> nsort_tmp, nperm_tmp;
+  const uint32_t *nsort = B->knn_nsort.get(), *nperm = B->knn_nperm.get();
+  if (!nsort || !nperm) {
+    knn_norm_order<kD>(c, B, nsort_tmp, nperm_tmp);
+    nsort = nsort_tmp.get();
+    nperm = nperm_tmp.get();
+  }
+  bool listed = true;                 // uncertified rows are listed in fb_rows for k_knn_exact_range (the filter path searches them in place)
   // few query tiles (SAC-IA's sampled rows): split the targets over `parts` blocks per query tile so
   // that the launch still has >= 2 blocks per CU
   int parts = 1;
@@ -1179,7 +1212,8 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
                 (const float *)Ap.get(), na, Bp, nb, nb_tiles, (const float *)theta.get(), cand_n.get(), cand_i.get());
     MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)((k + kThetaExtra) * kSampleStep * (kD * 4 + 4) + kD * 4), (k_knn_rerank_filter<kD>), dim3(div_up(na, 4)),
                 dim3(256), 0, Ad, na, Bd, nb, k, (const int *)cand_n.get(), (const int *)cand_i.get(), (const float *)theta.get(), colsum, inv_nb,
-                idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
+                nsort, nperm, idx.get(), d2.get(), (int *)(meta.get() + 1));
+    listed = false;
    }
   } else {
     // each part keeps its own 8 lists per query
@@ -1199,18 +1233,11 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
                   Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
                   idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
   }
-  // rows without a certificate: exact search over the targets whose norm is within the row's current k-th
-  // distance of its own (the grid is sized for the worst case; waves beyond the device-side count exit at once)
-  DevBuf<uint32_t> nsort_tmp, nperm_tmp;
-  const uint32_t *nsort = B->knn_nsort.get(), *nperm = B->knn_nperm.get();
-  if (!nsort || !nperm) {
-    knn_norm_order<kD>(c, B, nsort_tmp, nperm_tmp);
-    nsort = nsort_tmp.get();
-    nperm = nperm_tmp.get();
-  }
+  // listed rows (the grid is sized for the worst case; waves beyond the device-side count exit at once)
   const int fb_blocks = div_up(na, 4) < 1024 ? div_up(na, 4) : 1024;
-  MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, (k_knn_exact_range<kD>), dim3(fb_blocks), dim3(256), 0, Ad, Bd, nb, k,
-              (const int *)fb_rows.get(), (const int *)(meta.get() + 1), nsort, nperm, idx.get(), d2.get());
+  if (listed)
+    MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, (k_knn_exact_range<kD>), dim3(fb_blocks), dim3(256), 0, Ad, Bd, nb, k,
+                (const int *)fb_rows.get(), (const int *)(meta.get() + 1), nsort, nperm, idx.get(), d2.get());
   if (c->debug) {
     unsigned *h = (unsigned *)c->pin(64);
     MM3D_HIP(hipMemcpyAsync(h, meta.get(), 16, hipMemcpyDeviceToHost, c->stream));
