@@ -658,10 +658,14 @@ void icp_score_batch(Context *c, IcpScoreJob *jobs, int n_jobs, bool run_icp, do
   for (int b = 0; b < B; ++b)
     if (jobs[live[b].job].guess_dev)
       MM3D_HIP(hipMemcpyAsync(st.get() + b, jobs[live[b].job].guess_dev, 64, hipMemcpyDeviceToDevice, c->stream));
-  // iterations launched between two looks at the `done` flags: with the reference's loose epsilon 90 % of
-  // the pairs converge in one iteration and 98 % in two (launches after `done` are no-ops)
-  const int chunk = 2;
-  for (;;) {
+  // iterations launched between two looks at the `done` flags: with the reference's loose epsilon 86 % of the pairs
+  // converge in one iteration and 95 % in two.  A launch after `done` does nothing, but it is not free on a GPU
+  // that runs sixteen streams: its blocks still queue for 20 KB of LDS and 128 registers behind the other streams'
+  // kernels before they can find that out.  So the first look comes after ONE iteration (a batch of one or two
+  // pairs is then usually finished), later ones after two.
+  const int min_chunk = B <= 2 ? 1 : 2;
+  for (int round = 0;; ++round) {
+    const int chunk = round == 0 ? min_chunk : 2;
     if (run_icp) {
       for (int k = 0; k < chunk; ++k) {
         launch_nn<0>(c, "icp_corr_reduce", icp_bytes, d_jobs.get(), B, grid_x, split, max_d2, rmax);
