@@ -238,6 +238,34 @@ def test_desc_knn_filter_path_exact(ctx, po, mm, scene):
         assert rows > 0 and fb <= 0.05 * rows, (na, nb, rows, fb)
 
 
+def test_desc_knn_filter_candidate_overflow_is_searched_exactly(ctx, po, mm, scene):
+    """Thousands of identical target rows put more candidates under a query's threshold than its buffer holds (512):
+    the row loses its certificate and is searched exactly inside the re-rank kernel.  Indices (ties to the lower
+    index) and distance bits as the oracle's."""
+    rng = np.random.default_rng(23)
+    base = np.concatenate([scene[0]["desc"], scene[1]["desc"]])
+    nb = 4000
+    B = (base[rng.integers(0, len(base), nb)] + rng.normal(0, 0.3, (nb, 33))).astype(np.float32)
+    B[500:2500] = B[3000]                          # 2 000 copies of one row
+    A = (base[rng.integers(0, len(base), 300)] + rng.normal(0, 0.3, (300, 33))).astype(np.float32)
+    A[:40] = B[3000] + rng.normal(0, 1e-3, (40, 33)).astype(np.float32)   # queries whose neighbours ARE the copies
+    A[40:50] = B[3000]                             # and exact hits: 2 001 targets at distance zero
+    L = mm.lib()
+    L.mm3d_debug_knn_fallback_rows.restype = L.mm3d_debug_knn_rows.restype = __import__("ctypes").c_longlong
+    L.mm3d_set_debug(ctx._h, 1)
+    f0 = L.mm3d_debug_knn_fallback_rows(ctx._h)
+    da, db = ctx.descriptors(A), ctx.descriptors(B)
+    for k in (1, 10):
+        got = ctx.findFeatureCorrespondences(da, db, k)
+        ref = po.find_correspondences(A, B, k)
+        assert np.array_equal(got["index_query"], ref["index_query"]), k
+        assert np.array_equal(got["index_match"], ref["index_match"]), k
+        assert np.array_equal(got["distance"].view(np.uint32), ref["distance"].view(np.uint32)), k
+    fb = L.mm3d_debug_knn_fallback_rows(ctx._h) - f0
+    L.mm3d_set_debug(ctx._h, 0)
+    assert fb >= 40, fb                            # the rows among the copies did take the exact search
+
+
 def test_matching_k_is_any_positive_number(ctx, po, mm, scene):
     """matching_k is an arbitrary size_t in the reference (R/src/map_merging.cpp:43-47 -> FLANN nearestKSearch):
     beyond the 16 neighbours the register kernels keep, the plain exact kernel takes over; more neighbours than
