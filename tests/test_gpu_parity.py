@@ -146,6 +146,25 @@ def test_sift_keypoints_where_the_25_nearest_reach_beyond_the_scale_space_ball(c
     assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
 
 
+def test_sift_keypoints_with_a_dense_spot(ctx, po, scene):
+    """A solid block of points (every 0.1 m voxel of a 1.5 m cube occupied: ~1 800 neighbours within 3 sigma_max)
+    inside an ordinary scene: its work items overflow the first octave's LDS tile, go through the large
+    configuration and, where that does not hold them either, the global-memory lists; the extremum test is taken
+    again after each.  Same keypoints as the oracle."""
+    rng = np.random.default_rng(9)
+    filt = scene[0]["filt"]
+    c0 = xyz(filt).mean(axis=0)
+    blob = np.zeros(9000, dtype=filt.dtype)
+    p = rng.uniform(-0.75, 0.75, (9000, 3)).astype(np.float32) + c0.astype(np.float32)
+    blob["x"], blob["y"], blob["z"] = p[:, 0], p[:, 1], p[:, 2]
+    blob["rgba"] = rng.integers(0, 1 << 24, 9000).astype(np.uint32)
+    cloud = np.concatenate([filt, blob])
+    ref, _ = po.keypoints_sift(cloud, RES, 3, 3, 5.0)
+    got = ctx.detectKeypoints(ctx.cloud(cloud), None, 0, 5.0, R_NRM, RES).numpy()
+    assert len(got) == len(ref) > 100
+    assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
+
+
 def test_fpfh(ctx, scene):
     for m in scene:
         pts, nrm = ctx.cloud(m["filt"]), ctx.normals(m["nrm"])
