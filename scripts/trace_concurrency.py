@@ -28,3 +28,22 @@ win = t1 - lo
 print("window %.1f ms: busy %.1f %%, mean kernels in flight %.2f" % (win / 1e6, 100.0 * busy / win, area / win))
 for k in sorted(hist):
     print("  %d%s kernels: %.1f %%" % (k, "+" if k == 8 else "", 100.0 * hist[k] / win))
+
+# the longest stretches with nothing running (position in the window, what ended before and what started after)
+ended, started = {}, {}
+for r in rows:
+    ended[int(r["End_Timestamp"])] = r["Kernel_Name"].split("(")[0][-40:]
+    started[int(r["Start_Timestamp"])] = r["Kernel_Name"].split("(")[0][-40:]
+gaps = []
+cur, last_end = 0, None
+for t, d in ev:
+    if cur == 0 and d == 1 and last_end is not None and t > lo:
+        gaps.append((t - last_end, last_end, t))
+    cur += d
+    if cur == 0:
+        last_end = t
+gaps.sort(reverse=True)
+idle = sum(g[0] for g in gaps)
+print("idle stretches: %d, %.2f ms in all; stretches over 100 us: %.2f ms" % (len(gaps), idle / 1e6, sum(g[0] for g in gaps if g[0] > 100000) / 1e6))
+for g, a, b in gaps[:12]:
+    print("  %7.1f us at %6.1f ms   after %-40s before %s" % (g / 1e3, (a - lo) / 1e6, ended.get(a, "?"), started.get(b, "?")))
