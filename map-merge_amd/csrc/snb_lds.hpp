@@ -24,8 +24,11 @@
 // What does not fit is made to fit first: an item whose box holds more candidates than the tile is worked in
 // parts (runs of its queries, smaller boxes), a ball with more neighbours than the hit buffer in distance bands.
 // Only a dense spot beyond that (one query's own box larger than the tile, a list longer than the arena) sends the
-// item to an overflow list, redone by the global-scratch kernels of sorted_nb.hpp in a second, normally empty,
-// launch.  Results are the same bits on either path (the order is total).
+// item to an overflow list.  The list is counted (SnbCtl::ov_count); the caller reads the count at its next host sync
+// and only then launches what serves it -- the global-scratch kernels of sorted_nb.hpp, for SIFT's first octave the
+// large LDS configuration first (sub_items) -- because a launch that finds an empty list is not free on a GPU busy with
+// other streams: it queues for its LDS at the head of a hardware queue.  Results are the same bits on either path
+// (the order is total).
 //
 // The blocks run at two or three waves per SIMD (LDS), and measured (scripts/snb_stats.py, a build with
 // -DMM3D_SNB_STATS) they are bound by instruction issue, not by latency: every phase is written to spend few
