@@ -178,7 +178,7 @@ static void harris_response_launch(Context *c, const mm3d_cloud *points, const m
   MM3D_HIP(hipMemcpyAsync(ho, &ctl->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   c->sync();
   if (ho[0] == 0) return;
-  SnLaunch<float4> sn(c, n_items * 4, points->n, 4, kSnFallbackBlocks);
+  SnLaunch<float4> sn(c, ho[0] * 4, points->n, 4, 1024u);
   SnScratch sc{sn.tmp.get(), sn.fin.get(), ctl->fb_ctr, &ctl->error, sl.ov_items.get(), &ctl->ov_count};
   MM3D_LAUNCH(c, "harris_response_big", 0.0, k_harris_response_big, dim3(sn.blocks), dim3(256), 0, (const float4 *)points->hil_pts.get(),
               (const int2 *)points->wave_items.get(), n_items, g.view(), (const float4 *)points->pts.get(), (const float4 *)normals->nrm.get(), sr, r2,

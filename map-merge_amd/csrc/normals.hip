@@ -227,7 +227,8 @@ mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius)
     c->sync();
     if (getenv("MM3D_SNB_DEBUG")) fprintf(stderr, "normals: n=%d items=%d blocks=%u overflow items=%d\n", g.n, n_items, sl.blocks, ho[0]);
     if (ho[0] > 0) {
-      SnLaunch<float4> sn(c, n_items * 4, in->n, 4, kSnFallbackBlocks);
+      // (as many blocks as there are overflow items, up to 1024: a cloud that is dense everywhere is all overflow)
+      SnLaunch<float4> sn(c, ho[0] * 4, in->n, 4, 1024u);
       SnScratch sc{sn.tmp.get(), sn.fin.get(), ctl->fb_ctr, &ctl->error, sl.ov_items.get(), &ctl->ov_count};
       MM3D_LAUNCH(c, "normals_radius_big", 0.0, k_normals, dim3(sn.blocks), dim3(256), 0, (const float4 *)in->hil_pts.get(),
                   (const int2 *)in->wave_items.get(), n_items, g.view(), (const float4 *)in->pts.get(), (float)radius, r2, sc,

@@ -331,7 +331,7 @@ static SiftDogPending sift_dog_octave(Context *c, const mm3d_cloud *cur, const G
       ctl = sl2->ctl_dev();
       ov = sl2->ov_items.get();
     }
-    SnLaunch<float2> sn(c, n_items * 4, cur->n, 4, kSnFallbackBlocks);
+    SnLaunch<float2> sn(c, n_overflow * 4, cur->n, 4, 1024u);        // (at most n_overflow items are left: a block each)
     SnScratch scr{sn.tmp.get(), sn.fin.get(), ctl->fb_ctr, &ctl->error, ov, &ctl->ov_count};
     MM3D_LAUNCH(c, "sift_dog_big", 0.0, k_sift_dog, dim3(sn.blocks), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
                 (const int2 *)cur->wave_items.get(), n_items, grp->view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, scr, dog);

@@ -652,7 +652,6 @@ __device__ __forceinline__ void snb_run(const GridView &g, SnbLds<Cfg> &S, const
 
 // host side
 int snb_cu_count(int device);                    // grid.hip
-constexpr unsigned kSnFallbackBlocks = 128;      // grid of the fallback launches (sorted_nb.hpp kernels over the overflow list)
 
 template <class Cfg>
 struct SnbLaunch {
