@@ -608,8 +608,10 @@ __device__ __forceinline__ void snb_run(const GridView &g, SnbLds<Cfg> &S, const
         // every part is a staging of its own with fewer queries per wave: beyond kSnbMaxParts the item is a dense
         // spot for the fallback launch (measured: an item worked down to single queries took 3.5 ms of a 1.8 ms kernel)
         if (hi - lo == 1 || parts >= kSnbMaxParts) {
+          // (the item as a whole goes on the overflow list: what its other parts would still compute here is computed
+          // again there, so they are not worked -- a cloud that is dense everywhere is all such items)
           if (threadIdx.x == 0) S.overflow = 1;
-          ++part;
+          break;
         } else {                                   // the same queries again, in two halves
           parts *= 2;
           part *= 2;
