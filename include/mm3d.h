@@ -34,7 +34,8 @@ typedef enum {
   MM3D_EINVAL = -1,        /* bad argument (also: unknown enum string, like enums::from_string) */
   MM3D_EDEVICE = -2,       /* HIP runtime / device failure */
   MM3D_ENOMEM = -3,
-  MM3D_EUNSUPPORTED = -4,  /* a size outside what the kernels are built for (neighbourhoods beyond the scratch pass, nr_scales != 3) */
+  MM3D_EUNSUPPORTED = -4,  /* a size outside what the kernels are built for: an ordered-sum neighbourhood of more than 16384 points,
+                              an SPFH neighbourhood of more than 65535, nr_scales != 3 (INTEGRATION.md "Size limits") */
   MM3D_ECAPACITY = -5      /* caller buffer too small; required size is reported */
 } mm3d_status;
 

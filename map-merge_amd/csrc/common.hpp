@@ -131,7 +131,7 @@ class Pool {
 // Waits for a stream without burning a core: hipStreamSynchronize spins for as long as the wait lasts (measured:
 // CPU time inside the waits = wall time inside them, whatever hipDeviceScheduleBlockingSync / blocking events say
 // with this runtime), and a library that keeps sixteen streams busy then holds sixteen cores.  This polls
-// hipStreamQuery: a short spin for the waits that are over in microseconds, then naps that grow to 100 us.
+// hipStreamQuery: a short spin for the waits that are over in microseconds, then naps that grow from 5 to 60 us (the caller's timer slack is restored on return).
 // (Measured and dropped: letting the stream write a sequence number to pinned memory behind its work,
 // hipStreamWriteValue32, and polling that word -- the extra packet costs more than the runtime call it saves:
 // 650 against 700 map-pairs/s.  MM3D_WAIT=spin restores hipStreamSynchronize: 720 map-pairs/s on ten busy cores.)

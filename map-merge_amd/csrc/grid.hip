@@ -76,19 +76,28 @@ hipError_t stream_wait(hipStream_t stream)
   static const bool spin_only = [] { const char *e = getenv("MM3D_WAIT"); return e && std::string(e) == "spin"; }();
   if (spin_only) return hipStreamSynchronize(stream);
   static const long spin_us = [] { const char *e = getenv("MM3D_WAIT_SPIN_US"); return e ? atol(e) : 200L; }();
-  // (a nap of 10 us lasts 60 with Linux's default timer slack of 50 us: the waiting thread asks for 1 us once)
-  static thread_local bool slack_set = false;
-  if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }
+  // A nap of 10 us lasts 60 with Linux's default timer slack of 50 us, so a thread that starts napping asks for 1 us --
+  // and gives the caller's thread its own slack back before it returns: worker 0 is the application's thread, and a
+  // library has no business changing how that thread's later sleeps, selects and futex waits are rounded.
   const auto t0 = std::chrono::steady_clock::now();
   long nap_us = 5;
+  long old_slack = -1;                                           // >= 0: changed, to be restored
+  hipError_t e;
   for (;;) {
-    const hipError_t e = hipStreamQuery(stream);
-    if (e != hipErrorNotReady) return e;
+    e = hipStreamQuery(stream);
+    if (e != hipErrorNotReady) break;
     const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     if (waited < spin_us) continue;                              // most readbacks of a size are over by now
+    if (old_slack < 0) {
+      old_slack = (long)prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL);
+      if (old_slack < 0) old_slack = 50000;                      // the kernel's default, should the query fail
+      (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+    }
     std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
-    if (nap_us < 60) nap_us += 5;
+    if (nap_us < 60) nap_us += 5;                                // naps of 5 ... 60 us
   }
+  if (old_slack >= 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old_slack, 0UL, 0UL, 0UL);
+  return e;
 }
 
 void Context::sync()

@@ -185,6 +185,8 @@ void mo_estimate_transform(const mo_point *src, int ns, const mo_point *src_kp,
  * (R/src/registration_visualisation.cpp:129-130; MATCHING only) and the ICP trace */
 typedef struct { int n_correspondences, n_inliers, icp_iterations, icp_correspondences; } mo_pair_trace;
 void mo_last_pair_trace(mo_pair_trace *out);
+void mo_last_pair_init(float T[16]);                  /* the initial estimate the last mo_estimate_transform gave ICP */
+int mo_last_double_sums_correspondences(void);       /* last-iteration count of the last mo_icp_double_sums */
 /* transformScore: R/src/matching.cpp:259-268. */
 double mo_transform_score(const mo_point *src, int ns, const mo_point *tgt,
                           int nt, const float T[16], double max_distance);
@@ -224,6 +226,11 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
                                 float *out_T, mo_estimate *pair_out,
                                 int *n_pairs_out);
 int mo_last_run_traces(mo_pair_trace *out, int cap);
+/* Exact-arithmetic yardstick of a whole job (NOT the reference's arithmetic): with the switch on,
+ * mo_estimate_maps_transforms also runs mo_icp_double_sums from every pair's initial estimate; mo_last_run_exact copies
+ * the per-pair results (16 floats, iteration count, last-iteration correspondence count) and returns how many exist. */
+void mo_set_exact_yardstick(int on);
+int mo_last_run_exact(float *T, int *iters, int *corr, int cap);
 /* composeMaps: R/src/map_merging.cpp:277-305. returns -1 for empty input
  * (nullptr in the reference), -2 for size mismatch (the reference throws). */
 int mo_compose_maps(const mo_point *const *clouds, const int *sizes, int n_clouds,

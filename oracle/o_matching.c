@@ -350,6 +350,12 @@ void mo_sac_ia(const mo_point *src_kp, const float *src_desc, int ns, const mo_p
  * prints for MATCHING, plus the ICP trace); process-global like the rand() state */
 static mo_pair_trace g_trace;
 void mo_last_pair_trace(mo_pair_trace *out) { *out = g_trace; }
+/* the initial estimate (RANSAC | SAC-IA) mo_estimate_transform handed to ICP most recently, and the last-iteration
+ * correspondence count of the most recent mo_icp_double_sums: what the exact-arithmetic yardstick of a whole job needs */
+static float g_last_init[16];
+static int g_dbl_corr = 0;
+void mo_last_pair_init(float T[16]) { memcpy(T, g_last_init, sizeof(g_last_init)); }
+int mo_last_double_sums_correspondences(void) { return g_dbl_corr; }
 
 /* ICP */
 void mo_icp(const mo_point *src, int ns, const mo_point *tgt, int nt, const float guess[16],
@@ -478,6 +484,7 @@ void mo_icp_double_sums(const mo_point *src, int ns, const mo_point *tgt, int nt
         mse += nd_of[i];
         ++cnt;
       }
+      g_dbl_corr = cnt;
       if (cnt < 3) break;
       double Tinc[16], Tn[16];
       mo_umeyama_f64(cs, cd, cnt, Tinc);
@@ -558,6 +565,7 @@ void mo_estimate_transform(const mo_point *src, int ns, const mo_point *src_kp, 
     mo_sac_ia(src_kp, src_desc, nsk, tgt_kp, tgt_desc, ntk, dim, inlier_threshold,
               max_correspondence_distance, max_iterations, T0, NULL, NULL);
   }
+  memcpy(g_last_init, T0, sizeof(T0));
   if (refine) {
     /* ICP also runs on a zero initial transform (no guard at R/src/matching.cpp:250) */
     mo_icp(src, ns, tgt, nt, T0, max_correspondence_distance, inlier_threshold, max_iterations,

@@ -43,6 +43,21 @@ int mo_last_run_traces(mo_pair_trace *out, int cap)
   return g_n_traces;
 }
 
+static int g_yardstick = 0;
+static float *g_exact_T = NULL;
+static int *g_exact_it = NULL, *g_exact_corr = NULL;
+static int g_n_exact = 0;
+void mo_set_exact_yardstick(int on) { g_yardstick = on; }
+int mo_last_run_exact(float *T, int *iters, int *corr, int cap)
+{
+  for (int i = 0; i < g_n_exact && i < cap; ++i) {
+    memcpy(T + (size_t)i * 16, g_exact_T + (size_t)i * 16, sizeof(float) * 16);
+    iters[i] = g_exact_it[i];
+    corr[i] = g_exact_corr[i];
+  }
+  return g_n_exact;
+}
+
 static void identity16(float *T)
 {
   memset(T, 0, sizeof(float) * 16);
@@ -106,6 +121,14 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
   free(g_traces);
   g_traces = (mo_pair_trace *)calloc((size_t)(np > 0 ? np : 1), sizeof(mo_pair_trace));
   g_n_traces = np;
+  free(g_exact_T); free(g_exact_it); free(g_exact_corr);
+  g_exact_T = NULL; g_exact_it = NULL; g_exact_corr = NULL; g_n_exact = 0;
+  if (g_yardstick && params->refine_transform) {
+    g_exact_T = (float *)calloc((size_t)(np > 0 ? np : 1) * 16, sizeof(float));
+    g_exact_it = (int *)calloc((size_t)(np > 0 ? np : 1), sizeof(int));
+    g_exact_corr = (int *)calloc((size_t)(np > 0 ? np : 1), sizeof(int));
+    g_n_exact = np;
+  }
   for (int p = 0; p < np; ++p) {
     int i = (int)pairs[p].source_idx, j = (int)pairs[p].target_idx;
     mo_estimate_transform(resized[i], rn[i], kps[i], desc[i], kn[i], resized[j], rn[j], kps[j], desc[j],
@@ -114,6 +137,13 @@ int mo_estimate_maps_transforms(const mo_point *const *clouds, const int *sizes,
                           params->max_iterations, (size_t)params->matching_k,
                           params->transform_epsilon, pairs[p].transform);
     mo_last_pair_trace(&g_traces[p]);
+    if (g_n_exact) {                               /* test yardstick only: never feeds the results */
+      float T0[16];
+      mo_last_pair_init(T0);
+      mo_icp_double_sums(resized[i], rn[i], resized[j], rn[j], T0, params->max_correspondence_distance,
+                         params->max_iterations, params->transform_epsilon, g_exact_T + (size_t)p * 16, &g_exact_it[p]);
+      g_exact_corr[p] = mo_last_double_sums_correspondences();
+    }
     pairs[p].confidence = 1.0 / mo_transform_score(resized[i], rn[i], resized[j], rn[j], pairs[p].transform,
                                                    params->max_correspondence_distance);
   }

@@ -1,0 +1,94 @@
+// VALU issue peak of the MI355X as THIS library's kernels see it: independent f32 instruction streams at 1 / 2 / 4 / 8
+// waves per SIMD on all 256 CUs.  bench.py's VALU_PEAK_WINSTR_S (the denominator of every `valu_frac`) is what this prints
+// for v_fma_f32 at full occupancy; the guide's table says 2 cycles per wave64 instruction on a SIMD-32
+// (/opt/skills/guides/MI355X_MICROARCH.md "Per-instruction cycle constants").
+//   hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate
+// Output per (instruction, waves per SIMD): wave-instructions per second over the chip (HIP events), and shader cycles per
+// wave-instruction per SIMD (s_memtime around the loop of one wave x the waves that share its SIMD).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int kChains = 16;      // independent accumulators per lane: no instruction waits for the one before it
+
+// MODE 0 v_fma_f32, 1 v_add_f32, 2 v_pk_fma_f32 (two f32 per lane and instruction), 3 v_fma_f64, 4 v_add_f32 with a DPP quad broadcast
+template <int MODE>
+__global__ void __launch_bounds__(1024)
+k_rate(int iters, float *out, long long *cyc)
+{
+  const int l = threadIdx.x;
+  float f[kChains]; v2f p[kChains]; double d[kChains];
+#pragma unroll
+  for (int c = 0; c < kChains; ++c) { f[c] = 1.0f + (float)(l + c) * 1e-3f; p[c] = v2f{f[c], f[c] + 1.0f}; d[c] = (double)f[c]; }
+  const float a = 1.0000001f, b = 1e-7f;
+  const v2f pa = {a, a}, pb = {b, b};
+  const long long t0 = clock64();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int c = 0; c < kChains; ++c) {
+      if (MODE == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[c]) : "v"(a), "v"(b));
+      if (MODE == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[c]) : "v"(b));
+      if (MODE == 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[c]) : "v"(pa), "v"(pb));
+      if (MODE == 3) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[c]) : "v"((double)a), "v"((double)b));
+      if (MODE == 4) asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(f[c]) : "v"(f[(c + 1) % kChains]));
+    }
+  }
+  const long long t1 = clock64();
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < kChains; ++c) s += f[c] + p[c].x + p[c].y + (float)d[c];
+  if (s == 12345.678f) out[0] = s;               // keeps the chains alive
+  if ((l & 63) == 0 && blockIdx.x == 0 && l == 0) cyc[0] = t1 - t0;
+}
+
+template <int MODE>
+static int run(const char *name, int cus)
+{
+  float *out; long long *cyc;
+  CK(hipMalloc(&out, 64)); CK(hipMalloc(&cyc, 64));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int iters = 20000;
+  for (int wps : {1, 2, 4, 8}) {
+    // wps waves on each of a CU's four SIMDs: blocks of 4 * min(wps, 4) waves, one or two blocks per CU
+    const int waves_per_block = 4 * (wps < 4 ? wps : 4), blocks_per_cu = wps <= 4 ? 1 : wps / 4;
+    const dim3 grid(cus * blocks_per_cu), block(64 * waves_per_block);
+    hipLaunchKernelGGL(k_rate<MODE>, grid, block, 0, 0, 200, out, cyc);      // warm-up (clocks, code)
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    long long c = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k_rate<MODE>, grid, block, 0, 0, iters, out, cyc);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (ms < best) { best = ms; CK(hipMemcpy(&c, cyc, sizeof(c), hipMemcpyDeviceToHost)); }
+    }
+    const double winstr = (double)cus * blocks_per_cu * waves_per_block * (double)iters * kChains;
+    const double rate = winstr / (best * 1e-3);
+    // one wave's loop took c cycles for iters * kChains instructions while wps waves shared its SIMD
+    const double cyc_per_instr_simd = (double)c / ((double)iters * kChains * wps);
+    printf("%-22s %d waves/SIMD: %8.3f ms  %.3e wave-instr/s chip  = %.2f shader cycles per wave-instruction per SIMD  (effective clock %.2f GHz if 256 CU x 4 SIMD)\n",
+           name, wps, best, rate, cyc_per_instr_simd, rate * cyc_per_instr_simd / (cus * 4.0) * 1e-9);
+  }
+  CK(hipFree(out)); CK(hipFree(cyc));
+  return 0;
+}
+
+int main()
+{
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  printf("%s: %d CUs, clock %d MHz\n", prop.name, cus, prop.clockRate / 1000);
+  if (run<0>("v_fma_f32", cus)) return 1;
+  if (run<1>("v_add_f32", cus)) return 1;
+  if (run<2>("v_pk_fma_f32", cus)) return 1;
+  if (run<3>("v_fma_f64", cus)) return 1;
+  if (run<4>("v_add_f32_dpp quad", cus)) return 1;
+  return 0;
+}

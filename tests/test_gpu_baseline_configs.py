@@ -23,12 +23,16 @@ pytestmark = pytest.mark.gpu
 FPFH, PFHRGB, SHOT = 2, 1, 4
 MATCHING, SAC_IA = 0, 1
 
-# name -> (maps, raw points per map, descriptor, method): BASELINE.json configs[1..4]
+# name -> (maps, raw points per map, descriptor, method, scene / parameter overrides): BASELINE.json configs[1..4];
+# configs[3] twice: on the generator's default 120 m outdoor windows and as BASELINE.json words it, "dense indoor"
+# (30 m windows at resolution 0.05 -- nearly every neighbourhood overflows the LDS tiles there)
+INDOOR = dict(window=30.0, resolution=0.05)
 CONFIGS = {
-    "4x200k_FPFH": (4, 200000, FPFH, SAC_IA),
-    "16x500k_FPFH_ICP": (16, 500000, FPFH, SAC_IA),
-    "8x2M_SIFT_SHOT": (8, 2000000, SHOT, SAC_IA),
-    "64x50k_swarm": (64, 50000, FPFH, SAC_IA),
+    "4x200k_FPFH": (4, 200000, FPFH, SAC_IA, {}),
+    "16x500k_FPFH_ICP": (16, 500000, FPFH, SAC_IA, {}),
+    "8x2M_SIFT_SHOT": (8, 2000000, SHOT, SAC_IA, {}),
+    "8x2M_SIFT_SHOT_dense_indoor": (8, 2000000, SHOT, SAC_IA, INDOOR),
+    "64x50k_swarm": (64, 50000, FPFH, SAC_IA, {}),
 }
 
 
@@ -36,11 +40,11 @@ CONFIGS = {
 def workload(synth):
     cache = {}
 
-    def get(n_maps, n_points):
-        key = (n_maps, n_points)
+    def get(n_maps, n_points, window=None):
+        key = (n_maps, n_points, window)
         if key not in cache:
             cache.clear()                                   # one configuration resident at a time (8 x 2M = 256 MB)
-            cache[key] = synth.cached_maps(n_maps, n_points)
+            cache[key] = synth.cached_maps(n_maps, n_points, **({"window": window} if window else {}))
         return cache[key]
 
     return get
@@ -60,9 +64,11 @@ def records_equal(a, b):
 
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_full_size_configuration_runs_and_streams_do_not_change_a_bit(ctx, mm, workload, name):
-    n_maps, n_points, desc, method = CONFIGS[name]
-    raws, _, _ = workload(n_maps, n_points)
+    n_maps, n_points, desc, method, over = CONFIGS[name]
+    raws, _, _ = workload(n_maps, n_points, over.get("window"))
     params = mm.MapMergingParams(descriptor_type=desc, estimation_method=method, refine_transform=1)
+    if "resolution" in over:
+        params.resolution = over["resolution"]
     runs = []
     for streams in (16, 1):
         ctx.setStreams(streams)
@@ -116,9 +122,10 @@ def test_16x500k_stage_by_stage_against_the_oracle(ctx, po, mm, workload):
                            params.max_iterations, params.transform_epsilon)
     score = po.transform_score(ref[0]["filt"], ref[1]["filt"], T_ref, params.max_correspondence_distance)
     got = pairs[0]["transform"].reshape(4, 4).T
-    # ICP reduces in double on the device and in float on the CPU path: Frobenius 1e-3, confidence 1e-4 relative
-    assert int(pairs[0]["icp_iterations"]) == it_ref
-    assert np.linalg.norm(got - T_ref) <= 1e-3, np.linalg.norm(got - T_ref)
+    # ICP reduces in double on the device and in float on the CPU path: the stated tolerance (both clauses), confidence 1e-4 relative
+    T_ex, it_ex = po.icp_double_sums(ref[0]["filt"], ref[1]["filt"], T0, params.max_correspondence_distance, params.max_iterations,
+                                     params.transform_epsilon)
+    check_pair_tolerance(po, got, T_ref, T_ex, pairs[0]["icp_iterations"], it_ref, it_ex, len(ref[0]["filt"]), what="headline pair (0, 1)")
     assert pairs[0]["confidence"] == pytest.approx(1.0 / score, rel=1e-4)
     # the reference's default method on the same maps: cross-match and inlier counts exact
     # (R/src/registration_visualisation.cpp:129-130), transform bit-equal
@@ -130,6 +137,134 @@ def test_16x500k_stage_by_stage_against_the_oracle(ctx, po, mm, workload):
     T_g, inl_g = ctx.estimateTransformFromCorrespondences(ctx.cloud(dev[0]["kp"]), ctx.cloud(dev[1]["kp"]), got_corr,
                                                           params.inlier_threshold)
     assert len(inl_g) == len(inl_r) and np.array_equal(T_g.view(np.uint32), T_r.view(np.uint32))
+
+
+def oracle_threads():
+    """Threads for the oracle's OpenMP loops: the container's CPU quota (threads beyond it only get the group throttled)."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def check_pair_tolerance(po, T_dev, T_oracle, T_exact, it_dev, it_oracle, it_exact, n_src, what=""):
+    """THE stated pair-transform tolerance (oracle/pyoracle.py): both clauses."""
+    fro_exact = float(np.linalg.norm(np.asarray(T_dev, np.float64) - np.asarray(T_exact, np.float64)))
+    fro_oracle = float(np.linalg.norm(np.asarray(T_dev, np.float64) - np.asarray(T_oracle, np.float64)))
+    assert int(it_dev) == int(it_exact) == int(it_oracle), (what, it_dev, it_oracle, it_exact)
+    assert fro_exact <= po.TOL_T_EXACT, (what, fro_exact)
+    assert fro_oracle <= po.transform_tolerance(n_src), (what, fro_oracle, n_src)
+    return fro_oracle, fro_exact
+
+
+def test_16x500k_all_120_pairs_within_the_stated_tolerance(ctx, po, mm, workload):
+    """The WHOLE headline job against the oracle's restated estimateMapsTransforms (one rand() stream over all pairs,
+    R/src/map_merging.cpp:256-269) and against its exact-arithmetic yardstick: every one of the 120 pair transforms
+    within the stated tolerance, every ICP iteration count equal, confidences and global transforms within theirs.
+    About two minutes of oracle on the box's cores."""
+    import os
+    import time
+    raws, _, _ = workload(16, 500000)
+    params = mm.MapMergingParams(descriptor_type=FPFH, estimation_method=SAC_IA, refine_transform=1)
+    ctx.setStreams(16)
+    ctx.srand(1)
+    T_dev, dev = ctx.estimateMapsTransforms(raws, params, return_pairs=True)
+    n_filtered = []
+    for r in raws:
+        m = ctx.mapFeatures(ctx.cloud(r), params)
+        n_filtered.append(len(m.points))
+        m.free()
+    ctx.setStreams(1)
+    op = po.params_default(); op.descriptor_type = FPFH; op.estimation_method = SAC_IA; op.refine_transform = 1
+    po.set_threads(oracle_threads())
+    po.set_exact_yardstick(True)
+    po.srand(1)
+    t0 = time.perf_counter()
+    try:
+        T_ref, ref = po.estimate_maps_transforms(raws, op)
+        tr = po.last_run_traces()
+        T_ex, it_ex, corr_ex = po.last_run_exact()
+    finally:
+        po.set_exact_yardstick(False)
+        po.set_threads(1)
+    t_cpu = time.perf_counter() - t0
+    assert len(dev) == len(ref) == len(tr) == len(T_ex) == 120
+    fo, fe = [], []
+    for k in range(120):
+        assert int(dev[k]["source_idx"]) == int(ref[k]["source_idx"]) and int(dev[k]["target_idx"]) == int(ref[k]["target_idx"])
+        a, b = check_pair_tolerance(po, dev[k]["transform"], ref[k]["transform"], T_ex[k], dev[k]["icp_iterations"], tr[k]["icp_iterations"],
+                                    it_ex[k], n_filtered[int(dev[k]["source_idx"])], what=f"pair {k}")
+        fo.append(a); fe.append(b)
+    conf = np.array([abs(float(a["confidence"]) / float(b["confidence"]) - 1.0) for a, b in zip(dev, ref)])
+    assert conf.max() <= 1e-3, conf.max()
+    g = np.array([np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) for a, b in zip(T_dev, T_ref)])
+    assert g.max() <= 2e-3, g.max()
+    # integer observable of the last ICP iteration: against exact arithmetic the counts agree; against the CPU path's
+    # float-transformed cloud points at the max_correspondence_distance border flip (reported, not asserted)
+    corr_eq_exact = int(sum(int(a["icp_correspondences"]) == int(c) for a, c in zip(dev, corr_ex)))
+    corr_eq_oracle = int(sum(int(a["icp_correspondences"]) == int(t["icp_correspondences"]) for a, t in zip(dev, tr)))
+    fo, fe = np.array(fo), np.array(fe)
+    report = (f"120 pairs of 16 x 500000: ||T_dev - T_oracle||_F max {fo.max():.3e} median {np.median(fo):.3e} "
+              f"(tolerance {po.transform_tolerance(max(n_filtered)):.2e} at {max(n_filtered)} source points); "
+              f"||T_dev - T_exact||_F max {fe.max():.3e} median {np.median(fe):.3e} (tolerance {po.TOL_T_EXACT:g}); "
+              f"ICP iteration counts equal 120 of 120 (oracle and exact); last-iteration correspondence counts equal: "
+              f"{corr_eq_exact} of 120 vs exact arithmetic, {corr_eq_oracle} of 120 vs the CPU path; confidence rel max {conf.max():.3e}; "
+              f"global transforms max {g.max():.3e}; oracle {t_cpu:.0f} s on {oracle_threads()} threads")
+    print(report)
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
+    if os.path.isdir(out):
+        open(os.path.join(out, "all_pairs_tolerance.txt"), "w").write(report + "\n")
+    assert corr_eq_exact >= 114, corr_eq_exact
+
+
+def test_8x2M_dense_indoor_stage_by_stage_against_the_oracle(ctx, po, mm, workload):
+    """configs[3] as BASELINE.json words it (dense indoor: 30 m windows, resolution 0.05; SIFT + SHOT-1344): maps 0 and 1
+    and pair (0, 1) on the CPU oracle, stage by stage.  Nearly every neighbourhood of these clouds overflows the LDS tiles,
+    so this is the test of the dense-spot paths at size (R/src/features.cpp:45-62, dispatch_descriptors.h:46)."""
+    raws, _, _ = workload(8, 2000000, INDOOR["window"])
+    params = mm.MapMergingParams(descriptor_type=SHOT, estimation_method=SAC_IA, refine_transform=1)
+    params.resolution = INDOOR["resolution"]
+    ctx.setStreams(16)
+    ctx.srand(1)
+    _, pairs = ctx.estimateMapsTransforms(raws, params, return_pairs=True)
+    ctx.setStreams(1)
+    assert pairs[0]["source_idx"] == 0 and pairs[0]["target_idx"] == 1
+    po.set_threads(oracle_threads())
+    try:
+        ref = []
+        for i in (0, 1):
+            d = po.downsample(raws[i], params.resolution)
+            f = po.remove_outliers(d, params.descriptor_radius, params.outliers_min_neighbours)
+            n = po.normals(f, params.normal_radius)
+            kp_raw, _ = po.keypoints_sift(f, params.resolution, 3, 3, params.keypoint_threshold)
+            kp, desc = po.descriptors_shot(f, n, kp_raw, params.descriptor_radius)
+            ref.append(dict(filt=f, kp=kp, desc=desc))
+            m = ctx.mapFeatures(ctx.cloud(raws[i]), params)
+            g = dict(filt=m.points.numpy(), kp=m.keypoints.numpy(), desc=m.descriptors.numpy())
+            m.free()
+            assert len(f) > 1000000                         # dense: more than a million points survive the filters
+            assert np.array_equal(g["filt"].view(np.uint32), f.view(np.uint32))
+            assert np.array_equal(xyz(g["kp"]).view(np.uint32), xyz(kp).view(np.uint32)), (len(g["kp"]), len(kp))
+            same = (g["desc"].view(np.uint32) == desc.view(np.uint32)).all(axis=1)
+            assert same.mean() >= 0.99 and np.abs(g["desc"] - desc).max() <= 2e-6, (same.mean(), np.abs(g["desc"] - desc).max())
+        po.srand(1)
+        T0, _, _ = po.sac_ia(ref[0]["kp"], ref[0]["desc"], ref[1]["kp"], ref[1]["desc"], params.inlier_threshold,
+                             params.max_correspondence_distance, params.max_iterations)
+        T_ref, it_ref = po.icp(ref[0]["filt"], ref[1]["filt"], T0, params.max_correspondence_distance, params.inlier_threshold,
+                               params.max_iterations, params.transform_epsilon)
+        T_ex, it_ex = po.icp_double_sums(ref[0]["filt"], ref[1]["filt"], T0, params.max_correspondence_distance, params.max_iterations,
+                                         params.transform_epsilon)
+        score = po.transform_score(ref[0]["filt"], ref[1]["filt"], T_ref, params.max_correspondence_distance)
+    finally:
+        po.set_threads(1)
+    got = pairs[0]["transform"].reshape(4, 4).T
+    check_pair_tolerance(po, got, T_ref, T_ex, pairs[0]["icp_iterations"], it_ref, it_ex, len(ref[0]["filt"]), what="dense indoor pair (0, 1)")
+    assert pairs[0]["confidence"] == pytest.approx(1.0 / score, rel=1e-3)
 
 
 def test_ground_truth_is_recovered_where_the_reference_algorithm_finds_it(ctx, mm, synth, workload):

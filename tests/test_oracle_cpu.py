@@ -622,6 +622,35 @@ def test_threads_do_not_change_a_bit(po, synth):
     assert a == b
 
 
+def test_exact_yardstick_of_a_whole_job(po, synth):
+    """The stated pair-transform tolerance's second yardstick (pyoracle.TOL_T_EXACT, transform_tolerance): with the switch
+    on, estimate_maps_transforms also runs the double-sum ICP from every pair's own initial estimate.  On small clouds the
+    CPU path's float sums carry next to no noise, so the two agree closely and iterate equally often; the switch changes
+    no result."""
+    _, maps = synth.synth_maps(3, 5000)
+    raws = [synth.pack_points(x, c) for x, c, _ in maps]
+    op = po.params_default(); op.descriptor_type = 2; op.estimation_method = 1; op.refine_transform = 1
+    po.srand(1)
+    T_a, pairs_a = po.estimate_maps_transforms(raws, op)
+    assert len(po.last_run_exact()[0]) == 0
+    po.set_exact_yardstick(True)
+    try:
+        po.srand(1)
+        T_b, pairs_b = po.estimate_maps_transforms(raws, op)
+        tr = po.last_run_traces()
+        T_ex, it_ex, corr_ex = po.last_run_exact()
+    finally:
+        po.set_exact_yardstick(False)
+    assert pairs_a.tobytes() == pairs_b.tobytes() and all(a.tobytes() == b.tobytes() for a, b in zip(T_a, T_b))
+    assert len(T_ex) == len(pairs_b) == 3
+    for k in range(3):
+        assert int(it_ex[k]) == int(tr[k]["icp_iterations"])
+        # (the float path's own summation noise: within the oracle clause of the tolerance with room to spare)
+        assert np.linalg.norm(T_ex[k].astype(np.float64) - pairs_b[k]["transform"].astype(np.float64)) <= 0.5 * po.transform_tolerance(5000)
+        assert abs(int(corr_ex[k]) - int(tr[k]["icp_correspondences"])) <= 2
+    assert po.transform_tolerance(5000) == 1e-3 and po.transform_tolerance(406000) == pytest.approx(4.06e-3) and po.TOL_T_EXACT == 1e-4
+
+
 PCL_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pcl_pair_12k.bin")
 
 
