@@ -53,13 +53,35 @@ KERNEL_OF_SYMBOL = {"k_sift_dog_lds": "sift_dog", "k_normals_lds": "normals_radi
 # files as they were when the counters were collected (scripts/assemble_profiles.py); a figure whose files have changed
 # since is reported with "stale": true instead of passing for a measurement of the code that ran
 _CS = "map-merge_amd/csrc/"
+# root files per kernel; the hash covers their transitive local #includes too (device_util.hpp, common.hpp, types.hpp, ...),
+# plus grid.hip wherever a kernel reads a layout that file builds (neighbour-block lists, Hilbert items, cell tables)
 KERNEL_SOURCES = {
-    "sift_dog": ["sift.hip", "snb_lds.hpp", "libm_exact.hpp"], "sift_extrema": ["sift.hip", "device_util.hpp"],
-    "normals_radius": ["normals.hip", "snb_lds.hpp", "device_util.hpp"], "spfh": ["fpfh.hip", "device_util.hpp", "libm_exact.hpp"],
-    "fpfh_weight": ["fpfh.hip", "sorted_nb.hpp"], "fpfh_mark": ["fpfh.hip"], "icp_corr_reduce": ["nn.hip"], "score_nn_reduce": ["nn.hip"],
-    "sacia_err": ["registration.hip"], "sacia_seq_sum": ["registration.hip"], "desc_knn_mfma": ["desc_knn.hip"],
-    "desc_knn_rerank": ["desc_knn.hip"], "radius_outlier_count": ["filters.hip"], "voxel_centroid": ["filters.hip"],
+    "sift_dog": ["sift.hip", "grid.hip"], "sift_extrema": ["sift.hip", "grid.hip"],
+    "normals_radius": ["normals.hip", "grid.hip"], "spfh": ["fpfh.hip", "grid.hip"],
+    "fpfh_weight": ["fpfh.hip", "grid.hip"], "fpfh_mark": ["fpfh.hip", "grid.hip"], "icp_corr_reduce": ["nn.hip", "grid.hip"],
+    "score_nn_reduce": ["nn.hip", "grid.hip"], "sacia_err": ["registration.hip", "grid.hip"], "sacia_seq_sum": ["registration.hip"],
+    "desc_knn_mfma": ["desc_knn.hip"], "desc_knn_rerank": ["desc_knn.hip"], "radius_outlier_count": ["filters.hip", "grid.hip"],
+    "voxel_centroid": ["filters.hip", "grid.hip"],
 }
+
+
+def _source_closure(roots):
+    """The root files and every local header they include, transitively (names relative to csrc/, sorted)."""
+    import re
+    seen, todo = set(), list(roots)
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.add(f)
+        try:
+            with open(os.path.join(ROOT, _CS + f), "r", errors="replace") as fh:
+                for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), re.M):
+                    if os.path.exists(os.path.join(ROOT, _CS + m.group(1))):
+                        todo.append(m.group(1))
+        except OSError:
+            pass
+    return sorted(seen)
 
 
 # registration_visualisation's stage boundaries (R/src/registration_visualisation.cpp:51-158): which stage a kernel's
@@ -87,7 +109,7 @@ def kernel_source_hash(kernel):
     if not files:
         return None
     h = hashlib.sha256()
-    for f in files:
+    for f in _source_closure(files):
         try:
             with open(os.path.join(ROOT, _CS + f), "rb") as fh:
                 h.update(fh.read())

@@ -651,6 +651,20 @@ def test_exact_yardstick_of_a_whole_job(po, synth):
     assert po.transform_tolerance(5000) == 1e-3 and po.transform_tolerance(406000) == pytest.approx(4.06e-3) and po.TOL_T_EXACT == 1e-4
 
 
+def test_oracle_under_sanitizers():
+    """the CPU restatement under AddressSanitizer + UndefinedBehaviourSanitizer (+ LeakSanitizer).
+    `make -C oracle san` compiles every oracle source with -fsanitize=address,undefined -fno-sanitize-recover behind
+    oracle/san_driver.c, which runs all six descriptors, both keypoint detectors, both estimation methods, both ICPs, the
+    pose graph, composeMaps, the degenerate inputs of the reference's gtests and the OpenMP loops on two threads."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "san"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(root, "oracle", "_san", "oracle_san")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "sanitizer driver ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
 PCL_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pcl_pair_12k.bin")
 
 
