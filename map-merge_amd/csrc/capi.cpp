@@ -538,11 +538,19 @@ static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const m
   // NB: the outlier radius is the DESCRIPTOR radius (map_merging.cpp:219-220)
   std::unique_ptr<mm3d_cloud> filt(remove_outliers(ctx, down.get(), p->descriptor_radius, p->outliers_min_neighbours));
   down.reset();
-  std::unique_ptr<mm3d_normals> nrm(compute_normals(ctx, filt.get(), p->normal_radius));
-  // detectKeypoints(points, normals, type, keypoint_threshold, normal_radius, resolution)  (map_merging.cpp:231-233)
-  std::unique_ptr<mm3d_cloud> kp(p->keypoint_type == MM3D_KP_HARRIS
-                                     ? detect_keypoints_harris(ctx, filt.get(), nrm.get(), p->keypoint_threshold, p->normal_radius)
-                                     : detect_keypoints_sift(ctx, filt.get(), p->resolution, 3, 3, p->keypoint_threshold));
+  // computeSurfaceNormals, then detectKeypoints(points, normals, type, keypoint_threshold, normal_radius, resolution)
+  // (map_merging.cpp:225-233).  SIFT does not read the normals, and its first octave builds every point's sorted
+  // neighbour list over a ball that contains the normals': the two stages share that launch (sift.hip), same bits.
+  std::unique_ptr<mm3d_normals> nrm;
+  std::unique_ptr<mm3d_cloud> kp;
+  if (p->keypoint_type == MM3D_KP_HARRIS) {
+    nrm.reset(compute_normals(ctx, filt.get(), p->normal_radius));
+    kp.reset(detect_keypoints_harris(ctx, filt.get(), nrm.get(), p->keypoint_threshold, p->normal_radius));
+  } else {
+    mm3d_normals *n_out = nullptr;
+    kp.reset(detect_keypoints_sift(ctx, filt.get(), p->resolution, 3, 3, p->keypoint_threshold, p->normal_radius, &n_out));
+    nrm.reset(n_out);
+  }
   std::unique_ptr<mm3d_desc> desc(p->descriptor_type == MM3D_DESC_PFH    ? compute_pfh(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                   : p->descriptor_type == MM3D_DESC_SC3D ? compute_sc3d(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                   : p->descriptor_type == MM3D_DESC_RSD ? compute_rsd(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)

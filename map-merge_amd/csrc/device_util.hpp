@@ -408,4 +408,31 @@ __host__ __device__ inline void eigen33_smallest(float xx, float xy, float xz, f
   v[0] = sx / n; v[1] = sy / n; v[2] = sz / n;
 }
 
+// computePointNormal + flipNormalTowardsViewpoint(point, 0, 0, 0) (features/normal_3d.h) from the nine raw-moment sums
+// a = {xx, xy, xz, yy, yz, zz, x, y, z} over cnt neighbours: covariance E[x x^T] - E[x] E[x]^T, smallest eigenpair,
+// curvature |lambda0 / trace|; fewer than 3 neighbours: NaN.  One source for every normals kernel (normals.hip, sift.hip).
+__device__ __forceinline__ float4 normal_from_moments(const float *sums, int cnt, const float4 &pq)
+{
+  float4 o;
+  if (cnt < 3) {
+    o.x = o.y = o.z = o.w = __uint_as_float(0x7fc00000u);
+    return o;
+  }
+  float a[9];
+  const float fc = (float)cnt;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) a[k] = sums[k] / fc;
+  const float cxx = a[0] - a[6] * a[6], cxy = a[1] - a[6] * a[7], cxz = a[2] - a[6] * a[8];
+  const float cyy = a[3] - a[7] * a[7], cyz = a[4] - a[7] * a[8], czz = a[5] - a[8] * a[8];
+  float ev, v[3];
+  eigen33_smallest(cxx, cxy, cxz, cyy, cyz, czz, &ev, v);
+  const float eig_sum = cxx + cyy + czz;
+  o.w = (eig_sum != 0.0f) ? fabsf(ev / eig_sum) : 0.0f;
+  const float vx = 0.0f - pq.x, vy = 0.0f - pq.y, vz = 0.0f - pq.z;
+  const float cos_theta = vx * v[0] + vy * v[1] + vz * v[2];
+  if (cos_theta < 0.0f) { v[0] *= -1.0f; v[1] *= -1.0f; v[2] *= -1.0f; }
+  o.x = v[0]; o.y = v[1]; o.z = v[2];
+  return o;
+}
+
 }  // namespace mm3d

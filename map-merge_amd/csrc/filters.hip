@@ -74,6 +74,73 @@ __global__ void k_voxel_centroid(const float4 *__restrict__ pts, const uint32_t 
   out[v] = o;
 }
 
+// Does VoxelGrid(leaf = resolution) return this cloud unchanged, bit for bit?  True when every point is finite, the voxel
+// keys ascend strictly in input order (one point per voxel, and the output's voxel order is the input's order) and no
+// coordinate is -0.0f (the centroid 0.f + (-0.0f) is +0.0f).  That is the normal case of SIFT's first octave: the
+// reference calls detectKeypoints with min_scale = resolution on a cloud downSample(resolution) produced
+// (R/src/map_merging.cpp:231-233), whose points lie one to a voxel of the same global lattice.
+__global__ void k_voxel_identity(const float4 *__restrict__ pts, int n, float inv, int minbx, int minby, int minbz, int mul1, int mul2,
+                                 int *__restrict__ not_identity)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  auto key_of = [&](const float4 &p, bool &ok) {
+    ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && __float_as_uint(p.x) != 0x80000000u && __float_as_uint(p.y) != 0x80000000u &&
+         __float_as_uint(p.z) != 0x80000000u;
+    const int ijk0 = (int)(floorf(__fmul_rn(p.x, inv)) - (float)minbx);
+    const int ijk1 = (int)(floorf(__fmul_rn(p.y, inv)) - (float)minby);
+    const int ijk2 = (int)(floorf(__fmul_rn(p.z, inv)) - (float)minbz);
+    return (uint32_t)(ijk0 + ijk1 * mul1 + ijk2 * mul2);
+  };
+  bool ok, ok_prev = true;
+  const uint32_t k = key_of(pts[i], ok);
+  uint32_t kp = 0;
+  if (i > 0) kp = key_of(pts[i - 1], ok_prev);
+  if (!ok || (i > 0 && !(kp < k))) *not_identity = 1;      // (benign race: every writer stores 1)
+}
+
+struct VoxelSetup { bool overflow; float inv; int min_b[3], div_b[3]; };
+static VoxelSetup voxel_setup(const mm3d_cloud *in, float leaf)
+{
+  VoxelSetup v;
+  v.inv = 1.0f / leaf;
+  const float *mn = in->bmin, *mx = in->bmax;
+  // VoxelGrid's overflow guard: too many voxels => the input is returned unchanged
+  auto i64 = [](float x) -> int64_t {
+    if (!(x > -9.2e18f && x < 9.2e18f)) return INT64_MAX / 4;
+    return (int64_t)x;
+  };
+  const int64_t dx = i64((mx[0] - mn[0]) * v.inv) + 1, dy = i64((mx[1] - mn[1]) * v.inv) + 1, dz = i64((mx[2] - mn[2]) * v.inv) + 1;
+  const long double prod = (long double)dx * (long double)dy * (long double)dz;
+  v.overflow = prod > (long double)INT32_MAX || !(leaf > 0.0f);
+  for (int a = 0; a < 3; ++a) {
+    v.min_b[a] = v.div_b[a] = 0;
+    if (v.overflow) continue;
+    v.min_b[a] = (int)std::floor(mn[a] * v.inv);
+    const int max_b = (int)std::floor(mx[a] * v.inv);
+    v.div_b[a] = max_b - v.min_b[a] + 1;
+  }
+  return v;
+}
+
+bool downsample_is_identity(Context *c, const mm3d_cloud *in_, double resolution)
+{
+  auto *in = const_cast<mm3d_cloud *>(in_);
+  cloud_bbox(c, in);
+  const int n = (int)in->n;
+  if (n == 0 || in->n_finite != in->n) return false;
+  const VoxelSetup v = voxel_setup(in, (float)resolution);
+  if (v.overflow) return false;
+  DevBuf<int> flag(c, 1);
+  MM3D_HIP(hipMemsetAsync(flag.get(), 0, sizeof(int), c->stream));
+  MM3D_LAUNCH(c, "voxel_identity", n * 16.0, k_voxel_identity, dim3(div_up(n, 256)), dim3(256), 0, in->pts.get(), n, v.inv, v.min_b[0], v.min_b[1],
+              v.min_b[2], v.div_b[0], v.div_b[0] * v.div_b[1], flag.get());
+  int *h = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(h, flag.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  return h[0] == 0;
+}
+
 mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
 {
   auto *in = const_cast<mm3d_cloud *>(in_);
@@ -81,30 +148,14 @@ mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
   const int n = (int)in->n;
   if (n == 0 || in->n_finite == 0) return cloud_from_device(c, DevBuf<float4>(c, 0), 0);
   const float leaf = (float)resolution;
-  const float inv = 1.0f / leaf;
-  const float *mn = in->bmin, *mx = in->bmax;
-  // VoxelGrid's overflow guard: too many voxels => the input is returned unchanged
-  auto i64 = [](float v) -> int64_t {
-    if (!(v > -9.2e18f && v < 9.2e18f)) return INT64_MAX / 4;
-    return (int64_t)v;
-  };
-  int64_t dx = i64((mx[0] - mn[0]) * inv) + 1, dy = i64((mx[1] - mn[1]) * inv) + 1, dz = i64((mx[2] - mn[2]) * inv) + 1;
-  bool overflow = false;
-  {
-    long double prod = (long double)dx * (long double)dy * (long double)dz;
-    overflow = prod > (long double)INT32_MAX;
-  }
-  if (overflow || !(leaf > 0.0f)) {
+  const VoxelSetup vs = voxel_setup(in, leaf);
+  const float inv = vs.inv;
+  if (vs.overflow) {
     DevBuf<float4> copy(c, in->n);
     MM3D_HIP(hipMemcpyAsync(copy.get(), in->pts.get(), in->n * 16, hipMemcpyDeviceToDevice, c->stream));
     return cloud_from_device(c, std::move(copy), in->n);
   }
-  int min_b[3], div_b[3];
-  for (int a = 0; a < 3; ++a) {
-    min_b[a] = (int)std::floor(mn[a] * inv);
-    int max_b = (int)std::floor(mx[a] * inv);
-    div_b[a] = max_b - min_b[a] + 1;
-  }
+  const int *min_b = vs.min_b, *div_b = vs.div_b;
   const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
   DevBuf<uint32_t> keys(c, n), vals(c, n), keys2(c, n), vals2(c, n);
   MM3D_LAUNCH(c, "voxel_keys", n * 24.0, k_voxel_keys, dim3(div_up(n, 256)), dim3(256), 0, in->pts.get(), n, inv,

@@ -943,7 +943,7 @@ __global__ void k_hil_place(const float4 *__restrict__ pts, const uint32_t *__re
   out_keys[b + r] = key;
 }
 
-void cloud_hilbert(Context *c, const mm3d_cloud *cl_)
+void cloud_hilbert(Context *c, const mm3d_cloud *cl_, float min_cell)
 {
   auto *cl = const_cast<mm3d_cloud *>(cl_);
   std::lock_guard<std::recursive_mutex> lk(cl->cache_mu);
@@ -954,7 +954,7 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl_)
   // cell so that the larger box side spans at most 1024 cells, but never finer than 0.25 m
   float ext = 0.f;
   for (int a = 0; a < 3; ++a) ext = std::fmax(ext, cl->bmax[a] - cl->bmin[a]);
-  const float cell = std::fmax(0.25f, ext / 1023.0f);
+  const float cell = std::fmax(std::fmax(0.25f, min_cell), ext / 1023.0f);
   DevBuf<uint32_t> keys(c, total), vals(c, total), keys2(c, total);
   MM3D_LAUNCH(c, "hilbert_keys", total * 24.0, k_hilbert_keys, dim3(div_up(total, 256)), dim3(256), 0, cl->pts.get(), total,
               cl->bmin[0], cl->bmin[1], cl->bmin[2], 1.0f / cell, keys.get(), vals.get());

@@ -75,28 +75,7 @@ k_normals(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int 
       // one lane per point: covariance, eigen33, flip (features/normal_3d.h computePointNormal)
       if (lane < fit) {
         const float4 pq = q_pts[it.x + first + lane];
-        const int cnt = cnts[wave][lane];
-        float4 o;
-        if (cnt < 3) {
-          o.x = o.y = o.z = o.w = __uint_as_float(0x7fc00000u);
-        } else {
-          float a[9];
-          const float fc = (float)cnt;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) a[k] = sums[wave][lane][k] / fc;
-          const float cxx = a[0] - a[6] * a[6], cxy = a[1] - a[6] * a[7], cxz = a[2] - a[6] * a[8];
-          const float cyy = a[3] - a[7] * a[7], cyz = a[4] - a[7] * a[8], czz = a[5] - a[8] * a[8];
-          float ev, v[3];
-          eigen33_smallest(cxx, cxy, cxz, cyy, cyz, czz, &ev, v);
-          const float eig_sum = cxx + cyy + czz;
-          o.w = (eig_sum != 0.0f) ? fabsf(ev / eig_sum) : 0.0f;
-          // flipNormalTowardsViewpoint(point, 0, 0, 0)
-          const float vx = 0.0f - pq.x, vy = 0.0f - pq.y, vz = 0.0f - pq.z;
-          const float cos_theta = vx * v[0] + vy * v[1] + vz * v[2];
-          if (cos_theta < 0.0f) { v[0] *= -1.0f; v[1] *= -1.0f; v[2] *= -1.0f; }
-          o.x = v[0]; o.y = v[1]; o.z = v[2];
-        }
-        out[__float_as_int(pq.w)] = o;
+        out[__float_as_int(pq.w)] = normal_from_moments(sums[wave][lane], cnts[wave][lane], pq);
       }
       wave_lds_fence();
       first += fit;
@@ -158,30 +137,7 @@ k_normals_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, 
         }
         wave_lds_fence();
         // one lane per point: covariance, eigen33, flip (features/normal_3d.h computePointNormal)
-        if (lane < fit) {
-          const int cnt = cnts[wave][lane];
-          float4 o;
-          if (cnt < 3) {
-            o.x = o.y = o.z = o.w = __uint_as_float(0x7fc00000u);
-          } else {
-            float a[9];
-            const float fc = (float)cnt;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) a[k] = sums[wave][lane][k] / fc;
-            const float cxx = a[0] - a[6] * a[6], cxy = a[1] - a[6] * a[7], cxz = a[2] - a[6] * a[8];
-            const float cyy = a[3] - a[7] * a[7], cyz = a[4] - a[7] * a[8], czz = a[5] - a[8] * a[8];
-            float ev, v[3];
-            eigen33_smallest(cxx, cxy, cxz, cyy, cyz, czz, &ev, v);
-            const float eig_sum = cxx + cyy + czz;
-            o.w = (eig_sum != 0.0f) ? fabsf(ev / eig_sum) : 0.0f;
-            // flipNormalTowardsViewpoint(point, 0, 0, 0)
-            const float vx = 0.0f - pq.x, vy = 0.0f - pq.y, vz = 0.0f - pq.z;
-            const float cos_theta = vx * v[0] + vy * v[1] + vz * v[2];
-            if (cos_theta < 0.0f) { v[0] *= -1.0f; v[1] *= -1.0f; v[2] *= -1.0f; }
-            o.x = v[0]; o.y = v[1]; o.z = v[2];
-          }
-          out[__float_as_int(pq.w)] = o;
-        }
+        if (lane < fit) out[__float_as_int(pq.w)] = normal_from_moments(sums[wave][lane], cnts[wave][lane], pq);
         wave_lds_fence();
       });
 }
@@ -199,6 +155,24 @@ __global__ void k_fill_nan(float4 *out, size_t n)
 {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { float q = __uint_as_float(0x7fc00000u); out[i] = make_float4(q, q, q, q); }
+}
+
+// The normals of the work items on a device list (ov_items[0 .. *ov_count_dev), n_overflow = that count as the host read
+// it) with the lists in global memory (k_normals): what compute_normals runs for the items its LDS launch could not hold,
+// and what the fused scale-space + normals launch of sift.hip leaves behind.  Any grid of the cloud serves.
+void normals_of_items(Context *c, const mm3d_cloud *in, const Grid &g, double radius, const int *ov_items, const int *ov_count_dev, int n_overflow,
+                      float4 *out)
+{
+  const float r2 = (float)(radius * radius);
+  // (as many blocks as there are overflow items, up to 1024: a cloud that is dense everywhere is all overflow)
+  SnLaunch<float4> sn(c, n_overflow * 4, in->n, 4, 1024u);
+  SnScratch sc{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error(), ov_items, ov_count_dev};
+  MM3D_LAUNCH(c, "normals_radius_big", 0.0, k_normals, dim3(sn.blocks), dim3(256), 0, (const float4 *)in->hil_pts.get(),
+              (const int2 *)in->wave_items.get(), in->n_wave_items, g.view(), (const float4 *)in->pts.get(), (float)radius, r2, sc, out);
+  int *h = (int *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(h, sn.error(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  // (the scratch goes back to this context's pool; whoever gets it next is enqueued behind the kernel)
+  c->check_later(h, MM3D_EUNSUPPORTED, "computeSurfaceNormals: a point has more than 16384 neighbours within the radius");
 }
 
 mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius)
@@ -226,18 +200,7 @@ mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius)
     MM3D_HIP(hipMemcpyAsync(ho, &ctl->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->sync();
     if (getenv("MM3D_SNB_DEBUG")) fprintf(stderr, "normals: n=%d items=%d blocks=%u overflow items=%d\n", g.n, n_items, sl.blocks, ho[0]);
-    if (ho[0] > 0) {
-      // (as many blocks as there are overflow items, up to 1024: a cloud that is dense everywhere is all overflow)
-      SnLaunch<float4> sn(c, ho[0] * 4, in->n, 4, 1024u);
-      SnScratch sc{sn.tmp.get(), sn.fin.get(), ctl->fb_ctr, &ctl->error, sl.ov_items.get(), &ctl->ov_count};
-      MM3D_LAUNCH(c, "normals_radius_big", 0.0, k_normals, dim3(sn.blocks), dim3(256), 0, (const float4 *)in->hil_pts.get(),
-                  (const int2 *)in->wave_items.get(), n_items, g.view(), (const float4 *)in->pts.get(), (float)radius, r2, sc,
-                  res->nrm.get());
-      int *h = (int *)c->pin(64);
-      MM3D_HIP(hipMemcpyAsync(h, &ctl->error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      // (the scratch goes back to this context's pool; whoever gets it next is enqueued behind the kernel)
-      c->check_later(h, MM3D_EUNSUPPORTED, "computeSurfaceNormals: a point has more than 16384 neighbours within the radius");
-    }
+    if (ho[0] > 0) normals_of_items(c, in, g, radius, sl.ov_items.get(), &ctl->ov_count, ho[0], res->nrm.get());
   }
   return res;
 }

@@ -177,35 +177,59 @@ using SiftCfgSmall = SnbCfg<MM3D_SIFT_SMALL, true>;     // first octave: lists o
 #ifndef MM3D_SIFT_LARGE
 #define MM3D_SIFT_LARGE 8, 3584, 2560, 768, 256
 #endif
-using SiftCfgLarge = SnbCfg<MM3D_SIFT_LARGE, true>;     // later octaves: lists of 300-900 (longer ones in bands), 1 block of 8 waves per CU
+using SiftCfgLarge = SnbCfg<MM3D_SIFT_LARGE, true>;     // dense spots of the first octave (and what Large16 cannot hold): lists of 300-900, 1 block of 8 waves per CU
+// Later octaves (round 4): ONE block of SIXTEEN waves per CU around one tile.  A wave issues at most one instruction every
+// ~6 cycles (scripts/micro/valu_rate.hip), so the eight waves of SiftCfgLarge left two thirds of every SIMD's issue slots
+// empty; LDS is what limits the waves, so the per-wave share shrinks instead: four lists per round (16 lanes per query)
+// instead of eight, a 512-entry hit buffer (longer lists in distance bands), 128 buckets.
+#ifndef MM3D_SIFT_LARGE16
+#define MM3D_SIFT_LARGE16 16, 2816, 1408, 512, 128
+#endif
+using SiftCfgLarge16 = SnbCfg<MM3D_SIFT_LARGE16, true>;
 
-template <class Cfg>
-__global__ void __launch_bounds__(64 * Cfg::kWaves)
+// kNormals: the launch also computes the surface normals of its queries (computeSurfaceNormals, R/src/features.cpp:168-179)
+// from the SAME lists: with normal_radius <= 3 sigma_max the normals' neighbours of a point are the prefix d2 < nr2 of
+// the list built here, in the same (distance, index) order, so the nine raw-moment chains of k_normals_lds (normals.hip)
+// run over that prefix and the separate stage-and-sort launch of the normals disappears.  Same bits: the same entries
+// in the same order through the same arithmetic.
+// (second launch bound: waves per SIMD the registers must leave room for -- two blocks per CU with the small tile, one with
+// the large; without it the fused variant took 162 VGPRs, one block per CU)
+template <class Cfg, bool kNormals>
+__global__ void __launch_bounds__(64 * Cfg::kWaves, (Cfg::kTileCap <= 2048 ? 2 : 1) * Cfg::kWaves / 4)
 k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* .w = original index */,
                const float4 *__restrict__ pts /* original order: rgba */, float radius, float r2, SiftScales sc, SnbCtl *ctl,
                int *__restrict__ ov_items, float *__restrict__ dog /* [n][5] by original index */,
                int *__restrict__ knn /* [n][kKnn] by original index */, unsigned char *__restrict__ knn_ok /* [n], zeroed */,
-               const int *__restrict__ sub_items, const int *__restrict__ sub_count)
+               const int *__restrict__ sub_items, const int *__restrict__ sub_count, float nr2, float4 *__restrict__ nrm_out /* by original index */)
 {
   __shared__ SnbLds<Cfg> S;
-  __shared__ float resp[Cfg::kWaves][Cfg::kQ][kScales];
+  __shared__ float resp[Cfg::kWaves][Cfg::kQ][kNormals ? 9 : kScales];      // scale responses, then (kNormals) the nine moment sums
+  __shared__ int cnts[kNormals ? Cfg::kWaves : 1][Cfg::kQ];
   __shared__ uint64_t s_tab[32];
   constexpr int LPQ = Cfg::kLpq;
-  static_assert(LPQ == 8, "two quads per query");
-  constexpr int NS = 3;
+  static_assert(LPQ == 8 || LPQ == 16, "two or four quads per query");
+  // LPQ 8: two quads per query take the scales {5, 2, 1} and {4, 3, 0}; LPQ 16: four quads take {5}, {4, 0}, {3, 1}, {2}
+  // (the supports are nested: about equal numbers of list entries per quad either way)
+  constexpr int NS = LPQ == 8 ? 3 : 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 32) lm::exp2f_tab_copy(s_tab, threadIdx.x);       // (snb_run's first barrier publishes it)
-  const int sub4 = lane & 3, quad = (lane >> 2) & 1;
-  // this quad's scales, widest first
+  const int sub4 = lane & 3, quad = (lane >> 2) & (LPQ / 4 - 1);
+  // this quad's scales, widest first (-1: the quad has no scale in that slot)
   float sig[NS], thr[NS], rcp[NS];
   int ss[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
-    const int a = k == 0 ? 5 : (k == 1 ? 2 : 1), b = k == 0 ? 4 : (k == 1 ? 3 : 0);
-    ss[k] = quad ? b : a;
-    sig[k] = quad ? sc.sigma_sqr[b] : sc.sigma_sqr[a];
-    thr[k] = quad ? sc.thr9[b] : sc.thr9[a];
-    rcp[k] = quad ? sc.rcp[b] : sc.rcp[a];
+    int sk;
+    if (LPQ == 8) {
+      const int a = k == 0 ? 5 : (k == 1 ? 2 : 1), b = k == 0 ? 4 : (k == 1 ? 3 : 0);
+      sk = quad ? b : a;
+    } else {
+      sk = k == 0 ? (quad == 0 ? 5 : (quad == 1 ? 4 : (quad == 2 ? 3 : 2))) : (quad == 1 ? 0 : (quad == 2 ? 1 : -1));
+    }
+    ss[k] = sk;
+    sig[k] = sk >= 0 ? sc.sigma_sqr[sk] : 1.0f;
+    thr[k] = sk >= 0 ? sc.thr9[sk] : -1.0f;       // (no squared distance is <= -1: the slot never takes part)
+    rcp[k] = sk >= 0 ? sc.rcp[sk] : 1.0f;
   }
   SnbWave<Cfg> &W = S.w[wave];
   snb_run<Cfg>(
@@ -261,7 +285,8 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
         }
         if (mine && sub4 == 0) {
 #pragma unroll
-          for (int k = 0; k < NS; ++k) resp[wave][p][ss[k]] = num[k] / den[k];
+          for (int k = 0; k < NS; ++k)
+            if (ss[k] >= 0) resp[wave][p][ss[k]] = num[k] / den[k];
         }
         // The list's first 25 entries ARE the point's 25 nearest neighbours in nearestKSearch's (distance, index)
         // order whenever the ball holds that many: findScaleSpaceExtrema (k_sift_extrema_knn) reads them back
@@ -288,6 +313,52 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
           }
         }
         wave_lds_fence();
+        if (kNormals) {
+          // the normals' neighbours: the list's prefix with d2 < nr2 (the list ascends in d2; a lane looks at every eighth
+          // entry and stops at its first outside, the eight lanes of the query add their counts)
+          const int sub = lane & (LPQ - 1);
+          int mn = 0;
+          for (int e = sub; e < m; e += LPQ) {
+            const unsigned sl = W.arena[base + e];
+            if (!(dist2(q.x, q.y, q.z, S.tx[sl], S.ty[sl], S.tz[sl]) < nr2)) break;
+            ++mn;
+          }
+          mn += __shfl_xor(mn, 1, 64);
+          mn += __shfl_xor(mn, 2, 64);
+          mn += __shfl_xor(mn, 4, 64);
+          if (LPQ == 16) mn += __shfl_xor(mn, 8, 64);
+          if (mine && sub < 8) {                   // (eight accumulators: with sixteen lanes per query the upper eight watch)
+            // k_normals_lds' chains, bit for bit: lane sub owns accumulator sub of {xx, xy, xz, yy, yz, zz, x, y}, every lane sums z
+            const float *up = sub <= 2 ? S.tx : (sub <= 4 ? S.ty : (sub == 5 ? S.tz : (sub == 6 ? S.tx : S.ty)));
+            const float *vp = sub == 0 ? S.tx : ((sub == 1 || sub == 3) ? S.ty : S.tz);
+            const bool v1 = sub >= 6;
+            float a0 = 0.f, a2 = 0.f;
+            int e0 = 0;
+            for (; e0 + 4 <= mn; e0 += 4) {
+              unsigned sl[4];
+              float fu[4], fv[4], fz[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) sl[u] = W.arena[base + e0 + u];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { fu[u] = up[sl[u]]; fv[u] = vp[sl[u]]; fz[u] = S.tz[sl[u]]; }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                a0 = __fadd_rn(a0, __fmul_rn(fu[u], v1 ? 1.0f : fv[u]));
+                a2 = __fadd_rn(a2, fz[u]);
+              }
+            }
+            for (; e0 < mn; ++e0) {
+              const unsigned sl = W.arena[base + e0];
+              a0 = __fadd_rn(a0, __fmul_rn(up[sl], v1 ? 1.0f : vp[sl]));
+              a2 = __fadd_rn(a2, S.tz[sl]);
+            }
+            resp[wave][p][sub] = a0;
+            if (sub == 0) { resp[wave][p][8] = a2; cnts[wave][p] = mn; }
+          }
+          wave_lds_fence();
+          if (lane < fit) nrm_out[__float_as_int(pq.w)] = normal_from_moments(resp[wave][lane], cnts[wave][lane], pq);
+          wave_lds_fence();
+        }
       },
       sub_items, sub_count);
 }
@@ -302,19 +373,38 @@ struct SiftDogPending {
   std::function<void(int)> fallback;       // argument: *h_overflow
 };
 
+// nrm != nullptr: the launches also write the normals of the cloud's points (radius nrad, nr2 = float(nrad^2) <= r2) -- the
+// fused first octave of detect_keypoints_sift
 template <class Cfg>
-static SiftDogPending sift_dog_octave(Context *c, const mm3d_cloud *cur, const Grid &gr, int n_items, float max_radius, float r2,
-                                      const SiftScales &sc, float *dog, int *knn, unsigned char *knn_ok)
+static SiftDogPending sift_dog_octave(Context *c, int oct, const mm3d_cloud *cur, const Grid &gr, int n_items, float max_radius, float r2,
+                                      const SiftScales &sc, float *dog, int *knn, unsigned char *knn_ok, double nrad = 0.0, float4 *nrm = nullptr)
 {
-  auto sl = std::make_shared<SnbLaunch<Cfg>>(c, n_items, sizeof(float) * 64 * kScales + 256);
-  MM3D_LAUNCH(c, getenv("MM3D_SNB_DEBUG") ? (gr.n > 300000 ? "sift_dog_oct0" : (gr.n > 150000 ? "sift_dog_oct1" : "sift_dog_oct2")) : "sift_dog", gr.n * 36.0, k_sift_dog_lds<Cfg>, dim3(sl->blocks), dim3(64 * Cfg::kWaves), 0, (const float4 *)cur->hil_pts.get(),
-              (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, sl->ctl_dev(),
-              sl->ov_items.get(), dog, knn, knn_ok, (const int *)nullptr, (const int *)nullptr);
+  const float nr2 = (float)(nrad * nrad);      // KdTreeFLANN::radiusSearch: float(radius * radius), as compute_normals
+  const size_t extra_lds = sizeof(float) * 64 * (nrm ? 9 : kScales) + (nrm ? sizeof(int) * 64 : 0) + 256;
+  auto sl = std::make_shared<SnbLaunch<Cfg>>(c, n_items, extra_lds);
+  static const bool per_octave_names = getenv("MM3D_SNB_DEBUG") != nullptr;    // (read once, not per launch)
+  static const char *const oct_names[4] = {"sift_dog_oct0", "sift_dog_oct1", "sift_dog_oct2", "sift_dog_oct3+"};
+  const char *name = per_octave_names ? oct_names[std::min(oct, 3)] : (nrm ? "sift_dog_normals" : "sift_dog");
+  // algorithmic bytes: 36 B per point (SURVEY 8d's scale-space figure) + the normals' 28 B when they come out of the same launch
+  bool launched = false;
+  if constexpr (Cfg::kLpq == 8) {                // (the fused variant exists for the eight-wave configurations only)
+    if (nrm) {
+      MM3D_LAUNCH(c, name, gr.n * (36.0 + 28.0), (k_sift_dog_lds<Cfg, true>), dim3(sl->blocks), dim3(64 * Cfg::kWaves), 0, (const float4 *)cur->hil_pts.get(),
+                  (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, sl->ctl_dev(),
+                  sl->ov_items.get(), dog, knn, knn_ok, (const int *)nullptr, (const int *)nullptr, nr2, nrm);
+      launched = true;
+    }
+  }
+  if (nrm && !launched) throw Error(MM3D_EINVAL, "sift_dog_octave: fused normals asked of a configuration that has none");
+  if (!launched)
+    MM3D_LAUNCH(c, name, gr.n * 36.0, (k_sift_dog_lds<Cfg, false>), dim3(sl->blocks), dim3(64 * Cfg::kWaves), 0, (const float4 *)cur->hil_pts.get(),
+                (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, sl->ctl_dev(),
+                sl->ov_items.get(), dog, knn, knn_ok, (const int *)nullptr, (const int *)nullptr, 0.0f, (float4 *)nullptr);
   SiftDogPending pend;
   pend.h_overflow = (int *)c->pin(64);
   MM3D_HIP(hipMemcpyAsync(pend.h_overflow, &sl->ctl_dev()->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   const Grid *grp = &gr;
-  pend.fallback = [c, cur, grp, n_items, max_radius, r2, sc, dog, knn, knn_ok, sl](int n_overflow) {
+  pend.fallback = [c, cur, grp, n_items, max_radius, r2, sc, dog, knn, knn_ok, sl, nrad, nr2, nrm](int n_overflow) {
     SnbCtl *ctl = sl->ctl_dev();
     int *ov = sl->ov_items.get();
     // the first octave's configuration has the small tile: a few overflow items (dense spots of an outdoor map) go
@@ -323,11 +413,19 @@ static SiftDogPending sift_dog_octave(Context *c, const mm3d_cloud *cur, const G
     // 8 x 2 M indoor points: the large configuration is no faster per neighbour there, and it runs one block per CU)
     std::shared_ptr<SnbLaunch<SiftCfgLarge>> sl2;
     if (!std::is_same<Cfg, SiftCfgLarge>::value && n_overflow <= 256) {
-      sl2 = std::make_shared<SnbLaunch<SiftCfgLarge>>(c, n_items, sizeof(float) * 64 * kScales + 256);
-      MM3D_LAUNCH(c, "sift_dog_dense", 0.0, k_sift_dog_lds<SiftCfgLarge>, dim3(std::min(sl2->blocks, (unsigned)n_overflow)), dim3(64 * SiftCfgLarge::kWaves), 0,
-                  (const float4 *)cur->hil_pts.get(), (const int2 *)cur->wave_items.get(), n_items, grp->view(), (const float4 *)cur->pts.get(),
-                  max_radius, r2, sc, sl2->ctl_dev(), sl2->ov_items.get(), dog, knn, knn_ok, (const int *)sl->ov_items.get(),
-                  (const int *)&sl->ctl_dev()->ov_count);
+      const size_t extra2 = sizeof(float) * 64 * (nrm ? 9 : kScales) + (nrm ? sizeof(int) * 64 : 0) + 256;
+      sl2 = std::make_shared<SnbLaunch<SiftCfgLarge>>(c, n_items, extra2);
+      const dim3 grid2(std::min(sl2->blocks, (unsigned)n_overflow)), block2(64 * SiftCfgLarge::kWaves);
+      if (nrm)
+        MM3D_LAUNCH(c, "sift_dog_dense", 0.0, (k_sift_dog_lds<SiftCfgLarge, true>), grid2, block2, 0,
+                    (const float4 *)cur->hil_pts.get(), (const int2 *)cur->wave_items.get(), n_items, grp->view(), (const float4 *)cur->pts.get(),
+                    max_radius, r2, sc, sl2->ctl_dev(), sl2->ov_items.get(), dog, knn, knn_ok, (const int *)sl->ov_items.get(),
+                    (const int *)&sl->ctl_dev()->ov_count, nr2, nrm);
+      else
+        MM3D_LAUNCH(c, "sift_dog_dense", 0.0, (k_sift_dog_lds<SiftCfgLarge, false>), grid2, block2, 0,
+                    (const float4 *)cur->hil_pts.get(), (const int2 *)cur->wave_items.get(), n_items, grp->view(), (const float4 *)cur->pts.get(),
+                    max_radius, r2, sc, sl2->ctl_dev(), sl2->ov_items.get(), dog, knn, knn_ok, (const int *)sl->ov_items.get(),
+                    (const int *)&sl->ctl_dev()->ov_count, 0.0f, (float4 *)nullptr);
       ctl = sl2->ctl_dev();
       ov = sl2->ov_items.get();
     }
@@ -338,6 +436,9 @@ static SiftDogPending sift_dog_octave(Context *c, const mm3d_cloud *cur, const G
     int *he = (int *)c->pin(64);
     MM3D_HIP(hipMemcpyAsync(he, &ctl->error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->check_later(he, MM3D_EUNSUPPORTED, "detectKeypoints(SIFT): a point has more than 16384 neighbours within 3 sigma");
+    // the same items' normals, with the lists in global memory like their scale space (an item the large LDS configuration
+    // has worked gets its normals there; what is left on `ov` did not)
+    if (nrm) normals_of_items(c, cur, *grp, nrad, ov, &ctl->ov_count, n_overflow, nrm);
   };
   return pend;
 }
@@ -672,20 +773,37 @@ __global__ void k_sift_emit(const float4 *__restrict__ pts, const int *__restric
   }
 }
 
+// normals_radius > 0 and normals_out: the caller also wants computeSurfaceNormals(points, normals_radius) (it is about to
+// describe the keypoints).  When the first octave works on `points` itself and normal_radius <= 3 sigma_max, the normals
+// come out of the first octave's scale-space launch (k_sift_dog_lds<., true>); otherwise compute_normals runs as usual.
+// Either way *normals_out holds the same bits.
 mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double min_scale, int nr_octaves,
-                                  int nr_scales, double min_contrast)
+                                  int nr_scales, double min_contrast, double normals_radius, mm3d_normals **normals_out)
 {
+  std::unique_ptr<mm3d_normals> nrm_res;
+  static const bool fuse_normals = [] { const char *e = getenv("MM3D_SIFT_NO_FUSED_NORMALS"); return !(e && atoi(e)); }();   // A/B knob
   MM3D_REQUIRE(nr_scales == 3, "SIFT: only nr_scales_per_octave == 3 (the reference's setting) is built");
   std::vector<DevBuf<float4>> parts;
   std::vector<size_t> part_n;
   std::unique_ptr<mm3d_cloud> cur;
   const mm3d_cloud *input = points;
   float scale = (float)min_scale;
+  static const bool try_identity = [] { const char *e = getenv("MM3D_SIFT_NO_IDENTITY"); return !(e && atoi(e)); }();   // A/B knob
   for (int oct = 0; oct < nr_octaves; ++oct) {
-    std::unique_ptr<mm3d_cloud> next(downsample(c, input, (double)scale));
-    cur = std::move(next);
-    input = cur.get();
-    if (cur->n < 25) break;
+    // The octave's cloud: VoxelGrid(leaf = scale) of the previous octave's.  In the first octave of the reference's call
+    // (min_scale = resolution on a cloud downSample(resolution) made) that filter returns its input bit for bit; one
+    // small launch checks it, and the octave then works on `points` itself -- no voxel chain, and the Hilbert order and
+    // work items the normals built on that cloud are reused instead of being built again on a copy.
+    const mm3d_cloud *octave_cloud = nullptr;
+    if (oct == 0 && try_identity && downsample_is_identity(c, input, (double)scale)) {
+      octave_cloud = input;
+    } else {
+      std::unique_ptr<mm3d_cloud> next(downsample(c, input, (double)scale));
+      cur = std::move(next);
+      octave_cloud = cur.get();
+    }
+    input = octave_cloud;
+    if (octave_cloud->n < 25) break;
     float scales[kScales];
     for (int i = 0; i < kScales; ++i)
       scales[i] = scale * powf(2.0f, (1.0f * (float)i - 1.0f) / (float)nr_scales);
@@ -697,17 +815,33 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     }
     const float max_radius = 3.0f * scales[kScales - 1];
     const float r2 = (float)((double)max_radius * (double)max_radius);
-    const int n = (int)cur->n;
-    cloud_hilbert(c, cur.get());                       // query order + wave work items
-    const int n_items = cur->n_wave_items;
+    const int n = (int)octave_cloud->n;
+    // query order + wave work items.  An item never straddles a block of 8 x 8 Hilbert cells; with the default 0.25 m cell
+    // the later octaves' sparser clouds (leaf 0.2 m, 0.4 m) would fill such a block with 50 and 34 points instead of 64,
+    // and every item pays its staging and its end-of-item barrier whatever it holds: the cell grows with the leaf
+    // (2.5 leaves: 0.25 m in the first octave, as everywhere else)
+    static const float hil_factor = [] { const char *e = getenv("MM3D_SIFT_HIL_FACTOR"); return e ? (float)atof(e) : 2.5f; }();
+    cloud_hilbert(c, octave_cloud, hil_factor * scale);
+    const int n_items = octave_cloud->n_wave_items;
     // scale space on a grid with cell = r/2
-    const Grid &gr = cloud_grid(c, cur.get(), max_radius * 0.5f);
+    const Grid &gr = cloud_grid(c, octave_cloud, max_radius * 0.5f);
     DevBuf<float> dog(c, (size_t)n * kDog);
     DevBuf<int> knn(c, (size_t)n * kKnn);
     DevBuf<unsigned char> knn_ok(c, (size_t)n);
     MM3D_HIP(hipMemsetAsync(knn_ok.get(), 0, (size_t)n, c->stream));
-    SiftDogPending pend = oct == 0 ? sift_dog_octave<SiftCfgSmall>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get())
-                                   : sift_dog_octave<SiftCfgLarge>(c, cur.get(), gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get());
+    // the normals ride on the first octave when it works on `points` itself and their ball is inside the scale space's
+    const bool fused = oct == 0 && normals_out && fuse_normals && octave_cloud == points && normals_radius > 0.0 &&
+                       (float)(normals_radius * normals_radius) <= r2 && octave_cloud->n_finite == octave_cloud->n;
+    if (fused) {
+      nrm_res.reset(new mm3d_normals());
+      nrm_res->n = points->n;
+      nrm_res->nrm = DevBuf<float4>(c, points->n);
+    }
+    static const bool large16 = [] { const char *e = getenv("MM3D_SIFT_NO_LARGE16"); return !(e && atoi(e)); }();   // A/B knob
+    SiftDogPending pend = oct == 0 ? sift_dog_octave<SiftCfgSmall>(c, oct, octave_cloud, gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get(),
+                                                                   fused ? normals_radius : 0.0, fused ? nrm_res->nrm.get() : nullptr)
+                                   : (large16 ? sift_dog_octave<SiftCfgLarge16>(c, oct, octave_cloud, gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get())
+                                              : sift_dog_octave<SiftCfgLarge>(c, oct, octave_cloud, gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get()));
     // The extremum test: the points whose list held 25 neighbours read them back (k_sift_extrema_knn, nearly all
     // of them); the others -- borders and sparse places, where the 25 nearest reach beyond 3 sigma_max -- search the
     // same grid (k_sift_extrema over their compacted runs).  Both rare cases -- scale-space items left to the
@@ -721,7 +855,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     DevBuf<int> pos(c, (size_t)n * 3 + 1);
     DevBuf<int> n_search(c, 1);
     DevBuf<unsigned char> need_search(c, (size_t)n);
-    const int nh = (int)cur->n_finite;
+    const int nh = (int)octave_cloud->n_finite;
     int *h = (int *)c->pin(64);                          // [0] keypoints, [1] points for the searching kernel
     auto extremum_test = [&](bool search) {
       MM3D_LAUNCH(c, "sift_pack", n * 52.0, k_sift_dogx, dim3(div_up(n, 256)), dim3(256), 0, (const float *)dog.get(), n, dogx.get());
@@ -729,7 +863,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
       MM3D_HIP(hipMemsetAsync(n_search.get(), 0, sizeof(int), c->stream));
       MM3D_HIP(hipMemsetAsync(need_search.get(), 0, (size_t)n, c->stream));
       MM3D_LAUNCH(c, "sift_extrema_knn", nh * 16.0 + n * 0.25 * (kKnn * 36.0 + 20.0), k_sift_extrema_knn, dim3(div_up(nh, 256)), dim3(256), 0,
-                  (const float4 *)cur->hil_pts.get(), nh, n, (const float *)dog.get(), (const float4 *)dogx.get(), (const int *)knn.get(),
+                  (const float4 *)octave_cloud->hil_pts.get(), nh, n, (const float *)dog.get(), (const float4 *)dogx.get(), (const int *)knn.get(),
                   (const unsigned char *)knn_ok.get(), (float)min_contrast, flags.get(), need_search.get(), n_search.get());
       if (search) {
         DevBuf<int> lflag(c, (size_t)nh + 1), lpos(c, (size_t)nh + 1);
@@ -738,11 +872,11 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
         DevBuf<int> lheads(c, (size_t)nh + 1), lipos(c, (size_t)nh + 1);
         const int max_items = 2 * n_items + 4;                // a block's live run splits at most once more than its full run
         DevBuf<int2> litems(c, (size_t)max_items);
-        MM3D_LAUNCH(c, "sift_live", nh * 28.0, k_sift_live, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(), nh,
+        MM3D_LAUNCH(c, "sift_live", nh * 28.0, k_sift_live, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const float4 *)octave_cloud->hil_pts.get(), nh,
                     (const float *)dog.get(), (float)min_contrast, (const unsigned char *)need_search.get(), lflag.get());
         exclusive_scan_int(c, lflag.get(), lpos.get(), (size_t)nh + 1);
-        MM3D_LAUNCH(c, "sift_live", nh * 32.0, k_sift_live_compact, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const float4 *)cur->hil_pts.get(),
-                    (const uint32_t *)cur->hil_keys.get(), nh, (const int *)lflag.get(), (const int *)lpos.get(), lpts.get(), lkeys.get());
+        MM3D_LAUNCH(c, "sift_live", nh * 32.0, k_sift_live_compact, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const float4 *)octave_cloud->hil_pts.get(),
+                    (const uint32_t *)octave_cloud->hil_keys.get(), nh, (const int *)lflag.get(), (const int *)lpos.get(), lpts.get(), lkeys.get());
         MM3D_LAUNCH(c, "sift_live", nh * 8.0, k_sift_live_heads, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const uint32_t *)lkeys.get(),
                     (const int *)(lpos.get() + nh), nh, lheads.get());
         exclusive_scan_int(c, lheads.get(), lipos.get(), (size_t)nh + 1);
@@ -760,7 +894,21 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
       c->sync();
     };
     extremum_test(false);
-    if (getenv("MM3D_SNB_DEBUG"))
+#ifdef MM3D_SNB_STATS
+    {   // instrumentation build: the phase ticks of this octave alone (scripts/snb_stats.py prints the sum over the octaves)
+      unsigned long long v[32];
+      (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_snb_stats), sizeof(v));
+      const double q = (double)std::max<unsigned long long>(v[11], 1), it = (double)std::max<unsigned long long>(v[0], 1);
+      fprintf(stderr, "snb octave %d: n=%d items=%llu queries=%llu hits/query %.1f staged/item %.1f rounds/item %.2f | ticks per query: A %.0f B %.0f C %.0f D %.0f E %.0f "
+              "consume %.0f | per item per wave: claim %.0f stage %.0f stage_barrier %.0f end_barrier %.0f | total/query %.0f; parts: %llu items in %llu parts, extra bands %llu\n",
+              oct, n, v[0], v[11], v[12] / q, v[13] / it, v[14] / it, v[4] / q, v[5] / q, v[6] / q, v[7] / q, v[8] / q, v[9] / q, v[1] / it, v[2] / it, v[3] / it, v[10] / it,
+              v[15] / q, v[17], v[18], v[19]);
+      unsigned long long z[32] = {0};
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_snb_stats), z, sizeof(z));
+    }
+#endif
+    static const bool snb_debug = getenv("MM3D_SNB_DEBUG") != nullptr;
+    if (snb_debug)
       fprintf(stderr, "sift_dog: n=%d items=%d overflow items=%d, points for the searching extremum kernel %d\n", gr.n, n_items, *pend.h_overflow, h[1]);
     if (*pend.h_overflow > 0) {
       // the items the first pass left out get their scale space now (and, from the large LDS configuration, their
@@ -772,7 +920,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     const size_t nk = (size_t)h[0];
     DevBuf<float4> kp(c, nk);
     if (nk)
-      MM3D_LAUNCH(c, "sift_emit", n * 3 * 8.0, k_sift_emit, dim3(div_up((size_t)n * 3, 256)), dim3(256), 0, cur->pts.get(),
+      MM3D_LAUNCH(c, "sift_emit", n * 3 * 8.0, k_sift_emit, dim3(div_up((size_t)n * 3, 256)), dim3(256), 0, octave_cloud->pts.get(),
                   flags.get(), pos.get(), (size_t)n * 3, kp.get());
     c->settle();
     parts.emplace_back(std::move(kp));
@@ -789,6 +937,11 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     off += part_n[i];
   }
   c->settle();
+  if (normals_out) {
+    // not fused (another min_scale than the cloud's resolution, a wider normals ball, fewer than 25 points, ...): the usual launch
+    if (!nrm_res) nrm_res.reset(compute_normals(c, points, normals_radius));
+    *normals_out = nrm_res.release();
+  }
   return cloud_from_device(c, std::move(all), total);
 }
 

@@ -74,7 +74,7 @@ struct SnbCfg {
   static constexpr int kHitCap = HIT_CAP_;       // longest list
   static constexpr int kNB = NB_;                // distance buckets per query
   static constexpr bool kPay = PAY_;
-  static_assert(64 % WAVES_ == 0 && (WAVES_ == 4 || WAVES_ == 8), "4 or 8 waves per block");
+  static_assert(64 % WAVES_ == 0 && (WAVES_ == 4 || WAVES_ == 8 || WAVES_ == 16), "4, 8 or 16 waves per block");
   static_assert(TILE_CAP_ % 256 == 0 && TILE_CAP_ <= 65536, "the tile is read 256 candidates at a time; slots are 16 bits");
   static_assert(HIT_CAP_ % 128 == 0 && NB_ % 64 == 0 && (ARENA_ == 0 || ARENA_ >= HIT_CAP_), "sizes (kArena = 0: per-query consumers, snb_run_each)");
   static_assert(HIT_CAP_ + 8 >= 128, "the staging offsets live in d2buf");

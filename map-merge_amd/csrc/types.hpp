@@ -134,7 +134,9 @@ void grid_ensure_dt(Context *c, const Grid &g, int R);
 // per-cell merged candidate lists over the (2R+1)^3 block of cells, cached on the grid
 void grid_ensure_nblists(Context *c, const Grid &g, int R);
 // Hilbert-ordered copy of the finite points (.w = original index) + wave work items, cached on the cloud
-void cloud_hilbert(Context *c, const mm3d_cloud *cl);
+// min_cell: lower bound of the Hilbert cell (a work item never straddles a block of 8 x 8 cells); callers whose cloud is
+// sparser than 0.1 m (SIFT's later octaves) pass a larger one so that their items still hold 64 points
+void cloud_hilbert(Context *c, const mm3d_cloud *cl, float min_cell = 0.25f);
 mm3d_cloud *cloud_from_device(Context *c, DevBuf<float4> &&pts, size_t n);
 mm3d_cloud *cloud_from_memory(Context *c, const void *src, size_t n, size_t stride, size_t rgba_off);
 void cloud_download(Context *c, const mm3d_cloud *cl, void *dst, size_t stride, size_t rgba_off);
@@ -149,6 +151,7 @@ void sort_pairs_u32(Context *c, const uint32_t *kin, uint32_t *kout, const uint3
 
 // filters.hip
 mm3d_cloud *downsample(Context *c, const mm3d_cloud *in, double resolution);
+bool downsample_is_identity(Context *c, const mm3d_cloud *in, double resolution);   // would downsample() return `in` bit for bit? (one small launch + a wait)
 mm3d_cloud *remove_outliers(Context *c, const mm3d_cloud *in, double radius, int min_neighbours);
 mm3d_cloud *transform_concat(Context *c, const mm3d_cloud *const *clouds, size_t n, const float *T);
 
@@ -156,8 +159,10 @@ mm3d_cloud *transform_concat(Context *c, const mm3d_cloud *const *clouds, size_t
 mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius);
 
 // sift.hip
-mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double min_scale, int nr_octaves,
-                                  int nr_scales, double min_contrast);
+mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double min_scale, int nr_octaves, int nr_scales, double min_contrast,
+                                  double normals_radius = 0.0, mm3d_normals **normals_out = nullptr);   // (+ the points' normals, fused when possible)
+void normals_of_items(Context *c, const mm3d_cloud *in, const Grid &g, double radius, const int *ov_items, const int *ov_count_dev, int n_overflow,
+                      float4 *out);
 
 // harris.hip
 mm3d_cloud *detect_keypoints_harris(Context *c, const mm3d_cloud *points, const mm3d_normals *normals, double threshold,

@@ -3,8 +3,10 @@
 // for v_fma_f32 at full occupancy; the guide's table says 2 cycles per wave64 instruction on a SIMD-32
 // (/opt/skills/guides/MI355X_MICROARCH.md "Per-instruction cycle constants").
 //   hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate
-// Output per (instruction, waves per SIMD): wave-instructions per second over the chip (HIP events), and shader cycles per
-// wave-instruction per SIMD (s_memtime around the loop of one wave x the waves that share its SIMD).
+// Output per (instruction, waves per SIMD): wave-instructions per second over the chip (HIP events, best of 5 after two
+// full-length warm-up launches: the clocks ramp for milliseconds), the same as nanoseconds per wave-instruction per SIMD,
+// and the s_memtime ticks one wave's own instruction takes (the counter follows the shader clock, which the power
+// management moves with the load: compare rates by the wall clock, not by ticks).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -56,11 +58,11 @@ static int run(const char *name, int cus)
     // wps waves on each of a CU's four SIMDs: blocks of 4 * min(wps, 4) waves, one or two blocks per CU
     const int waves_per_block = 4 * (wps < 4 ? wps : 4), blocks_per_cu = wps <= 4 ? 1 : wps / 4;
     const dim3 grid(cus * blocks_per_cu), block(64 * waves_per_block);
-    hipLaunchKernelGGL(k_rate<MODE>, grid, block, 0, 0, 200, out, cyc);      // warm-up (clocks, code)
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_rate<MODE>, grid, block, 0, 0, iters, out, cyc);      // warm-up (clocks, code)
     CK(hipDeviceSynchronize());
     float best = 1e30f;
     long long c = 0;
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int rep = 0; rep < 5; ++rep) {
       CK(hipEventRecord(e0));
       hipLaunchKernelGGL(k_rate<MODE>, grid, block, 0, 0, iters, out, cyc);
       CK(hipEventRecord(e1));
@@ -70,10 +72,9 @@ static int run(const char *name, int cus)
     }
     const double winstr = (double)cus * blocks_per_cu * waves_per_block * (double)iters * kChains;
     const double rate = winstr / (best * 1e-3);
-    // one wave's loop took c cycles for iters * kChains instructions while wps waves shared its SIMD
-    const double cyc_per_instr_simd = (double)c / ((double)iters * kChains * wps);
-    printf("%-22s %d waves/SIMD: %8.3f ms  %.3e wave-instr/s chip  = %.2f shader cycles per wave-instruction per SIMD  (effective clock %.2f GHz if 256 CU x 4 SIMD)\n",
-           name, wps, best, rate, cyc_per_instr_simd, rate * cyc_per_instr_simd / (cus * 4.0) * 1e-9);
+    printf("%-22s %d waves/SIMD: %8.3f ms  %.3e wave-instr/s chip = %.3f ns per wave-instruction per SIMD (2 cycles at 2.4 GHz = 0.833 ns);"
+           " one wave's own instruction: %.2f ticks\n",
+           name, wps, best, rate, 1e9 * (double)cus * 4.0 / rate, (double)c / ((double)iters * kChains));
   }
   CK(hipFree(out)); CK(hipFree(cyc));
   return 0;
