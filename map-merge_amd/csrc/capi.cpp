@@ -548,7 +548,10 @@ static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const m
     kp.reset(detect_keypoints_harris(ctx, filt.get(), nrm.get(), p->keypoint_threshold, p->normal_radius));
   } else {
     mm3d_normals *n_out = nullptr;
-    kp.reset(detect_keypoints_sift(ctx, filt.get(), p->resolution, 3, 3, p->keypoint_threshold, p->normal_radius, &n_out));
+    static const bool share_grid = [] { const char *e = getenv("MM3D_SIFT_NO_SHARED_GRID"); return !(e && atoi(e)); }();   // A/B knob
+    // (every descriptor searches `filt` on a grid of descriptor_radius / 2 cells: the first octave uses that one too)
+    kp.reset(detect_keypoints_sift(ctx, filt.get(), p->resolution, 3, 3, p->keypoint_threshold, p->normal_radius, &n_out,
+                                   share_grid ? (float)(p->descriptor_radius * 0.5) : 0.0f));
     nrm.reset(n_out);
   }
   std::unique_ptr<mm3d_desc> desc(p->descriptor_type == MM3D_DESC_PFH    ? compute_pfh(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)

@@ -11,6 +11,7 @@
 #include <climits>
 
 #include "device_util.hpp"
+#include "scan_fused.hpp"
 
 namespace mm3d {
 
@@ -30,22 +31,25 @@ __global__ void k_voxel_keys(const float4 *__restrict__ pts, int n, float inv, i
   keys[i] = (uint32_t)(ijk0 + ijk1 * mul1 + ijk2 * mul2);
 }
 
-__global__ void k_voxel_heads(const uint32_t *__restrict__ keys, int n, int *__restrict__ heads)
-{
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > n) return;
-  if (j == n) { heads[j] = 0; return; }
-  uint32_t k = keys[j];
-  heads[j] = (k != 0xFFFFFFFFu && (j == 0 || keys[j - 1] != k)) ? 1 : 0;
-}
-
-__global__ void k_voxel_starts(const int *__restrict__ heads, const int *__restrict__ pos, int n,
-                               int *__restrict__ starts)
-{
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  if (heads[j]) starts[pos[j]] = j;
-}
+// a voxel starts where the sorted key changes (non-finite points carry the key 0xFFFFFFFF and sort last); the fused scan
+// numbers the voxels and writes every voxel's first position (scan_fused.hpp: one launch for heads + scan + starts)
+struct VoxelHeadLoad {
+  const uint32_t *keys; int n;
+  __device__ __forceinline__ int operator()(size_t j) const
+  {
+    if (j >= (size_t)n) return 0;
+    const uint32_t k = keys[j];
+    return (k != 0xFFFFFFFFu && (j == 0 || keys[j - 1] != k)) ? 1 : 0;
+  }
+};
+struct VoxelStartStore {
+  int n; int *starts; int *n_voxels;
+  __device__ __forceinline__ void operator()(size_t j, int prefix, int v) const
+  {
+    if (j == (size_t)n) { *n_voxels = prefix; return; }
+    if (v) starts[prefix] = (int)j;
+  }
+};
 
 // One thread per voxel walks its (stable-sorted, i.e. ascending input index) members and sums in
 // float in that order: bit-identical to CentroidPoint on the CPU restatement.
@@ -165,20 +169,17 @@ mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
   DevBuf<int> too_long(c, 1);
   counting_sort_pairs_u32(c, keys.get(), n, (uint64_t)div_b[0] * (uint64_t)div_b[1] * (uint64_t)div_b[2], keys2.get(), vals2.get(),
                           too_long.get());
-  DevBuf<int> heads(c, n + 1), pos(c, n + 1);
+  DevBuf<int> starts(c, (size_t)n + 1), n_vox_dev(c, 1);       // (starts sized by its bound: the count is only known after the wait)
   int *h = (int *)c->pin(64);
   for (int attempt = 0; attempt < 2; ++attempt) {
-    MM3D_LAUNCH(c, "voxel_heads", n * 8.0, k_voxel_heads, dim3(div_up(n + 1, 256)), dim3(256), 0, keys2.get(), n, heads.get());
-    exclusive_scan_int(c, heads.get(), pos.get(), n + 1);
-    MM3D_HIP(hipMemcpyAsync(h, pos.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    scan_fused(c, "voxel_starts", n * 12.0, (size_t)n + 1, VoxelHeadLoad{keys2.get(), n}, VoxelStartStore{n, starts.get(), n_vox_dev.get()});
+    MM3D_HIP(hipMemcpyAsync(h, n_vox_dev.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
     MM3D_HIP(hipMemcpyAsync(h + 1, too_long.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->sync();
     if (attempt == 1 || !h[1]) break;
     sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), n, 32);
   }
   const int nvox = h[0];
-  DevBuf<int> starts(c, nvox + 1);
-  MM3D_LAUNCH(c, "voxel_starts", n * 12.0, k_voxel_starts, dim3(div_up(n, 256)), dim3(256), 0, heads.get(), pos.get(), n, starts.get());
   DevBuf<float4> out(c, nvox);
   // 16 B read per raw point + 16 B written per voxel
   MM3D_LAUNCH(c, "voxel_centroid", in->n_finite * 16.0 + nvox * 16.0, k_voxel_centroid, dim3(div_up(nvox, 256)), dim3(256), 0,

@@ -14,6 +14,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "device_util.hpp"
+#include "scan_fused.hpp"
 
 namespace mm3d {
 
@@ -188,7 +189,6 @@ KernelScope::~KernelScope()
 // read as "not there yet", and tickets count on from launch to launch, so nothing is cleared in between.
 // The words carry their payload themselves and nothing else is read from another block, so the atomics are
 // relaxed: an agent-scope release / acquire per tile would write back / invalidate caches on this multi-XCD part.
-constexpr int kScanItems = 16, kScanTile = 256 * kScanItems;
 __global__ void __launch_bounds__(256)
 k_scan_int(const int *__restrict__ in, int *__restrict__ out, size_t n, unsigned long long *status, unsigned *ticket,
            unsigned ticket_base, unsigned epoch)
@@ -274,9 +274,10 @@ k_scan_int(const int *__restrict__ in, int *__restrict__ out, size_t n, unsigned
   }
 }
 
-void exclusive_scan_int(Context *c, const int *in, int *out, size_t n)
+// Bookkeeping of one chained-scan launch over n elements on this context: status words large enough, the next epoch, the
+// tickets this launch will take (k_scan_int here, k_scan_fused in scan_fused.hpp).
+ScanLaunchState scan_prepare(Context *c, size_t n)
 {
-  if (n == 0) return;
   const size_t tiles = (n + kScanTile - 1) / kScanTile;
   if (tiles > c->scan_tiles_cap) {
     c->sync();                                   // earlier scans on this stream are done with the old buffers
@@ -300,9 +301,16 @@ void exclusive_scan_int(Context *c, const int *in, int *out, size_t n)
     MM3D_HIP(hipMemsetAsync(c->scan_status, 0, c->scan_tiles_cap * sizeof(unsigned long long), c->stream));
     c->scan_epoch = 1;
   }
-  MM3D_LAUNCH(c, "scan_int", (double)n * 8.0, k_scan_int, dim3((unsigned)tiles), dim3(256), 0, in, out, n, c->scan_status, c->scan_ticket,
-              c->scan_tickets_taken, c->scan_epoch);
+  ScanLaunchState st{c->scan_status, c->scan_ticket, c->scan_tickets_taken, c->scan_epoch, (unsigned)tiles};
   c->scan_tickets_taken += (unsigned)tiles;      // unsigned wrap-around matches the device counter's
+  return st;
+}
+
+void exclusive_scan_int(Context *c, const int *in, int *out, size_t n)
+{
+  if (n == 0) return;
+  const ScanLaunchState st = scan_prepare(c, n);
+  MM3D_LAUNCH(c, "scan_int", (double)n * 8.0, k_scan_int, dim3(st.tiles), dim3(256), 0, in, out, n, st.status, st.ticket, st.ticket_base, st.epoch);
 }
 
 void sort_pairs_u32(Context *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
@@ -566,8 +574,11 @@ const Grid &cloud_grid(Context *c, const mm3d_cloud *cl_, float cell)
     for (int a = 0; a < 3; ++a) g->mn[a] = cl->bmin[a];
     const size_t ncell = (size_t)g->dims[0] * g->dims[1] * g->dims[2];
     const int n = (int)cl->n;
-    DevBuf<int> counts(c, ncell + 1);
-    MM3D_HIP(hipMemsetAsync(counts.get(), 0, (ncell + 1) * sizeof(int), c->stream));
+    // (the cell counts and the "a cell is too long for the counting sort" word share a buffer: one fill dispatch, not two --
+    // in the 16-stream runs every dispatch, however small, waits in line behind the other streams' kernels)
+    DevBuf<int> counts(c, ncell + 2);
+    MM3D_HIP(hipMemsetAsync(counts.get(), 0, (ncell + 2) * sizeof(int), c->stream));
+    int *const too_long = counts.get() + ncell + 1;
     DevBuf<uint32_t> keys(c, n), ranks(c, n);
     const uint32_t invalid = (uint32_t)ncell;   // sorts after every real cell
     MM3D_LAUNCH(c, "grid_cell_keys", n * 24.0, k_cell_keys, dim3(div_up(n, 256)), dim3(256), 0, cl->pts.get(), n,
@@ -576,15 +587,14 @@ const Grid &cloud_grid(Context *c, const mm3d_cloud *cl_, float cell)
     g->cell_start = DevBuf<int>(c, ncell + 1);
     exclusive_scan_int(c, counts.get(), g->cell_start.get(), ncell + 1);
     g->sorted = DevBuf<float4>(c, nfin);
-    DevBuf<int> slots(c, nfin), too_long(c, 1);
-    MM3D_HIP(hipMemsetAsync(too_long.get(), 0, sizeof(int), c->stream));
+    DevBuf<int> slots(c, nfin);
     MM3D_LAUNCH(c, "grid_cell_sort", n * 16.0, k_cell_scatter, dim3(div_up(n, 256)), dim3(256), 0, (const uint32_t *)keys.get(),
-                (const uint32_t *)ranks.get(), (const int *)g->cell_start.get(), n, invalid, slots.get(), too_long.get());
+                (const uint32_t *)ranks.get(), (const int *)g->cell_start.get(), n, invalid, slots.get(), too_long);
     MM3D_LAUNCH(c, "grid_cell_sort", n * 40.0, k_cell_place, dim3(div_up(n, 256)), dim3(256), 0, cl->pts.get(),
                 (const uint32_t *)keys.get(), (const int *)g->cell_start.get(), (const int *)slots.get(), n, invalid,
-                (const int *)too_long.get(), g->sorted.get());
+                (const int *)too_long, g->sorted.get());
     int *h_long = (int *)c->pin(64);
-    MM3D_HIP(hipMemcpyAsync(h_long, too_long.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MM3D_HIP(hipMemcpyAsync(h_long, too_long, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->sync();
     if (*h_long) {
       // a cell with thousands of points: stable radix sort of (cell, index) instead
@@ -812,21 +822,24 @@ __global__ void k_hilbert_gather(const float4 *__restrict__ pts, const uint32_t 
   out[j] = p;
 }
 
-__global__ void k_item_heads(const uint32_t *__restrict__ keys, int n, int *__restrict__ heads)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > n) return;
-  heads[j] = (j < n && (j == 0 || (keys[j] >> 16) != (keys[j - 1] >> 16) || (j & 63) == 0)) ? 1 : 0;
-}
-
-__global__ void k_item_fill(const int *__restrict__ heads, const int *__restrict__ pos, int n, int2 *__restrict__ items)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n || !heads[j]) return;
-  int cnt = 1;
-  while (cnt < 64 && j + cnt < n && !heads[j + cnt]) ++cnt;
-  items[pos[j]] = make_int2(j, cnt);
-}
+// a work item starts at the first point, at every change of the column block (key >> 16) and every 64 points
+struct ItemHeadLoad {
+  const uint32_t *keys; int n;
+  __device__ __forceinline__ bool head(size_t j) const { return j < (size_t)n && (j == 0 || (keys[j] >> 16) != (keys[j - 1] >> 16) || (j & 63) == 0); }
+  __device__ __forceinline__ int operator()(size_t j) const { return head(j) ? 1 : 0; }
+};
+struct ItemFillStore {
+  const uint32_t *keys; int n; int2 *items; int *n_items;
+  __device__ __forceinline__ void operator()(size_t j, int prefix, int v) const
+  {
+    if (j == (size_t)n) { *n_items = prefix; return; }        // (the scan runs over n + 1 elements: the last one carries the total)
+    if (!v) return;
+    const ItemHeadLoad h{keys, n};
+    int cnt = 1;
+    while (cnt < 64 && j + cnt < (size_t)n && !h.head(j + cnt)) ++cnt;
+    items[prefix] = make_int2((int)j, cnt);
+  }
+};
 
 // ---------------------------------------------------------------- counting sort of (key, index) pairs
 // Stable sort of sparse 32-bit keys whose equal-or-near values are few (voxel indices, Hilbert keys): bin = key /
@@ -959,10 +972,10 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl_, float min_cell)
   MM3D_LAUNCH(c, "hilbert_keys", total * 24.0, k_hilbert_keys, dim3(div_up(total, 256)), dim3(256), 0, cl->pts.get(), total,
               cl->bmin[0], cl->bmin[1], cl->bmin[2], 1.0f / cell, keys.get(), vals.get());
   cl->hil_pts = DevBuf<float4>(c, n);
-  DevBuf<int> counts(c, kHilColumns + 1), col_start(c, kHilColumns + 1), slots(c, n), too_long(c, 1);
+  DevBuf<int> counts(c, kHilColumns + 2), col_start(c, kHilColumns + 1), slots(c, n);
   DevBuf<uint32_t> ranks(c, total);
-  MM3D_HIP(hipMemsetAsync(counts.get(), 0, (kHilColumns + 1) * sizeof(int), c->stream));
-  MM3D_HIP(hipMemsetAsync(too_long.get(), 0, sizeof(int), c->stream));
+  MM3D_HIP(hipMemsetAsync(counts.get(), 0, (kHilColumns + 2) * sizeof(int), c->stream));   // (counts and the too_long word: one fill)
+  struct { int *p; int *get() const { return p; } } too_long{counts.get() + kHilColumns + 1};
   MM3D_LAUNCH(c, "hilbert_sort", total * 12.0, k_hil_count, dim3(div_up(total, 256)), dim3(256), 0, (const uint32_t *)keys.get(), total,
               counts.get(), ranks.get());
   exclusive_scan_int(c, counts.get(), col_start.get(), kHilColumns + 1);
@@ -971,13 +984,16 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl_, float min_cell)
   MM3D_LAUNCH(c, "hilbert_sort", total * 44.0, k_hil_place, dim3(div_up(total, 256)), dim3(256), 0, cl->pts.get(),
               (const uint32_t *)keys.get(), (const int *)col_start.get(), (const int *)slots.get(), total, (const int *)too_long.get(),
               cl->hil_pts.get(), keys2.get());
-  DevBuf<int> heads(c, (size_t)n + 1), blk(c, (size_t)n + 1);
+  // Work items: flag the heads, number them, write {first point, count} per head -- one launch (scan_fused.hpp) instead of
+  // three.  The item array is sized by its bound (a head every 64 points plus one per column block: key >> 16 < 2^14); the
+  // count comes back with the sort's too_long word in the one host wait of this function.
+  const size_t max_items = (size_t)n / 64 + 16384 + 2;
+  cl->wave_items = DevBuf<int2>(c, max_items);
+  DevBuf<int> n_items_dev(c, 1);
   int *h = (int *)c->pin(64);
   for (int attempt = 0; attempt < 2; ++attempt) {
-    MM3D_LAUNCH(c, "hilbert_items", n * 8.0, k_item_heads, dim3(div_up(n + 1, 256)), dim3(256), 0, (const uint32_t *)keys2.get(), n,
-                heads.get());
-    exclusive_scan_int(c, heads.get(), blk.get(), (size_t)n + 1);
-    MM3D_HIP(hipMemcpyAsync(h, blk.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    scan_fused(c, "hilbert_items", n * 20.0, (size_t)n + 1, ItemHeadLoad{keys2.get(), n}, ItemFillStore{keys2.get(), n, cl->wave_items.get(), n_items_dev.get()});
+    MM3D_HIP(hipMemcpyAsync(h, n_items_dev.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
     MM3D_HIP(hipMemcpyAsync(h + 1, too_long.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->sync();
     if (attempt == 1 || !h[1]) break;
@@ -990,9 +1006,6 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl_, float min_cell)
   }
   cl->n_wave_items = h[0];
   cl->hil_keys = std::move(keys2);
-  cl->wave_items = DevBuf<int2>(c, (size_t)h[0]);
-  MM3D_LAUNCH(c, "hilbert_items", n * 12.0, k_item_fill, dim3(div_up(n, 256)), dim3(256), 0, (const int *)heads.get(),
-              (const int *)blk.get(), n, cl->wave_items.get());
   c->settle();
 }
 

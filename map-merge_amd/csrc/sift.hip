@@ -170,12 +170,19 @@ __device__ __forceinline__ float quad_bcast(float v)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J * 0x55, 0xf, 0xf, false));
 }
 
+// The LDS of a block is a budget split between the tile (20 B per staged candidate, shared) and the eight waves' arenas
+// (2 B per list entry).  Round 4 moved it towards the arenas: a wave's consumer pass costs the same for three lists as for
+// eight, and with the round-3 sizes (1792 / 1024 and 3584 / 2560) the arena, not the eight-query budget, ended most rounds
+// (1.28, 1.42 and 1.86 rounds per item in the three octaves; 1.05 and 1.23 in the later octaves now).  The tile's capacity
+// was mostly unused (716 / 1246 / 1191 candidates per item on average); the few items that need more are worked in parts
+// (31 of 3930 in octave 1 of a headline map).  Measured, one 500 k map: octave 0 1.23 -> 1.18 ms, octave 1 1.65 -> 1.41,
+// octave 2 0.77 -> 0.63 (profiles/r04_sift_config_ab.txt).
 #ifndef MM3D_SIFT_SMALL
-#define MM3D_SIFT_SMALL 8, 1792, 1024, 384, 128
+#define MM3D_SIFT_SMALL 8, 1792, 1408, 256, 128
 #endif
-using SiftCfgSmall = SnbCfg<MM3D_SIFT_SMALL, true>;     // first octave: lists of ~100, 2 blocks of 8 waves per CU
+using SiftCfgSmall = SnbCfg<MM3D_SIFT_SMALL, true>;     // first octave: lists of ~110 (longer than 256: distance bands), 2 blocks of 8 waves per CU
 #ifndef MM3D_SIFT_LARGE
-#define MM3D_SIFT_LARGE 8, 3584, 2560, 768, 256
+#define MM3D_SIFT_LARGE 8, 2304, 4160, 768, 256
 #endif
 using SiftCfgLarge = SnbCfg<MM3D_SIFT_LARGE, true>;     // dense spots of the first octave (and what Large16 cannot hold): lists of 300-900, 1 block of 8 waves per CU
 // Later octaves (round 4): ONE block of SIXTEEN waves per CU around one tile.  A wave issues at most one instruction every
@@ -778,7 +785,7 @@ __global__ void k_sift_emit(const float4 *__restrict__ pts, const int *__restric
 // come out of the first octave's scale-space launch (k_sift_dog_lds<., true>); otherwise compute_normals runs as usual.
 // Either way *normals_out holds the same bits.
 mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double min_scale, int nr_octaves,
-                                  int nr_scales, double min_contrast, double normals_radius, mm3d_normals **normals_out)
+                                  int nr_scales, double min_contrast, double normals_radius, mm3d_normals **normals_out, float grid_cell_hint)
 {
   std::unique_ptr<mm3d_normals> nrm_res;
   static const bool fuse_normals = [] { const char *e = getenv("MM3D_SIFT_NO_FUSED_NORMALS"); return !(e && atoi(e)); }();   // A/B knob
@@ -823,12 +830,25 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     static const float hil_factor = [] { const char *e = getenv("MM3D_SIFT_HIL_FACTOR"); return e ? (float)atof(e) : 2.5f; }();
     cloud_hilbert(c, octave_cloud, hil_factor * scale);
     const int n_items = octave_cloud->n_wave_items;
-    // scale space on a grid with cell = r/2
-    const Grid &gr = cloud_grid(c, octave_cloud, max_radius * 0.5f);
+    // scale space on a grid with cell = r/2 -- or, in the first octave on `points` itself, on the grid the caller is about
+    // to build on that cloud anyway (the descriptors' radius / 2) when its cell is close to that: one grid build less per
+    // map; the cell size only sizes the staged boxes, no result depends on it
+    float grid_cell = max_radius * 0.5f;
+    if (octave_cloud == points && grid_cell_hint >= 0.8f * grid_cell && grid_cell_hint <= 1.25f * grid_cell) grid_cell = grid_cell_hint;
+    const Grid &gr = cloud_grid(c, octave_cloud, grid_cell);
     DevBuf<float> dog(c, (size_t)n * kDog);
     DevBuf<int> knn(c, (size_t)n * kKnn);
-    DevBuf<unsigned char> knn_ok(c, (size_t)n);
-    MM3D_HIP(hipMemsetAsync(knn_ok.get(), 0, (size_t)n, c->stream));
+    // everything the octave wants zeroed lies in ONE buffer -- knn_ok [n bytes, padded to 4] | flags [3 n + 1 ints] | n_search
+    // [1 int] | need_search [n bytes] -- and is cleared by one fill dispatch (a second extremum test clears from flags on)
+    const size_t z_knn = ((size_t)n + 3) & ~(size_t)3, z_flags = ((size_t)n * 3 + 1) * sizeof(int);
+    DevBuf<unsigned char> zeroed(c, z_knn + z_flags + sizeof(int) + (size_t)n);
+    MM3D_HIP(hipMemsetAsync(zeroed.get(), 0, z_knn + z_flags + sizeof(int) + (size_t)n, c->stream));
+    unsigned char *const knn_ok_p = zeroed.get();
+    int *const flags_p = reinterpret_cast<int *>(zeroed.get() + z_knn);
+    int *const n_search_p = flags_p + (size_t)n * 3 + 1;
+    unsigned char *const need_search_p = reinterpret_cast<unsigned char *>(n_search_p + 1);
+    bool zero_again = false;                             // (the first extremum test finds its words cleared by the fill above)
+    struct { unsigned char *p; unsigned char *get() const { return p; } } knn_ok{knn_ok_p};
     // the normals ride on the first octave when it works on `points` itself and their ball is inside the scale space's
     const bool fused = oct == 0 && normals_out && fuse_normals && octave_cloud == points && normals_radius > 0.0 &&
                        (float)(normals_radius * normals_radius) <= r2 && octave_cloud->n_finite == octave_cloud->n;
@@ -837,7 +857,10 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
       nrm_res->n = points->n;
       nrm_res->nrm = DevBuf<float4>(c, points->n);
     }
-    static const bool large16 = [] { const char *e = getenv("MM3D_SIFT_NO_LARGE16"); return !(e && atoi(e)); }();   // A/B knob
+    // (measured, round 4: the sixteen-wave configuration is bit-equal and NOT faster -- octave 1 1.74 against 1.69 ms, octave 2
+    // 0.88 against 0.78 -- every phase's ticks per query double with the waves: the kernel is bound by VALU issue, not by
+    // latency; it stays behind this knob)
+    static const bool large16 = [] { const char *e = getenv("MM3D_SIFT_LARGE16"); return e && atoi(e); }();
     SiftDogPending pend = oct == 0 ? sift_dog_octave<SiftCfgSmall>(c, oct, octave_cloud, gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get(),
                                                                    fused ? normals_radius : 0.0, fused ? nrm_res->nrm.get() : nullptr)
                                    : (large16 ? sift_dog_octave<SiftCfgLarge16>(c, oct, octave_cloud, gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get())
@@ -851,17 +874,15 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     // for LDS behind the other streams' kernels).
     const Grid &gk = gr;
     DevBuf<float4> dogx(c, (size_t)n * 2);
-    DevBuf<int> flags(c, (size_t)n * 3 + 1);
+    struct { int *p; int *get() const { return p; } } flags{flags_p}, n_search{n_search_p};
+    struct { unsigned char *p; unsigned char *get() const { return p; } } need_search{need_search_p};
     DevBuf<int> pos(c, (size_t)n * 3 + 1);
-    DevBuf<int> n_search(c, 1);
-    DevBuf<unsigned char> need_search(c, (size_t)n);
     const int nh = (int)octave_cloud->n_finite;
     int *h = (int *)c->pin(64);                          // [0] keypoints, [1] points for the searching kernel
     auto extremum_test = [&](bool search) {
       MM3D_LAUNCH(c, "sift_pack", n * 52.0, k_sift_dogx, dim3(div_up(n, 256)), dim3(256), 0, (const float *)dog.get(), n, dogx.get());
-      MM3D_HIP(hipMemsetAsync(flags.get(), 0, ((size_t)n * 3 + 1) * sizeof(int), c->stream));
-      MM3D_HIP(hipMemsetAsync(n_search.get(), 0, sizeof(int), c->stream));
-      MM3D_HIP(hipMemsetAsync(need_search.get(), 0, (size_t)n, c->stream));
+      if (zero_again) MM3D_HIP(hipMemsetAsync(flags.get(), 0, z_flags + sizeof(int) + (size_t)n, c->stream));
+      zero_again = true;
       MM3D_LAUNCH(c, "sift_extrema_knn", nh * 16.0 + n * 0.25 * (kKnn * 36.0 + 20.0), k_sift_extrema_knn, dim3(div_up(nh, 256)), dim3(256), 0,
                   (const float4 *)octave_cloud->hil_pts.get(), nh, n, (const float *)dog.get(), (const float4 *)dogx.get(), (const int *)knn.get(),
                   (const unsigned char *)knn_ok.get(), (float)min_contrast, flags.get(), need_search.get(), n_search.get());

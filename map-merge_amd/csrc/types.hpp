@@ -144,6 +144,10 @@ const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl);
 // ordered compaction: keeps in[i] where flags[i] != 0, preserving order; returns kept count
 size_t compact_points(Context *c, const float4 *in, const int *flags, size_t n, DevBuf<float4> &out);
 void exclusive_scan_int(Context *c, const int *in, int *out, size_t n);
+// one chained-scan launch's share of the context's scan state (grid.hip::scan_prepare; scan_fused.hpp)
+constexpr int kScanItems = 16, kScanTile = 256 * kScanItems;
+struct ScanLaunchState { unsigned long long *status; unsigned *ticket; unsigned ticket_base, epoch, tiles; };
+ScanLaunchState scan_prepare(Context *c, size_t n);
 void counting_sort_pairs_u32(Context *c, const uint32_t *keys, int n, uint64_t key_range, uint32_t *keys_out, uint32_t *idx_out,
                              int *too_long);
 void sort_pairs_u32(Context *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
@@ -160,7 +164,8 @@ mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius);
 
 // sift.hip
 mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double min_scale, int nr_octaves, int nr_scales, double min_contrast,
-                                  double normals_radius = 0.0, mm3d_normals **normals_out = nullptr);   // (+ the points' normals, fused when possible)
+                                  double normals_radius = 0.0, mm3d_normals **normals_out = nullptr, float grid_cell_hint = 0.0f);   // (+ the points' normals, fused when possible;
+                                  // grid_cell_hint: cell of a grid the caller will build on `points` anyway)
 void normals_of_items(Context *c, const mm3d_cloud *in, const Grid &g, double radius, const int *ov_items, const int *ov_count_dev, int n_overflow,
                       float4 *out);
 

@@ -16,7 +16,10 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kChains = 16;      // independent accumulators per lane: no instruction waits for the one before it
 
-// MODE 0 v_fma_f32, 1 v_add_f32, 2 v_pk_fma_f32 (two f32 per lane and instruction), 3 v_fma_f64, 4 v_add_f32 with a DPP quad broadcast
+// MODE 0 v_fma_f32, 1 v_add_f32, 2 v_pk_fma_f32 (two f32 per lane and instruction), 3 v_fma_f64, 4 v_add_f32 with a DPP quad broadcast,
+// 5 v_add_u32, 6 v_and_b32, 7 v_cndmask_b32 (vcc), 8 v_cmp_lt_f32 + v_cndmask_b32 (two instructions), 9 v_mul_f32, 10 v_max_f32,
+// 11 v_mbcnt_lo_u32_b32, 12 v_cvt_f32_i32, 13 v_rcp_f32, 14 v_exp_f32, 15 v_pk_add_f32, 16 v_pk_mul_f32, 17 v_sqrt_f32, 18 v_mul_lo_u32,
+// 19 v_lshlrev_b32, 20 v_fma_f32 + v_and_b32 alternating (do an fp32 and an integer stream share a SIMD's cycles?)
 template <int MODE>
 __global__ void __launch_bounds__(1024)
 k_rate(int iters, float *out, long long *cyc)
@@ -36,6 +39,22 @@ k_rate(int iters, float *out, long long *cyc)
       if (MODE == 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[c]) : "v"(pa), "v"(pb));
       if (MODE == 3) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[c]) : "v"((double)a), "v"((double)b));
       if (MODE == 4) asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(f[c]) : "v"(f[(c + 1) % kChains]));
+      if (MODE == 5) asm volatile("v_add_u32 %0, %0, %1" : "+v"(f[c]) : "v"(b));
+      if (MODE == 6) asm volatile("v_and_b32 %0, %0, %1" : "+v"(f[c]) : "v"(a));
+      if (MODE == 7) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[c]) : "v"(a));
+      if (MODE == 8) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(f[c]) : "v"(a), "v"(b) : "vcc");
+      if (MODE == 9) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[c]) : "v"(a));
+      if (MODE == 10) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[c]) : "v"(a));
+      if (MODE == 11) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(f[c]) : "v"(a));
+      if (MODE == 12) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(f[c]));
+      if (MODE == 13) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[c]));
+      if (MODE == 14) asm volatile("v_exp_f32 %0, %0" : "+v"(f[c]));
+      if (MODE == 15) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[c]) : "v"(pb));
+      if (MODE == 16) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[c]) : "v"(pa));
+      if (MODE == 17) asm volatile("v_sqrt_f32 %0, %0" : "+v"(f[c]));
+      if (MODE == 18) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(f[c]) : "v"(a));
+      if (MODE == 19) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(f[c]));
+      if (MODE == 20) { if (c & 1) asm volatile("v_and_b32 %0, %0, %1" : "+v"(f[c]) : "v"(a)); else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[c]) : "v"(a), "v"(b)); }
     }
   }
   const long long t1 = clock64();
@@ -55,6 +74,7 @@ static int run(const char *name, int cus)
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int iters = 20000;
   for (int wps : {1, 2, 4, 8}) {
+    if (MODE >= 5 && wps != 1 && wps != 4) continue;                 // the long table: one wave alone and the occupancy the kernels run at
     // wps waves on each of a CU's four SIMDs: blocks of 4 * min(wps, 4) waves, one or two blocks per CU
     const int waves_per_block = 4 * (wps < 4 ? wps : 4), blocks_per_cu = wps <= 4 ? 1 : wps / 4;
     const dim3 grid(cus * blocks_per_cu), block(64 * waves_per_block);
@@ -70,7 +90,7 @@ static int run(const char *name, int cus)
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       if (ms < best) { best = ms; CK(hipMemcpy(&c, cyc, sizeof(c), hipMemcpyDeviceToHost)); }
     }
-    const double winstr = (double)cus * blocks_per_cu * waves_per_block * (double)iters * kChains;
+    const double winstr = (double)cus * blocks_per_cu * waves_per_block * (double)iters * kChains * (MODE == 8 ? 2 : 1);
     const double rate = winstr / (best * 1e-3);
     printf("%-22s %d waves/SIMD: %8.3f ms  %.3e wave-instr/s chip = %.3f ns per wave-instruction per SIMD (2 cycles at 2.4 GHz = 0.833 ns);"
            " one wave's own instruction: %.2f ticks\n",
@@ -91,5 +111,21 @@ int main()
   if (run<2>("v_pk_fma_f32", cus)) return 1;
   if (run<3>("v_fma_f64", cus)) return 1;
   if (run<4>("v_add_f32_dpp quad", cus)) return 1;
+  if (run<5>("v_add_u32", cus)) return 1;
+  if (run<6>("v_and_b32", cus)) return 1;
+  if (run<7>("v_cndmask_b32", cus)) return 1;
+  if (run<8>("v_cmp+v_cndmask (x2)", cus)) return 1;
+  if (run<9>("v_mul_f32", cus)) return 1;
+  if (run<10>("v_max_f32", cus)) return 1;
+  if (run<11>("v_mbcnt_lo", cus)) return 1;
+  if (run<12>("v_cvt_f32_i32", cus)) return 1;
+  if (run<13>("v_rcp_f32", cus)) return 1;
+  if (run<14>("v_exp_f32", cus)) return 1;
+  if (run<15>("v_pk_add_f32", cus)) return 1;
+  if (run<16>("v_pk_mul_f32", cus)) return 1;
+  if (run<17>("v_sqrt_f32", cus)) return 1;
+  if (run<18>("v_mul_lo_u32", cus)) return 1;
+  if (run<19>("v_lshlrev_b32", cus)) return 1;
+  if (run<20>("v_fma_f32 | v_and_b32", cus)) return 1;
   return 0;
 }
