@@ -41,7 +41,14 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA (v_mfma_f32_32x32x2_f32)
 MFMA_KERNELS = {"desc_knn_mfma"}   # kernels whose profile "bytes" field carries FLOPs (csrc/desc_knn.hip)
-VALU_PEAK_WINSTR_S = 256 * 4 * 2.4e9 / 4   # wave-instructions per second: 256 CUs x 4 SIMDs, 4 cycles per wave64 instruction, 2.4 GHz
+# VALU issue peak, wave-instructions per second over the chip.  MEASURED: independent v_fma_f32 streams at 4 and 8 waves per
+# SIMD on all 256 CUs sustain 8.4e11 (scripts/micro/valu_rate.hip, profiles/r04_valu_rate.txt; v_add_f32 / v_mul_f32 /
+# integer adds and logic 6.5 - 8.3e11; v_max / v_cvt / shifts / v_mbcnt / packed f32 / DPP adds / f64 4.2 - 5.0e11;
+# v_exp / v_rcp / v_sqrt 2.9e11).  NOMINAL by the guide's table (MI355X_MICROARCH.md: v_fma_f32 2 cycles per wave64 on a
+# SIMD-32): 256 x 4 x 2.4e9 / 2 = 1.23e12, which the chip does not sustain -- the all-VALU loop clocks down as its waves
+# per SIMD go up and the rate stays at 8.4e11.  Round 3 used 6.14e11 (4 cycles per instruction): 27 % too low.
+VALU_PEAK_WINSTR_S = 8.4e11
+VALU_PEAK_NOMINAL_WINSTR_S = 256 * 4 * 2.4e9 / 2
 # profile name (MM3D_LAUNCH) of the kernels whose C++ symbol differs from it (scripts/pmc_summary.py prints symbols)
 KERNEL_OF_SYMBOL = {"k_sift_dog_lds": "sift_dog", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_sift_extrema": "sift_extrema", "k_spfh": "spfh", "k_normals": "normals_radius_big",
                     "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_sacia_seq_sum": "sacia_seq_sum",
@@ -492,7 +499,7 @@ def main():
         return not (now and pmc_hashes.get(kernel) == now)
 
     # VALU instructions per launch from the most recent committed SQ-counter pass (same maps 0 and 1, one stream)
-    valu_insts, valu_source = {}, None
+    valu_insts, valu_source, sq_ratios = {}, None, {}
     try:
         latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters.csv")))[-1]
         import csv
@@ -500,7 +507,18 @@ def main():
             for row in csv.DictReader(f):
                 d = float(row.get("dispatches") or 0)
                 if d > 0 and row.get("SQ_INSTS_VALU") not in (None, "", "nan"):
-                    valu_insts[KERNEL_OF_SYMBOL.get(row["kernel"], row["kernel"])] = float(row["SQ_INSTS_VALU"]) / d
+                    name = KERNEL_OF_SYMBOL.get(row["kernel"], row["kernel"])
+                    valu_insts[name] = float(row["SQ_INSTS_VALU"]) / d
+
+                    def ratio(a, b):
+                        try:
+                            return round(float(row[a]) / float(row[b]), 4) if float(row[b]) > 0 else None
+                        except (KeyError, ValueError, TypeError):
+                            return None
+                    # share of the wave cycles spent waiting, share of the LDS cycles lost to bank conflicts, VALU busy share
+                    # (SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES both count quad-cycles; divided by the waves per SIMD it is the SIMD's)
+                    sq_ratios[name] = {"stall": ratio("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"), "lds_conflict": ratio("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"),
+                                       "valu_active_per_wave_cycle": ratio("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES")}
         valu_source = "profiles/" + os.path.basename(latest)
     except Exception:
         pass
@@ -508,7 +526,7 @@ def main():
     def bound_of(name, launch_ms, work):
         """Which ceiling the kernel is nearest to, from what can be known here: algorithmic bytes (or flops) per launch
         against HBM (or MFMA) peak, and -- where the committed SQ counters cover the kernel -- VALU wave-instructions per
-        launch against the issue peak (256 CUs x 4 SIMDs, one wave-instruction per 4 cycles at 2.4 GHz)."""
+        launch against the measured issue peak (VALU_PEAK_WINSTR_S above)."""
         out = {}
         if launch_ms <= 0:
             return out
@@ -565,8 +583,17 @@ def main():
             if dom[0] in valu_insts and iso_us:
                 v = valu_insts[dom[0]] / (iso_us * 1e-6)
                 roofline["valu"] = {"wave_instructions_per_launch": round(valu_insts[dom[0]]), "achieved": round(v / 1e9, 2),
-                                    "peak": round(VALU_PEAK_WINSTR_S / 1e9, 1), "unit": "G wave-instr/s", "frac": round(v / VALU_PEAK_WINSTR_S, 4),
+                                    "peak": round(VALU_PEAK_WINSTR_S / 1e9, 1), "peak_source": "measured: scripts/micro/valu_rate.hip, profiles/r04_valu_rate.txt",
+                                    "peak_nominal": round(VALU_PEAK_NOMINAL_WINSTR_S / 1e9, 1), "unit": "G wave-instr/s",
+                                    "frac": round(v / VALU_PEAK_WINSTR_S, 4), "frac_of_nominal": round(v / VALU_PEAK_NOMINAL_WINSTR_S, 4),
                                     "source": valu_source, "timed": "isolated_avg_launch_us", "stale": stale(dom[0])}
+            if dom[0] in sq_ratios:
+                # from the same committed SQ-counter CSV (one stream): SQ_WAIT_ANY / SQ_WAVE_CYCLES and SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+                roofline["stall"] = sq_ratios[dom[0]]["stall"]
+                roofline["lds_conflict"] = sq_ratios[dom[0]]["lds_conflict"]
+                roofline["valu_active_per_wave_cycle"] = sq_ratios[dom[0]]["valu_active_per_wave_cycle"]
+                roofline["sq_counters_source"] = valu_source
+                roofline["sq_counters_stale"] = stale(dom[0])
             # `bound`: the ceiling the kernel is nearest to alone on the GPU -- "hbm" by algorithmic or by measured memory-side
             # bytes, "valu" by issued wave-instructions, "mfma" by flops -- the fractions beside it say how near
             cand = {"hbm": max(roofline.get("isolated_frac") or 0.0, roofline.get("traffic_frac") or 0.0) if dom[0] not in MFMA_KERNELS else 0.0,
@@ -575,8 +602,8 @@ def main():
             roofline["bound"] = max(cand.items(), key=lambda kv: kv[1])[0] if any(cand.values()) else roofline["bound"]
             roofline["bound_fractions"] = {k: round(v, 5) for k, v in cand.items()}
             roofline["note"] = ("timed region runs %d streams per GPU, so avg_launch_us includes time shared with other kernels; "
-                                "neighbourhood kernels (sift_dog, spfh, sacia_err, *_nn_reduce) are f32-VALU-bound on "
-                                "in-radius pair work, not HBM-bound: see DESIGN.md section 6" % S)
+                                "neighbourhood kernels (sift_dog, spfh, sacia_err, *_nn_reduce) are bound by VALU instruction issue on "
+                                "in-radius pair work, not by HBM: see DESIGN.md sections 5 and 6" % S)
         ranked = sorted(prof.items(), key=lambda kv: -kv[1]["ms"])
         top = ranked[:8]
         if args.kernel_table:
@@ -608,8 +635,12 @@ def main():
                        "points_after_filter_mean": int(np.mean(npts_f)), "keypoints_mean": int(np.mean(stats["keypoints"]))},
             "pair_stage_pairs_per_s": round(n_pairs / max(stats["t_pairs"], 1e-9), 3),
             "mpoints_per_s": {
+                # (FPFH + SIFT: the normals come out of the first octave's scale-space launch, sift.hip k_sift_dog_lds<., true>; there is
+                # no launch of their own to time, see "normals_fused" below)
                 "normals": round(sum(npts_f) / 1e6 / max(prof.get("normals_radius", {}).get("ms", 0) / 1e3 / max(args.steps, 1), 1e-9), 2)
                 if "normals_radius" in prof else None,
+                "normals_fused": "computeSurfaceNormals rides on detectKeypoints' first octave (same sorted neighbour lists, same bits)"
+                if "normals_radius" not in prof and "sift_dog" in prof else None,
                 # FPFH: support points per second of the SPFH kernel (|S| = its algorithmic bytes / 156 B) and
                 # keypoints per second of the weighting kernel
                 "fpfh_spfh": round(prof["spfh"]["bytes"] / 156.0 / 1e6 / max(prof["spfh"]["ms"] / 1e3, 1e-9), 2) if "spfh" in prof else None,

@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 BUILD=${BUILD_DIR:-build}
 OUT=${OUT:-libmm3d.so}
 mkdir -p $BUILD
-SRCS="libm_debug.hip grid.hip filters.hip normals.hip sift.hip harris.hip fpfh.hip pfh.hip rsd.hip shot.hip sc3d.hip desc_knn.hip registration.hip nn.hip linalg.cpp host_pipeline.cpp capi.cpp"
+SRCS="libm_debug.hip grid.hip filters.hip normals.hip sift.hip harris.hip fpfh.hip pfh.hip rsd.hip shot.hip sc3d.hip desc_knn.hip registration.hip nn.hip runtime.cpp linalg.cpp host_pipeline.cpp capi.cpp"
 OBJS=""
 pids=()
 for s in $SRCS; do

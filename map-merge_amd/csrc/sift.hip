@@ -391,7 +391,8 @@ static SiftDogPending sift_dog_octave(Context *c, int oct, const mm3d_cloud *cur
   auto sl = std::make_shared<SnbLaunch<Cfg>>(c, n_items, extra_lds);
   static const bool per_octave_names = getenv("MM3D_SNB_DEBUG") != nullptr;    // (read once, not per launch)
   static const char *const oct_names[4] = {"sift_dog_oct0", "sift_dog_oct1", "sift_dog_oct2", "sift_dog_oct3+"};
-  const char *name = per_octave_names ? oct_names[std::min(oct, 3)] : (nrm ? "sift_dog_normals" : "sift_dog");
+  // (one profile name for the three octaves, the fused first one included: the counters under profiles/ are per kernel symbol)
+  const char *name = per_octave_names ? oct_names[std::min(oct, 3)] : "sift_dog";
   // algorithmic bytes: 36 B per point (SURVEY 8d's scale-space figure) + the normals' 28 B when they come out of the same launch
   bool launched = false;
   if constexpr (Cfg::kLpq == 8) {                // (the fused variant exists for the eight-wave configurations only)
