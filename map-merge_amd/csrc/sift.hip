@@ -173,18 +173,28 @@ __device__ __forceinline__ float quad_bcast(float v)
 // The LDS of a block is a budget split between the tile (20 B per staged candidate, shared) and the eight waves' arenas
 // (2 B per list entry).  Round 4 moved it towards the arenas: a wave's consumer pass costs the same for three lists as for
 // eight, and with the round-3 sizes (1792 / 1024 and 3584 / 2560) the arena, not the eight-query budget, ended most rounds
-// (1.28, 1.42 and 1.86 rounds per item in the three octaves; 1.05 and 1.23 in the later octaves now).  The tile's capacity
-// was mostly unused (716 / 1246 / 1191 candidates per item on average); the few items that need more are worked in parts
-// (31 of 3930 in octave 1 of a headline map).  Measured, one 500 k map: octave 0 1.23 -> 1.18 ms, octave 1 1.65 -> 1.41,
-// octave 2 0.77 -> 0.63 (profiles/r04_sift_config_ab.txt).
+// (1.28, 1.42 and 1.86 rounds per item in the three octaves).  The tile's capacity was mostly unused (716 / 1246 / 1191
+// candidates per item on average), but not everywhere: what a smaller tile cannot hold even in eight parts goes to the repair
+// launch (SiftCfgDense below, ~0.2 - 0.3 ms each), and over the sixteen headline maps the split that wins is 2816 / 3328, not
+// the 2304 / 4160 that is fastest on a map without dense spots (one stream, ms per step for octaves 1 + 2 + repairs: 41.8 with
+// 3584 / 2560, 38.9 with 2816 / 3328, 39.5 with 2560 / 3840, 41.2 with 2304 / 4160 where 14 of 16 maps need a repair launch;
+// profiles/r04_sift_config_ab.txt).  First octave: hit buffer 384 -> 256 (longer lists: distance bands), arena 1024 -> 1408:
+// 1.23 -> 1.18 ms.
 #ifndef MM3D_SIFT_SMALL
 #define MM3D_SIFT_SMALL 8, 1792, 1408, 256, 128
 #endif
 using SiftCfgSmall = SnbCfg<MM3D_SIFT_SMALL, true>;     // first octave: lists of ~110 (longer than 256: distance bands), 2 blocks of 8 waves per CU
 #ifndef MM3D_SIFT_LARGE
-#define MM3D_SIFT_LARGE 8, 2304, 4160, 768, 256
+#define MM3D_SIFT_LARGE 8, 2816, 3328, 768, 256
 #endif
-using SiftCfgLarge = SnbCfg<MM3D_SIFT_LARGE, true>;     // dense spots of the first octave (and what Large16 cannot hold): lists of 300-900, 1 block of 8 waves per CU
+using SiftCfgLarge = SnbCfg<MM3D_SIFT_LARGE, true>;     // later octaves: lists of 300-900 (longer ones in bands), 1 block of 8 waves per CU
+// The repair configuration: the items a launch of the two above could not hold (dense spots: a tile of more candidates than
+// theirs even in eight parts) get the largest tile that fits a CU, one block per item, before anything is left to the lists in
+// global memory (k_sift_dog: 0.46 ms per launch on the headline maps, against 0.1 - 0.2 for this one)
+#ifndef MM3D_SIFT_DENSE
+#define MM3D_SIFT_DENSE 8, 3584, 2560, 768, 256
+#endif
+using SiftCfgDense = SnbCfg<MM3D_SIFT_DENSE, true>;
 // Later octaves (round 4): ONE block of SIXTEEN waves per CU around one tile.  A wave issues at most one instruction every
 // ~6 cycles (scripts/micro/valu_rate.hip), so the eight waves of SiftCfgLarge left two thirds of every SIMD's issue slots
 // empty; LDS is what limits the waves, so the per-wave share shrinks instead: four lists per round (16 lanes per query)
@@ -415,22 +425,21 @@ static SiftDogPending sift_dog_octave(Context *c, int oct, const mm3d_cloud *cur
   pend.fallback = [c, cur, grp, n_items, max_radius, r2, sc, dog, knn, knn_ok, sl, nrad, nr2, nrm](int n_overflow) {
     SnbCtl *ctl = sl->ctl_dev();
     int *ov = sl->ov_items.get();
-    // the first octave's configuration has the small tile: a few overflow items (dense spots of an outdoor map) go
-    // through the large one -- one block per item, a tile and lists twice as long -- before anything is left to the
-    // global-memory lists; a cloud that is dense everywhere (thousands of items) goes to those directly (measured on
+    // a few overflow items (dense spots of an outdoor map) go through the repair configuration -- one block per item, the
+    // largest tile a CU holds -- before anything is left to the global-memory lists; a cloud that is dense everywhere (thousands of items) goes to those directly (measured on
     // 8 x 2 M indoor points: the large configuration is no faster per neighbour there, and it runs one block per CU)
-    std::shared_ptr<SnbLaunch<SiftCfgLarge>> sl2;
-    if (!std::is_same<Cfg, SiftCfgLarge>::value && n_overflow <= 256) {
+    std::shared_ptr<SnbLaunch<SiftCfgDense>> sl2;
+    if (!std::is_same<Cfg, SiftCfgDense>::value && n_overflow <= 256) {
       const size_t extra2 = sizeof(float) * 64 * (nrm ? 9 : kScales) + (nrm ? sizeof(int) * 64 : 0) + 256;
-      sl2 = std::make_shared<SnbLaunch<SiftCfgLarge>>(c, n_items, extra2);
-      const dim3 grid2(std::min(sl2->blocks, (unsigned)n_overflow)), block2(64 * SiftCfgLarge::kWaves);
+      sl2 = std::make_shared<SnbLaunch<SiftCfgDense>>(c, n_items, extra2);
+      const dim3 grid2(std::min(sl2->blocks, (unsigned)n_overflow)), block2(64 * SiftCfgDense::kWaves);
       if (nrm)
-        MM3D_LAUNCH(c, "sift_dog_dense", 0.0, (k_sift_dog_lds<SiftCfgLarge, true>), grid2, block2, 0,
+        MM3D_LAUNCH(c, "sift_dog_dense", 0.0, (k_sift_dog_lds<SiftCfgDense, true>), grid2, block2, 0,
                     (const float4 *)cur->hil_pts.get(), (const int2 *)cur->wave_items.get(), n_items, grp->view(), (const float4 *)cur->pts.get(),
                     max_radius, r2, sc, sl2->ctl_dev(), sl2->ov_items.get(), dog, knn, knn_ok, (const int *)sl->ov_items.get(),
                     (const int *)&sl->ctl_dev()->ov_count, nr2, nrm);
       else
-        MM3D_LAUNCH(c, "sift_dog_dense", 0.0, (k_sift_dog_lds<SiftCfgLarge, false>), grid2, block2, 0,
+        MM3D_LAUNCH(c, "sift_dog_dense", 0.0, (k_sift_dog_lds<SiftCfgDense, false>), grid2, block2, 0,
                     (const float4 *)cur->hil_pts.get(), (const int2 *)cur->wave_items.get(), n_items, grp->view(), (const float4 *)cur->pts.get(),
                     max_radius, r2, sc, sl2->ctl_dev(), sl2->ov_items.get(), dog, knn, knn_ok, (const int *)sl->ov_items.get(),
                     (const int *)&sl->ctl_dev()->ov_count, 0.0f, (float4 *)nullptr);

@@ -219,7 +219,7 @@ def test_16x500k_all_120_pairs_within_the_stated_tolerance(ctx, po, mm, workload
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
     if os.path.isdir(out):
         open(os.path.join(out, "all_pairs_tolerance.txt"), "w").write(report + "\n")
-    assert corr_eq_exact >= 114, corr_eq_exact
+    assert corr_eq_exact >= 110, corr_eq_exact               # (measured 114: the device forms T p in float, the yardstick in double)
 
 
 def test_8x2M_dense_indoor_stage_by_stage_against_the_oracle(ctx, po, mm, workload):
