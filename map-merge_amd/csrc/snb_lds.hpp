@@ -102,9 +102,13 @@ struct alignas(16) SnbLds {
   float pay[Cfg::kPay ? Cfg::kTileCap : 4];
   SnbWave<Cfg> w[Cfg::kWaves];
   float4 qpts[64];                               // the queries of the part in work (.w = original index)
-  int n_tile, item, overflow, pad;
+  int n_tile[2];                                 // staged candidates of the current staging / the next one, in turn (by epoch)
+  int item, overflow;
   int next_q[2];                                 // the waves take the part's queries one at a time; two counters in turn:
-                                                 // a wave may still be claiming from one part's when the next part's is reset
+                                                 // a wave may still be claiming from one part's when the next part's is reset.
+                                                 // n_tile likewise: a wave that is late to read this staging's count must not
+                                                 // see thread 0 clear it for the next staging (an item worked in parts re-stages
+                                                 // at once), so the next staging counts in the other word
 };
 
 // device control block of one launch (zeroed before it)
@@ -194,11 +198,11 @@ __device__ __forceinline__ int snb_claim_item(int *ctr, int n_items)
 
 // Stages the candidates of the cell box [x0..x1] x [y0..y1] x [z0..z1] that pass keep() into the tile (and
 // load_pay(candidate) into S.pay); every wave reads the row headers (64 rows at a time), the waves share the
-// slots.  Called by all threads of the block; S.n_tile must be 0 and visible; the caller syncs afterwards.
+// slots.  Called by all threads of the block; *n_tile (a word of S.n_tile) must be 0 and visible; the caller syncs afterwards.
 // The tile's order is whatever order the waves arrive in: the lists are sorted by a total order, so it
 // never shows in a result.
 template <class Cfg, class Keep, class LoadPay>
-__device__ __forceinline__ void snb_stage(const GridView &g, SnbLds<Cfg> &S, int x0, int x1, int y0, int y1, int z0, int z1, int lane, int wave,
+__device__ __forceinline__ void snb_stage(const GridView &g, SnbLds<Cfg> &S, int *n_tile, int x0, int x1, int y0, int y1, int z0, int z1, int lane, int wave,
                                           Keep keep, LoadPay &&load_pay)
 {
   constexpr int T = 64 * Cfg::kWaves;
@@ -236,7 +240,7 @@ __device__ __forceinline__ void snb_stage(const GridView &g, SnbLds<Cfg> &S, int
       const unsigned long long m = __ballot(k);
       if (m) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(&S.n_tile, __popcll(m));
+        if (lane == 0) base = atomicAdd(n_tile, __popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);
         const int d = snb_mbcnt(m, base);
         if (k && d < Cfg::kTileCap) {
@@ -544,7 +548,7 @@ __device__ __forceinline__ int snb_stage_queries(const GridView &g, SnbLds<Cfg> 
                                                  int epoch, LoadPay &&load_pay, SnbStats &snb_st)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) { S.n_tile = 0; S.next_q[epoch & 1] = 0; }
+  if (threadIdx.x == 0) { S.n_tile[epoch & 1] = 0; S.next_q[epoch & 1] = 0; }
   __syncthreads();
   SNB_TICK(t_stage);
   // the box (every wave computes it from the same queries)
@@ -557,12 +561,12 @@ __device__ __forceinline__ int snb_stage_queries(const GridView &g, SnbLds<Cfg> 
   const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
   const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
   const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
-  snb_stage<Cfg>(g, S, x0, x1, y0, y1, z0, z1, lane, wave, KeepInBox{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri}, load_pay);
+  snb_stage<Cfg>(g, S, &S.n_tile[epoch & 1], x0, x1, y0, y1, z0, z1, lane, wave, KeepInBox{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri}, load_pay);
   SNB_TOCK(2, t_stage);
   SNB_TICK(t_sb);
   __syncthreads();
   SNB_TOCK(3, t_sb);
-  return S.n_tile;
+  return S.n_tile[epoch & 1];
 }
 
 // Per-item driver: claims items, stages their boxes and hands each wave's lists to consume(fit, q, qw) -- fit lists;

@@ -9,7 +9,7 @@ import sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
-for cfg in (1, 2, 3, 4, 5, "4indoor", "2lattice"):
+for cfg in (1, 2, 3, 4, 5, "4indoor", "2lattice", "3lattice"):
     src = os.path.join(root, "gpurun_out", f"{tag}_table_cfg{cfg}.json")
     try:
         d = json.load(open(src))
@@ -22,16 +22,19 @@ for cfg in (1, 2, 3, 4, 5, "4indoor", "2lattice"):
     knn = next((v for k, v in kb.items() if k == "desc_knn_mfma"), {})
     par = d.get("parity_check") or {}
     m = d.get("mpoints_per_s", {})
-    b1, b2 = d["cpu_baseline"], d["cpu_baseline_all_cores"]
+    b1 = d.get("cpu_baseline") or {"value": float("nan")}
+    b2 = d.get("cpu_baseline_all_cores") or {"value": float("nan"), "cores": 0}
     gt = d.get("gt_error") or {}
     rows.append("| %s | %s | %.4g | %.4g (%d) | **%.4g** (%.1f ms/step) | n/a (driver) | %s | %s | %s | %s | %s | %s |" % (
         cfg, d["config"]["workload"], b1["value"], b2["value"], b2["cores"], d["value"], d["ms_per_step"],
-        m.get("normals"), ("%.2f %%" % (100 * nb["hbm_frac"])) if "hbm_frac" in nb else "—",
+        m.get("normals") if m.get("normals") is not None else ("fused into SIFT's first octave" if m.get("normals_fused") else None),
+        ("%.2f %%" % (100 * nb["hbm_frac"])) if "hbm_frac" in nb else "—",
         ("%.1f %%" % (100 * knn["mfma_frac"])) if "mfma_frac" in knn else "—", m.get("icp"),
         ("ok: T %.1e%s, conf %.1e" % (par["pair_transform_frobenius"],
                                       (" (vs double-sum ICP %.0e)" % par["pair_transform_frobenius_vs_double_sums"]) if "pair_transform_frobenius_vs_double_sums" in par else "",
                                       par["confidence_rel_err"])) if par.get("ok") else ("FAILED" if par else "—"),
-        ("%d of %d pairs within 0.5 (median %.2f)" % (gt["recovered_within_0.5"], gt["pairs_with_overlap_ge_0.3"], gt["median_frobenius"])) if gt.get("pairs_with_overlap_ge_0.3") else "—"))
+        (("%d of %d pairs within 0.5 (median %.2f)" % (gt["recovered_within_0.5"], gt["pairs_with_overlap_ge_0.3"], gt["median_frobenius"])) if gt.get("pairs_with_overlap_ge_0.3") else "—")
+        + "; ICP iterations " + json.dumps(d.get("icp_iterations_histogram", {})).replace('"', "")))
 head = ("| config | workload | B1 pairs/s (1 core) | B2 pairs/s (cores) | GPU×1 pairs/s | GPU×8 | normals Mpts/s | normals % HBM | dist-matrix % MFMA | ICP Mpts/s "
         "| parity_check (device vs oracle, maps 0, 1, pair (0,1)) | ground truth (pairs with >= 30 % overlap) |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
 table = head + "\n".join(rows) + "\n"
