@@ -615,6 +615,36 @@ def test_bench_ranks_and_streams_give_the_same_bits():
     assert c["n_gpus"] == 2 and e["n_gpus"] == 3
 
 
+def test_round4_shortcuts_do_not_change_a_bit():
+    """The round-4 shortcuts of the whole-map path -- SIFT's first octave on the input cloud itself when its voxelisation is
+    the identity, the normals riding on that octave's sorted lists, the grid shared with the descriptors, the Hilbert blocks
+    scaled with the octave's leaf, the sixteen-wave configuration -- each switched off (or on) by its environment knob in a
+    fresh process: every combination prints the same pair-transform CRC as the default."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [sys.executable, "bench.py", "--maps", "3", "--points", "120000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pcie",
+              "--streams", "3"]
+
+    def run(env):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run(common, cwd=root, env=e, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+    base = run({})
+    variants = [{"MM3D_SIFT_NO_IDENTITY": "1"}, {"MM3D_SIFT_NO_FUSED_NORMALS": "1"}, {"MM3D_SIFT_NO_SHARED_GRID": "1"},
+                {"MM3D_SIFT_HIL_FACTOR": "0"}, {"MM3D_SIFT_LARGE16": "1"},
+                {"MM3D_SIFT_NO_IDENTITY": "1", "MM3D_SIFT_HIL_FACTOR": "0", "MM3D_SIFT_NO_SHARED_GRID": "1"}]
+    for v in variants:
+        r = run(v)
+        assert r["pair_transforms_crc32"] == base["pair_transforms_crc32"] and r["maps_estimated"] == base["maps_estimated"], (v, r["pair_transforms_crc32"])
+    # and the profile shows what the default does: no launch of the normals' own
+    assert base["mpoints_per_s"]["normals"] is None and base["mpoints_per_s"]["normals_fused"]
+    assert run({"MM3D_SIFT_NO_FUSED_NORMALS": "1"})["mpoints_per_s"]["normals"] is not None
+
+
 def test_pfh_neighbourhoods_beyond_lds(ctx, po, scene):
     """More than 1024 neighbours per keypoint: the neighbour list no longer fits the block's LDS and the
     keypoint goes through the global-scratch pass of the same kernel."""
