@@ -50,7 +50,7 @@ MFMA_KERNELS = {"desc_knn_mfma"}   # kernels whose profile "bytes" field carries
 VALU_PEAK_WINSTR_S = 8.4e11
 VALU_PEAK_NOMINAL_WINSTR_S = 256 * 4 * 2.4e9 / 2
 # profile name (MM3D_LAUNCH) of the kernels whose C++ symbol differs from it (scripts/pmc_summary.py prints symbols)
-KERNEL_OF_SYMBOL = {"k_sift_dog_lds": "sift_dog", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_sift_extrema": "sift_extrema", "k_spfh": "spfh", "k_normals": "normals_radius_big",
+KERNEL_OF_SYMBOL = {"k_sift_dog_lds": "sift_dog", "k_sift_dog_lds_dense": "sift_dog_dense", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_sift_extrema": "sift_extrema", "k_spfh": "spfh", "k_normals": "normals_radius_big",
                     "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_sacia_seq_sum": "sacia_seq_sum",
                     "k_fpfh_weight": "fpfh_weight", "k_knn_mfma": "desc_knn_mfma", "k_knn_rerank": "desc_knn_rerank",
                     "k_radius_outlier_count": "radius_outlier_count"}

@@ -6,6 +6,10 @@ def short(name):
     m = re.search(r"mm3d::(\w+)(?:<(\d+)(?:, *\d+)*>)?", name)
     if m:
         # the ICP / score search is one template (k_nn_wave<MODE, SPLIT>, MODE 0 / 1): keep the two modes apart
+        # and the SIFT scale-space kernel's repair configuration (largest tile, one block per overflow item: a handful of
+        # tiny launches) apart from the launches that work whole octaves, so that "per dispatch" means per octave
+        if m.group(1) == "k_sift_dog_lds" and re.search(r"SnbCfg<8, *3584", name):
+            return "k_sift_dog_lds_dense"
         return m.group(1) + ("<%s>" % m.group(2) if m.group(1) == "k_nn_wave" and m.group(2) else "")
     m = re.search(r"(\w+)<", name)
     return (m.group(1) if m else name)[:40]
