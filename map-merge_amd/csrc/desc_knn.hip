@@ -933,7 +933,7 @@ k_knn_rerank_wide(const float *__restrict__ A, int na, const float *__restrict__
   }
   float first_d = -INFINITY;
   if (my_first >= 0) first_d = knn_wide_dist<kD>(s_x[w], B + (size_t)ci_[my_first] * kD);
-  const int n_first = __popcll(__ballot(my_first >= 0));
+  const int n_first = __popcll(ballot(my_first >= 0));
   const float U = n_first >= k ? wave_max_f(first_d) : INFINITY;
   // 2. every candidate that can still be among the k nearest
   const float rho_u = (sqrtf(na2) + sqrtf(U)) * 1.001f + 1e-3f;
@@ -943,7 +943,7 @@ k_knn_rerank_wide(const float *__restrict__ A, int na, const float *__restrict__
   for (int e0 = 0; e0 < n_cand; e0 += kWave) {
     const int e = e0 + lane;
     const bool take = ci_[e] >= 0 && !(cd_[e] > thr);
-    const unsigned long long mask = __ballot(take);
+    const unsigned long long mask = ballot(take);
     if (take) s_sel[w][n_sel + __popcll(mask & ((1ull << lane) - 1ull))] = e;
     n_sel += __popcll(mask);
   }

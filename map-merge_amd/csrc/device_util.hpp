@@ -143,6 +143,11 @@ __device__ __forceinline__ bool acos_abs_greater(float a1, float a2)
   return (hi + (lo - (double)x1)) > (hi + (lo - (double)x2));
 }
 
+// Lane mask of a predicate.  HIP's ballot() takes an int: a bool argument is first materialised as 0 / 1 (v_cndmask) and
+// compared with zero again (v_cmp_ne) -- two VALU instructions per call in the inner loops that vote on every step; the
+// builtin takes the i1 as it is (the comparison's own lane mask).
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // ---- wave / block reductions -------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -269,7 +274,7 @@ __device__ __forceinline__ void wave_stream_box(const GridView &g, int x0, int x
       for (int u = 0; u < PER; ++u) {
         const int s = lane + u * kWave;
         const bool k = s < cnt && keep(st[u]);
-        const unsigned long long m = __ballot(k);
+        const unsigned long long m = ballot(k);
         if (k) {
           const int d = kept + __popcll(m & ((1ull << lane) - 1ull));
           s_pts[d] = st[u];

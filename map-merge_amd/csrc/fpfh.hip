@@ -139,7 +139,7 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
   const float4 q = q_pts[it.x + (valid ? lane : 0)];
   const int self = __float_as_int(q.w);
   const bool live = valid && in_set[self] != 0;
-  if (!__ballot(live)) return;                // wave-uniform: no support point in this patch
+  if (!ballot(live)) return;                // wave-uniform: no support point in this patch
   const float4 nq = nrm[self];
 #pragma unroll
   for (int b = 0; b < kDim; ++b) hist[wave][b][lane >> 1] = 0u;

@@ -298,7 +298,7 @@ k_harris_refine(float4 *__restrict__ corners, int nc, GridView g, const float4 *
         s_n[lane] = n;
         s_p[lane] = pts[oi];
       }
-      const unsigned long long mask = __ballot(ok);
+      const unsigned long long mask = ballot(ok);
       __syncthreads();
       if (lane < 12) {
         const int bn = min(64, m - b0);

@@ -174,14 +174,14 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
 #ifdef MM3D_NN_STATS
   const long long t_begin = wall_clock64();
   for (int e = 1; e <= 8; ++e) {          // what ring the lanes ask for before the first pass
-    const int c_ = __popcll(__ballot(active && (e < 8 ? need == e : need >= 8)));
+    const int c_ = __popcll(ballot(active && (e < 8 ? need == e : need >= 8)));
     if (MM3D_NN_STATS == 1 && lane == 0 && c_) atomicAdd(&g_nn_stats[55 + e], (unsigned long long)c_);
   }
 #endif
   for (int pass = 0; pass < 64; ++pass) {
-    if (!__ballot(active)) break;
+    if (!ballot(active)) break;
     MM3D_STAT(1, 1);
-    MM3D_STAT(4, __popcll(__ballot(active)));
+    MM3D_STAT(4, __popcll(ballot(active)));
     if (pass == 0) MM3D_STAT(0, 1);
     // box = bounding box of the active lanes' cells, grown by the largest radius any of them needs
     const int E = wave_max_i(active ? need : 0);
@@ -292,7 +292,7 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
               // groups take this exit, and a group that does costs 3 instead of 22 instructions on top of the distances
               // (round 4: the step is bound by VALU instructions).
               const float m4 = fminf(fminf(da.x, da.y), fminf(db.x, db.y));
-              if (__ballot(__float_as_uint(m4) <= (unsigned)(bkey >> 32))) {
+              if (ballot(__float_as_uint(m4) <= (unsigned)(bkey >> 32))) {
                 const uint4 W = *reinterpret_cast<const uint4 *>(&s_cw[wave][k]);
                 const unsigned long long k0 = ((unsigned long long)__float_as_uint(da.x) << 32) | W.x;
                 const unsigned long long k1 = ((unsigned long long)__float_as_uint(da.y) << 32) | W.y;

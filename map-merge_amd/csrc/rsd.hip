@@ -61,7 +61,7 @@ k_rsd(const float4 *__restrict__ kp, int nk, GridView g, const float4 *__restric
     if (lane == 0) { out[0] = 0.0f; out[1] = 0.0f; }
     return;
   }
-  const int owner = __ffsll((long long)__ballot(best == wbest)) - 1;
+  const int owner = __ffsll((long long)ballot(best == wbest)) - 1;
   const unsigned ref_j = __shfl(best_j, owner, 64);
   const float4 p0 = g.pts[ref_j];
   const float4 n0 = nrm[(unsigned)(wbest & 0xffffffffull)];

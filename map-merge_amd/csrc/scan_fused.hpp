@@ -54,7 +54,7 @@ k_scan_fused(size_t n, unsigned long long *status, unsigned *ticket, unsigned ti
         do w = __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while ((w >> 34) != epoch || ((w >> 32) & 3u) == 0u);
       }
-      const unsigned long long is_prefix = __ballot(((w >> 32) & 3u) == 2u);
+      const unsigned long long is_prefix = ballot(((w >> 32) & 3u) == 2u);
       const int first = __ffsll((long long)is_prefix) - 1;
       const int take = (first < 0 || lane <= first) ? (int)(unsigned)(w & 0xffffffffull) : 0;
       prefix += wave_sum(take);

@@ -322,7 +322,7 @@ k_shot(const float4 *__restrict__ kp, int nk, GridView g, const float4 *__restri
       ok = !(p.x == q.x && p.y == q.y && p.z == q.z);
       s_v[lane] = make_float4(p.x - q.x, p.y - q.y, p.z - q.z, __uint_as_float((unsigned)(key >> 32)));
     }
-    const unsigned long long mask = __ballot(ok);
+    const unsigned long long mask = ballot(ok);
     n_valid += __popcll(mask);
     __syncthreads();
     if (lane < 7) {
@@ -367,13 +367,13 @@ k_shot(const float4 *__restrict__ kp, int nk, GridView g, const float4 *__restri
         dpx = vx * v1[0] + vy * v1[1] + vz * v1[2];
         dpz = vx * v3[0] + vy * v3[1] + vz * v3[2];
       }
-      const unsigned long long mask = __ballot(ok);
+      const unsigned long long mask = ballot(ok);
       const int rank = base + __popcll(mask & ((1ull << lane) - 1ull));
       const bool mid = ok && rank >= median - 2 && rank <= median + 2;
-      plus_x += __popcll(__ballot(ok && dpx >= 0));
-      plus_z += __popcll(__ballot(ok && dpz >= 0));
-      five_x += __popcll(__ballot(mid && dpx > 0));
-      five_z += __popcll(__ballot(mid && dpz > 0));
+      plus_x += __popcll(ballot(ok && dpx >= 0));
+      plus_z += __popcll(ballot(ok && dpz >= 0));
+      five_x += __popcll(ballot(mid && dpx > 0));
+      five_z += __popcll(ballot(mid && dpz > 0));
       base += __popcll(mask);
     }
     int p = 2 * plus_x - n_valid;

@@ -100,7 +100,7 @@ k_sift_dog(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int
         int s = sA, e = 0;
         float sig = sigA, thr = thrA, rcp = rcpA, num = 0.0f, den = 0.0f;
         bool active = mine;
-        while (__ballot(active)) {
+        while (ballot(active)) {
           if (active) {
             // eight list entries are requested at a time (L2-resident scratch: one round trip per window);
             // past the end of the list they read as "beyond 3 sigma"
@@ -271,7 +271,7 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
             valid[j] = e < m;
             slot[j] = valid[j] ? (unsigned)W.arena[base + e] : 0u;
           }
-          if (!__ballot(valid[0])) break;          // wave-uniform: every list is exhausted
+          if (!ballot(valid[0])) break;          // wave-uniform: every list is exhausted
           float d2[4], val[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -281,7 +281,7 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
 #pragma unroll
           for (int k = 0; k < NS; ++k) {
             // the lists are sorted: if no lane's first entry of the four is inside 3 sigma, none of the others is
-            if (__ballot(valid[0] && d2[0] <= thr[k])) {
+            if (ballot(valid[0] && d2[0] <= thr[k])) {
               float w[4], vw[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -624,7 +624,7 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
   // a run of live points is normally one compact patch; where the Hilbert curve leaves the occupied
   // area and re-enters far away it is worked group by group (lanes near the first open lane)
   for (int grp = 0; grp < 64; ++grp) {
-  const unsigned long long open = __ballot(todo);
+  const unsigned long long open = ballot(todo);
   if (!open) break;
   const int leader = __ffsll((long long)open) - 1;
   const int ldx = cx - __shfl(cx, leader, 64), ldy = cy - __shfl(cy, leader, 64), ldz = cz - __shfl(cz, leader, 64);
@@ -632,7 +632,7 @@ k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
   todo = todo && !active;
   int need = 1;                 // most lanes are decided by the first ring; starting wider measured slower
   for (int pass = 0; pass < 4096; ++pass) {
-    if (!__ballot(active)) break;
+    if (!ballot(active)) break;
     const int E = wave_max_int(active ? need : 0);
     const int lx = wave_min_int(active ? cx : 0x7fffffff), hx = wave_max_int(active ? cx : -0x7fffffff);
     const int ly = wave_min_int(active ? cy : 0x7fffffff), hy = wave_max_int(active ? cy : -0x7fffffff);

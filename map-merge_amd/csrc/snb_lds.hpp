@@ -36,6 +36,8 @@
 // halves, values kept in registers between the phases.
 #pragma once
 
+#include <type_traits>
+
 #include "device_util.hpp"
 
 namespace mm3d {
@@ -237,7 +239,7 @@ __device__ __forceinline__ void snb_stage(const GridView &g, SnbLds<Cfg> &S, int
       const bool k = in && keep(c);
       float pv = 0.0f;
       if (Cfg::kPay && k) pv = load_pay(c);
-      const unsigned long long m = __ballot(k);
+      const unsigned long long m = ballot(k);
       if (m) {
         int base = 0;
         if (lane == 0) base = atomicAdd(n_tile, __popcll(m));
@@ -283,7 +285,10 @@ __device__ __forceinline__ int snb_sort_one(SnbLds<Cfg> &S, SnbWave<Cfg> &W, flo
   // ((dx dx + dy dy) + dz dz), two at a time: the packed operations round each half like the scalar ones)
   SNB_TICK(t_a);
   int nh = 0;
-  {
+  // (the whole ball -- lo2 = 0, every query whose list fits the hit buffer -- needs no lower test: d2 >= 0 always holds;
+  // two compares and two mask operations less per 128 candidates than a band)
+  auto phase_a = [&](auto banded_tag) {
+    constexpr bool kBanded = decltype(banded_tag)::value;
     // Two steps of 128 candidates per iteration, straight-line: a lane that has no hit stores to the dump entry
     // instead of branching around the store, so the two steps' instruction streams interleave (a wave is a chain
     // of dependent operations; what it gains here it gains in latency, not in instruction count).
@@ -303,8 +308,8 @@ __device__ __forceinline__ int snb_sort_one(SnbLds<Cfg> &S, SnbWave<Cfg> &W, flo
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int s = c0 + u * 2 * kWave + 2 * lane;
-        const bool h0 = d2[u].x < hi2 && d2[u].x >= lo2, h1 = d2[u].y < hi2 && d2[u].y >= lo2;
-        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+        const bool h0 = d2[u].x < hi2 && (!kBanded || d2[u].x >= lo2), h1 = d2[u].y < hi2 && (!kBanded || d2[u].y >= lo2);
+        const unsigned long long m0 = ballot(h0), m1 = ballot(h1);
         // (positions past the buffer are folded onto its last entry: nh > kHitCap is looked at after the loop)
         const int p0 = h0 ? min(snb_mbcnt(m0, nh), Cfg::kHitCap - 1) : kDump;
         nh += __popcll(m0);
@@ -314,7 +319,9 @@ __device__ __forceinline__ int snb_sort_one(SnbLds<Cfg> &S, SnbWave<Cfg> &W, flo
         W.d2buf[p1] = d2[u].y; W.sbuf[p1] = (unsigned short)(s + 1);
       }
     }
-  }
+  };
+  if (lo2 > 0.0f) phase_a(std::true_type());       // wave-uniform
+  else phase_a(std::false_type());
   wave_lds_fence();
   SNB_TOCK(4, t_a);
   if (nh > Cfg::kHitCap) return -1;              // wave-uniform
@@ -439,7 +446,7 @@ __device__ __forceinline__ int snb_sort_one(SnbLds<Cfg> &S, SnbWave<Cfg> &W, flo
       for (int u = 0; u < 2; ++u) {
         const int h = (u0 + u) * kWave + lane;
         const bool tie = eq[u] > 1 && h < nh;    // (the hit itself is one of the equal ones)
-        if (__ballot(tie)) {
+        if (ballot(tie)) {
           if (tie) {
             const unsigned idx = S.tw[slot[u0 + u]];
             for (int jj = bs[u]; jj < be[u]; ++jj)
