@@ -152,8 +152,8 @@ struct Context {
   // before the arena wraps around or is replaced
   void *pinned = nullptr;
   size_t pinned_bytes = 0, pinned_off = 0;
-  // exclusive_scan_int (grid.hip): per-tile status words and the ticket counter of the single-launch scan; the
-  // words carry the launch's epoch, so nothing is cleared between launches
+  // the chained scans (runtime.cpp::scan_prepare; k_scan_int in grid.hip, k_scan_fused in scan_fused.hpp): per-tile status
+  // words and the ticket counter; the words carry the launch's epoch, so nothing is cleared between launches
   unsigned long long *scan_status = nullptr;
   unsigned *scan_ticket = nullptr;
   size_t scan_tiles_cap = 0;
@@ -188,6 +188,14 @@ struct Context {
   }
   int prof_slot(const char *name);
   void prof_resolve();
+};
+
+// A raw device pointer with DevBuf's accessor, for a region carved out of a larger buffer (several small arrays that are
+// zeroed by one fill dispatch live in one DevBuf): code written against `.get()` works on either.
+template <typename T>
+struct DevPtr {
+  T *p = nullptr;
+  T *get() const { return p; }
 };
 
 template <typename T>

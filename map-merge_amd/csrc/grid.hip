@@ -780,7 +780,7 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl_, float min_cell)
   DevBuf<int> counts(c, kHilColumns + 2), col_start(c, kHilColumns + 1), slots(c, n);
   DevBuf<uint32_t> ranks(c, total);
   MM3D_HIP(hipMemsetAsync(counts.get(), 0, (kHilColumns + 2) * sizeof(int), c->stream));   // (counts and the too_long word: one fill)
-  struct { int *p; int *get() const { return p; } } too_long{counts.get() + kHilColumns + 1};
+  const DevPtr<int> too_long{counts.get() + kHilColumns + 1};
   MM3D_LAUNCH(c, "hilbert_sort", total * 12.0, k_hil_count, dim3(div_up(total, 256)), dim3(256), 0, (const uint32_t *)keys.get(), total,
               counts.get(), ranks.get());
   exclusive_scan_int(c, counts.get(), col_start.get(), kHilColumns + 1);

@@ -858,7 +858,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     int *const n_search_p = flags_p + (size_t)n * 3 + 1;
     unsigned char *const need_search_p = reinterpret_cast<unsigned char *>(n_search_p + 1);
     bool zero_again = false;                             // (the first extremum test finds its words cleared by the fill above)
-    struct { unsigned char *p; unsigned char *get() const { return p; } } knn_ok{knn_ok_p};
+    const DevPtr<unsigned char> knn_ok{knn_ok_p};
     // the normals ride on the first octave when it works on `points` itself and their ball is inside the scale space's
     const bool fused = oct == 0 && normals_out && fuse_normals && octave_cloud == points && normals_radius > 0.0 &&
                        (float)(normals_radius * normals_radius) <= r2 && octave_cloud->n_finite == octave_cloud->n;
@@ -884,8 +884,8 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     // for LDS behind the other streams' kernels).
     const Grid &gk = gr;
     DevBuf<float4> dogx(c, (size_t)n * 2);
-    struct { int *p; int *get() const { return p; } } flags{flags_p}, n_search{n_search_p};
-    struct { unsigned char *p; unsigned char *get() const { return p; } } need_search{need_search_p};
+    const DevPtr<int> flags{flags_p}, n_search{n_search_p};
+    const DevPtr<unsigned char> need_search{need_search_p};
     DevBuf<int> pos(c, (size_t)n * 3 + 1);
     const int nh = (int)octave_cloud->n_finite;
     int *h = (int *)c->pin(64);                          // [0] keypoints, [1] points for the searching kernel
