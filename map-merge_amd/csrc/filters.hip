@@ -49,33 +49,46 @@ struct VoxelStartStore {
     if (j == (size_t)n) { *n_voxels = prefix; return; }
     if (v) starts[prefix] = (int)j;
   }
+  __device__ __forceinline__ void done() const {}
 };
 
 // One thread per voxel walks its (stable-sorted, i.e. ascending input index) members and sums in
 // float in that order: bit-identical to CentroidPoint on the CPU restatement.
-__global__ void k_voxel_centroid(const float4 *__restrict__ pts, const uint32_t *__restrict__ order,
-                                 const int *__restrict__ starts, int nvox, int nvalid, float4 *__restrict__ out)
+__global__ void __launch_bounds__(256)
+k_voxel_centroid(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, const int *__restrict__ starts,
+                 const int *__restrict__ nvox_dev, const int *__restrict__ unsorted, int nvalid, float4 *__restrict__ out,
+                 unsigned *__restrict__ box)
 {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= nvox) return;
-  int b = starts[v], e = (v + 1 < nvox) ? starts[v + 1] : nvalid;
-  float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f;
-  for (int j = b; j < e; ++j) {
-    float4 p = pts[order[j]];
-    unsigned c = __float_as_uint(p.w);
-    sx += p.x; sy += p.y; sz += p.z;
-    sr += (float)((c >> 16) & 255u);
-    sg += (float)((c >> 8) & 255u);
-    sb += (float)(c & 255u);
-    sa += (float)((c >> 24) & 255u);
+  // (the grid is sized by the bound -- one thread per finite input point --: the number of voxels is still on the device
+  // when this is launched; the centroids' bounding box is reduced on the way out, scan_fused.hpp::BoxAcc)
+  // `unsorted`: the counting sort's "a bin was too long, nothing was placed" word -- `order` is not valid then, and the host,
+  // which sees that word at the same wait as the count, sorts by radix and launches this again (unsorted = nullptr)
+  const int nvox = (unsorted && *unsorted) ? 0 : *nvox_dev;
+  BoxAcc acc;
+  // (grid-stride over the voxels with a capped grid, and every block leaves its box in its own slot: blocks that finish
+  // together and meet at seven shared words pay ~50 ns per atomic, one after the other -- 1 750 blocks did, 8 x the launch)
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += gridDim.x * blockDim.x) {
+    int b = starts[v], e = (v + 1 < nvox) ? starts[v + 1] : nvalid;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f;
+    for (int j = b; j < e; ++j) {
+      float4 p = pts[order[j]];
+      unsigned c = __float_as_uint(p.w);
+      sx += p.x; sy += p.y; sz += p.z;
+      sr += (float)((c >> 16) & 255u);
+      sg += (float)((c >> 8) & 255u);
+      sb += (float)(c & 255u);
+      sa += (float)((c >> 24) & 255u);
+    }
+    float cnt = (float)(e - b);
+    float4 o;
+    o.x = sx / cnt; o.y = sy / cnt; o.z = sz / cnt;
+    unsigned rgba = ((unsigned)(sa / cnt) << 24) | ((unsigned)(sr / cnt) << 16) | ((unsigned)(sg / cnt) << 8) |
+                    (unsigned)(sb / cnt);
+    o.w = __uint_as_float(rgba);
+    out[v] = o;
+    acc.add(o);
   }
-  float cnt = (float)(e - b);
-  float4 o;
-  o.x = sx / cnt; o.y = sy / cnt; o.z = sz / cnt;
-  unsigned rgba = ((unsigned)(sa / cnt) << 24) | ((unsigned)(sr / cnt) << 16) | ((unsigned)(sg / cnt) << 8) |
-                  (unsigned)(sb / cnt);
-  o.w = __uint_as_float(rgba);
-  out[v] = o;
+  acc.flush_slot(box);
 }
 
 // Does VoxelGrid(leaf = resolution) return this cloud unchanged, bit for bit?  True when every point is finite, the voxel
@@ -169,23 +182,36 @@ mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
   DevBuf<int> too_long(c, 1);
   counting_sort_pairs_u32(c, keys.get(), n, (uint64_t)div_b[0] * (uint64_t)div_b[1] * (uint64_t)div_b[2], keys2.get(), vals2.get(),
                           too_long.get());
-  DevBuf<int> starts(c, (size_t)n + 1), n_vox_dev(c, 1);       // (starts sized by its bound: the count is only known after the wait)
-  int *h = (int *)c->pin(64);
+  // One wait for the whole filter: the centroid launch is sized by its bound and reads the voxel count on the device, so the
+  // count, the counting sort's "bin too long" word and the centroids' bounding box come back together (the new cloud needs no
+  // k_bbox launch and no wait of its own).
+  const size_t bound = in->n_finite;                            // a voxel holds at least one finite point
+  DevBuf<int> starts(c, (size_t)n + 1);
+  const unsigned cblocks = std::min<unsigned>(div_up(bound, 256), 512u);
+  DevBuf<unsigned> ctl(c, 16 + 8 * (size_t)cblocks);             // [0] voxels, [16 + 8 b ..] block b's box of centroids
+  DevBuf<float4> out(c, bound);
+  const size_t ctl_bytes = (16 + 8 * (size_t)cblocks) * sizeof(unsigned);
+  unsigned *h = (unsigned *)c->pin(64 + ctl_bytes);
   for (int attempt = 0; attempt < 2; ++attempt) {
-    scan_fused(c, "voxel_starts", n * 12.0, (size_t)n + 1, VoxelHeadLoad{keys2.get(), n}, VoxelStartStore{n, starts.get(), n_vox_dev.get()});
-    MM3D_HIP(hipMemcpyAsync(h, n_vox_dev.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    MM3D_HIP(hipMemcpyAsync(h + 1, too_long.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    scan_fused(c, "voxel_starts", n * 12.0, (size_t)n + 1, VoxelHeadLoad{keys2.get(), n}, VoxelStartStore{n, starts.get(), (int *)ctl.get()});
+    // 16 B read per raw point + 16 B written per voxel
+    MM3D_LAUNCH(c, "voxel_centroid", in->n_finite * 32.0, k_voxel_centroid, dim3(cblocks), dim3(256), 0, in->pts.get(),
+                (const uint32_t *)vals2.get(), (const int *)starts.get(), (const int *)ctl.get(), attempt == 0 ? (const int *)too_long.get() : (const int *)nullptr, (int)in->n_finite, out.get(),
+                ctl.get() + 16);
+    MM3D_HIP(hipMemcpyAsync(h + 16, ctl.get(), ctl_bytes, hipMemcpyDeviceToHost, c->stream));
+    MM3D_HIP(hipMemcpyAsync(h + 15, too_long.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->sync();
-    if (attempt == 1 || !h[1]) break;
+    if (attempt == 1 || !h[15]) break;
+    // (a bin of the counting sort was too long and nothing was placed: the launches above found no voxel; radix sort, once more)
     sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), n, 32);
   }
-  const int nvox = h[0];
-  DevBuf<float4> out(c, nvox);
-  // 16 B read per raw point + 16 B written per voxel
-  MM3D_LAUNCH(c, "voxel_centroid", in->n_finite * 16.0 + nvox * 16.0, k_voxel_centroid, dim3(div_up(nvox, 256)), dim3(256), 0,
-              in->pts.get(), vals2.get(), starts.get(), nvox, (int)in->n_finite, out.get());
+  const size_t nvox = h[16];
+  mm3d_cloud *res = cloud_from_device(c, std::move(out), nvox);
+  unsigned box[8];
+  box_of_slots(h + 32, cblocks, box);
+  cloud_set_bbox(res, box);
   c->settle();
-  return cloud_from_device(c, std::move(out), (size_t)nvox);
+  return res;
 }
 
 // ---------------------------------------------------------------- radius outlier removal
@@ -231,8 +257,11 @@ mm3d_cloud *remove_outliers(Context *c, const mm3d_cloud *in, double radius, int
     }
   }
   DevBuf<float4> out;
-  size_t m = compact_points(c, in->pts.get(), keep.get(), n, out);
-  return cloud_from_device(c, std::move(out), m);
+  unsigned box[7];
+  size_t m = compact_points(c, in->pts.get(), keep.get(), n, out, box);     // (the kept points' bounding box comes back with the count)
+  mm3d_cloud *res = cloud_from_device(c, std::move(out), m);
+  cloud_set_bbox(res, box);
+  return res;
 }
 
 // ---------------------------------------------------------------- composeMaps: transform + concat

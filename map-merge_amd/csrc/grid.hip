@@ -594,8 +594,9 @@ void grid_ensure_nblists(Context *c, const Grid &g_, int R)
 // z below it; a work item is a run of at most 64 consecutive points that never straddles a
 // 2 m x 2 m column block (8 x 8 Hilbert cells): the curve may leave the occupied area and re-enter
 // far away, but never inside one block.
+// (counts / ranks != null: the counting sort's first step -- a point's arrival rank in its Hilbert column -- in the same launch)
 __global__ void k_hilbert_keys(const float4 *__restrict__ pts, int n, float minx, float miny, float minz, float inv,
-                               uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+                               uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, int *__restrict__ counts, uint32_t *__restrict__ ranks)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -614,7 +615,9 @@ __global__ void k_hilbert_keys(const float4 *__restrict__ pts, int n, float minx
       const unsigned t = x; x = y; y = t;
     }
   }
-  keys[i] = (d << 10) | z;
+  const uint32_t key = (d << 10) | z;
+  keys[i] = key;
+  if (counts) ranks[i] = (uint32_t)atomicAdd(&counts[key >> 10], 1);
 }
 
 __global__ void k_hilbert_gather(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, int n, float4 *__restrict__ out)
@@ -644,6 +647,7 @@ struct ItemFillStore {
     while (cnt < 64 && j + cnt < (size_t)n && !h.head(j + cnt)) ++cnt;
     items[prefix] = make_int2((int)j, cnt);
   }
+  __device__ __forceinline__ void done() const {}
 };
 
 // ---------------------------------------------------------------- counting sort of (key, index) pairs
@@ -716,19 +720,11 @@ void counting_sort_pairs_u32(Context *c, const uint32_t *keys, int n, uint64_t k
 }
 
 // Hilbert order by counting sort on the column index (key >> 10, at most 2^20 columns): a point's arrival rank in
-// its column comes with the histogram, a scan gives the columns' starts, and inside its column (a handful of
+// its column comes with the histogram (k_hilbert_keys computes both), a scan gives the columns' starts, and inside its column (a handful of
 // points; a wall: a hundred) every point counts the smaller (key, index) pairs -- the order a stable radix sort
 // of the keys gives, in four small launches instead of rocPRIM's seven.
 constexpr int kHilColumns = 1 << 20;
 constexpr int kHilColumnMax = 1024;      // longer columns (degenerate clouds) leave it to the radix sort
-__global__ void k_hil_count(const uint32_t *__restrict__ keys, int n, int *__restrict__ counts, uint32_t *__restrict__ ranks)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t key = keys[i];
-  if (key == 0xFFFFFFFFu) return;               // non-finite point
-  ranks[i] = (uint32_t)atomicAdd(&counts[key >> 10], 1);
-}
 __global__ void k_hil_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ranks, const int *__restrict__ col_start, int n,
                               int *__restrict__ slots, int *__restrict__ too_long)
 {
@@ -774,15 +770,13 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl_, float min_cell)
   for (int a = 0; a < 3; ++a) ext = std::fmax(ext, cl->bmax[a] - cl->bmin[a]);
   const float cell = std::fmax(std::fmax(0.25f, min_cell), ext / 1023.0f);
   DevBuf<uint32_t> keys(c, total), vals(c, total), keys2(c, total);
-  MM3D_LAUNCH(c, "hilbert_keys", total * 24.0, k_hilbert_keys, dim3(div_up(total, 256)), dim3(256), 0, cl->pts.get(), total,
-              cl->bmin[0], cl->bmin[1], cl->bmin[2], 1.0f / cell, keys.get(), vals.get());
   cl->hil_pts = DevBuf<float4>(c, n);
   DevBuf<int> counts(c, kHilColumns + 2), col_start(c, kHilColumns + 1), slots(c, n);
   DevBuf<uint32_t> ranks(c, total);
   MM3D_HIP(hipMemsetAsync(counts.get(), 0, (kHilColumns + 2) * sizeof(int), c->stream));   // (counts and the too_long word: one fill)
   const DevPtr<int> too_long{counts.get() + kHilColumns + 1};
-  MM3D_LAUNCH(c, "hilbert_sort", total * 12.0, k_hil_count, dim3(div_up(total, 256)), dim3(256), 0, (const uint32_t *)keys.get(), total,
-              counts.get(), ranks.get());
+  MM3D_LAUNCH(c, "hilbert_keys", total * 36.0, k_hilbert_keys, dim3(div_up(total, 256)), dim3(256), 0, cl->pts.get(), total,
+              cl->bmin[0], cl->bmin[1], cl->bmin[2], 1.0f / cell, keys.get(), vals.get(), counts.get(), ranks.get());
   exclusive_scan_int(c, counts.get(), col_start.get(), kHilColumns + 1);
   MM3D_LAUNCH(c, "hilbert_sort", total * 16.0, k_hil_scatter, dim3(div_up(total, 256)), dim3(256), 0, (const uint32_t *)keys.get(),
               (const uint32_t *)ranks.get(), (const int *)col_start.get(), total, slots.get(), too_long.get());
@@ -815,30 +809,52 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl_, float min_cell)
 }
 
 // ---------------------------------------------------------------- ordered compaction
-__global__ void k_compact(const float4 *__restrict__ in, const int *__restrict__ flags, const int *__restrict__ pos,
-                          size_t n, float4 *__restrict__ out)
-{
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (flags[i]) out[pos[i]] = in[i];
-}
+// Ordered compaction, the count and the bounding box of what is kept in ONE launch and one wait (scan_fused.hpp): the output is
+// sized by its bound n, the kept points -- all finite: the callers' flags are only set for finite points -- are scattered by
+// the scan's own store, and their box rides along (box_out: 7 words as cloud_bbox reads them, or null).
+struct CompactLoad {
+  const int *flags; size_t n;
+  __device__ __forceinline__ int operator()(size_t j) const { return j < n ? (flags[j] ? 1 : 0) : 0; }
+};
+struct CompactStore {
+  const float4 *in; size_t n; float4 *out; int *total; unsigned *box;
+  BoxAcc acc;
+  __device__ __forceinline__ void operator()(size_t j, int prefix, int v)
+  {
+    if (j == n) { *total = prefix; return; }
+    if (!v) return;
+    const float4 p = in[j];
+    out[prefix] = p;
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) acc.add(p);     // (min_neighbours < 0 keeps every point, finite or not)
+  }
+  __device__ __forceinline__ void done() { acc.flush(box); }
+};
 
-size_t compact_points(Context *c, const float4 *in, const int *flags, size_t n, DevBuf<float4> &out)
+size_t compact_points(Context *c, const float4 *in, const int *flags, size_t n, DevBuf<float4> &out, unsigned *box_host)
 {
   if (n == 0) { out = DevBuf<float4>(c, 0); return 0; }
-  DevBuf<int> pos(c, n + 1);
-  // scan n+1 entries so pos[n] is the total (flags has n+1 readable entries: see callers)
-  exclusive_scan_int(c, flags, pos.get(), n + 1);
-  int *h = (int *)c->pin(64);
-  MM3D_HIP(hipMemcpyAsync(h, pos.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  out = DevBuf<float4>(c, n);
+  DevBuf<unsigned> ctl(c, 16);                       // [0] kept count, [8..14] box
+  unsigned *h = (unsigned *)c->pin(64);
+  std::memset(h, 0, 64);
+  std::memcpy(h + 8, kBoxInit, sizeof(kBoxInit));
+  MM3D_HIP(hipMemcpyAsync(ctl.get(), h, 64, hipMemcpyHostToDevice, c->stream));
+  scan_fused(c, "compact", n * 24.0, n + 1, CompactLoad{flags, n}, CompactStore{in, n, out.get(), (int *)ctl.get(), ctl.get() + 8, BoxAcc()});
+  unsigned *r = (unsigned *)c->pin(64);
+  MM3D_HIP(hipMemcpyAsync(r, ctl.get(), 64, hipMemcpyDeviceToHost, c->stream));
   c->sync();
-  size_t m = (size_t)h[0];
-  out = DevBuf<float4>(c, m);
-  if (m) {
-    MM3D_LAUNCH(c, "compact", n * 24.0, k_compact, dim3(div_up(n, 256)), dim3(256), 0, in, flags, pos.get(), n, out.get());
-    c->settle();
-  }
-  return m;
+  if (box_host) std::memcpy(box_host, r + 8, 7 * sizeof(unsigned));
+  return (size_t)r[0];
+}
+
+// a cloud whose producer reduced its bounding box (scan_fused.hpp::BoxAcc): no k_bbox launch, no wait
+void cloud_set_bbox(mm3d_cloud *cl, const unsigned box[7])
+{
+  std::lock_guard<std::recursive_mutex> lk(cl->cache_mu);
+  cl->have_bbox = true;
+  cl->n_finite = box[6];
+  if (cl->n_finite)
+    for (int a = 0; a < 3; ++a) { cl->bmin[a] = ord2f(box[a]); cl->bmax[a] = ord2f(box[3 + a]); }
 }
 
 // compute units of a device (the persistent grids of snb_lds.hpp are sized from it)

@@ -11,6 +11,79 @@
 
 namespace mm3d {
 
+// Bounding box of the points a kernel produces, reduced on the way out: every thread folds its points into (mn, mx, cnt) and
+// calls flush() once, all threads of its 256-thread block together; the block's box lands in box[0..6] (the ordered-uint
+// encoding and word order of grid.hip::k_bbox / cloud_bbox: min x y z, max x y z, count; initialised to FFFFFFFF x 3, 0 x 4).
+// A cloud made this way carries its box and needs no k_bbox launch and no wait of its own.
+struct BoxAcc {
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int cnt = 0;
+  __device__ __forceinline__ void add(const float4 &p)
+  {
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    ++cnt;
+  }
+  // Called by every thread of a 256-thread block (four whole waves).  One reduction per block, and a block only touches a
+  // word of the shared box when it would move it: a first version with one set of unconditional atomics per WAVE made the
+  // 500 k-point centroid launch 30 x slower (55 000 atomics on one cache line).
+  template <bool kSlot>
+  __device__ __forceinline__ void flush_impl(unsigned *box)
+  {
+    __shared__ float s_mn[4][3], s_mx[4][3];
+    __shared__ int s_cnt[4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      for (int o = 32; o > 0; o >>= 1) {
+        mn[a] = fminf(mn[a], __shfl_down(mn[a], o, kWave));
+        mx[a] = fmaxf(mx[a], __shfl_down(mx[a], o, kWave));
+      }
+    const int total = wave_sum(cnt);
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; }
+      s_cnt[wave] = total;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int n = 0;
+      for (int w = 0; w < 4; ++w) n += s_cnt[w];
+      if (kSlot) box[6] = (unsigned)n;
+      if (n > 0 || kSlot) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          float lo = s_mn[0][a], hi = s_mx[0][a];
+          for (int w = 1; w < 4; ++w) { lo = fminf(lo, s_mn[w][a]); hi = fmaxf(hi, s_mx[w][a]); }
+          const unsigned ol = n > 0 ? f2ord(lo) : 0xFFFFFFFFu, oh = n > 0 ? f2ord(hi) : 0u;
+          if (kSlot) { box[a] = ol; box[3 + a] = oh; continue; }
+          if (ol < __hip_atomic_load(&box[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&box[a], ol);
+          if (oh > __hip_atomic_load(&box[3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&box[3 + a], oh);
+        }
+        if (!kSlot) atomicAdd(&box[6], (unsigned)n);
+      }
+    }
+  }
+  // flush() into shared words (above) suits launches whose blocks finish one after the other (the chained scan: ~100 blocks,
+  // most of which find the box already wider than theirs).  A launch whose blocks all finish together pays ~50 ns per atomic on
+  // the one cache line, one after the other; flush_slot() instead leaves each block's box in its own eight words, plain stores,
+  // and whoever reads them (the host, next to the count it waits for anyway: box_of_slots) folds them.
+  __device__ __forceinline__ void flush(unsigned *box) { flush_impl<false>(box); }
+  __device__ __forceinline__ void flush_slot(unsigned *slots) { flush_impl<true>(slots + 8 * (size_t)blockIdx.x); }
+};
+// host: fold `blocks` slots (eight words each, as flush_slot leaves them) into box[0..6]
+inline void box_of_slots(const unsigned *slots, unsigned blocks, unsigned *box)
+{
+  for (int a = 0; a < 3; ++a) { box[a] = 0xFFFFFFFFu; box[3 + a] = 0u; }
+  box[6] = 0u;
+  for (unsigned b = 0; b < blocks; ++b) {
+    const unsigned *s = slots + 8 * (size_t)b;
+    for (int a = 0; a < 3; ++a) { box[a] = s[a] < box[a] ? s[a] : box[a]; box[3 + a] = s[3 + a] > box[3 + a] ? s[3 + a] : box[3 + a]; }
+    box[6] += s[6];
+  }
+}
+constexpr unsigned kBoxInit[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+
 template <class Load, class Store>
 __global__ void __launch_bounds__(256)
 k_scan_fused(size_t n, unsigned long long *status, unsigned *ticket, unsigned ticket_base, unsigned epoch, Load load, Store store)
@@ -73,9 +146,10 @@ k_scan_fused(size_t n, unsigned long long *status, unsigned *ticket, unsigned ti
     if (base + k < n) store(base + k, run, v[k]);
     run += v[k];
   }
+  store.done();        // called by EVERY thread of the grid once, after its elements (a store that reduces something flushes here)
 }
 
-// load: size_t -> int (device callable), store: (size_t index, int exclusive_prefix, int value) -> void
+// load: size_t -> int (device callable), store: (size_t index, int exclusive_prefix, int value) -> void, plus done()
 template <class Load, class Store>
 void scan_fused(Context *c, const char *name, double bytes, size_t n, Load load, Store store)
 {

@@ -142,7 +142,8 @@ mm3d_cloud *cloud_from_memory(Context *c, const void *src, size_t n, size_t stri
 void cloud_download(Context *c, const mm3d_cloud *cl, void *dst, size_t stride, size_t rgba_off);
 const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl);
 // ordered compaction: keeps in[i] where flags[i] != 0, preserving order; returns kept count
-size_t compact_points(Context *c, const float4 *in, const int *flags, size_t n, DevBuf<float4> &out);
+size_t compact_points(Context *c, const float4 *in, const int *flags, size_t n, DevBuf<float4> &out, unsigned *box_host = nullptr);   // box_host: 7 words for cloud_set_bbox
+void cloud_set_bbox(mm3d_cloud *cl, const unsigned box[7]);
 void exclusive_scan_int(Context *c, const int *in, int *out, size_t n);
 // one chained-scan launch's share of the context's scan state (grid.hip::scan_prepare; scan_fused.hpp)
 constexpr int kScanItems = 16, kScanTile = 256 * kScanItems;
