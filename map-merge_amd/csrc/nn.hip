@@ -43,12 +43,25 @@ constexpr int kAcc = 17;     // sum p(3) | sum q(3) | sum q p^T (9, row = q) | s
 #define MM3D_NN_ATTR
 #endif
 constexpr int kTile = MM3D_NN_TILE;   // staged target points per wave and tile (8 KiB of LDS)
+#ifndef MM3D_NN_ROWS_PER_LANE
+#define MM3D_NN_ROWS_PER_LANE 4
+#endif
+// MM3D_NN_PREFETCH=1: the next tile's gathers are issued into registers before this tile is scanned.  Measured and left off:
+// 16 more VGPRs (112: four waves per SIMD instead of five for the ICP variant) for a latency that the other resident waves
+// already cover -- headline 955 against 960 map-pairs/s, 64 x 50 k 10 250 against 10 520 (interleaved A/B, round 4).
+#ifndef MM3D_NN_PREFETCH
+#define MM3D_NN_PREFETCH 0
+#endif
+constexpr bool kPrefetch = MM3D_NN_PREFETCH != 0;
+constexpr int kRowsPerLane = MM3D_NN_ROWS_PER_LANE;   // row headers a lane reads per chunk
+constexpr int kRows = kWave * kRowsPerLane;           // rows of the box per chunk (power of two: the slot -> row search halves it)
 
 #ifdef MM3D_NN_STATS
 __device__ unsigned long long g_nn_stats[64];   // 0 waves, 1 passes, 2 row chunks, 3 staged points, 4 active lanes at pass, 5 rows, 6 max wave cycles, 7 sum wave cycles, 8.. log2 histogram of wave cycles
 #define MM3D_STAT(i_, v_) do { if (MM3D_NN_STATS == 1 && lane == 0) atomicAdd(&g_nn_stats[i_], (unsigned long long)(v_)); } while (0)
 #define MM3D_TICK(var_) const long long var_ = wall_clock64()
-#define MM3D_TOCK(i_, from_) do { if (lane == 0) atomicAdd(&g_nn_stats[i_], (unsigned long long)(wall_clock64() - (from_))); } while (0)
+// (phase ticks are summed in registers and flushed once per wave: an atomic per chunk on one word slowed the kernel threefold)
+#define MM3D_TOCK(i_, from_) do { stat_ticks[(i_) - 32] += wall_clock64() - (from_); } while (0)
 #else
 #define MM3D_STAT(i_, v_)
 #define MM3D_TICK(var_)
@@ -130,8 +143,8 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
   // broadcast read, and the distance arithmetic of candidate pairs packs into v_pk_* instructions
   __shared__ __attribute__((aligned(16))) float s_cx[4][kTile], s_cy[4][kTile], s_cz[4][kTile];
   __shared__ __attribute__((aligned(16))) unsigned s_cw[4][kTile];
-  __shared__ int s_off[4][64];
-  __shared__ int s_beg[4][64];
+  __shared__ int s_off[4][kRows];
+  __shared__ int s_beg[4][kRows];
   __shared__ unsigned long long s_merge[SPLIT == 4 ? 4 : 1][64];
   if (MODE == 0 && st->done) return;
   // the score of a pair's ICP result: once, in the first round after its ICP has finished
@@ -172,6 +185,7 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
   float best = INFINITY, bestd = INFINITY;
 
 #ifdef MM3D_NN_STATS
+  long long stat_ticks[3] = {0, 0, 0};
   const long long t_begin = wall_clock64();
   for (int e = 1; e <= 8; ++e) {          // what ring the lanes ask for before the first pass
     const int c_ = __popcll(ballot(active && (e < 8 ? need == e : need >= 8)));
@@ -194,18 +208,31 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
     const int z0 = max(lz - E, 0), z1 = min(hz + E, g.dz - 1);
     const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
     const int nrows = (x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
-    for (int r0 = 0; r0 < nrows; r0 += kWave) {
+    for (int r0 = 0; r0 < nrows; r0 += kRows) {
       MM3D_TICK(t_hdr);
-      // one row header per lane, exclusive scan of the span lengths
-      const int r = r0 + lane;
-      int b = 0, len = 0;
-      if (r < nrows) {
-        const int z = z0 + r / ny, y = y0 + r % ny;
-        const int row = (z * g.dy + y) * g.dx;
-        b = g.cell_start[row + x0];
-        len = g.cell_start[row + x1 + 1] - b;
+      // Row headers, FOUR per lane (rows r0 + 4 lane .. + 3): a box of up to 256 rows costs one header round trip and fuller
+      // tiles instead of a header, a prefix scan and a ragged last tile per 64 rows (a pass has ~150 - 250 rows, a row ~3 points).
+      // Worth 2 % where the searches are short and many (64 maps x 50 k points), nothing on the headline, whose step is bound
+      // by instruction issue.  Exclusive scan of the span lengths.
+      int hb[kRowsPerLane], hl[kRowsPerLane];
+      {
+        const int r = r0 + kRowsPerLane * lane;
+        int zq = r / ny, yr = r - zq * ny;
+#pragma unroll
+        for (int u = 0; u < kRowsPerLane; ++u) {
+          hb[u] = 0; hl[u] = 0;
+          if (r + u < nrows) {
+            const int row = ((z0 + zq) * g.dy + (y0 + yr)) * g.dx;
+            hb[u] = g.cell_start[row + x0];
+            hl[u] = g.cell_start[row + x1 + 1];
+          }
+          if (++yr == ny) { yr = 0; ++zq; }
+        }
       }
-      int incl = len;
+      int mine = 0;
+#pragma unroll
+      for (int u = 0; u < kRowsPerLane; ++u) { hl[u] -= hb[u]; mine += hl[u]; }
+      int incl = mine;
 #pragma unroll
       for (int o = 1; o < kWave; o <<= 1) {
         const int t = __shfl_up(incl, o, kWave);
@@ -214,54 +241,60 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
       const int total = __shfl(incl, kWave - 1, kWave);
       MM3D_STAT(2, 1);
       MM3D_STAT(3, total);
-      MM3D_STAT(5, min(nrows - r0, kWave));
-      wave_lds_sync();                 // previous tile's readers are done
-      s_off[wave][lane] = incl - len;
-      s_beg[wave][lane] = b;
+      MM3D_STAT(5, min(nrows - r0, kRows));
+      wave_lds_sync();                 // previous chunk's readers are done
+      {
+        int off = incl - mine;
+#pragma unroll
+        for (int u = 0; u < kRowsPerLane; ++u) {
+          s_off[wave][kRowsPerLane * lane + u] = off;
+          s_beg[wave][kRowsPerLane * lane + u] = hb[u];
+          off += hl[u];
+        }
+      }
       wave_lds_sync();
       MM3D_TOCK(32, t_hdr);
       // SPLIT 4: this wave's quarter of the chunk's candidates (a multiple of four, so the padding stays at the end)
       const int share = SPLIT == 4 ? ((total + 15) >> 4) << 2 : total;
       const int t_first = SPLIT == 4 ? min(total, wave * share) : 0;
       const int t_last = SPLIT == 4 ? min(total, t_first + share) : total;
-      for (int t0 = t_first; t0 < t_last; t0 += kTile) {
+      // Tiles of kTile candidates: slot -> (row by binary search over the chunk's offsets) -> sorted target index
+      // (all of a lane's gathers are issued before the first LDS store: one memory round trip per tile).
+      constexpr int kPer = kTile / kWave;
+      float4 stage[kPer];
+      auto fetch_tile = [&](int t0, int cnt) {
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+          const int s = lane + u * kWave;
+          const int slot = t0 + (s < cnt ? s : 0);
+          int lo = 0;
+#pragma unroll
+          for (int step = kRows / 2; step > 0; step >>= 1)
+            if (s_off[wave][lo + step] <= slot) lo += step;   // offsets are non-decreasing; empty rows collapse
+          stage[u] = g.pts[s_beg[wave][lo] + (slot - s_off[wave][lo])];
+        }
+      };
+      int t0 = t_first, cnt = min(kTile, t_last - t0);
+      if (kPrefetch && cnt > 0) fetch_tile(t0, cnt);
+      while (cnt > 0) {
         MM3D_TICK(t_stage);
-        const int cnt = min(kTile, t_last - t0);
-        // stage: slot -> (row by binary search over the 64 offsets) -> sorted target index
-        // (all of a lane's gathers are issued before the first LDS store: one memory round trip per tile)
-        // two fully unrolled variants (4 or 8 slots per lane): most chunks stage < 256 points, and the short
-        // variant neither searches nor loads the slots it does not have; inside a variant nothing branches,
-        // so the gathers still go out back to back
-        auto stage_tile = [&](auto per_tag) {
-          constexpr int kPer = decltype(per_tag)::value;
-          float4 stage[kPer];
+        if (!kPrefetch) fetch_tile(t0, cnt);
 #pragma unroll
-          for (int u = 0; u < kPer; ++u) {
-            const int s = lane + u * kWave;
-            const int slot = t0 + (s < cnt ? s : 0);
-            int lo = 0;
-#pragma unroll
-            for (int step = 32; step > 0; step >>= 1)
-              if (s_off[wave][lo + step] <= slot) lo += step;   // offsets are non-decreasing; empty rows collapse
-            stage[u] = g.pts[s_beg[wave][lo] + (slot - s_off[wave][lo])];
+        for (int u = 0; u < kPer; ++u) {
+          const int s = lane + u * kWave;
+          if (s < cnt) {
+            s_cx[wave][s] = stage[u].x; s_cy[wave][s] = stage[u].y; s_cz[wave][s] = stage[u].z;
+            s_cw[wave][s] = __float_as_uint(stage[u].w);
           }
-#pragma unroll
-          for (int u = 0; u < kPer; ++u) {
-            const int s = lane + u * kWave;
-            if (s < cnt) {
-              s_cx[wave][s] = stage[u].x; s_cy[wave][s] = stage[u].y; s_cz[wave][s] = stage[u].z;
-              s_cw[wave][s] = __float_as_uint(stage[u].w);
-            }
-          }
-        };
-        if (cnt <= kTile / 2) stage_tile(std::integral_constant<int, kTile / kWave / 2>());
-        else stage_tile(std::integral_constant<int, kTile / kWave>());
+        }
         // pad to a multiple of four with points at infinity (distance +inf never wins)
         if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) {
           s_cx[wave][cnt + lane] = INFINITY; s_cy[wave][cnt + lane] = INFINITY; s_cz[wave][cnt + lane] = INFINITY;
           s_cw[wave][cnt + lane] = 0x7fffffffu;
         }
         wave_lds_sync();
+        const int t0n = t0 + kTile, cntn = min(kTile, t_last - t0n);
+        if (kPrefetch && cntn > 0) fetch_tile(t0n, cntn);
         MM3D_TOCK(33, t_stage);
         MM3D_TICK(t_scan);
         if (active) {
@@ -305,8 +338,9 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
             }
           }
         }
-        wave_lds_sync();
+        wave_lds_sync();                 // the tile's readers are done before the next one is stored
         MM3D_TOCK(34, t_scan);
+        t0 = t0n; cnt = cntn;
       }
     }
     if (SPLIT == 4) {      // the four quarters' minima (every wave then goes on with the same state)
@@ -338,7 +372,7 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
       }
     }
 #ifdef MM3D_NN_STATS
-    if (lane == 0) {     // per ring size: passes, their ticks, active lanes
+    if (MM3D_NN_STATS == 1 && lane == 0) {     // per ring size: passes, their ticks, active lanes
       const int e = E < 7 ? E : 7;
       atomicAdd(&g_nn_stats[40 + e], 1ull);
       atomicAdd(&g_nn_stats[48 + e], (unsigned long long)(wall_clock64() - t_pass));
@@ -351,6 +385,7 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
     const unsigned long long dt = (unsigned long long)(wall_clock64() - t_begin);   // 100 MHz ticks
     atomicMax(&g_nn_stats[6], dt);
     atomicAdd(&g_nn_stats[7], dt);
+    for (int k_ = 0; k_ < 3; ++k_) atomicAdd(&g_nn_stats[32 + k_], (unsigned long long)stat_ticks[k_]);
     int b = 0;
     while ((dt >> b) > 1 && b < 30) ++b;
     atomicAdd(&g_nn_stats[8 + b], 1ull);
