@@ -187,8 +187,12 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
           }
           wave_lds_fence();
           const int n = min(kSpfhPool, total - base);
-          for (int e0 = 0; e0 < n; e0 += kWave) {                 // all 64 lanes take part in the cross-lane reads
-            const int e = e0 + lane;
+          // Lane l takes the entries l * per .. l * per + per - 1: the pool is numbered owner by owner, so 64 CONSECUTIVE
+          // entries are mostly one owner's hits, whose votes all land in the two banks of that owner's counter column
+          // (bank = owner / 2 + 32 (bin & 1)); entries `per` apart belong to different owners and spread over the banks.
+          const int per = (n + kWave - 1) / kWave;
+          for (int i = 0; i < per; ++i) {                         // all 64 lanes take part in the cross-lane reads
+            const int e = lane * per + i;
             const bool has = e < n;
             const unsigned ent = has ? pool[e] : 0u;
             const int o = (int)(ent >> 6), k = (int)(ent & 63u);
