@@ -44,29 +44,46 @@ k_fpfh_mark(const float4 *__restrict__ kp, int nk, GridView g, float radius, flo
     }
 }
 
+// hil_pos (optional): Hilbert position by original index; a support point's normal then carries that position in .w (-1 for
+// the others), which is how k_spfh recognises a candidate that is one of its own block's points
 __global__ void k_fpfh_support(const float4 *__restrict__ sorted, int n, const int *__restrict__ in_set,
                                const int *__restrict__ pos, int *__restrict__ row_of_sorted /* by sorted position, -1 if none */,
-                               const float4 *__restrict__ nrm, float4 *__restrict__ nrm_sorted)
+                               const float4 *__restrict__ nrm, const int *__restrict__ hil_pos, float4 *__restrict__ nrm_sorted)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int oi = __float_as_int(sorted[j].w);
-  nrm_sorted[j] = nrm[oi];
-  row_of_sorted[j] = in_set[oi] ? pos[oi] : -1;
+  float4 v = nrm[oi];
+  const bool in = in_set[oi] != 0;
+  if (hil_pos) v.w = __int_as_float(in ? hil_pos[oi] : -1);
+  nrm_sorted[j] = v;
+  row_of_sorted[j] = in ? pos[oi] : -1;
+}
+__global__ void k_hil_inverse(const float4 *__restrict__ hil_pts, int n, int *__restrict__ hil_pos)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) hil_pos[__float_as_int(hil_pts[i].w)] = i;
 }
 
-// pcl::computePairFeatures (features/src/pfh.cpp); returns f1,f2,f3 (all 0 on the degenerate exits)
+// pcl::computePairFeatures (features/src/pfh.cpp); returns f1,f2,f3 (all 0 on the degenerate exits).
+// `symmetric` (optional): would the call with the two points exchanged return the same bits?  It works on the negated
+// difference vector, so its angles are (-angle2, -angle1): whenever exactly one of the two calls takes the "switch p1 and p2"
+// branch, both continue with the same source point, difference vector and normals.  On a tie neither switches and the
+// results differ (tests/test_oracle_cpu.py::test_pair_features_are_symmetric_under_the_swap_except_on_ties).
 __device__ __forceinline__ void pair_features(const float4 &p1, const float4 &n1, const float4 &p2, const float4 &n2,
-                                              float &f1, float &f2, float &f3)
+                                              float &f1, float &f2, float &f3, bool *symmetric = nullptr)
 {
   float dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
   const float f4 = sqrtf(dx * dx + dy * dy + dz * dz);
+  if (symmetric) *symmetric = true;
   if (f4 == 0.0f) { f1 = f2 = f3 = 0.0f; return; }
   float ax = n1.x, ay = n1.y, az = n1.z, bx = n2.x, by = n2.y, bz = n2.z;
   const float angle1 = (ax * dx + ay * dy + az * dz) / f4;
   const float angle2 = (bx * dx + by * dy + bz * dz) / f4;
   // acos(fabs(angle1)) > acos(fabs(angle2)) evaluated in double on the CPU: device_util.hpp::acos_abs_greater
-  if (acos_abs_greater(angle1, angle2)) {
+  const bool sw = acos_abs_greater(angle1, angle2);
+  if (symmetric) *symmetric = sw || acos_abs_greater(angle2, angle1);
+  if (sw) {
     float t;
     t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; t = az; az = bz; bz = t;
     dx *= -1.0f; dy *= -1.0f; dz *= -1.0f;
@@ -96,135 +113,203 @@ __device__ __forceinline__ int bin_of(double x)
 // order, the lanes that belong to the support set are live), streams the box of cells those lanes
 // can reach through LDS together with the candidates' normals, and bins the pairs inside every live
 // lane's radius.  Every hit of one point adds the SAME float 100/(|N|-1), so a bin's value depends
-// only on its hit count: hits are counted in integers (LDS, bin-major so lane l owns bank l) in
-// whatever order they are processed, and the float chain "0 + incr + incr + ..." of the CPU loop is
-// replayed once per bin at the end, bit for bit.
+// only on its hit count: hits are counted in integers (LDS) in whatever order they are processed, and
+// the float chain "0 + incr + incr + ..." of the CPU loop is replayed once per bin at the end, bit for bit.
 //
 // The expensive part is the pair feature (~300 VALU instructions: atan2f, two square roots, five
-// IEEE divisions, three double bin computations), so its lanes must be full.  Per tile the cheap
-// in-radius test leaves a per-lane bitset; the (owner lane, candidate) hits of the whole wave are
-// then numbered by a prefix sum, written to an LDS pool and dealt round-robin to the 64 lanes: a lane
-// works on ANY point's hit (the owner's position and normal come through the cross-lane network) and
-// bumps the owner's counters with LDS atomics.  Trip count = total hits / 64 instead of the largest
-// per-lane hit count.
+// IEEE divisions, three double bin computations), so (a) its lanes must be full and (b) it should run
+// once per PAIR, not once per histogram:
+//  (a) per tile the cheap in-radius test leaves a per-lane bitset; the (owner lane, candidate) hits of the
+//      whole wave are numbered by a prefix sum, written to an LDS pool and dealt to the 64 lanes: a lane
+//      works on ANY point's hit (the owner's position and normal are in LDS) and bumps the owner's counters
+//      with LDS atomics.  Trip count = total hits / 64 instead of the largest per-lane hit count.
+//  (b) computePairFeatures(p, q) and (q, p) return the same bits unless the pair is a tie of its two angles
+//      (pair_features above), and a quarter of a point's neighbours are among the 256 consecutive points of
+//      its BLOCK (kSpfhWaves waves, whose points and counters share the block's LDS).  A candidate that is a
+//      live point of this block carries its block offset; of the two hits (o, c) and (c, o) only the one with
+//      the lower offset as owner is pooled -- by whichever wave owns o --, and its lane votes into BOTH
+//      histograms (a tie is evaluated the second way as well).  The neighbour count |N| of each point still
+//      comes from its own in-radius test.  The waves stream their own boxes and never wait for each other
+//      (a first version staged one box per block: 1 340 candidates to test per point instead of ~600, which
+//      cost what the shared pairs saved).
 constexpr int kSpfhTile = 64;
 #ifndef MM3D_SPFH_POOL
 #define MM3D_SPFH_POOL 1536
 #endif
 constexpr int kSpfhPool = MM3D_SPFH_POOL;
 #ifndef MM3D_SPFH_WAVES
-#define MM3D_SPFH_WAVES 2
+#define MM3D_SPFH_WAVES 4
 #endif
 constexpr int kSpfhWaves = MM3D_SPFH_WAVES;
-__global__ void __launch_bounds__(64 * kSpfhWaves)
+#ifdef MM3D_SPFH_STATS
+__device__ unsigned long long g_spfh_stats[8];   // 0 waves, 1 candidates tested per wave, 2 in-radius hits, 3 pooled hits, 4 second votes, 5 ties, 6 live points
+#define MM3D_SPFH_STAT(i_, v_) atomicAdd(&g_spfh_stats[i_], (unsigned long long)(v_))
+#else
+#define MM3D_SPFH_STAT(i_, v_)
+#endif
+constexpr int kSpfhT = 64 * kSpfhWaves;       // points per block
+constexpr int kSpfhNone = 0xFFFF;             // a candidate that is not a live point of the block: above every offset
+__global__ void __launch_bounds__(kSpfhT)
 k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g,
-       const float4 *__restrict__ nrm /* original order */, const float4 *__restrict__ nrm_sorted,
+       const float4 *__restrict__ nrm /* original order */, const float4 *__restrict__ nrm_sorted /* .w = Hilbert position of a support point, -1 */,
        const int *__restrict__ in_set, const int *__restrict__ pos, float radius, float r2, float *__restrict__ spfh /* [ns][33] */,
        int *__restrict__ error)
 {
-  __shared__ float4 s_pts[kSpfhWaves][kSpfhTile];
+  __shared__ float4 s_pts[kSpfhWaves][kSpfhTile];           // a wave's staged tile (.w of a point: its block offset if it is a live point of this block)
   __shared__ float4 s_nrm[kSpfhWaves][kSpfhTile];
   __shared__ int s_off[kSpfhWaves][64];
   __shared__ int s_beg[kSpfhWaves][64];
-  // hit counters, two 16-bit counts to a word (lanes 2w and 2w + 1): half the LDS of one word per lane, which is
+  __shared__ float4 s_q[kSpfhT], s_nq[kSpfhT];              // the block's points and normals by block offset
+  // hit counters, two 16-bit counts to a word (offsets 2w and 2w + 1): half the LDS of one word per point, which is
   // what bounds the blocks per CU; a point with more than 65535 neighbours is reported, not miscounted
-  __shared__ unsigned hist[kSpfhWaves][kDim][32];
+  __shared__ unsigned hist[kDim][kSpfhT / 2];
   __shared__ unsigned short s_pool[kSpfhWaves][kSpfhPool];
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = bid * kSpfhWaves + wave;
-  const int2 it = item < n_items ? items[item] : make_int2(0, 0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int item0 = (int)bid * kSpfhWaves;
+  const int blk_first = items[item0].x;                      // (the grid has no block without an item)
+  const int last_item = min(item0 + kSpfhWaves, n_items) - 1;
+  const int blk_count = items[last_item].x + items[last_item].y - blk_first;   // items are consecutive and hold <= 64 points
+  const int2 it = item0 + wave < n_items ? items[item0 + wave] : make_int2(blk_first, 0);
   const bool valid = lane < it.y;
-  if (it.y == 0) return;                      // wave-uniform
-  const float4 q = q_pts[it.x + (valid ? lane : 0)];
-  const int self = __float_as_int(q.w);
-  const bool live = valid && in_set[self] != 0;
-  if (!ballot(live)) return;                // wave-uniform: no support point in this patch
-  const float4 nq = nrm[self];
-#pragma unroll
-  for (int b = 0; b < kDim; ++b) hist[wave][b][lane >> 1] = 0u;
-  const float ri = radius * 1.0001f + 1e-4f;
-  const float lx = wave_min_f(live ? q.x : INFINITY), hx = wave_max_f(live ? q.x : -INFINITY);
-  const float ly = wave_min_f(live ? q.y : INFINITY), hy = wave_max_f(live ? q.y : -INFINITY);
-  const float lz = wave_min_f(live ? q.z : INFINITY), hz = wave_max_f(live ? q.z : -INFINITY);
-  const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
-  const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
-  const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
-  const float d_pi = 1.0f / (2.0f * 3.14159274f);
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f), nq = make_float4(0.f, 0.f, 0.f, 0.f);
+  int self = 0;
+  bool live = false;
+  const int wave_off0 = it.x - blk_first, my_off = wave_off0 + lane;
+  if (valid) {
+    q = q_pts[it.x + lane];
+    self = __float_as_int(q.w);
+    live = in_set[self] != 0;
+    if (live) nq = nrm[self];
+    s_q[my_off] = q;
+    s_nq[my_off] = nq;
+  }
+  for (int i = tid; i < kDim * (kSpfhT / 2); i += kSpfhT) (&hist[0][0])[i] = 0u;
+  __syncthreads();                                            // the block's points and zeroed counters are in LDS
   int cnt = 0;
-  const float4 *sp = s_pts[wave];
-  const float4 *sn = s_nrm[wave];
-  unsigned(*hw)[32] = hist[wave];
-  unsigned short *pool = s_pool[wave];
-  wave_stream_box<kSpfhTile, 1>(
-      g, x0, x1, y0, y1, z0, z1, s_pts[wave], s_nrm[wave], s_off[wave], s_beg[wave], lane,
-      [&](int j, float4 (&out)[1]) { out[0] = nrm_sorted[j]; },
-      [&](int n_tile) {
-        unsigned hits[kSpfhTile / 32];
-        tile_hit_mask<kSpfhTile>(sp, n_tile, q.x, q.y, q.z, r2, live, hits);
-        const int mine = __popc(hits[0]) + __popc(hits[1]);
-        cnt += mine;
-        // number the wave's hits: exclusive prefix of the per-lane counts
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-          const int t = __shfl_up(incl, o, kWave);
-          if (lane >= o) incl += t;
-        }
-        const int total = __shfl(incl, kWave - 1, kWave);
-        const int first = incl - mine;
-        for (int base = 0; base < total; base += kSpfhPool) {   // one chunk unless nearly every lane hits every candidate
-          {
-            unsigned m0 = hits[0], m1 = hits[1];
-            int r = first;
-            while (m0 | m1) {
-              int k;
-              if (m0) { k = __ffs((int)m0) - 1; m0 &= m0 - 1u; }
-              else { k = 32 + __ffs((int)m1) - 1; m1 &= m1 - 1u; }
-              if (r >= base && r < base + kSpfhPool) pool[r - base] = (unsigned short)((lane << 6) | k);
-              ++r;
-            }
+  if (ballot(live)) {                                         // wave-uniform: a patch without a support point has nothing to bin
+    if (lane == 0) MM3D_SPFH_STAT(0, 1);
+    if (live) MM3D_SPFH_STAT(6, 1);
+    const float ri = radius * 1.0001f + 1e-4f;
+    const float lx = wave_min_f(live ? q.x : INFINITY), hx = wave_max_f(live ? q.x : -INFINITY);
+    const float ly = wave_min_f(live ? q.y : INFINITY), hy = wave_max_f(live ? q.y : -INFINITY);
+    const float lz = wave_min_f(live ? q.z : INFINITY), hz = wave_max_f(live ? q.z : -INFINITY);
+    const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
+    const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
+    const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
+    const float d_pi = 1.0f / (2.0f * 3.14159274f);
+    const float4 *sp = s_pts[wave];
+    const float4 *sn = s_nrm[wave];
+    unsigned short *pool = s_pool[wave];
+    wave_stream_box<kSpfhTile, 1>(
+        g, x0, x1, y0, y1, z0, z1, s_pts[wave], s_nrm[wave], s_off[wave], s_beg[wave], lane,
+        [&](int j, float4 (&out)[1]) { out[0] = nrm_sorted[j]; },
+        [&](int n_tile) {
+          if (lane == 0) MM3D_SPFH_STAT(1, n_tile);
+          // the staged normal's .w is the candidate's Hilbert position if it is a support point (-1 otherwise): a live
+          // point of this block becomes its block offset in the POINT's .w (the original index is not needed any more:
+          // "is it me" is an offset test), everything else kSpfhNone
+          if (lane < n_tile) {
+            const int hp = __float_as_int(s_nrm[wave][lane].w), off = hp - blk_first;
+            s_pts[wave][lane].w = __int_as_float((hp >= 0 && off >= 0 && off < blk_count) ? off : kSpfhNone);
           }
           wave_lds_fence();
-          const int n = min(kSpfhPool, total - base);
-          // Lane l takes the entries l * per .. l * per + per - 1: the pool is numbered owner by owner, so 64 CONSECUTIVE
-          // entries are mostly one owner's hits, whose votes all land in the two banks of that owner's counter column
-          // (bank = owner / 2 + 32 (bin & 1)); entries `per` apart belong to different owners and spread over the banks.
-          const int per = (n + kWave - 1) / kWave;
-          for (int i = 0; i < per; ++i) {                         // all 64 lanes take part in the cross-lane reads
-            const int e = lane * per + i;
-            const bool has = e < n;
-            const unsigned ent = has ? pool[e] : 0u;
-            const int o = (int)(ent >> 6), k = (int)(ent & 63u);
-            float4 qo, no;
-            qo.x = __shfl(q.x, o, kWave); qo.y = __shfl(q.y, o, kWave); qo.z = __shfl(q.z, o, kWave); qo.w = __shfl(q.w, o, kWave);
-            no.x = __shfl(nq.x, o, kWave); no.y = __shfl(nq.y, o, kWave); no.z = __shfl(nq.z, o, kWave); no.w = 0.f;
-            if (has) {
-              const float4 p = sp[k];
-              if (__float_as_int(p.w) != __float_as_int(qo.w)) {   // p_idx == indices[idx] is skipped
-                float f1, f2, f3;
-                pair_features(qo, no, p, sn[k], f1, f2, f3);
-                const int h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
-                const int h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
-                const int h3 = bin_of(kBins * (((double)f3 + 1.0) * 0.5));
-                const unsigned one = 1u << ((o & 1) << 4);
-                atomicAdd(&hw[h1][o >> 1], one);
-                atomicAdd(&hw[kBins + h2][o >> 1], one);
-                atomicAdd(&hw[2 * kBins + h3][o >> 1], one);
+          unsigned all[kSpfhTile / 32], todo[kSpfhTile / 32];
+#pragma unroll
+          for (int gq = 0; gq < kSpfhTile / 32; ++gq) {
+            unsigned bits = 0, skip = 0;
+            if (gq * 32 < n_tile) {                           // wave-uniform
+#pragma unroll 4
+              for (int b = 0; b < 32; ++b) {
+                const float4 p = sp[gq * 32 + b];             // slots >= n_tile hold stale points: masked off below
+                bits |= (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) ? (1u << b) : 0u;
+                // the pair belongs to the end point with the lower block offset (== : the point itself, "p_idx == indices[idx]")
+                skip |= (__float_as_int(p.w) <= my_off) ? (1u << b) : 0u;
+              }
+              const int rem = n_tile - gq * 32;
+              if (rem < 32) bits &= (1u << rem) - 1u;
+            }
+            all[gq] = live ? bits : 0u;
+            todo[gq] = all[gq] & ~skip;
+          }
+          cnt += __popc(all[0]) + __popc(all[1]);
+          const int mine = __popc(todo[0]) + __popc(todo[1]);
+          MM3D_SPFH_STAT(2, __popc(all[0]) + __popc(all[1]));
+          MM3D_SPFH_STAT(3, mine);
+          // number the wave's hits: exclusive prefix of the per-lane counts
+          int incl = mine;
+#pragma unroll
+          for (int o = 1; o < kWave; o <<= 1) {
+            const int t = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += t;
+          }
+          const int total = __shfl(incl, kWave - 1, kWave);
+          const int first = incl - mine;
+          for (int base = 0; base < total; base += kSpfhPool) {   // one chunk unless nearly every lane hits every candidate
+            {
+              unsigned m0 = todo[0], m1 = todo[1];
+              int r = first;
+              while (m0 | m1) {
+                int k;
+                if (m0) { k = __ffs((int)m0) - 1; m0 &= m0 - 1u; }
+                else { k = 32 + __ffs((int)m1) - 1; m1 &= m1 - 1u; }
+                if (r >= base && r < base + kSpfhPool) pool[r - base] = (unsigned short)((lane << 6) | k);
+                ++r;
               }
             }
+            wave_lds_fence();
+            const int n = min(kSpfhPool, total - base);
+            // Lane l takes the entries l * per .. l * per + per - 1: the pool is numbered owner by owner, so 64 CONSECUTIVE
+            // entries are mostly one owner's hits, whose votes all land in the two banks of that owner's counter column;
+            // entries `per` apart belong to different owners and spread over the banks.
+            const int per = (n + kWave - 1) / kWave;
+            for (int i = 0; i < per; ++i) {
+              const int e = lane * per + i;
+              if (e < n) {
+                const unsigned ent = pool[e];
+                const int o = wave_off0 + (int)(ent >> 6), k = (int)(ent & 63u);
+                const float4 qo = s_q[o], no = s_nq[o];
+                const float4 p = sp[k], np = sn[k];
+                const int c = __float_as_int(p.w);
+                float f1, f2, f3;
+                bool sym;
+                pair_features(qo, no, p, np, f1, f2, f3, &sym);
+                int h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
+                int h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
+                int h3 = bin_of(kBins * (((double)f3 + 1.0) * 0.5));
+                const unsigned one = 1u << ((o & 1) << 4);
+                atomicAdd(&hist[h1][o >> 1], one);
+                atomicAdd(&hist[kBins + h2][o >> 1], one);
+                atomicAdd(&hist[2 * kBins + h3][o >> 1], one);
+                if (c != kSpfhNone) {                          // the same pair seen from the candidate, a point of this block
+                  MM3D_SPFH_STAT(4, 1);
+                  if (!sym) {
+                    MM3D_SPFH_STAT(5, 1);
+                    pair_features(p, np, qo, no, f1, f2, f3);
+                    h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
+                    h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
+                    h3 = bin_of(kBins * (((double)f3 + 1.0) * 0.5));
+                  }
+                  const unsigned onec = 1u << ((c & 1) << 4);
+                  atomicAdd(&hist[h1][c >> 1], onec);
+                  atomicAdd(&hist[kBins + h2][c >> 1], onec);
+                  atomicAdd(&hist[2 * kBins + h3][c >> 1], onec);
+                }
+              }
+            }
+            wave_lds_fence();
           }
-          wave_lds_fence();
-        }
-      },
-      // only points inside the patch's bounding box grown by the radius can be in range
-      KeepInBox{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri});
+        },
+        // only points inside the patch's bounding box grown by the radius can be in range
+        KeepInBox{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri});
+  }
+  __syncthreads();                                            // all votes are in (other waves vote into this wave's columns)
   if (!live) return;
   if (cnt > 65535) { atomicExch(error, 1); return; }
   const float hist_incr = 100.0f / (float)(cnt - 1);
   float *o = spfh + (size_t)pos[self] * kDim;
   for (int b = 0; b < kDim; ++b) {
-    const unsigned hits = (hw[b][lane >> 1] >> ((lane & 1) << 4)) & 0xffffu;
+    const unsigned hits = (hist[b][my_off >> 1] >> ((my_off & 1) << 4)) & 0xffffu;
     float v = 0.0f;
     for (unsigned i = 0; i < hits; ++i) v += hist_incr;
     o[b] = v;
@@ -355,16 +440,22 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
   const int ns = h[0];
   DevBuf<int> row_of(c, g.n);
   DevBuf<float4> nrm_sorted(c, g.n);
+  DevBuf<int> hil_pos;
+  if (ns > 0) {
+    cloud_hilbert(c, points);                            // query order + wave work items (shared with ICP / score)
+    hil_pos = DevBuf<int>(c, (size_t)n + 1);
+    MM3D_LAUNCH(c, "fpfh_support", points->n_finite * 20.0, k_hil_inverse, dim3(div_up(points->n_finite, 256)), dim3(256), 0,
+                (const float4 *)points->hil_pts.get(), (int)points->n_finite, hil_pos.get());
+  }
   MM3D_LAUNCH(c, "fpfh_support", g.n * 44.0, k_fpfh_support, dim3(div_up(g.n, 256)), dim3(256), 0, g.sorted.get(), g.n,
-              in_set.get(), pos.get(), row_of.get(), normals->nrm.get(), nrm_sorted.get());
+              in_set.get(), pos.get(), row_of.get(), normals->nrm.get(), (const int *)hil_pos.get(), nrm_sorted.get());
   DevBuf<float> spfh(c, (size_t)(ns > 0 ? ns : 1) * kDim);
   int *hse = nullptr;                                   // the SPFH kernel's error word, looked at with the weighting's below
   if (ns > 0) {
-    cloud_hilbert(c, points);                            // query order + wave work items (shared with ICP / score)
     const int n_items = points->n_wave_items;
     DevBuf<int> spfh_err(c, 1);
     MM3D_HIP(hipMemsetAsync(spfh_err.get(), 0, sizeof(int), c->stream));
-    MM3D_LAUNCH(c, "spfh", ns * 156.0, k_spfh, dim3(div_up(n_items, kSpfhWaves)), dim3(64 * kSpfhWaves), 0, (const float4 *)points->hil_pts.get(),
+    MM3D_LAUNCH(c, "spfh", ns * 156.0, k_spfh, dim3(div_up(n_items, kSpfhWaves)), dim3(kSpfhT), 0, (const float4 *)points->hil_pts.get(),
                 (const int2 *)points->wave_items.get(), n_items, g.view(), (const float4 *)normals->nrm.get(),
                 (const float4 *)nrm_sorted.get(), (const int *)in_set.get(), (const int *)pos.get(), (float)radius, r2, spfh.get(), spfh_err.get());
     hse = (int *)c->pin(64);
@@ -416,3 +507,12 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
 }
 
 }  // namespace mm3d
+
+#ifdef MM3D_SPFH_STATS
+extern "C" void mm3d_debug_spfh_stats(unsigned long long *out, int reset)
+{
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mm3d::g_spfh_stats), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mm3d::g_spfh_stats), z, sizeof(z)); }
+}
+#endif

@@ -95,6 +95,8 @@ int mo_keypoints_sift(const mo_point *in, int n, double min_scale,
 int mo_keypoints_harris(const mo_point *in, const mo_normal *normals, int n, double threshold, double radius,
                         mo_point **out, int **kept_idx, float *response_out);
 void mo_harris_response(const mo_point *in, const mo_normal *normals, int n, double radius, float *response);
+/* test hook (o_fpfh.c): pcl::computePairFeatures on n pairs, out[5 i ..] = {f1, f2, f3, f4, branch taken} */
+void mo_pair_features(const mo_point *p1, const mo_normal *n1, const mo_point *p2, const mo_normal *n2, int n, float *out);
 /* computeLocalDescriptors(FPFH): R/src/features.cpp:99-150 +
  * dispatch_descriptors.h:40.  keypoints are pruned IN PLACE (n_kp updated);
  * desc must hold n_kp*33 floats; returns the number of surviving keypoints. */

@@ -46,6 +46,24 @@ static void pair_features(const mo_point *p1, const mo_normal *n1, const mo_poin
   *f1 = atan2f(w[0] * b[0] + w[1] * b[1] + w[2] * b[2], a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
 }
 
+/* Test hook: pcl::computePairFeatures on n pairs, out[5 i ..] = {f1, f2, f3, f4, branch}, branch = 1 when the "switch p1 and
+ * p2" branch was taken, 0 when not, 2 on the f4 == 0 exit.  tests/test_oracle_cpu.py uses it to show that the features of
+ * (p1, p2) and (p2, p1) are the same bits whenever exactly one of the two calls switches (the device computes such a pair
+ * once and votes into both histograms, csrc/fpfh.hip::k_spfh) -- and that they differ on ties, which it evaluates twice. */
+void mo_pair_features(const mo_point *p1, const mo_normal *n1, const mo_point *p2, const mo_normal *n2, int n, float *out)
+{
+  for (int i = 0; i < n; ++i) {
+    float *o = out + 5 * (size_t)i;
+    pair_features(&p1[i], &n1[i], &p2[i], &n2[i], &o[0], &o[1], &o[2], &o[3]);
+    float d[3] = {p2[i].x - p1[i].x, p2[i].y - p1[i].y, p2[i].z - p1[i].z};
+    float f4 = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (f4 == 0.0f) { o[4] = 2.0f; continue; }
+    float angle1 = (n1[i].nx * d[0] + n1[i].ny * d[1] + n1[i].nz * d[2]) / f4;
+    float angle2 = (n2[i].nx * d[0] + n2[i].ny * d[1] + n2[i].nz * d[2]) / f4;
+    o[4] = (acos(fabs(angle1)) > acos(fabs(angle2))) ? 1.0f : 0.0f;
+  }
+}
+
 /* static_cast<int>(floor(x)) with x86 cvttsd2si semantics for NaN/out-of-range (INT_MIN) */
 static inline int floor_to_int(double x)
 {

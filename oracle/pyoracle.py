@@ -132,6 +132,17 @@ def fpfh_raw(surface, nrm, keypoints, radius):
     return desc, support[:ns].copy(), spfh[:ns].copy()
 
 
+def pair_features(p1, n1, p2, n2):
+    """pcl::computePairFeatures on n pairs (test hook): rows {f1, f2, f3, f4, branch} with branch = 1 when the call switched
+    p1 and p2, 0 when not, 2 on the coincident-points exit."""
+    p1, p2 = _pts(p1), _pts(p2)
+    n1 = np.ascontiguousarray(n1, dtype=NORMAL)
+    n2 = np.ascontiguousarray(n2, dtype=NORMAL)
+    out = np.empty((len(p1), 5), dtype=np.float32)
+    lib().mo_pair_features(_p(p1), _p(n1), _p(p2), _p(n2), len(p1), _p(out))
+    return out
+
+
 def descriptors_pfh(surface, nrm, keypoints, radius):
     """computeLocalDescriptors(PFH): returns (pruned keypoints, desc[n, 125])."""
     surface = _pts(surface)

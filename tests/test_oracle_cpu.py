@@ -651,6 +651,53 @@ def test_exact_yardstick_of_a_whole_job(po, synth):
     assert po.transform_tolerance(5000) == 1e-3 and po.transform_tolerance(406000) == pytest.approx(4.06e-3) and po.TOL_T_EXACT == 1e-4
 
 
+def test_pair_features_are_symmetric_under_the_swap_except_on_ties(po):
+    """pcl::computePairFeatures(p1, p2) and (p2, p1): whenever exactly ONE of the two calls takes the "switch p1 and p2"
+    branch they work on the same source point, the same difference vector and the same normals, so f1, f2, f3, f4 are the
+    same BITS -- the device's SPFH kernel computes such a pair once and votes into both points' histograms
+    (csrc/fpfh.hip::k_spfh).  On a tie (|angle1| == |angle2|, both tiny, an |angle| above 1) neither call switches, the
+    two results differ in general, and the device evaluates both: this test pins both halves of that argument."""
+    rng = np.random.default_rng(77)
+    n = 200000
+    def pts(a):
+        out = np.zeros(len(a), dtype=po.POINT)
+        out["x"], out["y"], out["z"] = a[:, 0], a[:, 1], a[:, 2]
+        return out
+    def nrm(a):
+        out = np.zeros(len(a), dtype=po.NORMAL)
+        out["nx"], out["ny"], out["nz"] = a[:, 0], a[:, 1], a[:, 2]
+        return out
+    a = rng.uniform(-50, 50, (n, 3)).astype(np.float32)
+    b = (a + rng.normal(0, 0.4, (n, 3))).astype(np.float32)
+    na = rng.normal(0, 1, (n, 3)); na /= np.linalg.norm(na, axis=1, keepdims=True)
+    nb = rng.normal(0, 1, (n, 3)); nb /= np.linalg.norm(nb, axis=1, keepdims=True)
+    na, nb = na.astype(np.float32), nb.astype(np.float32)
+    # crafted rows: coincident points, equal normals (|angle1| == |angle2|: a tie), opposite normals (a tie as well), a normal
+    # orthogonal to the difference up to rounding (angles below 2^-28), an unnormalised normal (|angle| > 1), a zero normal
+    b[:100] = a[:100]
+    nb[100:400] = na[100:400]
+    nb[400:700] = -na[400:700]
+    d = (b[700:1000] - a[700:1000]).astype(np.float64)
+    t = np.cross(d, rng.normal(0, 1, d.shape)); t /= np.linalg.norm(t, axis=1, keepdims=True)
+    na[700:1000] = t.astype(np.float32)
+    na[1000:1200] *= 3.0
+    nb[1200:1300] = 0.0
+    fwd = po.pair_features(pts(a), nrm(na), pts(b), nrm(nb))
+    rev = po.pair_features(pts(b), nrm(nb), pts(a), nrm(na))
+    sw_f, sw_r = fwd[:, 4], rev[:, 4]
+    coincident = sw_f == 2
+    assert (coincident == (sw_r == 2)).all() and coincident.sum() >= 100
+    one_switch = (~coincident) & ((sw_f == 1) != (sw_r == 1))
+    ties = (~coincident) & (sw_f == 0) & (sw_r == 0)
+    assert not ((sw_f == 1) & (sw_r == 1)).any()                     # both switching is impossible
+    assert one_switch.sum() > 0.9 * n and ties.sum() >= 500
+    same = (fwd[:, :4].view(np.uint32) == rev[:, :4].view(np.uint32)).all(axis=1) | \
+           (np.isnan(fwd[:, :4]) & np.isnan(rev[:, :4])).all(axis=1)
+    assert same[one_switch].all(), int((~same[one_switch]).sum())
+    assert same[coincident].all()
+    assert (~same[ties]).any()                                      # ties are NOT symmetric: they are evaluated twice
+
+
 def test_oracle_under_sanitizers():
     """the CPU restatement under AddressSanitizer + UndefinedBehaviourSanitizer (+ LeakSanitizer).
     `make -C oracle san` compiles every oracle source with -fsanitize=address,undefined -fno-sanitize-recover behind
