@@ -258,6 +258,11 @@ void mm3d_set_debug(mm3d_ctx *ctx, int on)
 }
 long long mm3d_debug_knn_fallback_rows(mm3d_ctx *ctx) { return ctx ? ctx->knn_fallback_rows : 0; }
 long long mm3d_debug_knn_rows(mm3d_ctx *ctx) { return ctx ? ctx->knn_rows : 0; }
+void mm3d_debug_waits(mm3d_ctx *ctx, long long out[2])
+{
+  out[0] = ctx ? ctx->waits : 0;
+  out[1] = ctx ? ctx->wait_ns : 0;
+}
 int mm3d_debug_float_chain(mm3d_ctx *ctx, const float *incr, const unsigned *hits, int n, float *out)
 {
   if (n < 0 || (n && (!incr || !hits || !out))) return MM3D_EINVAL;

@@ -147,6 +147,7 @@ struct Context {
   int last_icp_iterations = 0, last_icp_converged = 0;
   bool debug = false;            // mm3d_set_debug: collect counters that cost a host sync
   long long knn_fallback_rows = 0, knn_rows = 0;
+  long long waits = 0, wait_ns = 0;      // host waits for the stream (sync()): how many, how long (mm3d_debug_waits)
   // pinned host arena for small asynchronous H2D / D2H copies: pin() bumps through it, so regions
   // handed out earlier stay untouched while their copies are in flight; the stream is drained
   // before the arena wraps around or is replaced

@@ -99,7 +99,10 @@ hipError_t stream_wait(hipStream_t stream)
 
 void Context::sync()
 {
+  const auto t0 = std::chrono::steady_clock::now();
   MM3D_HIP(stream_wait(stream));
+  ++waits;
+  wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
   if (!deferred.empty()) {
     std::vector<Deferred> d;
     d.swap(deferred);

@@ -12,8 +12,12 @@ dev = torch.device("cuda", 0)
 raw_t = torch.from_numpy(host[0].view(np.uint8).reshape(-1, 16)).to(dev)
 ctx = mm.Context(0)
 P = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
-for rep in range(3):
-    ctx.profile_reset(); ctx.profile(rep == 2)
+import ctypes as C
+L = mm.lib()
+w0, w1 = (C.c_longlong * 2)(), (C.c_longlong * 2)()
+for rep in range(4):
+    ctx.profile_reset(); ctx.profile(rep == 3)
+    L.mm3d_debug_waits(ctx._h, w0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     raw = ctx.cloud_from_ptr(raw_t.data_ptr(), len(host[0]))
@@ -22,6 +26,9 @@ for rep in range(3):
     ctx.mapPrepare(m, P)
     ctx.synchronize()
     t2 = time.perf_counter()
+    L.mm3d_debug_waits(ctx._h, w1)
+    if rep == 2:     # (the last run without kernel events)
+        print(f"no events: features {1e3 * (t1 - t0):.2f} ms + prepare {1e3 * (t2 - t1):.2f} ms wall, {w1[0] - w0[0]} host waits taking {1e-6 * (w1[1] - w0[1]):.2f} ms")
     raw.free(); m.free()
 e = ctx.profile_entries()
 tot = sum(v["ms"] for v in e.values()); n = sum(v["launches"] for v in e.values())
