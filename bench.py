@@ -164,8 +164,8 @@ def make_workload(n_maps, n_points, cache=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--maps", type=int, default=16)
     ap.add_argument("--points", type=int, default=500000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
