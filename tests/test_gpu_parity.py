@@ -179,6 +179,45 @@ def test_fpfh(ctx, scene):
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def test_fpfh_pairs_shared_inside_a_block_and_their_ties(ctx, po):
+    """The SPFH kernel evaluates a pair of support points of one 256-point block once and votes into both histograms
+    (computePairFeatures is symmetric under the swap, tests/test_oracle_cpu.py), EXCEPT when the pair's two angles tie: then
+    the two calls differ and both are evaluated.  Three surfaces against the oracle's bits: a lattice plane with one normal for
+    every point (angle1 == angle2 on every pair: all ties), the same with every other normal flipped (|angle1| == |angle2|),
+    and a noisy sheet with duplicated points (f4 == 0 pairs) and some unnormalised / zero normals (|angle| > 1: no switch
+    either way)."""
+    rng = np.random.default_rng(5)
+    def cloud(xyz):
+        c = np.zeros(len(xyz), dtype=po.POINT)
+        c["x"], c["y"], c["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+        c["rgba"] = 0xFF808080
+        return c
+    def normals(n):
+        out = np.zeros(len(n), dtype=po.NORMAL)
+        out["nx"], out["ny"], out["nz"] = n[:, 0], n[:, 1], n[:, 2]
+        return out
+    gx, gy = np.meshgrid(np.arange(60, dtype=np.float32) * 0.1, np.arange(50, dtype=np.float32) * 0.1)
+    plane = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, 1.5, np.float32)], axis=1)
+    up = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (len(plane), 1))
+    flip = up.copy(); flip[::2] *= -1.0
+    sheet = plane + rng.normal(0, 0.02, plane.shape).astype(np.float32)
+    sheet[100:130] = sheet[200:230]                                   # coincident points
+    nsh = up + rng.normal(0, 0.2, up.shape).astype(np.float32)
+    nsh /= np.linalg.norm(nsh, axis=1, keepdims=True)
+    nsh[300:340] *= 2.5                                               # |angle| can exceed 1
+    nsh[400:420] = 0.0
+    for xyz, nrm in ((plane, up), (plane, flip), (sheet, nsh.astype(np.float32))):
+        pts, nn = cloud(xyz), normals(nrm)
+        kp = pts[rng.choice(len(pts), 120, replace=False)].copy()
+        kp_ref, desc_ref = po.descriptors_fpfh(pts, nn, kp, 0.45)
+        k = ctx.cloud(kp)
+        desc = ctx.computeLocalDescriptors(ctx.cloud(pts), ctx.normals(nn), k, 2, 0.45)
+        got = desc.numpy()
+        assert got.shape == desc_ref.shape and len(got) > 100
+        assert np.array_equal(k.numpy().view(np.uint32), kp_ref.view(np.uint32))
+        assert np.array_equal(got.view(np.uint32), desc_ref.view(np.uint32))
+
+
 def test_fpfh_prunes_isolated_keypoints(ctx, po, scene, mm):
     m = scene[0]
     kp = m["kp_raw"][:50].copy()
