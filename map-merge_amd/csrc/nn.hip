@@ -181,7 +181,10 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
   }
   // (d2 bits, original index) as one 64-bit key: d2 >= 0 so its bits order like the value, and the
   // low word breaks ties towards the lower original index, like the CPU path
-  unsigned long long bkey = ~0ull;
+  // The key starts at (max_d2, no index): a candidate beyond the correspondence distance is never a correspondence, so it
+  // need not be found -- and must not send its group of four through the key-forming path below.  A candidate AT max_d2
+  // still wins (any real index is below 0xffffffff), and "nothing in range yet" is the index word 0xffffffff.
+  unsigned long long bkey = ((unsigned long long)__float_as_uint(max_d2) << 32) | 0xffffffffull;
   float best = INFINITY, bestd = INFINITY;
 
 #ifdef MM3D_NN_STATS
@@ -320,7 +323,7 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
             } else {
               // The (distance, index) key is only formed where it can matter: if the nearest of these four candidates is
               // farther than what EVERY active lane already holds, no key of the group can win or tie (d2 >= 0: its bits
-              // order like its value; the initial key ~0 compares above everything).  Candidates arrive row by row, so a
+              // order like its value; the initial key holds max_d2).  Candidates arrive row by row, so a
               // wave's lanes stop improving together once the rows near their patch are behind them: about half of the
               // groups take this exit, and a group that does costs 3 instead of 22 instructions on top of the distances
               // (round 4: the step is bound by VALU instructions).
@@ -354,7 +357,7 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
       else bkey = m;
     }
     // what the scanned box proves: every target point closer than `guard` to this lane has been seen
-    best = MODE == 1 ? bestd : ((bkey == ~0ull) ? INFINITY : __uint_as_float((unsigned)(bkey >> 32)));
+    best = MODE == 1 ? bestd : (((unsigned)bkey == 0xffffffffu) ? INFINITY : __uint_as_float((unsigned)(bkey >> 32)));
     if (active) {
       const float gx0 = (lx - E > 0) ? p.x - (g.minx + (float)(lx - E) * g.cell) : INFINITY;
       const float gx1 = (hx + E < g.dx - 1) ? (g.minx + (float)(hx + E + 1) * g.cell) - p.x : INFINITY;
