@@ -224,6 +224,17 @@ struct KeepInBox {
     return p.x >= lx && p.x <= hx && p.y >= ly && p.y <= hy && p.z >= lz && p.z <= hz;
   }
 };
+// ... or, tighter: inside the box [l, h] grown by r with its edges and corners ROUNDED -- the points within r of the box.  A
+// candidate within r of a query inside [l, h] is within r of the box, so nothing is lost; what goes is the grown box's corner
+// regions (a tenth of it in the plane, more in space), which every query of the item would otherwise test and reject.
+struct KeepNearBox {
+  float lx, hx, ly, hy, lz, hz, r2;
+  __device__ __forceinline__ bool operator()(const float4 &p) const
+  {
+    const float dx = fmaxf(fmaxf(lx - p.x, p.x - hx), 0.0f), dy = fmaxf(fmaxf(ly - p.y, p.y - hy), 0.0f), dz = fmaxf(fmaxf(lz - p.z, p.z - hz), 0.0f);
+    return dx * dx + dy * dy + dz * dz <= r2;
+  }
+};
 template <int TILE, int NX, class LoadX, class Scan, class Keep = KeepAll>
 __device__ __forceinline__ void wave_stream_box(const GridView &g, int x0, int x1, int y0, int y1, int z0, int z1,
                                                 float4 *s_pts, float4 *s_x, int *s_off, int *s_beg, int lane,

@@ -300,8 +300,8 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
             wave_lds_fence();
           }
         },
-        // only points inside the patch's bounding box grown by the radius can be in range
-        KeepInBox{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri});
+        // only points within the radius of the patch's bounding box can be in range
+        KeepNearBox{lx, hx, ly, hy, lz, hz, ri * ri});
   }
   __syncthreads();                                            // all votes are in (other waves vote into this wave's columns)
   if (!live) return;

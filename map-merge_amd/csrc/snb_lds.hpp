@@ -568,7 +568,7 @@ __device__ __forceinline__ int snb_stage_queries(const GridView &g, SnbLds<Cfg> 
   const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
   const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
   const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
-  snb_stage<Cfg>(g, S, &S.n_tile[epoch & 1], x0, x1, y0, y1, z0, z1, lane, wave, KeepInBox{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri}, load_pay);
+  snb_stage<Cfg>(g, S, &S.n_tile[epoch & 1], x0, x1, y0, y1, z0, z1, lane, wave, KeepNearBox{lx, hx, ly, hy, lz, hz, ri * ri}, load_pay);
   SNB_TOCK(2, t_stage);
   SNB_TICK(t_sb);
   __syncthreads();
