@@ -133,7 +133,7 @@ __device__ __forceinline__ int sn_build_lists(const GridView &g, SnLds &L, float
   const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
   const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
   const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
-  const KeepInBox keep{lx - ri, hx + ri, ly - ri, hy + ri, lz - ri, hz + ri};
+  const KeepNearBox keep{lx, hx, ly, hy, lz, hz, ri * ri};
   const float bscale = (float)kSnNB / r2;
   for (int p = 0; p < kSnG; ++p) L.cnt[p][lane] = 0u;
   if ((lane & 3) == 0) L.q[lane >> 2] = make_float4(qx, qy, qz, 0.0f);
