@@ -8,8 +8,9 @@ TAG=${1:-round}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 mkdir -p gpurun_out
-run() {   # run <cfg> <bench args...>
+run() {   # run <cfg> <bench args...>       (ONLY="5 1": just those rows)
   local cfg=$1; shift
+  if [ -n "${ONLY:-}" ] && [[ " $ONLY " != *" $cfg "* ]]; then return; fi
   timeout 1500 python3 bench.py "$@" 2> "/tmp/table_cfg$cfg.err" | tail -1 > "gpurun_out/${TAG}_table_cfg$cfg.json"
   python3 -c "import json; d=json.load(open('gpurun_out/${TAG}_table_cfg$cfg.json')); print('cfg$cfg', d['value'], (d.get('cpu_baseline') or {}).get('value'), (d.get('cpu_baseline_all_cores') or {}).get('value'), (d.get('parity_check') or {}).get('ok'), d.get('icp_iterations_histogram'), d.get('gt_error', {}).get('recovered_within_0.5'))" \
     || { echo "cfg$cfg failed:"; tail -5 "/tmp/table_cfg$cfg.err"; }
@@ -17,7 +18,7 @@ run() {   # run <cfg> <bench args...>
 run 1 --maps 2 --points 10000 --steps 10 --warmup 2
 run 2 --maps 4 --points 200000 --steps 5 --warmup 1
 run 3
-run 5 --maps 64 --points 50000 --steps 2 --warmup 1
+run 5 --maps 64 --points 50000 --steps 5 --warmup 1
 run 4 --maps 8 --points 2000000 --descriptor SHOT --steps 2 --warmup 1
 # configs[3] as SURVEY 8d words it: dense indoor -- 30 m windows, resolution 0.05 (the radii keep the reference's defaults)
 run 4indoor --maps 8 --points 2000000 --descriptor SHOT --window 30 --resolution 0.05 --steps 1 --warmup 1
