@@ -484,6 +484,72 @@ def test_icp_and_score_known_answers(po):
     assert po.transform_score(flat, flat, up, 1.0) == np.finfo(np.float64).max
 
 
+def test_sac_ia_known_answers(po):
+    """SampleConsensusInitialAlignment (R/src/matching.cpp:159-173) draws three source keypoints at least min_sample_distance
+    apart, gives each a random one of its TEN nearest target descriptors, fits a rigid transform and keeps the hypothesis with
+    the lowest truncated error.  Known answer: every target keypoint stored ten times (same position, same descriptor) makes
+    every draw a correct correspondence, so the very first hypothesis is the exact transform; with distinct descriptors only a
+    fraction of the draws is right and the result still has to be one of the exact hypotheses (error ~ 0) given enough of them."""
+    rng = np.random.default_rng(21)
+    T = rand_se3(rng, 1.0, 4.0)
+    base = rng.uniform(-10, 10, (60, 3)).astype(np.float32)
+    desc = rng.uniform(0, 100, (60, 33)).astype(np.float32)
+    tgt_xyz, tgt_desc = np.repeat(base, 10, axis=0), np.repeat(desc, 10, axis=0)
+    Ti = np.linalg.inv(T)
+    src_xyz = (base.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+    po.srand(1)
+    Tg, best_iter, best_err = po.sac_ia(cloud(po, src_xyz), desc, cloud(po, tgt_xyz), tgt_desc, 1.0, 0.5, 1)
+    assert np.abs(Tg - T).max() < 1e-3 and best_iter == 0
+    # the error metric: sum over the source keypoints of min(d2 / threshold, 1) with threshold = max_corr^2 (TruncatedError),
+    # which is ~ 0 for the exact transform and 60 for one that puts every keypoint out of range
+    assert 0.0 <= best_err < 1e-3
+    # a third of the source keypoints without a counterpart (displaced by tens of metres): a draw is right with probability
+    # (2/3)^3, so two hundred hypotheses contain exact ones, and an exact one has the lowest error
+    src2 = src_xyz.copy(); src2[40:] += rng.uniform(30, 60, (20, 3)).astype(np.float32)
+    po.srand(1)
+    T2, it2, err2 = po.sac_ia(cloud(po, src2), desc, cloud(po, tgt_xyz), tgt_desc, 1.0, 0.5, 200)
+    assert np.abs(T2 - T).max() < 1e-2
+    assert 19.5 < err2 < 20.5          # the twenty displaced keypoints count 1 each, the forty matched ones ~ 0
+    # fewer than three source keypoints: selectSamples cannot draw, the guess (identity in the reference's call) is left alone
+    po.srand(1)
+    T3, _, _ = po.sac_ia(cloud(po, src_xyz[:2]), desc[:2], cloud(po, base), desc, 1.0, 0.5, 10)
+    assert np.array_equal(T3, np.zeros((4, 4), np.float32)) or np.array_equal(T3, np.eye(4, dtype=np.float32))
+
+
+def test_sift_known_answers(po):
+    """SIFTKeypoint on a flat lattice whose intensity is uniform except for ONE Gaussian blob: the difference-of-Gaussians
+    scale space has its extremum at the blob's centre and at a scale near the blob's own sigma (the classical blob-detector
+    property the algorithm rests on), nothing is reported in the uniform part, and a blob below min_contrast is not reported
+    at all.  Independent of any implementation detail: only positions, scales and the contrast threshold are looked at."""
+    step = 0.1
+    gx, gy = np.meshgrid(np.arange(-40, 41) * step, np.arange(-40, 41) * step)
+    xyz = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], 1).astype(np.float32)
+    def with_blob(amplitude, sigma, cx=0.33, cy=-0.21):
+        c = cloud(po, xyz)
+        g = amplitude * np.exp(-((xyz[:, 0] - cx) ** 2 + (xyz[:, 1] - cy) ** 2) / (2 * sigma * sigma))
+        lum = np.clip(60.0 + g, 0, 255).astype(np.uint32)          # r = g = b: the intensity PCL's SIFT reads is the luminance
+        c["rgba"] = (0xFF << 24) | (lum << 16) | (lum << 8) | lum
+        return c
+    for sigma in (0.25, 0.4):
+        kp, sc = po.keypoints_sift(with_blob(150.0, sigma), 0.1, 3, 3, 5.0)
+        assert len(kp) >= 1
+        d = np.hypot(kp["x"] - 0.33, kp["y"] + 0.21)
+        # every keypoint sits on the blob (within its sigma), none in the uniform part or at the lattice's border
+        assert (d < sigma).all(), (sigma, d.max())
+        best = np.argmin(d)
+        # (a keypoint is a point of its octave's voxelised cloud: the sample nearest the centre, at most a leaf's diagonal away)
+        assert d[best] < 0.6 * sigma
+        # scale selection: the DoG response of a Gaussian blob of width s peaks for a filter sigma ~ s (the scales are sampled
+        # three per octave, a factor 2^(1/3) = 1.26 apart)
+        assert sigma / 1.3 <= sc[best] <= 1.3 * sigma, (sigma, sc[best])
+    # contrast threshold: the same blob at a twentieth of the amplitude disappears, and so does everything on a uniform lattice
+    assert len(po.keypoints_sift(with_blob(4.0, 0.4), 0.1, 3, 3, 5.0)[0]) == 0
+    assert len(po.keypoints_sift(with_blob(0.0, 0.4), 0.1, 3, 3, 5.0)[0]) == 0
+    # a darker blob (a minimum of the scale space) is found as well: the extrema are maxima AND minima
+    kp, _ = po.keypoints_sift(with_blob(-55.0, 0.4), 0.1, 3, 3, 5.0)
+    assert len(kp) >= 1 and (np.hypot(kp["x"] - 0.33, kp["y"] + 0.21) < 0.4).all()
+
+
 # ---------------------------------------------------------------- pose graph
 def test_pose_graph_quirks(po):
     I = np.eye(4)
