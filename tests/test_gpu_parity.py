@@ -132,6 +132,26 @@ def test_sift_keypoints(ctx, scene):
         assert (got["rgba"] == 0).all()
 
 
+def test_sift_blob_known_answer(ctx, po):
+    """The blob-detector property through the device path (tests/test_oracle_cpu.py::test_sift_known_answers has the CPU side):
+    a flat lattice with ONE Gaussian intensity blob gives one keypoint, on the blob; a uniform lattice and a blob under the
+    contrast threshold give none.  And the device agrees with the oracle on each."""
+    gx, gy = np.meshgrid(np.arange(-40, 41) * 0.1, np.arange(-40, 41) * 0.1)
+    pts = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], 1).astype(np.float32)
+    for amplitude, sigma, expect in ((150.0, 0.25, 1), (150.0, 0.4, 1), (-55.0, 0.4, 1), (4.0, 0.4, 0), (0.0, 0.4, 0)):
+        c = np.zeros(len(pts), dtype=po.POINT)
+        c["x"], c["y"], c["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+        g = amplitude * np.exp(-((pts[:, 0] - 0.33) ** 2 + (pts[:, 1] + 0.21) ** 2) / (2 * sigma * sigma))
+        lum = np.clip(60.0 + g, 0, 255).astype(np.uint32)
+        c["rgba"] = (0xFF << 24) | (lum << 16) | (lum << 8) | lum
+        got = ctx.detectKeypoints(ctx.cloud(c), None, 0, 5.0, R_NRM, 0.1).numpy()
+        ref, _ = po.keypoints_sift(c, 0.1, 3, 3, 5.0)
+        assert len(got) == len(ref) == expect
+        assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
+        if expect:
+            assert np.hypot(got["x"] - 0.33, got["y"] + 0.21).max() < 0.6 * sigma
+
+
 def test_sift_keypoints_where_the_25_nearest_reach_beyond_the_scale_space_ball(ctx, po, scene):
     """The extremum test reads a point's 25 nearest neighbours from the scale-space kernel's sorted list when the
     3 sigma_max ball holds that many, and searches for them otherwise.  A cloud thinned to a fifth (most balls hold
