@@ -421,14 +421,30 @@ def main():
         c.profile_reset()
         c.profile(not args.no_kernel_events)
     barrier()
+    def host_waits():
+        # (host waits for a stream, summed over the library's worker contexts: mm3d_debug_waits)
+        import ctypes as C
+        tot = [0, 0]
+        for c in ctxs:
+            w = (C.c_longlong * 2)()
+            try:
+                mm.lib().mm3d_debug_waits(c._h, w)
+            except Exception:
+                return None
+            tot[0] += w[0]; tot[1] += w[1]
+        return tot
+    w0 = host_waits()
     cpu0, thr0 = time.process_time(), cgroup_throttle()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    w1 = host_waits()
     host_cpu = {"cores_busy": round((time.process_time() - cpu0) / max(elapsed, 1e-9), 2), "cgroup_cpu_limit": cgroup_cpu_limit(),
                 "cgroup_throttled_ms_per_step": round((cgroup_throttle() - thr0) / 1e3 / max(args.steps, 1), 2)}
+    if w0 and w1:
+        host_cpu["stream_waits_per_step"] = round((w1[0] - w0[0]) / max(args.steps, 1), 1)
     for c in ctxs:
         c.profile(False)
     # N = 1: the same step with the clouds handed over the way the reference's callers hold them -- host arrays of

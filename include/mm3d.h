@@ -103,7 +103,8 @@ int mm3d_last_icp_converged(const mm3d_ctx *ctx);
 void mm3d_set_debug(mm3d_ctx *ctx, int on);
 long long mm3d_debug_knn_fallback_rows(mm3d_ctx *ctx);
 long long mm3d_debug_knn_rows(mm3d_ctx *ctx);
-/* host waits for the context's stream since the context was made: out[0] = their number, out[1] = nanoseconds spent in them */
+/* host waits for the context's stream (and its mm3d_set_streams workers') since the context was made: out[0] = their number,
+ * out[1] = nanoseconds spent in them */
 void mm3d_debug_waits(mm3d_ctx *ctx, long long out[2]);
 /* test hook: out[i] = the float sum "0 + incr[i] + incr[i] + ..." (hits[i] additions) as the PFH kernels
  * replay it for a histogram bin (PFHEstimation: "histogram[h] += hist_incr" once per pair) */

@@ -262,6 +262,8 @@ void mm3d_debug_waits(mm3d_ctx *ctx, long long out[2])
 {
   out[0] = ctx ? ctx->waits : 0;
   out[1] = ctx ? ctx->wait_ns : 0;
+  if (ctx)                        // (with the worker contexts of mm3d_set_streams: the whole library call's waits)
+    for (mm3d_ctx *h : ctx->helpers) { out[0] += h->waits; out[1] += h->wait_ns; }
 }
 int mm3d_debug_float_chain(mm3d_ctx *ctx, const float *incr, const unsigned *hits, int n, float *out)
 {

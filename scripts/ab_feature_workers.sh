@@ -1,0 +1,8 @@
+run() { python3 bench.py --no-cpu-baseline --no-pcie --steps 10 --warmup 2 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d['value'], d['ms_per_step'], d['stage_seconds_last_step']['t_features'])" "$1"; }
+for r in 1 2; do
+run default
+MM3D_FEATURE_WORKERS=4 run fw4
+MM3D_FEATURE_WORKERS=5 run fw5
+MM3D_FEATURE_WORKERS=8 run fw8
+MM3D_FEATURE_WORKERS=10 run fw10
+done
