@@ -848,7 +848,13 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
       if (avail) {
         // a batch shares its TARGET (the pairs (i, t) of one t): one descriptor search for the sampled rows of all
         // its sources, and one target grid under every search of the batch
-        const size_t take = std::min(kPairBatch, std::max<size_t>(1, avail / (2 * S)));
+        // How large a batch: round 4 measured take = avail / (share * S) on the headline (16 streams, 120 pairs trickling in behind
+        // the feature stage): share 4 / 2 / 1 / 0.5 / 0.25 / 0.125 -> 989 / 990 / 1004 / 1013 / 1021 / 1022 map-pairs/s.  The pair
+        // stage's kernels are latency-bound and only four run at a time (hardware queues), so a launch that serves four pairs
+        // costs little more queue time than one that serves one; with share 2 most batches were a single pair.
+        static const double share = getenv("MM3D_PAIR_SHARE") ? atof(getenv("MM3D_PAIR_SHARE")) : 0.25;
+        static const size_t cap = getenv("MM3D_PAIR_BATCH") ? (size_t)atoi(getenv("MM3D_PAIR_BATCH")) : kPairBatch;   // (experiment knob: 8 / 16 / 32 the same)
+        const size_t take = std::min(cap, std::max<size_t>(1, (size_t)((double)avail / (share * (double)S))));
         size_t target = n;
         for (size_t q = 0; q < P && out.size() < take; ++q)
           if (!claimed[q] && all[q].first < prefix && ready[all[q].second] && (target == n || all[q].second == target)) {
@@ -1193,7 +1199,8 @@ int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *min
     // batches of pairs with the same target (pairs_estimate_batch), at most kPairBatch of them and not so many that
     // a stream runs dry: every map exists already, so the whole list can be cut up front
     const size_t S = ctx->helpers.size() + 1;
-    const size_t take = std::min(kPairBatch, std::max<size_t>(1, todo.size() / (2 * S)));
+    static const double share = getenv("MM3D_PAIR_SHARE") ? atof(getenv("MM3D_PAIR_SHARE")) : 0.25;        // (as claim_pairs above)
+    const size_t take = std::min(kPairBatch, std::max<size_t>(1, (size_t)((double)todo.size() / (share * (double)S))));
     std::stable_sort(todo.begin(), todo.end(), [&](size_t a, size_t b) { return live[a].second < live[b].second; });
     std::vector<std::pair<size_t, size_t>> batches;           // [first, last) into todo
     for (size_t a = 0; a < todo.size();) {
