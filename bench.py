@@ -834,10 +834,10 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", me
         # clauses must hold.  exact: within TOL_T_EXACT of the same ICP with its sums in double, equal iteration counts;
         # oracle: within transform_tolerance(n_src) of the CPU path, whose sequential float sums carry their own summation
         # noise (reported as cpu_path_own_noise_vs_double_sums), equal iteration counts.
-        t_tol = po.transform_tolerance(len(f0))
+        t_tol = po.transform_tolerance(len(f0), cpu_noise)        # min(per-point slope, this pair's own CPU noise + TOL_T_EXACT)
         it_dev = int(rec["icp_iterations"])
         exact_ok = fro_dbl <= po.TOL_T_EXACT and it_dev == int(it_dbl)
-        oracle_ok = fro <= t_tol and it_dev == int(it)
+        oracle_ok = fro <= t_tol and cpu_noise <= po.transform_tolerance(len(f0)) and it_dev == int(it)
         parity = {
             "sample": "maps 0 and 1 and pair (0, 1) of the timed workload: device (this run) vs CPU oracle",
             "filtered_points_bit_equal": bool(same(g[0]["points"], f0) and same(g[1]["points"], f1)),

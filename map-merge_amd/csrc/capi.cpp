@@ -644,6 +644,27 @@ static void pair_estimate_impl(mm3d_ctx *ctx, const mm3d_map *s, const mm3d_map 
 }
 
 constexpr size_t kPairBatch = 16;     // pairs whose tails and scoring share launches
+// the two experiment knobs of the pair batches, validated once (a share <= 0 or not a number would divide by zero and cast
+// inf to size_t; a batch cap of 0 would never claim a pair and leave the scheduler waiting for ever)
+static double pair_share_knob()
+{
+  static const double v = [] {
+    const char *e = getenv("MM3D_PAIR_SHARE");
+    double s = e ? atof(e) : 0.25;
+    if (!(s >= 1.0 / 64.0)) s = 1.0 / 64.0;           // (also catches NaN)
+    return std::min(s, 64.0);
+  }();
+  return v;
+}
+static size_t pair_batch_knob()
+{
+  static const size_t v = [] {
+    const char *e = getenv("MM3D_PAIR_BATCH");
+    const long b = e ? atol(e) : (long)kPairBatch;
+    return (size_t)std::min<long>(std::max<long>(b, 1), 32);      // (32: the largest batch ever run)
+  }();
+  return v;
+}
 
 // Several pairs on one context: the initial estimates one after the other (each from its own generator state),
 // then every pair's ICP + score tail in lockstep, one launch per step for the whole batch (icp_score_batch).
@@ -852,8 +873,8 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
         // the feature stage): share 4 / 2 / 1 / 0.5 / 0.25 / 0.125 -> 989 / 990 / 1004 / 1013 / 1021 / 1022 map-pairs/s.  The pair
         // stage's kernels are latency-bound and only four run at a time (hardware queues), so a launch that serves four pairs
         // costs little more queue time than one that serves one; with share 2 most batches were a single pair.
-        static const double share = getenv("MM3D_PAIR_SHARE") ? atof(getenv("MM3D_PAIR_SHARE")) : 0.25;
-        static const size_t cap = getenv("MM3D_PAIR_BATCH") ? (size_t)atoi(getenv("MM3D_PAIR_BATCH")) : kPairBatch;   // (experiment knob: 8 / 16 / 32 the same)
+        const double share = pair_share_knob();
+        const size_t cap = pair_batch_knob();              // (experiment knob: 8 / 16 / 32 the same)
         const size_t take = std::min(cap, std::max<size_t>(1, (size_t)((double)avail / (share * (double)S))));
         size_t target = n;
         for (size_t q = 0; q < P && out.size() < take; ++q)
@@ -1199,7 +1220,7 @@ int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *min
     // batches of pairs with the same target (pairs_estimate_batch), at most kPairBatch of them and not so many that
     // a stream runs dry: every map exists already, so the whole list can be cut up front
     const size_t S = ctx->helpers.size() + 1;
-    static const double share = getenv("MM3D_PAIR_SHARE") ? atof(getenv("MM3D_PAIR_SHARE")) : 0.25;        // (as claim_pairs above)
+    const double share = pair_share_knob();                  // (as claim_pairs above)
     const size_t take = std::min(kPairBatch, std::max<size_t>(1, (size_t)((double)todo.size() / (share * (double)S))));
     std::stable_sort(todo.begin(), todo.end(), [&](size_t a, size_t b) { return live[a].second < live[b].second; });
     std::vector<std::pair<size_t, size_t>> batches;           // [first, last) into todo

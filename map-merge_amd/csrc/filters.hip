@@ -187,7 +187,11 @@ mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
   // k_bbox launch and no wait of its own).
   const size_t bound = in->n_finite;                            // a voxel holds at least one finite point
   DevBuf<int> starts(c, (size_t)n + 1);
-  const unsigned cblocks = std::min<unsigned>(div_up(bound, 256), 512u);
+  // (240 blocks: their slots come back in ONE 7.7 KB copy.  Round 4's 512 blocks made it 16.5 KB, and the HIP runtime hands a
+  // device-to-host copy of more than 16 KB to an SDMA engine instead of its blit kernel: every kernel trace since showed 6 - 8 ms
+  // without a kernel behind k_voxel_centroid at every step start, all feature workers parked at this wait -- DESIGN.md section 6)
+  static const unsigned cblocks_cap = [] { const char *e = getenv("MM3D_VOXEL_BLOCKS"); return e ? (unsigned)std::max(1, atoi(e)) : 240u; }();
+  const unsigned cblocks = std::min<unsigned>(div_up(bound, 256), cblocks_cap);
   DevBuf<unsigned> ctl(c, 16 + 8 * (size_t)cblocks);             // [0] voxels, [16 + 8 b ..] block b's box of centroids
   DevBuf<float4> out(c, bound);
   const size_t ctl_bytes = (16 + 8 * (size_t)cblocks) * sizeof(unsigned);
@@ -206,6 +210,16 @@ mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
     sort_pairs_u32(c, keys.get(), keys2.get(), vals.get(), vals2.get(), n, 32);
   }
   const size_t nvox = h[16];
+  // The output was allocated at its bound (one wait for the whole filter).  A large cloud that shrank to less than half of it
+  // (2 M raw points -> 200 k voxels would keep 32 MB for the cloud's lifetime, times sixteen streams) moves to a buffer
+  // of its size; small or well-filled ones stay (a copy dispatch per SIFT octave would cost the headline more than the
+  // memory is worth: 406 k -> 100 k points is 6.5 MB for the octave's lifetime).
+  if (bound >= ((size_t)1 << 20) && nvox * 2 < bound) {
+    DevBuf<float4> fit(c, nvox);
+    if (nvox) MM3D_HIP(hipMemcpyAsync(fit.get(), out.get(), nvox * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    c->settle();                                      // (`out` returns to the pool behind the copy)
+    out = std::move(fit);
+  }
   mm3d_cloud *res = cloud_from_device(c, std::move(out), nvox);
   unsigned box[8];
   box_of_slots(h + 32, cblocks, box);
@@ -259,6 +273,12 @@ mm3d_cloud *remove_outliers(Context *c, const mm3d_cloud *in, double radius, int
   DevBuf<float4> out;
   unsigned box[7];
   size_t m = compact_points(c, in->pts.get(), keep.get(), n, out, box);     // (the kept points' bounding box comes back with the count)
+  if (n >= ((size_t)1 << 20) && m * 2 < n) {           // as in downsample: a large, mostly empty bound-sized buffer is not kept
+    DevBuf<float4> fit(c, m);
+    if (m) MM3D_HIP(hipMemcpyAsync(fit.get(), out.get(), m * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    c->settle();
+    out = std::move(fit);
+  }
   mm3d_cloud *res = cloud_from_device(c, std::move(out), m);
   cloud_set_bbox(res, box);
   return res;

@@ -630,19 +630,22 @@ __global__ void k_hilbert_gather(const float4 *__restrict__ pts, const uint32_t 
   out[j] = p;
 }
 
-// a work item starts at the first point, at every change of the column block (key >> 16) and every 64 points
+// a work item starts at the first point, at every change of the column block (key >> 16) and every 64 points.
+// `inert` (device word or null): when it is set the keys were never written (the counting sort gave up, k_hil_place
+// returned early) -- no head is seen and no item is stored, so the scan cannot write past the items' bound n / 64 + 16386
+// on recycled pool memory that shows a head at every j
 struct ItemHeadLoad {
-  const uint32_t *keys; int n;
+  const uint32_t *keys; int n; const int *inert;
   __device__ __forceinline__ bool head(size_t j) const { return j < (size_t)n && (j == 0 || (keys[j] >> 16) != (keys[j - 1] >> 16) || (j & 63) == 0); }
-  __device__ __forceinline__ int operator()(size_t j) const { return head(j) ? 1 : 0; }
+  __device__ __forceinline__ int operator()(size_t j) const { return (inert && *inert) ? 0 : (head(j) ? 1 : 0); }
 };
 struct ItemFillStore {
-  const uint32_t *keys; int n; int2 *items; int *n_items;
+  const uint32_t *keys; int n; int2 *items; int *n_items; const int *inert;
   __device__ __forceinline__ void operator()(size_t j, int prefix, int v) const
   {
     if (j == (size_t)n) { *n_items = prefix; return; }        // (the scan runs over n + 1 elements: the last one carries the total)
     if (!v) return;
-    const ItemHeadLoad h{keys, n};
+    const ItemHeadLoad h{keys, n, nullptr};
     int cnt = 1;
     while (cnt < 64 && j + cnt < (size_t)n && !h.head(j + cnt)) ++cnt;
     items[prefix] = make_int2((int)j, cnt);
@@ -791,7 +794,9 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl_, float min_cell)
   DevBuf<int> n_items_dev(c, 1);
   int *h = (int *)c->pin(64);
   for (int attempt = 0; attempt < 2; ++attempt) {
-    scan_fused(c, "hilbert_items", n * 20.0, (size_t)n + 1, ItemHeadLoad{keys2.get(), n}, ItemFillStore{keys2.get(), n, cl->wave_items.get(), n_items_dev.get()});
+    const int *inert = attempt == 0 ? (const int *)too_long.get() : nullptr;      // (attempt 1: the radix sort always writes the keys)
+    scan_fused(c, "hilbert_items", n * 20.0, (size_t)n + 1, ItemHeadLoad{keys2.get(), n, inert},
+               ItemFillStore{keys2.get(), n, cl->wave_items.get(), n_items_dev.get(), inert});
     MM3D_HIP(hipMemcpyAsync(h, n_items_dev.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
     MM3D_HIP(hipMemcpyAsync(h + 1, too_long.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->sync();

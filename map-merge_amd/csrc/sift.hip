@@ -838,7 +838,10 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     // and every item pays its staging and its end-of-item barrier whatever it holds: the cell grows with the leaf
     // (2.5 leaves: 0.25 m in the first octave, as everywhere else)
     static const float hil_factor = [] { const char *e = getenv("MM3D_SIFT_HIL_FACTOR"); return e ? (float)atof(e) : 2.5f; }();
-    cloud_hilbert(c, octave_cloud, hil_factor * scale);
+    // (only on the octave clouds SIFT owns: the caller's `points` keeps the default cell, so the query order its later users --
+    // FPFH blocks, ICP and score reductions -- inherit does not depend on whether SIFT ran first; at the reference's resolution
+    // 0.1 the two cells are the same 0.25 m)
+    cloud_hilbert(c, octave_cloud, octave_cloud == points ? 0.25f : hil_factor * scale);
     const int n_items = octave_cloud->n_wave_items;
     // scale space on a grid with cell = r/2 -- or, in the first octave on `points` itself, on the grid the caller is about
     // to build on that cloud anyway (the descriptors' radius / 2) when its cell is close to that: one grid build less per

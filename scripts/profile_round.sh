@@ -28,7 +28,7 @@ with_retries() {
   return 1
 }
 
-with_retries 3 /tmp/prof_kt -- rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 bench.py --steps 3 --warmup 1 \
+with_retries 3 /tmp/prof_kt -- rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 bench.py --steps 3 --warmup 1 --no-pcie \
     --no-cpu-baseline --kernel-table "$R/gpurun_out/${TAG}_hip_event_table.csv" || fail "kernel trace"
 cp /tmp/prof_kt/*/*kernel_stats.csv "gpurun_out/${TAG}_kernel_stats.csv" || fail "no kernel_stats.csv"
 need "gpurun_out/${TAG}_kernel_stats.csv"; need "gpurun_out/${TAG}_hip_event_table.csv"

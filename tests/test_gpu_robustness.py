@@ -118,3 +118,29 @@ def test_a_column_of_thousands_of_points(ctx, po, mm, textured):
     n_ref = po.normals(src, 0.3)
     n_got = ctx.computeSurfaceNormals(ctx.cloud(src), 0.3).numpy()
     assert np.array_equal(n_got.view(np.uint32), n_ref.view(np.uint32))
+
+
+def test_a_long_column_inside_a_large_cloud(ctx, po, mm):
+    """More than 16.6 k points AND a column of more than 1024 of them: attempt 0 of the Hilbert work-item scan reads
+    keys the counting sort never wrote (it gave up); it must stay inert instead of scattering a head per point past
+    the items' bound n / 64 + 16386.  Run twice so that the second pass works on recycled pool memory."""
+    rng = np.random.default_rng(11)
+    n_ground, n_pole = 40000, 3000
+    src = np.zeros(n_ground + n_pole, dtype=mm.POINT)
+    src["x"][:n_ground] = rng.uniform(-20, 20, n_ground)
+    src["y"][:n_ground] = rng.uniform(-20, 20, n_ground)
+    src["z"][:n_ground] = rng.normal(0, 0.02, n_ground)
+    src["x"][n_ground:] = 3.1 + rng.normal(0, 0.01, n_pole)
+    src["y"][n_ground:] = -4.2 + rng.normal(0, 0.01, n_pole)
+    src["z"][n_ground:] = rng.uniform(0, 30, n_pole)
+    src["rgba"] = 0xFF000000 | rng.integers(0, 1 << 24, len(src)).astype(np.uint32)
+    tgt = src.copy()
+    tgt["y"] += 0.04
+    T0 = np.eye(4, dtype=np.float32)
+    s_ref = po.transform_score(src, tgt, T0, 1.0)
+    for _ in range(2):
+        s_got = ctx.transformScore(ctx.cloud(src), ctx.cloud(tgt), T0, 1.0)
+        assert s_got == pytest.approx(s_ref, rel=1e-6)
+    T_ref, it_ref = po.icp(src, tgt, T0, 1.0, 0.5, 50, 1e-2)
+    T_got = ctx.estimateTransformICP(ctx.cloud(src), ctx.cloud(tgt), T0, 1.0, 0.5, 50, 1e-2)
+    assert np.linalg.norm(T_got - T_ref) < 1e-3 and ctx.last_icp_iterations == it_ref

@@ -715,6 +715,8 @@ def test_exact_yardstick_of_a_whole_job(po, synth):
         assert np.linalg.norm(T_ex[k].astype(np.float64) - pairs_b[k]["transform"].astype(np.float64)) <= 0.5 * po.transform_tolerance(5000)
         assert abs(int(corr_ex[k]) - int(tr[k]["icp_correspondences"])) <= 2
     assert po.transform_tolerance(5000) == 1e-3 and po.transform_tolerance(406000) == pytest.approx(4.06e-3) and po.TOL_T_EXACT == 1e-4
+    # with the pair's own CPU noise known the oracle clause is noise + TOL_T_EXACT, never above the per-point slope
+    assert po.transform_tolerance(406000, 1.1e-3) == pytest.approx(1.2e-3) and po.transform_tolerance(5000, 0.5) == 1e-3
 
 
 def test_pair_features_are_symmetric_under_the_swap_except_on_ties(po):
