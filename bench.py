@@ -171,10 +171,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--streams", type=int, default=16, help="contexts (HIP stream + host thread) per GPU")
-    ap.add_argument("--engine", choices=["library", "shard", "python"], default="library",
+    ap.add_argument("--engine", choices=["library", "shard", "python", "devices"], default="library",
                     help="one GPU only: 'library' = one mm3d_estimate_maps_transforms call, streams inside libmm3d; "
                          "'shard' = the N > 1 driver (mm3d_shard_*: what several ranks always use) on one rank; "
-                         "'python' = the shardable pieces driven from Python threads (diagnostic)")
+                         "'python' = the shardable pieces driven from Python threads (diagnostic); "
+                         "'devices' = ONE process (launch without torchrun), --gpus N devices behind the one mm3d_estimate_maps_transforms "
+                         "call (mm3d_create_devices: sharded inside the library, pair records through an in-library RCCL all-gather) -- "
+                         "what the reference's single-process callers get; MM3D_BENCH_DEVICES=0,0 overrides the list (test hook)")
     ap.add_argument("--feature-streams", type=int, default=6,
                     help="one GPU only: pipeline the stages, this many streams extract features (0 = two barriered stages)")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -213,7 +216,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    if args.gpus != world:
+    if args.gpus != world and args.engine != "devices":
         if rank == 0:
             print(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
@@ -221,7 +224,15 @@ def main():
 
     mm = ge.load()
     from map_merge_amd import sharding
-    ctx = mm.Context(local_rank)
+    dev_list = None
+    if args.engine == "devices":
+        if world != 1:
+            raise SystemExit("--engine devices is ONE process over --gpus N devices: launch it without torchrun")
+        dev_list = [int(x) for x in os.environ["MM3D_BENCH_DEVICES"].split(",")] if os.environ.get("MM3D_BENCH_DEVICES") else list(range(max(1, args.gpus)))
+        ctx = mm.Context(devices=dev_list)                 # (creates the RCCL communicators: seconds, once, outside the timed region)
+    else:
+        ctx = mm.Context(local_rank)
+    n_gpus = len(dev_list) if dev_list else world
     # BASELINE.json's configuration is FPFH + SAC_IA; the other combinations (PFH is the reference's default
     # descriptor, MATCHING its default method) can be timed with the flags
     desc_type = mm.Descriptor[args.descriptor]
@@ -266,7 +277,7 @@ def main():
     if os.environ.get("MM3D_WAIT") == "spin":
         S = max(1, min(S, max(2, int(cpus // max(world, 1)) - (1 if world > 1 else 0))))
     else:
-        S = max(1, min(S, max(2, int(cpus / (0.2 * max(world, 1))))))
+        S = max(1, min(S, max(2, int(cpus / (0.2 * max(n_gpus, 1))))))
     ctxs = [ctx] + [mm.Context(local_rank) for _ in range(S - 1)]
     tpool = ThreadPoolExecutor(S) if S > 1 else None
 
@@ -391,19 +402,24 @@ def main():
         pts, kps = (C.c_size_t * n_maps)(), (C.c_size_t * n_maps)()
         L.mm3d_last_run_map_sizes.restype = C.c_size_t
         L.mm3d_last_run_map_sizes(ctx._h, pts, kps, C.c_size_t(n_maps))
-        stats.update(dict(n_pairs=len(mine), t_features=f_s.value, t_exchange=0.0, t_pairs=tot_s.value - f_s.value,
-                          t_gather_graph=0.0, pts_filtered=list(pts), keypoints=list(kps),
+        t_exchange, t_pairs, t_gather = 0.0, tot_s.value - f_s.value, 0.0
+        if dev_list:                                       # per-stage seconds of the slowest device, and the RCCL gather alone
+            ex_s, pr_s, g_s = ctx.lastRunDeviceSeconds()
+            t_exchange, t_pairs, t_gather = ex_s - f_s.value, pr_s - ex_s, tot_s.value - pr_s
+            stats["rccl_gather_us"] = round(1e6 * g_s, 1)
+        stats.update(dict(n_pairs=len(mine), t_features=f_s.value, t_exchange=t_exchange, t_pairs=t_pairs,
+                          t_gather_graph=t_gather, pts_filtered=list(pts), keypoints=list(kps),
                           icp_iters=[int(x) for x in mine["icp_iterations"]],
                           n_estimated=int(sum(1 for t in T if np.any(t))),
                           crc=zlib.crc32(np.ascontiguousarray(mine["transform"]).tobytes()) & 0xffffffff, records=mine))
         return T
 
-    if world > 1 or args.engine in ("library", "shard"):
+    if world > 1 or args.engine in ("library", "shard", "devices"):
         for c in ctxs[1:]:
             c.close()
         ctxs = [ctx]
         ctx.setStreams(S)
-        step = step_library if (world == 1 and args.engine == "library") else step_sharded
+        step = step_library if (world == 1 and args.engine in ("library", "devices")) else step_sharded
     else:
         step = step_pipelined
 
@@ -635,7 +651,7 @@ def main():
         out = {
             "metric": "map-pairs/sec (normals+%s+%s+ICP, end to end incl. per-map features)"
                       % (args.descriptor, "SAC-IA" if args.method == "SAC_IA" else "matching+RANSAC"),
-            "value": round(value, 4), "unit": "map-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 4), "unit": "map-pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n_maps} maps x {n_pts} raw pts, {args.descriptor} + {args.method} + ICP refine, {n_pairs} pairs"
@@ -643,7 +659,11 @@ def main():
                                    + (f", '{args.scenes}' scenes, windows {args.overlap_step:g} of a side apart" if args.scenes != "independent" or args.overlap_step != 0.5 else "")
                                    + (f", {args.sac_iterations} SAC-IA hypotheses" if args.sac_iterations > 0 else "")
                                    + (" [DIAGNOSTIC: host pcl::PointXYZRGB input, upload inside the step]" if args.host_input != "none" else ""),
-                       "parallelism": (f"one mm3d_estimate_maps_transforms call, {S} streams inside the library"
+                       "parallelism": (f"ONE process, one mm3d_estimate_maps_transforms call on the device list {dev_list} (mm3d_create_devices): maps by owner, "
+                                       f"bundles pulled with hipMemcpyPeerAsync, pairs by target owner, {S} streams per device, pair records through "
+                                       + ("one in-library ncclAllGather" if ctx.uses_rccl else "host memory (duplicate-device test hook: no RCCL)")
+                                       if dev_list else
+                                       f"one mm3d_estimate_maps_transforms call, {S} streams inside the library"
                                        if world == 1 and args.engine == "library" else
                                        f"mm3d_shard_*: maps by owner, pairs by target owner over {world} GPU(s) x {S} streams inside the library"
                                        if step is step_sharded else
@@ -676,6 +696,7 @@ def main():
             "icp_iterations_histogram": {str(k): int(v) for k, v in zip(*np.unique(stats["icp_iters"], return_counts=True))},
             "host_cpu": host_cpu,                           # the box's CPU quota bounds how many host threads can wait at once
             "pair_transforms_crc32": stats["crc"],          # same job, same bits: independent of --gpus / --streams
+            **({"rccl_gather_us": stats["rccl_gather_us"]} if "rccl_gather_us" in stats else {}),
             "roofline": roofline,
         }
         # ground truth: the generator knows every map's pose.  Error of the estimated pair transforms (source -> target)

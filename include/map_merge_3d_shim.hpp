@@ -40,11 +40,35 @@ namespace map_merge_3d
 {
 namespace mm3d_shim
 {
-inline mm3d_ctx *make_ctx(int streams)
+// MM3D_DEVICES="0,1,2,3,4,5,6,7" (or "all"): the node's ONE process uses that many GPUs -- estimateMapsTransforms is then
+// sharded over them inside the library, the pair records gathered by one RCCL all-gather (mm3d_create_devices); no source
+// change in the node.  Otherwise one GPU: MM3D_DEVICE (default 0).
+inline mm3d_ctx *make_ctx(int streams, bool may_use_device_list = false)
 {
-  const char *d = std::getenv("MM3D_DEVICE");
   mm3d_ctx *p = nullptr;
-  if (mm3d_create(d ? std::atoi(d) : 0, &p) != MM3D_OK) throw std::runtime_error("mm3d: no MI355X device");
+  const char *list = may_use_device_list ? std::getenv("MM3D_DEVICES") : nullptr;
+  if (list && *list) {
+    std::vector<int> devs;
+    if (std::string(list) == "all") {
+      for (int d = 0; d < 64; ++d) {                       // as many as exist: creation fails at the first that does not
+        mm3d_ctx *probe = nullptr;
+        if (mm3d_create(d, &probe) != MM3D_OK) break;
+        mm3d_destroy(probe);
+        devs.push_back(d);
+      }
+    } else {
+      for (const char *q = list; *q;) {
+        devs.push_back(std::atoi(q));
+        while (*q && *q != ',') ++q;
+        if (*q == ',') ++q;
+      }
+    }
+    if (devs.empty() || mm3d_create_devices(devs.data(), (int)devs.size(), &p) != MM3D_OK)
+      throw std::runtime_error("mm3d: MM3D_DEVICES does not name usable MI355X devices");
+  } else {
+    const char *d = std::getenv("MM3D_DEVICE");
+    if (mm3d_create(d ? std::atoi(d) : 0, &p) != MM3D_OK) throw std::runtime_error("mm3d: no MI355X device");
+  }
   (void)mm3d_set_streams(p, streams);
   return p;
 }
@@ -60,7 +84,7 @@ inline mm3d_ctx *ctx()
   static mm3d_ctx *c = [] {
     const char *s = std::getenv("MM3D_STREAMS");
     const int n = s ? std::atoi(s) : 16;
-    return make_ctx(n >= 1 && n <= 64 ? n : 16);
+    return make_ctx(n >= 1 && n <= 64 ? n : 16, true);      // (the estimation engine is the one that may span several GPUs)
   }();
   return c;
 }

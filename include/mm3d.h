@@ -93,6 +93,20 @@ typedef struct mm3d_desc mm3d_desc;        /* device-resident descriptors (PCLPo
 
 /* ---- context -------------------------------------------------------------------------- */
 int mm3d_create(int device, mm3d_ctx **out);
+/* One process, several GPUs.  The reference's callers are single processes (MapMerge3d::transformsEstimation, a ROS timer
+ * callback: R/src/map_merge_node.cpp:133-153; map_merge_tool's main: R/src/map_merge_tool.cpp:37-38), so the multi-GPU form
+ * of the path sits behind the same entry point: a context made from a device list runs mm3d_estimate_maps_transforms
+ * sharded over those devices INSIDE the library -- features by map owner, the other maps' bundles pulled GPU to GPU
+ * (hipMemcpyPeerAsync over xGMI), pairs by target owner, ONE RCCL all-gather (ncclAllGather, communicators from
+ * ncclCommInitAll) of the 104-byte pair records, pose graph on the host -- with the bits of one device.  Every other entry
+ * point of such a context works on its first device.  mm3d_set_streams applies to every device of the list.
+ * Creating the communicators takes seconds (once, here).  A device listed twice is MM3D_EINVAL (test hook:
+ * MM3D_DEVICES_ALLOW_DUPLICATES=1 admits it, the records are then gathered through host memory instead of RCCL, which
+ * refuses a device twice; mm3d_devices_use_rccl tells). */
+int mm3d_create_devices(const int *devices, int n_devices, mm3d_ctx **out);
+int mm3d_device_count(const mm3d_ctx *ctx);          /* 1 for a context made by mm3d_create */
+int mm3d_device_at(const mm3d_ctx *ctx, int i);      /* the i-th device of the list, or MM3D_EINVAL */
+int mm3d_devices_use_rccl(const mm3d_ctx *ctx);      /* 1: pair records travel through ncclAllGather; 0: plain context or the test hook */
 void mm3d_destroy(mm3d_ctx *ctx);
 const char *mm3d_last_error(const mm3d_ctx *ctx);
 /* diagnostics of the most recent ICP run on this context (pcl::Registration::nr_iterations_, converged_) */
@@ -123,9 +137,9 @@ void mm3d_srand(mm3d_ctx *ctx, unsigned seed);
  * stream replays the rand() draws of the pairs it does not run.  When many pairs are ready at once (many small
  * maps) a stream takes up to 16 of them that share their target and runs them as one batch (one descriptor
  * search, one launch per step for all of them); the results are the sequential loop's all the same.
- * A stream's host thread spins while it waits for the device: more streams than the process has CPUs (a
- * container's quota counts) slow everything down, and the device runs four kernels at a time anyway.
- * 1 <= n <= 64. */
+ * A stream's host thread polls and naps while it waits for the device (about 0.2 of a core per busy stream; MM3D_WAIT=spin
+ * makes it spin): far more streams than the process has CPUs (a container's quota counts) slow everything down, and the
+ * device runs four kernels at a time anyway.  1 <= n <= 64. */
 int mm3d_set_streams(mm3d_ctx *ctx, int n_streams);
 int mm3d_get_streams(const mm3d_ctx *ctx);
 /* diagnostics of the most recent mm3d_estimate_maps_transforms on this context: seconds from entry
@@ -133,6 +147,9 @@ int mm3d_get_streams(const mm3d_ctx *ctx);
  * of points after downSample + removeOutliers and of keypoints after descriptor pruning (returns
  * the number of clouds; at most `capacity` entries are written) */
 int mm3d_last_run_stage_seconds(const mm3d_ctx *ctx, double *features_s, double *total_s);
+/* the same for a device-list context: seconds from entry until the slowest device had pulled the other maps' bundles, until
+ * the slowest device had finished its pairs, and the duration of the RCCL gather of the pair records alone */
+int mm3d_last_run_device_seconds(const mm3d_ctx *ctx, double *exchange_s, double *pairs_s, double *gather_s);
 size_t mm3d_last_run_map_sizes(const mm3d_ctx *ctx, size_t *points, size_t *keypoints, size_t capacity);
 
 /* ---- cloud objects -------------------------------------------------------------------- */

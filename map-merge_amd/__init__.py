@@ -132,14 +132,39 @@ def _Tout(a):
 
 
 class Context:
-    """One registration engine on one GPU (mm3d_ctx)."""
+    """One registration engine on one GPU (mm3d_ctx) -- or, with `devices`, on a list of GPUs of this one process
+    (mm3d_create_devices): estimateMapsTransforms then shards over them inside the library and gathers the pair
+    records through RCCL; every other call works on the first device of the list."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, devices=None):
         self._h = C.c_void_p()
-        st = lib().mm3d_create(int(device), C.byref(self._h))
-        if st != 0:
-            raise Mm3dError(st, "mm3d_create failed: no usable MI355X/HIP device (there is no CPU path)")
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            arr = (C.c_int * max(len(devices), 1))(*devices)
+            st = lib().mm3d_create_devices(arr, len(devices), C.byref(self._h))
+            if st != 0:
+                raise Mm3dError(st, f"mm3d_create_devices({devices}) failed: bad list, a device twice, no such device, or RCCL could not "
+                                    "create its communicators (there is no CPU path)")
+            device = devices[0]
+        else:
+            st = lib().mm3d_create(int(device), C.byref(self._h))
+            if st != 0:
+                raise Mm3dError(st, "mm3d_create failed: no usable MI355X/HIP device (there is no CPU path)")
         self.device = device
+
+    @property
+    def devices(self):
+        return [lib().mm3d_device_at(self._h, i) for i in range(lib().mm3d_device_count(self._h))]
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(lib().mm3d_devices_use_rccl(self._h))
+
+    def lastRunDeviceSeconds(self):
+        """(exchange_s, pairs_s, gather_s) of the most recent estimateMapsTransforms on a device list."""
+        a, b, g = C.c_double(), C.c_double(), C.c_double()
+        self._ck(lib().mm3d_last_run_device_seconds(self._h, C.byref(a), C.byref(b), C.byref(g)))
+        return a.value, b.value, g.value
 
     def close(self):
         if self._h:

@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 BUILD=${BUILD_DIR:-build}
 OUT=${OUT:-libmm3d.so}
 mkdir -p $BUILD
-SRCS="libm_debug.hip grid.hip filters.hip normals.hip sift.hip harris.hip fpfh.hip pfh.hip rsd.hip shot.hip sc3d.hip desc_knn.hip registration.hip nn.hip runtime.cpp linalg.cpp host_pipeline.cpp capi.cpp"
+SRCS="libm_debug.hip grid.hip filters.hip normals.hip sift.hip harris.hip fpfh.hip pfh.hip rsd.hip shot.hip sc3d.hip desc_knn.hip registration.hip nn.hip runtime.cpp linalg.cpp host_pipeline.cpp devices.cpp capi.cpp"
 OBJS=""
 pids=()
 for s in $SRCS; do
@@ -21,5 +21,6 @@ for s in $SRCS; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
+# librccl: the one collective of the path, the all-gather of the pair records between the devices of one process (devices.cpp)
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS -L/opt/rocm/lib -lrccl
 echo "built $(pwd)/$OUT"

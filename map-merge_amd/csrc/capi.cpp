@@ -28,9 +28,13 @@ int guarded(mm3d_ctx *ctx, F &&f)
     mm3d_ctx *c;
     ~Clean()
     {
-      c->deferred.clear();
-      c->private_objects = false;
-      for (mm3d_ctx *h : c->helpers) { h->deferred.clear(); h->private_objects = false; }
+      auto one = [](mm3d_ctx *r) {
+        r->deferred.clear();
+        r->private_objects = false;
+        for (mm3d_ctx *h : r->helpers) { h->deferred.clear(); h->private_objects = false; }
+      };
+      one(c);
+      for (mm3d_ctx *p : c->peers) one(p);
     }
   } clean{ctx};
   try {
@@ -194,20 +198,66 @@ int mm3d_create(int device, mm3d_ctx **out)
   return MM3D_OK;
 }
 
+// One process, several GPUs (the reference's caller is one process: R/src/map_merge_node.cpp:133-153).  The context is the
+// first device's; the others' root contexts hang off it (mm3d_ctx::peers), and a DeviceSet holds the RCCL communicators.
+int mm3d_create_devices(const int *devices, int n_devices, mm3d_ctx **out)
+{
+  if (!out) return MM3D_EINVAL;
+  *out = nullptr;
+  if (!devices || n_devices < 1 || n_devices > 64) return MM3D_EINVAL;
+  mm3d_ctx *root = nullptr;
+  int st = mm3d_create(devices[0], &root);
+  if (st != MM3D_OK) return st;
+  for (int d = 1; d < n_devices && st == MM3D_OK; ++d) {
+    mm3d_ctx *p = nullptr;
+    st = mm3d_create(devices[d], &p);
+    if (st == MM3D_OK) root->peers.push_back(p);
+  }
+  if (st == MM3D_OK) {
+    try {
+      root->device_set = device_set_create(devices, n_devices);
+    } catch (const Error &e) {
+      st = e.status;
+    } catch (...) {
+      st = MM3D_EDEVICE;
+    }
+  }
+  if (st != MM3D_OK) { mm3d_destroy(root); return st; }
+  (void)hipSetDevice(devices[0]);
+  *out = root;
+  return MM3D_OK;
+}
+
+int mm3d_device_count(const mm3d_ctx *ctx) { return ctx ? (int)ctx->peers.size() + 1 : 0; }
+int mm3d_device_at(const mm3d_ctx *ctx, int i)
+{
+  if (!ctx || i < 0 || i > (int)ctx->peers.size()) return MM3D_EINVAL;
+  return i == 0 ? ctx->device : ctx->peers[(size_t)i - 1]->device;
+}
+int mm3d_devices_use_rccl(const mm3d_ctx *ctx) { return ctx && device_set_has_comms(ctx->device_set) ? 1 : 0; }
+
+static void set_streams_one(mm3d_ctx *ctx, int n_streams)
+{
+  if (hipSetDevice(ctx->device) != hipSuccess) throw Error(MM3D_EDEVICE, "hipSetDevice failed");
+  while ((int)ctx->helpers.size() + 1 > n_streams) {
+    mm3d_destroy(ctx->helpers.back());
+    ctx->helpers.pop_back();
+  }
+  while ((int)ctx->helpers.size() + 1 < n_streams) {
+    mm3d_ctx *h = nullptr;
+    const int st = mm3d_create(ctx->device, &h);
+    if (st != MM3D_OK) throw Error(st, "mm3d_set_streams: could not create a helper context");
+    ctx->helpers.push_back(h);
+  }
+}
+
 int mm3d_set_streams(mm3d_ctx *ctx, int n_streams)
 {
   if (n_streams < 1 || n_streams > 64) return MM3D_EINVAL;
   return guarded(ctx, [&] {
-    while ((int)ctx->helpers.size() + 1 > n_streams) {
-      mm3d_destroy(ctx->helpers.back());
-      ctx->helpers.pop_back();
-    }
-    while ((int)ctx->helpers.size() + 1 < n_streams) {
-      mm3d_ctx *h = nullptr;
-      const int st = mm3d_create(ctx->device, &h);
-      if (st != MM3D_OK) throw Error(st, "mm3d_set_streams: could not create a helper context");
-      ctx->helpers.push_back(h);
-    }
+    set_streams_one(ctx, n_streams);
+    for (mm3d_ctx *p : ctx->peers) set_streams_one(p, n_streams);     // (every device of an mm3d_create_devices context)
+    (void)hipSetDevice(ctx->device);
   });
 }
 
@@ -216,6 +266,10 @@ int mm3d_get_streams(const mm3d_ctx *ctx) { return ctx ? (int)ctx->helpers.size(
 void mm3d_destroy(mm3d_ctx *ctx)
 {
   if (!ctx) return;
+  device_set_destroy(ctx->device_set);                  // (the communicators go before the streams they were used on)
+  ctx->device_set = nullptr;
+  for (mm3d_ctx *p : ctx->peers) mm3d_destroy(p);
+  ctx->peers.clear();
   for (mm3d_ctx *h : ctx->helpers) mm3d_destroy(h);
   ctx->helpers.clear();
   (void)hipSetDevice(ctx->device);
@@ -240,6 +294,14 @@ int mm3d_last_run_stage_seconds(const mm3d_ctx *ctx, double *features_s, double 
   if (total_s) *total_s = ctx->last_total_s;
   return MM3D_OK;
 }
+int mm3d_last_run_device_seconds(const mm3d_ctx *ctx, double *exchange_s, double *pairs_s, double *gather_s)
+{
+  if (!ctx) return MM3D_EINVAL;
+  if (exchange_s) *exchange_s = ctx->last_exchange_s;
+  if (pairs_s) *pairs_s = ctx->last_pairs_s;
+  if (gather_s) *gather_s = ctx->last_gather_s;
+  return MM3D_OK;
+}
 size_t mm3d_last_run_map_sizes(const mm3d_ctx *ctx, size_t *points, size_t *keypoints, size_t capacity)
 {
   if (!ctx) return 0;
@@ -262,8 +324,13 @@ void mm3d_debug_waits(mm3d_ctx *ctx, long long out[2])
 {
   out[0] = ctx ? ctx->waits : 0;
   out[1] = ctx ? ctx->wait_ns : 0;
-  if (ctx)                        // (with the worker contexts of mm3d_set_streams: the whole library call's waits)
+  if (ctx) {                      // (with the worker contexts of mm3d_set_streams, on every device: the whole library call's waits)
     for (mm3d_ctx *h : ctx->helpers) { out[0] += h->waits; out[1] += h->wait_ns; }
+    for (mm3d_ctx *p : ctx->peers) {
+      out[0] += p->waits; out[1] += p->wait_ns;
+      for (mm3d_ctx *h : p->helpers) { out[0] += h->waits; out[1] += h->wait_ns; }
+    }
+  }
 }
 int mm3d_debug_float_chain(mm3d_ctx *ctx, const float *incr, const unsigned *hits, int n, float *out)
 {
@@ -1050,38 +1117,42 @@ static void on_streams(mm3d_ctx *ctx, Fn &&fn)
 }
 extern "C" {
 
+// (no lock, no device selection: the callers -- mm3d_shard_begin under guarded(), estimate_maps_devices on a device's own thread -- did both)
+static mm3d_shard *shard_begin_impl(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, const mm3d_params *params, int rank, int world)
+{
+  std::unique_ptr<mm3d_shard> sh(new mm3d_shard());
+  sh->ctx = ctx; sh->rank = rank; sh->world = world; sh->n = n; sh->params = *params;
+  sh->maps.assign(n, nullptr);
+  std::vector<size_t> mine;
+  for (size_t i = 0; i < n; ++i)
+    if (mm3d_shard_map_owner(i, world) == rank) mine.push_back(i);
+  std::atomic<size_t> next{0};
+  on_streams(ctx, [&](size_t, mm3d_ctx *c, const std::atomic<bool> &failed) {
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= mine.size() || failed.load()) break;
+      const size_t i = mine[k];
+      std::unique_ptr<mm3d_cloud> raw(cloud_from_memory(c, clouds[i].points, clouds[i].points ? clouds[i].n : 0,
+                                                        clouds[i].stride ? clouds[i].stride : 16,
+                                                        clouds[i].stride ? clouds[i].rgba_offset : 12));
+      // nobody else sees the map before on_streams has drained every stream: no waits for other contexts' sake
+      c->private_objects = true;
+      mm3d_map *m = map_features_impl(c, raw.get(), params);
+      sh->maps[i] = m;                         // (distinct slots: no lock needed; the shard owns it from here)
+      map_prepare_impl(c, m, params);          // this rank is the map's target-side owner
+      c->private_objects = false;
+      c->sync();                               // also looks at the error flags the kernels left
+    }
+  });
+  return sh.release();
+}
+
 int mm3d_shard_begin(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, const mm3d_params *params, int rank, int world,
                      mm3d_shard **out)
 {
   if (!ctx || !params || !out || (n && !clouds) || world < 1 || rank < 0 || rank >= world) return MM3D_EINVAL;
   *out = nullptr;
-  return guarded(ctx, [&] {
-    std::unique_ptr<mm3d_shard> sh(new mm3d_shard());
-    sh->ctx = ctx; sh->rank = rank; sh->world = world; sh->n = n; sh->params = *params;
-    sh->maps.assign(n, nullptr);
-    std::vector<size_t> mine;
-    for (size_t i = 0; i < n; ++i)
-      if (mm3d_shard_map_owner(i, world) == rank) mine.push_back(i);
-    std::atomic<size_t> next{0};
-    on_streams(ctx, [&](size_t, mm3d_ctx *c, const std::atomic<bool> &failed) {
-      for (;;) {
-        const size_t k = next.fetch_add(1);
-        if (k >= mine.size() || failed.load()) break;
-        const size_t i = mine[k];
-        std::unique_ptr<mm3d_cloud> raw(cloud_from_memory(c, clouds[i].points, clouds[i].points ? clouds[i].n : 0,
-                                                          clouds[i].stride ? clouds[i].stride : 16,
-                                                          clouds[i].stride ? clouds[i].rgba_offset : 12));
-        // nobody else sees the map before on_streams has drained every stream: no waits for other contexts' sake
-        c->private_objects = true;
-        mm3d_map *m = map_features_impl(c, raw.get(), params);
-        sh->maps[i] = m;                         // (distinct slots: no lock needed; the shard owns it from here)
-        map_prepare_impl(c, m, params);          // this rank is the map's target-side owner
-        c->private_objects = false;
-        c->sync();                               // also looks at the error flags the kernels left
-      }
-    });
-    *out = sh.release();
-  });
+  return guarded(ctx, [&] { *out = shard_begin_impl(ctx, clouds, n, params, rank, world); });
 }
 
 int mm3d_shard_bundle_sizes(const mm3d_shard *sh, uint64_t *n_points, uint64_t *n_keypoints)
@@ -1177,77 +1248,80 @@ int mm3d_shard_unpack_many(mm3d_shard *sh, size_t count, const size_t *maps, con
   });
 }
 
+static void shard_pairs_impl(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *mine, size_t capacity, size_t *n_pairs)
+{
+  mm3d_ctx *ctx = sh->ctx;
+  for (size_t i = 0; i < sh->n; ++i)
+    if (!sh->maps[i]) throw Error(MM3D_EINVAL, "mm3d_shard_pairs: a map has neither been computed here nor unpacked");
+  const mm3d_params *params = &sh->params;
+  // the live pairs in the reference's order, and the generator state before each of them (the draws of a pair
+  // depend on its source keypoints only: every rank replays the whole stream on the host, ~30 us per pair)
+  std::vector<std::pair<size_t, size_t>> live;
+  for (size_t i = 0; i + 1 < sh->n; ++i)
+    for (size_t j = i + 1; j < sh->n; ++j)
+      if (sh->maps[i]->keypoints->n > 0 && sh->maps[j]->keypoints->n > 0) live.emplace_back(i, j);
+  const size_t P = live.size();
+  *n_pairs = P;
+  if (P > capacity) throw Error(MM3D_ECAPACITY, "mm3d_shard_pairs: room for every live pair is needed");
+  // state_at[q] = the generator before pair q, advanced on demand (under rng_mu) as far as a worker needs it:
+  // the first pairs start at once, the table's tail (~30 us of host work per pair) is filled in while they run
+  std::vector<GlibcRand> state_at(P + 1, ctx->rnd);
+  size_t known_upto = 0;
+  std::mutex rng_mu;
+  std::vector<const std::vector<float4> *> src_kp(sh->n, nullptr);
+  for (size_t i = 0; i < sh->n; ++i) src_kp[i] = &cloud_host(ctx, sh->maps[i]->keypoints);   // (cached at prepare / unpack time)
+  auto advance_states = [&](size_t upto) {
+    std::lock_guard<std::mutex> lk(rng_mu);
+    while (known_upto < upto) {
+      GlibcRand r = state_at[known_upto];
+      pair_rand_replay(r, params->estimation_method, *src_kp[live[known_upto].first], params->inlier_threshold, params->max_iterations);
+      state_at[++known_upto] = r;
+    }
+  };
+  std::vector<size_t> todo;
+  for (size_t q = 0; q < P; ++q) {
+    std::memset(&pairs[q], 0, sizeof(mm3d_pair_result));
+    pairs[q].source_idx = live[q].first;
+    pairs[q].target_idx = live[q].second;
+    mine[q] = mm3d_shard_map_owner(live[q].second, sh->world) == sh->rank ? 1 : 0;
+    if (mine[q]) todo.push_back(q);
+  }
+  // batches of pairs with the same target (pairs_estimate_batch), at most kPairBatch of them and not so many that
+  // a stream runs dry: every map exists already, so the whole list can be cut up front
+  const size_t S = ctx->helpers.size() + 1;
+  const double share = pair_share_knob();                  // (as claim_pairs above)
+  const size_t take = std::min(kPairBatch, std::max<size_t>(1, (size_t)((double)todo.size() / (share * (double)S))));
+  std::stable_sort(todo.begin(), todo.end(), [&](size_t a, size_t b) { return live[a].second < live[b].second; });
+  std::vector<std::pair<size_t, size_t>> batches;           // [first, last) into todo
+  for (size_t a = 0; a < todo.size();) {
+    size_t b = a + 1;
+    while (b < todo.size() && b - a < take && live[todo[b]].second == live[todo[a]].second) ++b;
+    batches.emplace_back(a, b);
+    a = b;
+  }
+  std::atomic<size_t> next{0};
+  on_streams(ctx, [&](size_t, mm3d_ctx *c, const std::atomic<bool> &failed) {
+    std::vector<PairWork> work;
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= batches.size() || failed.load()) break;
+      work.clear();
+      for (size_t e = batches[k].first; e < batches[k].second; ++e) {
+        const size_t q = todo[e];
+        advance_states(q);
+        work.push_back(PairWork{sh->maps[live[q].first], sh->maps[live[q].second], &pairs[q], state_at[q]});
+      }
+      pairs_estimate_batch(c, work.data(), work.size(), params);
+    }
+  });
+  advance_states(P);
+  ctx->rnd = state_at[P];                       // where the reference's sequential loop leaves the generator
+}
+
 int mm3d_shard_pairs(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned char *mine, size_t capacity, size_t *n_pairs)
 {
   if (!sh || !n_pairs || !pairs || !mine) return MM3D_EINVAL;
-  mm3d_ctx *ctx = sh->ctx;
-  return guarded(ctx, [&] {
-    for (size_t i = 0; i < sh->n; ++i)
-      if (!sh->maps[i]) throw Error(MM3D_EINVAL, "mm3d_shard_pairs: a map has neither been computed here nor unpacked");
-    const mm3d_params *params = &sh->params;
-    // the live pairs in the reference's order, and the generator state before each of them (the draws of a pair
-    // depend on its source keypoints only: every rank replays the whole stream on the host, ~30 us per pair)
-    std::vector<std::pair<size_t, size_t>> live;
-    for (size_t i = 0; i + 1 < sh->n; ++i)
-      for (size_t j = i + 1; j < sh->n; ++j)
-        if (sh->maps[i]->keypoints->n > 0 && sh->maps[j]->keypoints->n > 0) live.emplace_back(i, j);
-    const size_t P = live.size();
-    *n_pairs = P;
-    if (P > capacity) throw Error(MM3D_ECAPACITY, "mm3d_shard_pairs: room for every live pair is needed");
-    // state_at[q] = the generator before pair q, advanced on demand (under rng_mu) as far as a worker needs it:
-    // the first pairs start at once, the table's tail (~30 us of host work per pair) is filled in while they run
-    std::vector<GlibcRand> state_at(P + 1, ctx->rnd);
-    size_t known_upto = 0;
-    std::mutex rng_mu;
-    std::vector<const std::vector<float4> *> src_kp(sh->n, nullptr);
-    for (size_t i = 0; i < sh->n; ++i) src_kp[i] = &cloud_host(ctx, sh->maps[i]->keypoints);   // (cached at prepare / unpack time)
-    auto advance_states = [&](size_t upto) {
-      std::lock_guard<std::mutex> lk(rng_mu);
-      while (known_upto < upto) {
-        GlibcRand r = state_at[known_upto];
-        pair_rand_replay(r, params->estimation_method, *src_kp[live[known_upto].first], params->inlier_threshold, params->max_iterations);
-        state_at[++known_upto] = r;
-      }
-    };
-    std::vector<size_t> todo;
-    for (size_t q = 0; q < P; ++q) {
-      std::memset(&pairs[q], 0, sizeof(mm3d_pair_result));
-      pairs[q].source_idx = live[q].first;
-      pairs[q].target_idx = live[q].second;
-      mine[q] = mm3d_shard_map_owner(live[q].second, sh->world) == sh->rank ? 1 : 0;
-      if (mine[q]) todo.push_back(q);
-    }
-    // batches of pairs with the same target (pairs_estimate_batch), at most kPairBatch of them and not so many that
-    // a stream runs dry: every map exists already, so the whole list can be cut up front
-    const size_t S = ctx->helpers.size() + 1;
-    const double share = pair_share_knob();                  // (as claim_pairs above)
-    const size_t take = std::min(kPairBatch, std::max<size_t>(1, (size_t)((double)todo.size() / (share * (double)S))));
-    std::stable_sort(todo.begin(), todo.end(), [&](size_t a, size_t b) { return live[a].second < live[b].second; });
-    std::vector<std::pair<size_t, size_t>> batches;           // [first, last) into todo
-    for (size_t a = 0; a < todo.size();) {
-      size_t b = a + 1;
-      while (b < todo.size() && b - a < take && live[todo[b]].second == live[todo[a]].second) ++b;
-      batches.emplace_back(a, b);
-      a = b;
-    }
-    std::atomic<size_t> next{0};
-    on_streams(ctx, [&](size_t, mm3d_ctx *c, const std::atomic<bool> &failed) {
-      std::vector<PairWork> work;
-      for (;;) {
-        const size_t k = next.fetch_add(1);
-        if (k >= batches.size() || failed.load()) break;
-        work.clear();
-        for (size_t e = batches[k].first; e < batches[k].second; ++e) {
-          const size_t q = todo[e];
-          advance_states(q);
-          work.push_back(PairWork{sh->maps[live[q].first], sh->maps[live[q].second], &pairs[q], state_at[q]});
-        }
-        pairs_estimate_batch(c, work.data(), work.size(), params);
-      }
-    });
-    advance_states(P);
-    ctx->rnd = state_at[P];                       // where the reference's sequential loop leaves the generator
-  });
+  return guarded(sh->ctx, [&] { shard_pairs_impl(sh, pairs, mine, capacity, n_pairs); });
 }
 
 void mm3d_shard_end(mm3d_shard *sh)
@@ -1260,6 +1334,172 @@ void mm3d_shard_end(mm3d_shard *sh)
     for (mm3d_ctx *h : ctx->helpers) (void)stream_wait(h->stream);
   }
   delete sh;
+}
+
+// ---------------------------------------------------------------- the same job on N devices of ONE process
+// estimateMapsTransforms behind the reference's own entry point on a device list (mm3d_create_devices): the reference's
+// caller is one process -- a ROS timer callback, R/src/map_merge_node.cpp:133-153 -- and cannot be relaunched under torchrun.
+// One host thread per device drives that device's root context and its streams through the mm3d_shard_* scheme:
+//   1. features of the maps the device owns (zig-zag ownership, shard_begin_impl) incl. their target-side structures;
+//   2. when every device is done, each PULLS the other maps' bundles and source-side structures from their owners with
+//      hipMemcpyPeerAsync (devices.cpp::cloud_clone_from_peer), dealt to its streams -- xGMI is point to point, every
+//      device reads from up to seven peers at once; nothing is recomputed (the multi-process form re-builds the Hilbert
+//      orders from the bundles: 2.3 ms per rank at N = 8);
+//   3. the pairs whose TARGET the device owns (shard_pairs_impl), every device replaying the reference's single rand() stream;
+//   4. ONE RCCL all-gather of the 104-byte pair records (devices.cpp::gather_pair_records), then the pose graph on the host.
+// Same bits as one device: the ownership only decides where a map or a pair is computed.
+namespace {
+// a barrier the device threads can leave through a failure: whoever throws releases the others, who then throw too
+struct FailBarrier {
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t n, waiting = 0, generation = 0;
+  bool failed = false;
+  explicit FailBarrier(size_t n_) : n(n_) {}
+  void wait()
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    if (failed) throw Error(MM3D_EDEVICE, "another device failed");
+    const size_t gen = generation;
+    if (++waiting == n) { waiting = 0; ++generation; cv.notify_all(); return; }
+    cv.wait(lk, [&] { return failed || generation != gen; });
+    if (failed) throw Error(MM3D_EDEVICE, "another device failed");
+  }
+  void fail()
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    failed = true;
+    cv.notify_all();
+  }
+};
+}  // namespace
+
+static void estimate_maps_devices(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, const mm3d_params *params, float *out_T,
+                                  size_t *n_out, mm3d_pair_result *pairs_out, size_t *n_pairs_out)
+{
+  std::vector<mm3d_ctx *> roots{ctx};
+  roots.insert(roots.end(), ctx->peers.begin(), ctx->peers.end());
+  const size_t D = roots.size();
+  const size_t max_pairs = n * (n - 1) / 2;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+  std::vector<std::unique_ptr<mm3d_shard>> sh(D);
+  std::vector<std::vector<mm3d_pair_result>> rec(D, std::vector<mm3d_pair_result>(max_pairs));
+  std::vector<std::vector<unsigned char>> mine(D, std::vector<unsigned char>(max_pairs, 0));
+  std::vector<size_t> np(D, 0);
+  std::vector<double> t_feat(D, 0.0), t_exch(D, 0.0), t_pairs(D, 0.0);
+  FailBarrier bar(D);
+  std::mutex err_mu;
+  std::exception_ptr first_error;
+  for (size_t d = 1; d < D; ++d) roots[d]->rnd = ctx->rnd;        // every device replays the one rand() stream from the caller's state
+  auto body = [&](size_t d) {
+    mm3d_ctx *root = roots[d];
+    // (the peers are reached only through this call, which holds the first context's lock: theirs is taken for the helpers'
+    // sake of invariants only -- nothing else can be using them)
+    std::unique_lock<std::mutex> peer_lock;
+    if (d > 0) peer_lock = std::unique_lock<std::mutex>(root->mu);
+    try {
+      if (hipSetDevice(root->device) != hipSuccess) throw Error(MM3D_EDEVICE, "hipSetDevice failed");
+      sh[d].reset(shard_begin_impl(root, clouds, n, params, (int)d, (int)D));
+      t_feat[d] = since_start();
+      bar.wait();                                         // every owner's maps exist and its streams are drained
+      // the other devices' maps: bundle + source-side structures straight from the owner's memory, dealt to this device's streams
+      std::vector<size_t> theirs;
+      for (size_t i = 0; i < n; ++i)
+        if (!sh[d]->maps[i]) theirs.push_back(i);
+      std::atomic<size_t> next{0};
+      on_streams(root, [&](size_t, mm3d_ctx *c, const std::atomic<bool> &failed) {
+        for (;;) {
+          const size_t k = next.fetch_add(1);
+          if (k >= theirs.size() || failed.load()) break;
+          const size_t i = theirs[k];
+          const size_t o = (size_t)mm3d_shard_map_owner(i, (int)D);
+          const mm3d_map *src = sh[o]->maps[i];
+          const int src_dev = roots[o]->device;
+          c->private_objects = true;
+          std::unique_ptr<mm3d_cloud> pts(cloud_clone_from_peer(c, src->points, src_dev));
+          std::unique_ptr<mm3d_cloud> kp(cloud_clone_from_peer(c, src->keypoints, src_dev));
+          std::unique_ptr<mm3d_desc> desc(desc_clone_from_peer(c, src->desc, src_dev));
+          // source role only (as mm3d_shard_unpack): whatever of the query orders / host copy did not come with the clone
+          if (pts->n) cloud_hilbert(c, pts.get());
+          if (kp->n) cloud_hilbert(c, kp.get());
+          (void)cloud_host(c, kp.get());
+          c->private_objects = false;
+          c->sync();
+          auto *m = new mm3d_map();
+          m->points = pts.release(); m->keypoints = kp.release(); m->desc = desc.release();
+          sh[d]->maps[i] = m;                             // distinct slots; nobody reads another device's non-owned slots
+        }
+      });
+      t_exch[d] = since_start();
+      shard_pairs_impl(sh[d].get(), rec[d].data(), mine[d].data(), max_pairs, &np[d]);
+      t_pairs[d] = since_start();
+      // an owner's maps are read by its peers' pulls: nobody leaves (and nothing is freed) before everybody has pulled
+      bar.wait();
+    } catch (...) {
+      bar.fail();
+      std::lock_guard<std::mutex> lk(err_mu);
+      if (!first_error) first_error = std::current_exception();
+    }
+  };
+  {
+    std::vector<std::thread> threads;
+    for (size_t d = 1; d < D; ++d) threads.emplace_back(body, d);
+    body(0);
+    for (auto &t : threads) t.join();
+  }
+  (void)hipSetDevice(ctx->device);
+  if (first_error) {
+    for (size_t d = 0; d < D; ++d) {                      // drain before the shards (and their maps) go
+      (void)hipSetDevice(roots[d]->device);
+      (void)stream_wait(roots[d]->stream);
+      for (mm3d_ctx *h : roots[d]->helpers) (void)stream_wait(h->stream);
+    }
+    (void)hipSetDevice(ctx->device);
+    std::rethrow_exception(first_error);
+  }
+  ctx->last_points.assign(n, 0);
+  ctx->last_keypoints.assign(n, 0);
+  for (size_t i = 0; i < n; ++i) {
+    ctx->last_points[i] = sh[0]->maps[i]->points->n;
+    ctx->last_keypoints[i] = sh[0]->maps[i]->keypoints->n;
+  }
+  ctx->last_features_s = *std::max_element(t_feat.begin(), t_feat.end());
+  ctx->last_exchange_s = *std::max_element(t_exch.begin(), t_exch.end());
+  ctx->last_pairs_s = *std::max_element(t_pairs.begin(), t_pairs.end());
+  // the gather: rank d sends the records of its own pairs, in pair order, padded to the largest rank's count
+  const size_t P = np[0];
+  for (size_t d = 1; d < D; ++d)
+    if (np[d] != P) throw Error(MM3D_EDEVICE, "estimate_maps_devices: the devices disagree on the live pairs");
+  std::vector<std::vector<mm3d_pair_result>> send(D);
+  std::vector<std::vector<size_t>> which(D);
+  for (size_t d = 0; d < D; ++d)
+    for (size_t q = 0; q < P; ++q)
+      if (mine[d][q]) { send[d].push_back(rec[d][q]); which[d].push_back(q); }
+  size_t slots = 0;
+  for (size_t d = 0; d < D; ++d) slots = std::max(slots, send[d].size());
+  std::vector<mm3d_pair_result> gathered;
+  ctx->last_gather_s = gather_pair_records(ctx->device_set, roots, send, slots, gathered);
+  std::vector<mm3d_pair_result> pairs(P);
+  std::vector<char> seen(P, 0);
+  for (size_t d = 0; d < D; ++d)
+    for (size_t k = 0; k < which[d].size(); ++k) {
+      pairs[which[d][k]] = gathered[d * slots + k];
+      seen[which[d][k]] = 1;
+    }
+  for (size_t q = 0; q < P; ++q)
+    if (!seen[q]) throw Error(MM3D_EDEVICE, "estimate_maps_devices: a pair has no owner");
+  // the shards (maps on every device) go now; every stream was drained by its device's thread
+  for (size_t d = 0; d < D; ++d) {
+    (void)hipSetDevice(roots[d]->device);
+    sh[d].reset();
+  }
+  (void)hipSetDevice(ctx->device);
+  if (pairs_out) std::memcpy(pairs_out, pairs.data(), pairs.size() * sizeof(mm3d_pair_result));
+  if (n_pairs_out) *n_pairs_out = pairs.size();
+  const int st = global_transforms(pairs.data(), pairs.size(), params->confidence_threshold, n, out_T, n_out);
+  if (st != MM3D_OK) throw Error(st, "computeGlobalTransforms failed");
+  ctx->last_total_s = since_start();
 }
 
 // ---------------------------------------------------------------- map_merging.h
@@ -1277,6 +1517,10 @@ int mm3d_estimate_maps_transforms(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
     return MM3D_OK;
   }
   return guarded(ctx, [&] {
+    if (ctx->device_set) {                             // a device list (mm3d_create_devices), even of one device
+      estimate_maps_devices(ctx, clouds, n, params, out_T, n_out, pairs_out, n_pairs_out);
+      return;
+    }
     if (!ctx->helpers.empty()) {
       estimate_maps_streams(ctx, clouds, n, params, out_T, n_out, pairs_out, n_pairs_out);
       return;
@@ -1340,26 +1584,41 @@ int mm3d_profile_enable(mm3d_ctx *ctx, int on)
     ctx->prof_resolve();
     ctx->prof_on = on != 0;
     for (mm3d_ctx *h : ctx->helpers) { h->prof_resolve(); h->prof_on = on != 0; }   // mm3d_set_streams helpers
+    for (mm3d_ctx *p : ctx->peers) {                                                // mm3d_create_devices: the other devices
+      (void)hipSetDevice(p->device);
+      p->prof_resolve();
+      p->prof_on = on != 0;
+      for (mm3d_ctx *h : p->helpers) { h->prof_resolve(); h->prof_on = on != 0; }
+    }
+    (void)hipSetDevice(ctx->device);
   });
 }
 void mm3d_profile_reset(mm3d_ctx *ctx)
 {
   if (!ctx) return;
   std::lock_guard<std::mutex> lock(ctx->mu);
-  try { ctx->prof_resolve(); } catch (...) {}
-  for (auto &e : ctx->prof) e = ProfEntry();
-  for (mm3d_ctx *h : ctx->helpers) {
-    try { h->prof_resolve(); } catch (...) {}
-    for (auto &e : h->prof) e = ProfEntry();
-  }
+  auto reset_one = [](mm3d_ctx *r) {
+    (void)hipSetDevice(r->device);
+    try { r->prof_resolve(); } catch (...) {}
+    for (auto &e : r->prof) e = ProfEntry();
+    for (mm3d_ctx *h : r->helpers) {
+      try { h->prof_resolve(); } catch (...) {}
+      for (auto &e : h->prof) e = ProfEntry();
+    }
+  };
+  reset_one(ctx);
+  for (mm3d_ctx *p : ctx->peers) reset_one(p);
+  (void)hipSetDevice(ctx->device);
 }
 int mm3d_profile_count(mm3d_ctx *ctx)
 {
   if (!ctx) return 0;
   std::lock_guard<std::mutex> lock(ctx->mu);
   try { ctx->prof_resolve(); } catch (...) {}
-  // fold what the helper streams recorded into this context's table (summed over streams)
-  for (mm3d_ctx *h : ctx->helpers) {
+  // fold what the helper streams (and, for a device list, the other devices' contexts) recorded into this context's
+  // table (summed over streams and devices)
+  auto fold = [&](mm3d_ctx *h) {
+    (void)hipSetDevice(h->device);
     try { h->prof_resolve(); } catch (...) {}
     for (size_t i = 0; i < h->prof.size(); ++i) {
       const int s = ctx->prof_slot(h->prof_names[i].c_str());
@@ -1368,7 +1627,13 @@ int mm3d_profile_count(mm3d_ctx *ctx)
       ctx->prof[s].bytes += h->prof[i].bytes;
       h->prof[i] = ProfEntry();
     }
+  };
+  for (mm3d_ctx *h : ctx->helpers) fold(h);
+  for (mm3d_ctx *p : ctx->peers) {
+    fold(p);
+    for (mm3d_ctx *h : p->helpers) fold(h);
   }
+  (void)hipSetDevice(ctx->device);
   return (int)ctx->prof.size();
 }
 int mm3d_profile_entry(mm3d_ctx *ctx, int i, const char **name, double *total_ms, uint64_t *launches, double *bytes)

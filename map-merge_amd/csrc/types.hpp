@@ -12,13 +12,21 @@
 
 #include "common.hpp"
 
+namespace mm3d { struct DeviceSet; }
+
 // the opaque C handles are these structs
 struct mm3d_ctx : mm3d::Context {
   // mm3d_set_streams: helper contexts (one HIP stream + one host thread each while a call is running)
   // that mm3d_estimate_maps_transforms deals maps and pairs to; owned by this context
   std::vector<mm3d_ctx *> helpers;
+  // mm3d_create_devices: the root contexts of the OTHER devices of the list (this context is the first device's); each has
+  // its own helpers.  mm3d_estimate_maps_transforms then shards its two loops over the devices inside the library
+  // (capi.cpp::estimate_maps_devices) and gathers the pair records through RCCL (devices.cpp).  Owned by this context.
+  std::vector<mm3d_ctx *> peers;
+  mm3d::DeviceSet *device_set = nullptr;                 // non-null exactly for contexts made by mm3d_create_devices
   // diagnostics of the most recent mm3d_estimate_maps_transforms (mm3d_last_run_*)
   double last_features_s = 0.0, last_total_s = 0.0;      // when the last map was ready / when the call returned
+  double last_exchange_s = 0.0, last_pairs_s = 0.0, last_gather_s = 0.0;   // several devices: bundles moved / pairs done (slowest device) / the RCCL gather alone
   std::vector<size_t> last_points, last_keypoints;       // per input cloud, after filtering / after pruning
 };
 
@@ -301,6 +309,22 @@ int estimate_transform(Context *c, const mm3d_cloud *sp, const mm3d_cloud *skp, 
                        double eps, float T[16], bool execute);
 int global_transforms(const mm3d_pair_result *pairs, size_t n_pairs, double thr, size_t n_clouds, float *out,
                       size_t *n_out);
+
+// devices.cpp (host only): one process, several GPUs
+// The RCCL communicators of a device list (ncclCommInitAll) and what the devices exchange: the maps' bundles, pulled by the
+// device that needs them with hipMemcpyPeerAsync over xGMI, and the pair records, all-gathered with ncclAllGather.
+struct DeviceSet;
+DeviceSet *device_set_create(const int *devices, int n);          // throws Error; distinct devices get a communicator each
+void device_set_destroy(DeviceSet *ds);
+bool device_set_has_comms(const DeviceSet *ds);                   // false only for the duplicate-device test hook
+// a copy of `src` (which lives on src_device) on c's device: points, bounding box and the source-side search structures
+// (Hilbert query copy, work items, their keys), and the host copy when `src` has one.  Asynchronous on c's stream.
+mm3d_cloud *cloud_clone_from_peer(Context *c, const mm3d_cloud *src, int src_device);
+mm3d_desc *desc_clone_from_peer(Context *c, const mm3d_desc *src, int src_device);
+// rank r contributes send[r] (its records, `slots` of them, zero padded); out receives world * slots records, rank by rank,
+// as they arrived on roots[0]'s device.  One ncclAllGather per rank inside one group; returns the seconds it took.
+double gather_pair_records(DeviceSet *ds, const std::vector<mm3d_ctx *> &roots, const std::vector<std::vector<mm3d_pair_result>> &send,
+                           size_t slots, std::vector<mm3d_pair_result> &out);
 
 // linalg (host)
 void umeyama_f32(const float *src, const float *dst, int n, float T[16]);

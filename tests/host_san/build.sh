@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds the library's host code -- runtime.cpp, capi.cpp, host_pipeline.cpp, linalg.cpp, unchanged -- with a sanitizer against
+# Builds the library's host code -- runtime.cpp, capi.cpp, host_pipeline.cpp, linalg.cpp, devices.cpp, unchanged -- with a sanitizer against
 # the fake HIP runtime and the fake device layer of this directory, into tests/host_san/_build/san_<kind> (git-ignored):
 #   tests/host_san/build.sh thread | address
 # clang's host pass of the HIP language (--cuda-host-only): the headers' __device__ helpers are parsed, never emitted.
@@ -13,7 +13,7 @@ FLAGS="-x hip --cuda-host-only -nogpulib -std=c++17 -O1 -g -fno-omit-frame-point
 mkdir -p _build
 objs=""
 pids=()
-for f in $CSRC/runtime.cpp $CSRC/capi.cpp $CSRC/host_pipeline.cpp $CSRC/linalg.cpp fake_hip.cpp fake_device.cpp san_main.cpp; do
+for f in $CSRC/runtime.cpp $CSRC/capi.cpp $CSRC/host_pipeline.cpp $CSRC/linalg.cpp $CSRC/devices.cpp fake_hip.cpp fake_rccl.cpp fake_device.cpp san_main.cpp; do
   o=_build/$(basename "${f%.*}")_$KIND.o
   objs="$objs $o"
   ( $CLANG $FLAGS -c "$f" -o "$o" ) &

@@ -41,9 +41,16 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
   *ms = std::chrono::duration<float, std::milli>(((FakeEvent *)b)->t - ((FakeEvent *)a)->t).count();
   return hipSuccess;
 }
-hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+// several fake devices (MM3D_FAKE_DEVICES, default 1): the current device is per thread, like HIP's; memory is host memory
+// whichever "device" it belongs to, so a peer copy is a memmove
+static thread_local int t_device = 0;
+static int fake_device_count() { const char *e = std::getenv("MM3D_FAKE_DEVICES"); const int n = e ? std::atoi(e) : 1; return n > 0 ? n : 1; }
+hipError_t hipSetDevice(int d) { if (d < 0 || d >= fake_device_count()) return hipErrorInvalidDevice; t_device = d; return hipSuccess; }
+hipError_t hipGetDevice(int *d) { *d = t_device; return hipSuccess; }
+hipError_t hipGetDeviceCount(int *n) { *n = fake_device_count(); return hipSuccess; }
+hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
+hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { if (n) std::memmove(d, s, n); return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 const char *hipGetErrorString(hipError_t) { return "fake HIP runtime"; }

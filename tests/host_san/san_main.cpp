@@ -1,6 +1,7 @@
 // san_main.cpp -- TEST INFRASTRUCTURE: drives the library's host code through its C ABI (include/mm3d.h) on the fake device
 // layer: mm3d_estimate_maps_transforms on 1 and 16 streams (same bits required), both estimation methods, every descriptor
-// type's table entry, the shard driver for a world of 3 ranks emulated in one process, composeMaps, the stage-by-stage
+// type's table entry, the shard driver for a world of 3 ranks emulated in one process, the device-list driver (mm3d_create_devices: 1, 2 and 3
+// fake devices and the duplicate-device hook, the pair records through the fake RCCL), composeMaps, the stage-by-stage
 // calls, parameter parsing, the degenerate inputs of the reference's gtests and the error paths.  Built with
 // -fsanitize=thread or -fsanitize=address,undefined by tests/host_san/build.sh; exit code 0 = the checks passed and no
 // sanitizer spoke.
@@ -28,6 +29,7 @@ static std::vector<Pt> make_cloud(int n, unsigned seed)
 
 int main()
 {
+  setenv("MM3D_FAKE_DEVICES", "3", 1);                         // fake_hip.cpp: three "devices"
   const int kMaps = 7, kPts = 2400;
   std::vector<std::vector<Pt>> clouds;
   std::vector<mm3d_cloud_view> views;
@@ -115,6 +117,54 @@ int main()
     CHECK(mm3d_global_transforms(merged.data(), npm, p.confidence_threshold, n, Tg.data(), &ng) == MM3D_OK);
     CHECK(ng == n1 && std::memcmp(Tg.data(), T1.data(), ng * 16 * sizeof(float)) == 0);
     for (int r = 0; r < world; ++r) { mm3d_shard_end(sh[r]); mm3d_destroy(rctx[r]); }
+    // the same job behind the reference's one entry point on a DEVICE LIST (mm3d_create_devices): one, two and three fake
+    // devices, a thread and a stream set per device inside the library, bundles pulled from the owner, the pair records
+    // through the (fake) RCCL all-gather -- and the bits of one device; then two "devices" that are the same one (the test
+    // hook: no communicator, records through host memory)
+    for (int nd = 1; nd <= 4; ++nd) {
+      const int list3[3] = {0, 1, 2}, dup[2] = {0, 0};
+      const bool hook = nd == 4;
+      mm3d_ctx *dc = nullptr;
+      if (hook) {
+        CHECK(mm3d_create_devices(dup, 2, &dc) == MM3D_EINVAL && dc == nullptr);        // not without the hook
+        setenv("MM3D_DEVICES_ALLOW_DUPLICATES", "1", 1);
+      }
+      CHECK(mm3d_create_devices(hook ? dup : list3, hook ? 2 : nd, &dc) == MM3D_OK && dc);
+      if (hook) unsetenv("MM3D_DEVICES_ALLOW_DUPLICATES");
+      if (!dc) continue;
+      CHECK(mm3d_device_count(dc) == (hook ? 2 : nd) && mm3d_device_at(dc, 0) == 0 && mm3d_devices_use_rccl(dc) == (hook ? 0 : 1));
+      CHECK(mm3d_set_streams(dc, nd == 2 ? 1 : 4) == MM3D_OK);
+      mm3d_set_debug(dc, 1);                                  // every device's gathered copy is read back and compared
+      for (int rep = 0; rep < 2; ++rep) {
+        std::vector<float> Td(n * 16);
+        std::vector<mm3d_pair_result> Pd(max_pairs);
+        size_t ndn = 0, npd = 0;
+        mm3d_srand(dc, 1);
+        CHECK(mm3d_estimate_maps_transforms(dc, views.data(), n, &p, Td.data(), &ndn, Pd.data(), &npd) == MM3D_OK);
+        CHECK(ndn == n1 && npd == np1 && std::memcmp(Td.data(), T1.data(), n1 * 16 * sizeof(float)) == 0);
+        for (size_t q = 0; q < np1 && q < npd; ++q)
+          CHECK(Pd[q].source_idx == P1[q].source_idx && Pd[q].target_idx == P1[q].target_idx && std::memcmp(Pd[q].transform, P1[q].transform, 64) == 0 &&
+                Pd[q].confidence == P1[q].confidence && Pd[q].icp_iterations == P1[q].icp_iterations);
+        double ex = -1, ps = -1, gs = -1;
+        CHECK(mm3d_last_run_device_seconds(dc, &ex, &ps, &gs) == MM3D_OK && ex >= 0 && ps >= ex && gs >= 0);
+      }
+      // a failing job on a device list leaves the context usable (every device's thread leaves through the barrier)
+      mm3d_params bad = p;
+      bad.descriptor_type = 17;
+      std::vector<float> Tb(n * 16);
+      size_t nb = 0, npb = 0;
+      CHECK(mm3d_estimate_maps_transforms(dc, views.data(), n, &bad, Tb.data(), &nb, nullptr, &npb) != MM3D_OK && std::strlen(mm3d_last_error(dc)) > 0);
+      mm3d_srand(dc, 1);
+      CHECK(mm3d_estimate_maps_transforms(dc, views.data(), n, &p, Tb.data(), &nb, nullptr, &npb) == MM3D_OK && npb == np1 &&
+            std::memcmp(Tb.data(), T1.data(), n1 * 16 * sizeof(float)) == 0);
+      mm3d_destroy(dc);
+    }
+    {
+      const int beyond[2] = {0, 7};
+      mm3d_ctx *dc = nullptr;
+      CHECK(mm3d_create_devices(beyond, 2, &dc) != MM3D_OK && dc == nullptr);          // no such device
+      CHECK(mm3d_create_devices(nullptr, 1, &dc) == MM3D_EINVAL && mm3d_create_devices(beyond, 0, &dc) == MM3D_EINVAL);
+    }
   }
 
   // many small maps (the pairs run in same-target batches) with a map that turns out to have no keypoints at the END of the
