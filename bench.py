@@ -109,6 +109,19 @@ def stage_of(kernel):
     return "search structures (grids, Hilbert order, scans, sorts)"
 
 
+# The PMC / SQ counters under profiles/ are per-launch figures of ONE workload (scripts/profile_round.sh: the headline maps,
+# 500 000 raw points each, FPFH + SAC_IA, 'independent' scenes, default resolution / window / hypotheses).  A launch on
+# another workload does other work: the figures are only used when the running workload is the counted one (round 4 printed
+# VALU "fractions" of 1.40 on 64 x 50 k by dividing the headline's instructions by a 50 k-point launch's time).
+COUNTERS_WORKLOAD_DEFAULT = {"points": 500000, "descriptor": "FPFH", "method": "SAC_IA", "scenes": "independent", "window": 0.0,
+                             "resolution": 0.0, "sac_iterations": 0}
+
+
+def workload_signature(args):
+    return {"points": int(args.points), "descriptor": args.descriptor, "method": args.method, "scenes": args.scenes,
+            "window": float(args.window), "resolution": float(args.resolution), "sac_iterations": int(args.sac_iterations)}
+
+
 def kernel_source_hash(kernel):
     """sha256 over the kernel's source files (None for kernels without an entry in KERNEL_SOURCES)."""
     import hashlib
@@ -198,6 +211,7 @@ def main():
     ap.add_argument("--window", type=float, default=0.0, help="side of a map's window in metres (0 = 60 m at 500 k points, constant raw density)")
     ap.add_argument("--resolution", type=float, default=0.0, help="MapMergingParams.resolution (0 = the reference's default 0.1; the radii keep their defaults, "
                     "as with the reference's --resolution option)")
+    ap.add_argument("--no-pair-stage", action="store_true", help="skip the untimed pair-loop-alone pass (pair_stage_pairs_per_s) at N = 1")
     ap.add_argument("--no-pcie", action="store_true", help="skip the extra PCIe-inclusive step (host pcl::PointXYZRGB input) at N = 1")
     args = ap.parse_args()
 
@@ -501,19 +515,74 @@ def main():
         ctx.profile(True)
         ctx.srand(1)
         two = []
+        sift_fused_ms_map0 = None
         for i in (0, 1):
             raw = ctx.cloud_from_ptr(dev_raw[i].data_ptr(), len(host[i]))
             two.append(ctx.mapFeatures(raw, params))
             raw.free()
+            if i == 0:
+                ctx.synchronize()
+                sift_fused_ms_map0 = ctx.profile_entries().get("sift_dog", {}).get("ms")
         rec01 = ctx.pairEstimate(two[0], two[1], params)
         ctx.synchronize()
         ctx.profile(False)
         iso = ctx.profile_entries()
+        # computeSurfaceNormals as a launch of its own (in the whole-map path with SIFT keypoints the normals ride on the first
+        # octave's sorted lists and have no launch to time): map 0's filtered points through the stand-alone entry point, and
+        # detectKeypoints stand-alone (no fused normals) to price what the fusion adds to the first octave
+        normals_alone = None
+        try:
+            ctx.profile_reset(); ctx.profile(True)
+            nrm0 = ctx.computeSurfaceNormals(two[0].points, params.normal_radius)
+            ctx.synchronize(); ctx.profile(False)
+            e_n = ctx.profile_entries()
+            ctx.profile_reset(); ctx.profile(True)
+            kp0 = ctx.detectKeypoints(two[0].points, nrm0, int(params.keypoint_type), params.keypoint_threshold, params.normal_radius, params.resolution)
+            ctx.synchronize(); ctx.profile(False)
+            e_k = ctx.profile_entries()
+            n0 = len(two[0].points)
+            t_n = sum(v["ms"] for k, v in e_n.items() if k.startswith("normals")) / 1e3
+            normals_alone = {"mpoints_per_s": round(n0 / 1e6 / max(t_n, 1e-9), 2), "points": n0, "kernel_ms": round(1e3 * t_n, 3),
+                             "hbm_frac": round(n0 * 28.0 / max(t_n, 1e-9) / (HBM_PEAK_GBS * 1e9), 5),
+                             "what": "mm3d_compute_normals on map 0's filtered points, alone on the GPU (the launch the fused path no longer has)"}
+            if "sift_dog" in e_k and sift_fused_ms_map0:
+                normals_alone["sift_dog_unfused_ms_map0"] = round(e_k["sift_dog"]["ms"], 3)
+                normals_alone["sift_dog_fused_ms_map0"] = round(sift_fused_ms_map0, 3)
+                normals_alone["fused_marginal_ms_map0"] = round(sift_fused_ms_map0 - e_k["sift_dog"]["ms"], 3)
+            del nrm0, kp0
+        except Exception as exc:                            # (a diagnostic: never fails the bench line)
+            normals_alone = {"error": str(exc)[:200]}
         # what the device computed for maps 0 and 1 and pair (0, 1): bench's parity_check holds it against the oracle
         gpu_sample = {"maps": [dict(points=m.points.numpy(), keypoints=m.keypoints.numpy(), descriptors=m.descriptors.numpy())
                                for m in two], "pair": rec01}
         for m in two:
             m.free()
+    # map-pairs/sec = surviving pairs / wall time of the PER-PAIR stage (R/src/map_merging.cpp:256-269) -- the pair
+    # loop alone, on maps whose features and search structures already exist.  Untimed extra after the step loop: every map
+    # prepared once (mm3d_shard_begin as the only rank), then the whole pair loop (mm3d_shard_pairs: all pairs, same-target
+    # batches on the context's streams) three times.  The pipelined step overlaps this stage with the features, so
+    # "step time minus the time the last map was ready" says nothing about it.
+    pair_stage = None
+    if rank == 0 and world == 1 and args.engine in ("library", "devices") and not dev_list and not args.no_pair_stage:
+        try:
+            views = [(dev_raw[i].data_ptr(), len(host[i])) for i in range(n_maps)]
+            ctx.srand(1)
+            sh = ctx.shardBegin(views, params, 0, 1)
+            ctx.srand(1)
+            sh.pairs()                                     # (untimed: first touch)
+            reps = 3
+            tq0 = time.perf_counter()
+            for _ in range(reps):
+                ctx.srand(1)
+                recs_ps, _ = sh.pairs()
+            tq = (time.perf_counter() - tq0) / reps
+            sh.end()
+            pair_stage = {"pairs_per_s": round(len(recs_ps) / max(tq, 1e-9), 2), "ms_per_pair_loop": round(1e3 * tq, 3), "pairs": int(len(recs_ps)), "repeats": reps,
+                          "pair_transforms_crc32": zlib.crc32(np.ascontiguousarray(recs_ps["transform"]).tobytes()) & 0xffffffff,
+                          "what": "the pair loop alone (estimateTransform + transformScore of every live pair, map_merging.cpp:256-269) on prepared maps, "
+                                  "%d streams, features excluded" % S}
+        except Exception as exc:                            # (a secondary figure: never fails the bench line)
+            pair_stage = {"error": str(exc)[:200]}
     # HBM-side traffic per launch from the most recent committed PMC passes (scripts/profile_round.sh)
     pmc_traffic, pmc_source, pmc_hashes = {}, None, {}
     try:
@@ -522,8 +591,13 @@ def main():
             doc = json.load(f)
         pmc_traffic, pmc_hashes = doc["bytes_per_launch"], doc.get("source_sha256", {})
         pmc_source = "profiles/" + os.path.basename(latest).replace("traffic.json", "pmc_hbm_traffic.csv")
+        counters_workload = doc.get("workload", COUNTERS_WORKLOAD_DEFAULT)
     except Exception:
-        pass
+        counters_workload = None
+    # per-launch counters only speak about the workload they were counted on
+    counters_apply = counters_workload is not None and counters_workload == workload_signature(args)
+    if not counters_apply:
+        pmc_traffic = {}
 
     def stale(kernel):
         """True when the kernel's sources are not the ones the committed counters were collected on (or that is unknown)."""
@@ -554,6 +628,8 @@ def main():
         valu_source = "profiles/" + os.path.basename(latest)
     except Exception:
         pass
+    if not counters_apply:
+        valu_insts, sq_ratios = {}, {}
 
     def bound_of(name, launch_ms, work):
         """Which ceiling the kernel is nearest to, from what can be known here: algorithmic bytes (or flops) per launch
@@ -567,7 +643,9 @@ def main():
         else:
             out["hbm_frac"] = round(work / (launch_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 5)
         if name in valu_insts and not stale(name):
-            out["valu_frac"] = round(valu_insts[name] / (launch_ms * 1e-3) / VALU_PEAK_WINSTR_S, 4)
+            vf = valu_insts[name] / (launch_ms * 1e-3) / VALU_PEAK_WINSTR_S
+            if vf <= 1.0:                                  # (above 1: the counted launch was not this launch's work -- not evidence)
+                out["valu_frac"] = round(vf, 4)
         out["nearest"] = max(((v, k[:-5]) for k, v in out.items()), default=(0, None))[1]
         return out
 
@@ -595,6 +673,8 @@ def main():
                             "algorithmic_bytes_per_launch": round(work_per_launch, 1)}
             # HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 per
             # the gfx950 note + WRITE_SIZE); null when that kernel was not in the counted run
+            roofline["counters_workload"] = counters_workload
+            roofline["counters_apply_to_this_workload"] = bool(counters_apply)
             roofline["traffic"] = pmc_traffic.get(dom[0])
             roofline["traffic_source"] = pmc_source if dom[0] in pmc_traffic else None
             # the counters under profiles/ were collected on some commit: "stale" says whether the kernel's sources have
@@ -612,7 +692,7 @@ def main():
                 # bytes where a kernel keeps scratch lists in global memory (sift_dog, normals_radius)
                 roofline["traffic_gbs"] = round(roofline["traffic"] / (iso_us * 1e-6) / 1e9, 1)
                 roofline["traffic_frac"] = round(roofline["traffic"] / (iso_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
-            if dom[0] in valu_insts and iso_us:
+            if dom[0] in valu_insts and iso_us and valu_insts[dom[0]] / (iso_us * 1e-6) <= VALU_PEAK_NOMINAL_WINSTR_S:
                 v = valu_insts[dom[0]] / (iso_us * 1e-6)
                 roofline["valu"] = {"wave_instructions_per_launch": round(valu_insts[dom[0]]), "achieved": round(v / 1e9, 2),
                                     "peak": round(VALU_PEAK_WINSTR_S / 1e9, 1), "peak_source": "measured: scripts/micro/valu_rate.hip, profiles/r04_valu_rate.txt",
@@ -633,6 +713,20 @@ def main():
                     "valu": (roofline.get("valu") or {}).get("frac", 0.0) if not (roofline.get("valu") or {}).get("stale") else 0.0}
             roofline["bound"] = max(cand.items(), key=lambda kv: kv[1])[0] if any(cand.values()) else roofline["bound"]
             roofline["bound_fractions"] = {k: round(v, 5) for k, v in cand.items()}
+            if roofline["bound"] == "valu":
+                # The kernel is nearest to the VALU issue ceiling: achieved / peak / unit / frac at the top level speak about THAT
+                # ceiling -- against the guide's NOMINAL peak (MI355X_MICROARCH.md: 2 cycles per wave64 v_fma_f32 -> 1.23e12 /s),
+                # with the measured peak beside it -- and the HBM figures (the contract's default reading) move to "hbm".
+                # Both VALU figures use the kernel's launch time alone on the GPU (the counters were collected that way);
+                # frac_in_step divides the same instructions by the launch's duration inside the timed 16-stream region.
+                v = roofline["valu"]
+                hbm = {k: roofline.get(k) for k in ("achieved", "peak", "unit", "frac", "isolated_frac", "traffic_gbs", "traffic_frac")}
+                roofline["hbm"] = hbm
+                roofline["achieved"], roofline["peak"], roofline["unit"] = v["achieved"], v["peak_nominal"], v["unit"]
+                roofline["frac"] = v["frac_of_nominal"]
+                roofline["frac_of_measured_peak"] = v["frac"]
+                roofline["frac_in_step"] = round(v["wave_instructions_per_launch"] / (avg_ms * 1e-3) / VALU_PEAK_NOMINAL_WINSTR_S, 4) if avg_ms > 0 else None
+                roofline["frac_timed_on"] = "isolated_avg_launch_us (the kernel alone on the GPU, as the SQ counters were collected)"
             roofline["note"] = ("timed region runs %d streams per GPU, so avg_launch_us includes time shared with other kernels; "
                                 "neighbourhood kernels (sift_dog, spfh, sacia_err, *_nn_reduce) are bound by VALU instruction issue on "
                                 "in-radius pair work, not by HBM: see DESIGN.md sections 5 and 6" % S)
@@ -669,12 +763,17 @@ def main():
                                        if step is step_sharded else
                                        f"maps and pairs dealt over {S} streams (Python threads)"),
                        "points_after_filter_mean": int(np.mean(npts_f)), "keypoints_mean": int(np.mean(stats["keypoints"]))},
-            "pair_stage_pairs_per_s": round(n_pairs / max(stats["t_pairs"], 1e-9), 3),
+            # pairs / wall time of the per-pair stage alone, on prepared maps (measured after the step loop; null when
+            # that pass did not run).  NOT n_pairs / (step - features): in the pipelined step most pairs run beside the features.
+            "pair_stage_pairs_per_s": (pair_stage or {}).get("pairs_per_s"),
+            "pair_stage": pair_stage,
+            "pair_tail_after_last_map_ms": round(1e3 * stats["t_pairs"], 3),
             "mpoints_per_s": {
                 # (FPFH + SIFT: the normals come out of the first octave's scale-space launch, sift.hip k_sift_dog_lds<., true>; there is
                 # no launch of their own to time, see "normals_fused" below)
                 "normals": round(sum(npts_f) / 1e6 / max(prof.get("normals_radius", {}).get("ms", 0) / 1e3 / max(args.steps, 1), 1e-9), 2)
-                if "normals_radius" in prof else None,
+                if "normals_radius" in prof else ((normals_alone or {}).get("mpoints_per_s")),
+                "normals_alone": normals_alone,
                 "normals_fused": "computeSurfaceNormals rides on detectKeypoints' first octave (same sorted neighbour lists, same bits)"
                 if "normals_radius" not in prof and "sift_dog" in prof else None,
                 # FPFH: support points per second of the SPFH kernel (|S| = its algorithmic bytes / 156 B) and
@@ -727,7 +826,13 @@ def main():
             out["cpu_baseline_all_cores"] = b2
             out["parity_check"] = parity
             out["stage_seconds"].update(cpu_stages)
-        print(json.dumps(out))
+        # RCCL writes its version banner through C stdio when a communicator is made, and a redirected stdout only flushes
+        # that buffer at exit -- after our line.  The contract is ONE JSON line, last: empty C's buffer first.
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if tpool is not None:
         tpool.shutdown()
     for c in ctxs:
@@ -793,7 +898,10 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", me
         pair.last_init = T_init
         return T, it, score
 
-    n_sample = min(3, len(host))
+    # (many SAC-IA hypotheses, the 'lattice' rows' 20 000: a pair costs 40 x the default's, so the sample is two maps and
+    # ONE pair, and B1 extracts the features of one map only -- still the same code on the same workload, still bounded)
+    heavy_pairs = method == "SAC_IA" and int(p.max_iterations) > 2000
+    n_sample = min(2 if heavy_pairs else 3, len(host))
     sample_pairs = [(i, j) for i in range(n_sample - 1) for j in range(i + 1, n_sample)]
     # B2 (fast): all cores; it also provides map 2's features for B1's pairs
     po.set_threads(cores)
@@ -818,7 +926,7 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", me
     # B1: one thread; maps 0 and 1 (map 2's features are B2's, the same bits), the same pairs
     po.set_threads(1)
     st1 = {}
-    n_b1 = min(2, n_sample)
+    n_b1 = min(1 if heavy_pairs else 2, n_sample)
     t0 = time.perf_counter()
     F1 = [features(host[i], st1) for i in range(n_b1)] + F2[n_b1:]
     t_map = (time.perf_counter() - t0) / n_b1

@@ -32,6 +32,9 @@ for k, (d, fs) in f.items():
 json.dump({"_note": "HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / dispatches (MI355X_MICROARCH.md: gfx950 FETCH_SIZE "
                     "reads half of a wide coalesced stream; separate --pmc passes; Infinity-Cache hits are counted).  bench.py --steps 1 "
                     "--warmup 1 --streams 1 under rocprofv3 --pmc.  rocprim_radix_sort_pairs is the average over ALL rocPRIM kernels (sort and scan passes).",
+           # the workload these per-launch figures (and the SQ counters of the same tag) were counted on: bench.py uses them only
+           # for a run of the same workload (bench.COUNTERS_WORKLOAD_DEFAULT = what scripts/profile_round.sh runs)
+           "workload": bench.COUNTERS_WORKLOAD_DEFAULT,
            "bytes_per_launch": out,
            "source_sha256": {k: bench.kernel_source_hash(k) for k in out if bench.kernel_source_hash(k)}}, open(dst("traffic.json"), "w"), indent=1)
 with open(dst("pmc_hbm_traffic.csv"), "w") as fo:
