@@ -90,12 +90,17 @@ k_normals(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int 
 // x, y} (and every lane sums z; sub 0's copy is read) and walks the point's list: 16-bit slots into the block's
 // tile, every read an LDS read.  Bit for bit k_normals' chains.
 using NormalsCfg = SnbCfg<8, 1792, 1024, 256, 128, false>;      // lists of ~70 (up to 256), 2 blocks of 8 waves per CU
+// Dense clouds (round 5; BASELINE configs[3], 8 x 2 M indoor points at resolution 0.05: the normals' ball of 0.6 m holds 500 -
+// 2 000 neighbours and an item's box thousands of candidates): the small configuration left 45 % of the items to the lists in
+// global memory, after working them itself -- 47 ms of normals per map.  One block per CU around the largest tile that leaves
+// room for 4 096-entry arenas (a single list must fit its wave's arena); longer lists than the hit buffer go in distance bands.
+using NormalsCfgLarge = SnbCfg<8, 3584, 4096, 512, 128, false>;
 
+template <class Cfg>
 __global__ void __launch_bounds__(512)
 k_normals_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g, float radius, float r2, SnbCtl *ctl,
               int *__restrict__ ov_items, float4 *__restrict__ out /* by original index */)
 {
-  using Cfg = NormalsCfg;
   __shared__ SnbLds<Cfg> S;
   __shared__ float sums[Cfg::kWaves][Cfg::kQ][9];
   __shared__ int cnts[Cfg::kWaves][Cfg::kQ];
@@ -157,6 +162,40 @@ __global__ void k_fill_nan(float4 *out, size_t n)
   if (i < n) { float q = __uint_as_float(0x7fc00000u); out[i] = make_float4(q, q, q, q); }
 }
 
+// How many candidates would the boxes of the cloud's work items hold?  A sample of up to 256 items, one thread each: the item's
+// bounding box grown by the radius, the points of its cells counted from the cell table.  out[0] = sum of the counts, out[1] =
+// sampled items, out[2] = items whose box holds more than `cap` candidates.  (~30 us; decides which LDS configuration
+// compute_normals launches first.)
+__global__ void __launch_bounds__(256)
+k_item_box_probe(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g, float radius, int cap, int *__restrict__ out)
+{
+  const int n_sample = min(n_items, 256);
+  const int t = threadIdx.x;
+  if (t >= n_sample) return;
+  const int2 it = items[(int)((long long)t * n_items / n_sample)];
+  float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+  for (int k = 0; k < it.y; ++k) {
+    const float4 p = q_pts[it.x + k];
+    lx = fminf(lx, p.x); hx = fmaxf(hx, p.x);
+    ly = fminf(ly, p.y); hy = fmaxf(hy, p.y);
+    lz = fminf(lz, p.z); hz = fmaxf(hz, p.z);
+  }
+  const float ri = radius * 1.0001f + 1e-4f;
+  const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
+  const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
+  const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
+  int cnt = 0;
+  if (x0 <= x1)
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        const int row = (z * g.dy + y) * g.dx;
+        cnt += g.cell_start[row + x1 + 1] - g.cell_start[row + x0];
+      }
+  atomicAdd(&out[0], cnt);
+  atomicAdd(&out[1], 1);
+  if (cnt > cap) atomicAdd(&out[2], 1);
+}
+
 // The normals of the work items on a device list (ov_items[0 .. *ov_count_dev), n_overflow = that count as the host read
 // it) with the lists in global memory (k_normals): what compute_normals runs for the items its LDS launch could not hold,
 // and what the fused scale-space + normals launch of sift.hip leaves behind.  Any grid of the cloud serves.
@@ -192,15 +231,38 @@ mm3d_normals *compute_normals(Context *c, const mm3d_cloud *in, double radius)
     // not zero the launch with the lists in global memory follows.  The look at the count costs a host wait here; an
     // empty launch of that kernel cost more: it queues for LDS behind the other streams' kernels (0.4 ms of stream time
     // on the 16-stream bench) and holds its hardware queue meanwhile.
-    SnbLaunch<NormalsCfg> sl(c, n_items, sizeof(float) * 64 * 10 + 256);
-    SnbCtl *ctl = sl.ctl_dev();
-    MM3D_LAUNCH(c, "normals_radius", g.n * 28.0, k_normals_lds, dim3(sl.blocks), dim3(64 * NormalsCfg::kWaves), 0, (const float4 *)in->hil_pts.get(),
-                (const int2 *)in->wave_items.get(), n_items, g.view(), (float)radius, r2, ctl, sl.ov_items.get(), res->nrm.get());
-    int *ho = (int *)c->pin(64);
-    MM3D_HIP(hipMemcpyAsync(ho, &ctl->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // Which configuration: a probe counts the candidates in the boxes of a sample of the items.  Where a third of them
+    // would not fit the small tile even in two parts -- or the mean box is nearly a tile -- the cloud is dense and the large
+    // configuration (one block per CU, 4 096-entry arenas) works it at once; the small one would work every such item and
+    // then leave it to the lists in global memory.
+    DevBuf<int> probe(c, 4);
+    MM3D_HIP(hipMemsetAsync(probe.get(), 0, 4 * sizeof(int), c->stream));
+    MM3D_LAUNCH(c, "normals_probe", 0.0, k_item_box_probe, dim3(1), dim3(256), 0, (const float4 *)in->hil_pts.get(), (const int2 *)in->wave_items.get(), n_items,
+                g.view(), (float)radius, 2 * NormalsCfg::kTileCap, probe.get());
+    int *hp = (int *)c->pin(64);
+    MM3D_HIP(hipMemcpyAsync(hp, probe.get(), 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->sync();
-    if (getenv("MM3D_SNB_DEBUG")) fprintf(stderr, "normals: n=%d items=%d blocks=%u overflow items=%d\n", g.n, n_items, sl.blocks, ho[0]);
-    if (ho[0] > 0) normals_of_items(c, in, g, radius, sl.ov_items.get(), &ctl->ov_count, ho[0], res->nrm.get());
+    static const int force_cfg = [] { const char *e = getenv("MM3D_NORMALS_CFG"); return e ? atoi(e) : 0; }();   // A/B knob: 1 small, 2 large
+    const double mean_box = hp[1] > 0 ? (double)hp[0] / hp[1] : 0.0;
+    const bool dense = force_cfg ? force_cfg == 2 : (hp[1] > 0 && (3 * hp[2] >= hp[1] || mean_box > 0.8 * NormalsCfg::kTileCap));
+    int *ho = (int *)c->pin(64);
+    auto run = [&](auto cfg_tag) {
+      using Cfg = typename decltype(cfg_tag)::type;
+      SnbLaunch<Cfg> sl(c, n_items, sizeof(float) * 64 * 10 + 256);
+      SnbCtl *ctl = sl.ctl_dev();
+      MM3D_LAUNCH(c, "normals_radius", g.n * 28.0, k_normals_lds<Cfg>, dim3(sl.blocks), dim3(64 * Cfg::kWaves), 0, (const float4 *)in->hil_pts.get(),
+                  (const int2 *)in->wave_items.get(), n_items, g.view(), (float)radius, r2, ctl, sl.ov_items.get(), res->nrm.get());
+      MM3D_HIP(hipMemcpyAsync(ho, &ctl->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      c->sync();
+      if (getenv("MM3D_SNB_DEBUG"))
+        fprintf(stderr, "normals: n=%d items=%d blocks=%u mean box %.0f, %d of %d sampled boxes over two small tiles -> %s configuration, overflow items=%d\n", g.n, n_items,
+                sl.blocks, mean_box, hp[2], hp[1], dense ? "large" : "small", ho[0]);
+      if (ho[0] > 0) normals_of_items(c, in, g, radius, sl.ov_items.get(), &ctl->ov_count, ho[0], res->nrm.get());
+    };
+    struct SmallTag { using type = NormalsCfg; };
+    struct LargeTag { using type = NormalsCfgLarge; };
+    if (dense) run(LargeTag{});
+    else run(SmallTag{});
   }
   return res;
 }

@@ -500,6 +500,9 @@ __device__ __forceinline__ int snb_build(SnbLds<Cfg> &S, SnbWave<Cfg> &W, int n_
     // whole pass for itself.
     int qi = *pending;
     *pending = -1;
+    // (some wave found a list this configuration cannot hold: the whole item goes to the overflow list and is computed again
+    // there, so nothing more of it is worked here -- on a cloud that is dense everywhere that is nearly every item)
+    if (*(volatile int *)overflow) break;
     if (qi < 0) {
       if (*budget <= 0) break;
       --*budget;
@@ -557,6 +560,9 @@ __device__ __forceinline__ int snb_stage_queries(const GridView &g, SnbLds<Cfg> 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) { S.n_tile[epoch & 1] = 0; S.next_q[epoch & 1] = 0; }
   __syncthreads();
+  // an earlier part of this item put it on the overflow list (snb_build): block-uniform here -- every wave reads the word
+  // between this barrier and the next, and it is only written while lists are built, behind the next barrier
+  if (S.overflow) return -1;
   SNB_TICK(t_stage);
   // the box (every wave computes it from the same queries)
   const bool live = lane < count;
@@ -613,6 +619,7 @@ __device__ __forceinline__ void snb_run(const GridView &g, SnbLds<Cfg> &S, const
       const int lo = (int)((long long)it.y * part / parts), hi = (int)((long long)it.y * (part + 1) / parts);
       if (hi == lo) { ++part; continue; }
       const int n_tile = snb_stage_queries<Cfg>(g, S, q_pts, it.x + lo, hi - lo, ri, epoch, load_pay, snb_st);
+      if (n_tile < 0) break;                       // abandoned (block-uniform)
       SNB_COUNT(13, n_tile);
       if (n_tile > Cfg::kTileCap) {                // block-uniform
         // Halving the run of queries shrinks the box only by the patch's share of it (the radius margin stays), and
