@@ -469,17 +469,32 @@ extern "C" void mm3d_debug_sn_stats_sift(unsigned long long *out, int reset)
 }
 #endif
 
+// the next float below / above x (NaN and the infinity on that side stay; -0 and +0 count as one zero)
+__device__ __forceinline__ float float_pred(float x)
+{
+  const unsigned u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u || u == 0xff800000u) return x;          // NaN, -inf
+  if ((u & 0x7fffffffu) == 0u) return __uint_as_float(0x80000001u);            // +-0 -> the smallest negative number
+  return __uint_as_float((u & 0x80000000u) ? u + 1u : u - 1u);
+}
+__device__ __forceinline__ float float_succ(float x) { return -float_pred(-x); }
+
 // per point, by original index, two float4: (mn1, mn2, mn3, mx1) and (mx2, mx3, -, -)
 __global__ void k_sift_dogx(const float *__restrict__ dog, int n, float4 *__restrict__ dogx)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float *d = dog + (size_t)i * kDog;
-  // what a neighbour contributes to the extremum tests of scale s = 1, 2, 3: the min and the max of its
-  // own DoG over s-1, s, s+1 (computed once per point instead of once per (query, neighbour))
-  dogx[i] = make_float4(fminf(fminf(d[0], d[1]), d[2]), fminf(fminf(d[1], d[2]), d[3]), fminf(fminf(d[2], d[3]), d[4]),
-                        fmaxf(fmaxf(d[0], d[1]), d[2]));
-  dogx[n + i] = make_float4(fmaxf(fmaxf(d[1], d[2]), d[3]), fmaxf(fmaxf(d[2], d[3]), d[4]), 0.f, 0.f);
+  // What a neighbour contributes to the extremum tests of scale s = 1, 2, 3 (computed once per point instead of once per
+  // (query, neighbour)).  SIFTKeypoint::findScaleSpaceExtrema asks of a minimum `val == min_val[s] && val < min_val[s - 1] &&
+  // val < min_val[s + 1]`: the point's own scale with equality, the ADJACENT scales strictly.  A neighbour therefore spoils
+  // a minimum v when its DoG at s is below v, or its DoG at s - 1 or s + 1 is below OR EQUAL to v -- and "a <= v" is
+  // "pred(a) < v" (no float lies between a and the one below it).  One value per scale and one strict comparison in the
+  // kernels below, as before: mn_s = min(d_s, pred(min(d_{s-1}, d_{s+1}))); maxima mirrored.
+  // (Rounds 1 - 4 compared the adjacent scales with <=, >=: the same keypoints unless two DoG values tie exactly.)
+  dogx[i] = make_float4(fminf(d[1], float_pred(fminf(d[0], d[2]))), fminf(d[2], float_pred(fminf(d[1], d[3]))), fminf(d[3], float_pred(fminf(d[2], d[4]))),
+                        fmaxf(d[1], float_succ(fmaxf(d[0], d[2]))));
+  dogx[n + i] = make_float4(fmaxf(d[2], float_succ(fmaxf(d[1], d[3]))), fmaxf(d[3], float_succ(fmaxf(d[2], d[4]))), 0.f, 0.f);
 }
 
 // findScaleSpaceExtrema from the neighbours the scale-space kernel left behind (knn, knn_ok = how many: 25, or

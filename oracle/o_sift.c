@@ -108,9 +108,12 @@ static void detect_octave(const mo_point *cloud, int n, float base_scale, int nr
     for (int s = 1; s < nd - 1; ++s) {
       float val = dog[(size_t)i * nd + s];
       if (fabs(val) >= min_contrast) {
-        if ((val == min_val[s]) && (val <= min_val[s - 1]) && (val <= min_val[s + 1]))
+        /* equality at the point's own scale, STRICT against the adjacent scales (sift_keypoint.hpp, findScaleSpaceExtrema:
+         * "(val == min_val[i_scale]) && (val < min_val[i_scale - 1]) && (val < min_val[i_scale + 1])"; rounds 1 - 4 had
+         * <= / >= here: the same keypoints unless two DoG values tie exactly -- DESIGN.md section 4, audit table) */
+        if ((val == min_val[s]) && (val < min_val[s - 1]) && (val < min_val[s + 1]))
           is_kp[(size_t)i * nd + s] = 1;
-        else if ((val == max_val[s]) && (val >= max_val[s - 1]) && (val >= max_val[s + 1]))
+        else if ((val == max_val[s]) && (val > max_val[s - 1]) && (val > max_val[s + 1]))
           is_kp[(size_t)i * nd + s] = 1;
       }
     }

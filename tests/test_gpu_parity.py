@@ -152,6 +152,26 @@ def test_sift_blob_known_answer(ctx, po):
             assert np.hypot(got["x"] - 0.33, got["y"] + 0.21).max() < 0.6 * sigma
 
 
+def test_sift_ties_across_scales_are_not_extrema(ctx, po):
+    """Equality at a point's own scale, STRICT comparisons against the adjacent scales (sift_keypoint.hpp,
+    findScaleSpaceExtrema): a uniform grey-128 lattice with the contrast threshold at zero makes every DoG value 0.0f and
+    every comparison a tie (tests/test_oracle_cpu.py has the arithmetic) -- no keypoint, on the device as on the oracle;
+    and a scene with ordinary texture still gives the oracle's keypoints with the threshold at zero."""
+    gx, gy = np.meshgrid(np.arange(-20, 21) * 0.1, np.arange(-20, 21) * 0.1)
+    pts = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], 1).astype(np.float32)
+    c = np.zeros(len(pts), dtype=po.POINT)
+    c["x"], c["y"], c["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    c["rgba"] = 0xFF808080
+    assert len(po.keypoints_sift(c, 0.1, 3, 3, 0.0)[0]) == 0
+    assert len(ctx.detectKeypoints(ctx.cloud(c), None, 0, 0.0, R_NRM, 0.1)) == 0
+    # a step edge in grey levels that are powers of two: many exact ties among the responses away from the edge
+    c["rgba"] = np.where(c["x"] < 0.0, 0xFF404040, 0xFF808080).astype(np.uint32)
+    ref, _ = po.keypoints_sift(c, 0.1, 3, 3, 0.0)
+    got = ctx.detectKeypoints(ctx.cloud(c), None, 0, 0.0, R_NRM, 0.1).numpy()
+    assert len(got) == len(ref)
+    assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
+
+
 def test_sift_keypoints_where_the_25_nearest_reach_beyond_the_scale_space_ball(ctx, po, scene):
     """The extremum test reads a point's 25 nearest neighbours from the scale-space kernel's sorted list when the
     3 sigma_max ball holds that many, and searches for them otherwise.  A cloud thinned to a fifth (most balls hold

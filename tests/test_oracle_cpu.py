@@ -550,6 +550,21 @@ def test_sift_known_answers(po):
     assert len(kp) >= 1 and (np.hypot(kp["x"] - 0.33, kp["y"] + 0.21) < 0.4).all()
 
 
+def test_sift_ties_across_scales_are_not_extrema(po):
+    """findScaleSpaceExtrema compares a point with its own scale by equality and with the ADJACENT scales strictly
+    ("val == min_val[s] && val < min_val[s - 1] && val < min_val[s + 1]").  A lattice of uniform grey 128 with the contrast
+    threshold at zero makes every comparison a tie: the intensity is 128000 / 1000 = 128 exactly, every weighted sum is
+    128 * (sum of the weights) exactly (a power of two scales without rounding), every response is 128 and every
+    difference of Gaussians 0.0f.  Strict comparisons report nothing; <= / >= (what rounds 1 - 4 had) would report every
+    point at every scale."""
+    gx, gy = np.meshgrid(np.arange(-20, 21) * 0.1, np.arange(-20, 21) * 0.1)
+    xyz = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], 1).astype(np.float32)
+    c = cloud(po, xyz)
+    c["rgba"] = 0xFF808080
+    kp, _ = po.keypoints_sift(c, 0.1, 3, 3, 0.0)
+    assert len(kp) == 0
+
+
 # ---------------------------------------------------------------- pose graph
 def test_pose_graph_quirks(po):
     I = np.eye(4)
