@@ -52,6 +52,15 @@ constexpr int kTile = MM3D_NN_TILE;   // staged target points per wave and tile 
 #ifndef MM3D_NN_PREFETCH
 #define MM3D_NN_PREFETCH 0
 #endif
+#ifndef MM3D_NN_TIGHT_BOX
+#define MM3D_NN_TIGHT_BOX 1
+#endif
+#ifndef MM3D_NN_SHELL
+#define MM3D_NN_SHELL 1
+#endif
+#ifndef MM3D_NN_LOWER_BOUND
+#define MM3D_NN_LOWER_BOUND 1
+#endif
 constexpr bool kPrefetch = MM3D_NN_PREFETCH != 0;
 constexpr int kRowsPerLane = MM3D_NN_ROWS_PER_LANE;   // row headers a lane reads per chunk
 constexpr int kRows = kWave * kRowsPerLane;           // rows of the box per chunk (power of two: the slot -> row search halves it)
@@ -171,6 +180,18 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
       const int d0 = g.dt[((size_t)cz * g.dy + cy) * g.dx + cx];
       if (d0 > max_ring) active = false;          // nothing within range of this cell
       need = d0 > 1 ? d0 : 1;
+#if MM3D_NN_LOWER_BOUND
+      // The nearest occupied cell is d0 cells away along some axis, so no target point is nearer than (d0 - 1) cells plus the
+      // way from this point to the nearest face of its own cell.  Where that already exceeds rmax the lane has no neighbour
+      // in range and need not search: with 0.25 m cells and a range of 1 m that is every lane with d0 = 6 and nearly every
+      // one with d0 = 5 -- a twelfth of the lanes of a headline ICP launch, and the ones whose boxes (11 and 13 cells wide)
+      // were the largest of their waves (round 5; max_ring = ceil(rmax / cell) + 1 admitted them).
+      if (active && d0 >= 2) {
+        const float fx = p.x - (g.minx + (float)cx * g.cell), fy = p.y - (g.miny + (float)cy * g.cell), fz = p.z - (g.minz + (float)cz * g.cell);
+        const float mface = fmaxf(fminf(fminf(fminf(fx, g.cell - fx), fminf(fy, g.cell - fy)), fminf(fz, g.cell - fz)), 0.0f);
+        if ((float)(d0 - 1) * g.cell + mface * 0.999f - 1e-5f >= rmax) active = false;
+      }
+#endif
     } else {
       // outside the grid: farther than rmax from its box means no neighbour in range
       const float ex = fmaxf(fmaxf(g.minx - p.x, p.x - (g.minx + g.dx * g.cell)), 0.0f);
@@ -195,41 +216,74 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
     if (MM3D_NN_STATS == 1 && lane == 0 && c_) atomicAdd(&g_nn_stats[55 + e], (unsigned long long)c_);
   }
 #endif
+  bool have_old = false;                 // the previous pass's box (wave-uniform; SPLIT 4: the same in the four waves)
+  int ox0 = 0, ox1 = -1, oy0 = 0, oy1 = -1, oz0 = 0, oz1 = -1;
   for (int pass = 0; pass < 64; ++pass) {
     if (!ballot(active)) break;
     MM3D_STAT(1, 1);
     MM3D_STAT(4, __popcll(ballot(active)));
     if (pass == 0) MM3D_STAT(0, 1);
-    // box = bounding box of the active lanes' cells, grown by the largest radius any of them needs
+    // box = bounding box of the active lanes' OWN boxes (a lane's cell grown by the radius that lane needs).  Until round 5 it
+    // was the bounding box of the lanes' cells grown by the LARGEST radius any of them needs; the needs of a patch's lanes
+    // differ (the distance transform changes by up to a cell per cell), and a lane with a small need at one end of the patch
+    // does not have to be covered as if it had the largest.
     const int E = wave_max_i(active ? need : 0);
     MM3D_TICK(t_pass);
-    const int lx = wave_min_i(active ? cx : 0x7fffffff), hx = wave_max_i(active ? cx : -0x7fffffff);
-    const int ly = wave_min_i(active ? cy : 0x7fffffff), hy = wave_max_i(active ? cy : -0x7fffffff);
-    const int lz = wave_min_i(active ? cz : 0x7fffffff), hz = wave_max_i(active ? cz : -0x7fffffff);
-    const int x0 = max(lx - E, 0), x1 = min(hx + E, g.dx - 1);
-    const int y0 = max(ly - E, 0), y1 = min(hy + E, g.dy - 1);
-    const int z0 = max(lz - E, 0), z1 = min(hz + E, g.dz - 1);
+#if MM3D_NN_TIGHT_BOX
+    const int bx0 = wave_min_i(active ? cx - need : 0x7fffffff), bx1 = wave_max_i(active ? cx + need : -0x7fffffff);
+    const int by0 = wave_min_i(active ? cy - need : 0x7fffffff), by1 = wave_max_i(active ? cy + need : -0x7fffffff);
+    const int bz0 = wave_min_i(active ? cz - need : 0x7fffffff), bz1 = wave_max_i(active ? cz + need : -0x7fffffff);
+#else
+    const int bx0 = wave_min_i(active ? cx : 0x7fffffff) - E, bx1 = wave_max_i(active ? cx : -0x7fffffff) + E;
+    const int by0 = wave_min_i(active ? cy : 0x7fffffff) - E, by1 = wave_max_i(active ? cy : -0x7fffffff) + E;
+    const int bz0 = wave_min_i(active ? cz : 0x7fffffff) - E, bz1 = wave_max_i(active ? cz : -0x7fffffff) + E;
+#endif
+    const int x0 = max(bx0, 0), x1 = min(bx1, g.dx - 1);
+    const int y0 = max(by0, 0), y1 = min(by1, g.dy - 1);
+    const int z0 = max(bz0, 0), z1 = min(bz1, g.dz - 1);
     const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
     const int nrows = (x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
-    for (int r0 = 0; r0 < nrows; r0 += kRows) {
+    // A later pass only looks at what the earlier ones have not shown its lanes: every lane that is still active scanned ALL
+    // the candidates of the previous pass's box (every lane scans every staged candidate), and by induction of every box
+    // before it.  So the part of the new box that lies inside the previous one is skipped: a row of the new box whose (y, z)
+    // lies in the old box's range contributes the span LEFT of the old box, [x0, ox0 - 1], and -- as one of the `n_inner` extra
+    // spans behind the rows -- the span RIGHT of it, [ox1 + 1, x1]; either may be empty.  (Round 5.  The second passes,
+    // 0.5 per wave with the tight boxes, staged their first pass's candidates again: a sixth of all staged candidates.)
+    const bool skip_old = MM3D_NN_SHELL && have_old && ox0 <= x1 && ox1 >= x0;
+    const int iy0 = max(y0, oy0), iy1 = min(y1, oy1), iz0 = max(z0, oz0), iz1 = min(z1, oz1);
+    const int iny = iy1 - iy0 + 1, inz = iz1 - iz0 + 1;
+    const int n_inner = (skip_old && nrows > 0 && iny > 0 && inz > 0) ? iny * inz : 0;
+    const int nspans = nrows + n_inner;
+    for (int r0 = 0; r0 < nspans; r0 += kRows) {
       MM3D_TICK(t_hdr);
-      // Row headers, FOUR per lane (rows r0 + 4 lane .. + 3): a box of up to 256 rows costs one header round trip and fuller
+      // Span headers, FOUR per lane (spans r0 + 4 lane .. + 3): a box of up to 256 rows costs one header round trip and fuller
       // tiles instead of a header, a prefix scan and a ragged last tile per 64 rows (a pass has ~150 - 250 rows, a row ~3 points).
       // Worth 2 % where the searches are short and many (64 maps x 50 k points), nothing on the headline, whose step is bound
       // by instruction issue.  Exclusive scan of the span lengths.
       int hb[kRowsPerLane], hl[kRowsPerLane];
       {
         const int r = r0 + kRowsPerLane * lane;
-        int zq = r / ny, yr = r - zq * ny;
+        // (y, z) of span r: a row of the new box (r < nrows) or an inner row's right-hand span
+        bool second = r >= nrows;
+        int t = second ? r - nrows : r;
+        int wy = second ? iny : ny;                    // rows per z layer of the group
+        int zq = t / max(wy, 1), yr = t - zq * wy;
 #pragma unroll
         for (int u = 0; u < kRowsPerLane; ++u) {
           hb[u] = 0; hl[u] = 0;
-          if (r + u < nrows) {
-            const int row = ((z0 + zq) * g.dy + (y0 + yr)) * g.dx;
-            hb[u] = g.cell_start[row + x0];
-            hl[u] = g.cell_start[row + x1 + 1];
+          if (!second && r + u == nrows) { second = true; wy = iny; zq = 0; yr = 0; }   // this lane's spans straddle the two groups
+          if (r + u < nspans) {
+            const int y = (second ? iy0 : y0) + yr, z = (second ? iz0 : z0) + zq;
+            int xa = x0, xb = x1;
+            if (second) xa = max(x0, ox1 + 1);
+            else if (n_inner && y >= iy0 && y <= iy1 && z >= iz0 && z <= iz1) xb = min(x1, ox0 - 1);
+            if (xa <= xb) {
+              const int row = (z * g.dy + y) * g.dx;
+              hb[u] = g.cell_start[row + xa];
+              hl[u] = g.cell_start[row + xb + 1];
+            }
           }
-          if (++yr == ny) { yr = 0; ++zq; }
+          if (++yr == wy) { yr = 0; ++zq; }
         }
       }
       int mine = 0;
@@ -244,7 +298,7 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
       const int total = __shfl(incl, kWave - 1, kWave);
       MM3D_STAT(2, 1);
       MM3D_STAT(3, total);
-      MM3D_STAT(5, min(nrows - r0, kRows));
+      MM3D_STAT(5, min(nspans - r0, kRows));
       wave_lds_sync();                 // previous chunk's readers are done
       {
         int off = incl - mine;
@@ -357,22 +411,26 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
       if (MODE == 1) bestd = __uint_as_float((unsigned)m);
       else bkey = m;
     }
+    if (nrows > 0) { have_old = true; ox0 = x0; ox1 = x1; oy0 = y0; oy1 = y1; oz0 = z0; oz1 = z1; }
     // what the scanned box proves: every target point closer than `guard` to this lane has been seen
     best = MODE == 1 ? bestd : (((unsigned)bkey == 0xffffffffu) ? INFINITY : __uint_as_float((unsigned)(bkey >> 32)));
     if (active) {
-      const float gx0 = (lx - E > 0) ? p.x - (g.minx + (float)(lx - E) * g.cell) : INFINITY;
-      const float gx1 = (hx + E < g.dx - 1) ? (g.minx + (float)(hx + E + 1) * g.cell) - p.x : INFINITY;
-      const float gy0 = (ly - E > 0) ? p.y - (g.miny + (float)(ly - E) * g.cell) : INFINITY;
-      const float gy1 = (hy + E < g.dy - 1) ? (g.miny + (float)(hy + E + 1) * g.cell) - p.y : INFINITY;
-      const float gz0 = (lz - E > 0) ? p.z - (g.minz + (float)(lz - E) * g.cell) : INFINITY;
-      const float gz1 = (hz + E < g.dz - 1) ? (g.minz + (float)(hz + E + 1) * g.cell) - p.z : INFINITY;
+      // (a face of the box that lies on the grid's own border proves everything beyond it: there is nothing there)
+      const float gx0 = (bx0 > 0) ? p.x - (g.minx + (float)bx0 * g.cell) : INFINITY;
+      const float gx1 = (bx1 < g.dx - 1) ? (g.minx + (float)(bx1 + 1) * g.cell) - p.x : INFINITY;
+      const float gy0 = (by0 > 0) ? p.y - (g.miny + (float)by0 * g.cell) : INFINITY;
+      const float gy1 = (by1 < g.dy - 1) ? (g.miny + (float)(by1 + 1) * g.cell) - p.y : INFINITY;
+      const float gz0 = (bz0 > 0) ? p.z - (g.minz + (float)bz0 * g.cell) : INFINITY;
+      const float gz1 = (bz1 < g.dz - 1) ? (g.minz + (float)(bz1 + 1) * g.cell) - p.z : INFINITY;
       const float guard = fminf(fminf(fminf(gx0, gx1), fminf(gy0, gy1)), fminf(gz0, gz1)) * 0.9999f - 1e-5f;
       if (guard >= rmax || best <= guard * guard) {
         active = false;
       } else {
         const float reach = best < INFINITY ? fminf(sqrtf(best), rmax) : rmax;
         const int want = (int)ceilf(reach * g.inv * 1.001f + 0.01f);   // guard >= want*cell*0.9999 - 1e-5 >= reach
-        need = min(max(want, E + 1), max_ring + pass + 1);
+        // (at least one ring more than this lane had: best > guard^2 and guard >= need cells already make `want` that large;
+        // with the common radius of rounds 1 - 4 it was E + 1, the wave's largest plus one)
+        need = min(max(want, (MM3D_NN_TIGHT_BOX ? need : E) + 1), max_ring + pass + 1);
       }
     }
 #ifdef MM3D_NN_STATS

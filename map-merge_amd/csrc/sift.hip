@@ -180,6 +180,9 @@ __device__ __forceinline__ float quad_bcast(float v)
 // 3584 / 2560, 38.9 with 2816 / 3328, 39.5 with 2560 / 3840, 41.2 with 2304 / 4160 where 14 of 16 maps need a repair launch;
 // profiles/r04_sift_config_ab.txt).  First octave: hit buffer 384 -> 256 (longer lists: distance bands), arena 1024 -> 1408:
 // 1.23 -> 1.18 ms.
+#ifndef MM3D_SIFT_STEPWISE
+#define MM3D_SIFT_STEPWISE 0
+#endif
 #ifndef MM3D_SIFT_SMALL
 #define MM3D_SIFT_SMALL 8, 1792, 1408, 256, 128
 #endif
@@ -282,6 +285,22 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
           for (int k = 0; k < NS; ++k) {
             // the lists are sorted: if no lane's first entry of the four is inside 3 sigma, none of the others is
             if (ballot(valid[0] && d2[0] <= thr[k])) {
+#if MM3D_SIFT_STEPWISE
+              // (round 5) ... and the same holds step by step: quad step j of this iteration is worked only while some lane's
+              // entry of that step is inside -- the weights of the steps behind a scale's support (a third of the evaluations
+              // of the narrow scales, whose whole support is one or two iterations) are not computed at all
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const bool in = valid[j] && d2[j] <= thr[k];
+                if (j > 0 && !ballot(in)) break;
+                const float wj = lm::expf_glibc_t<false>(lm::fdiv_const(-0.5f * d2[j], sig[k], rcp[k]), [&](unsigned i) { return s_tab[i]; });
+                const float w1 = in ? wj : 0.0f, vw1 = in ? __fmul_rn(val[j], wj) : 0.0f;
+                num[k] = __fadd_rn(num[k], quad_bcast<0>(vw1)); den[k] = __fadd_rn(den[k], quad_bcast<0>(w1));
+                num[k] = __fadd_rn(num[k], quad_bcast<1>(vw1)); den[k] = __fadd_rn(den[k], quad_bcast<1>(w1));
+                num[k] = __fadd_rn(num[k], quad_bcast<2>(vw1)); den[k] = __fadd_rn(den[k], quad_bcast<2>(w1));
+                num[k] = __fadd_rn(num[k], quad_bcast<3>(vw1)); den[k] = __fadd_rn(den[k], quad_bcast<3>(w1));
+              }
+#else
               float w[4], vw[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -297,6 +316,7 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
                 num[k] = __fadd_rn(num[k], quad_bcast<2>(vw[j])); den[k] = __fadd_rn(den[k], quad_bcast<2>(w[j]));
                 num[k] = __fadd_rn(num[k], quad_bcast<3>(vw[j])); den[k] = __fadd_rn(den[k], quad_bcast<3>(w[j]));
               }
+#endif
             }
           }
         }
