@@ -510,7 +510,9 @@ def main():
     # timed region several streams share the CUs, so a kernel's HIP-event duration there includes the
     # time it spent sharing; the isolated figure is what speaks about the kernel itself.
     iso, gpu_sample = {}, None
-    if rank == 0:
+    normals_alone = None
+    # (MM3D_BENCH_NO_ISOLATED=1: a kernel-trace run wants nothing behind the timed steps -- scripts/profile_round.sh)
+    if rank == 0 and not os.environ.get("MM3D_BENCH_NO_ISOLATED"):
         ctx.profile_reset()
         ctx.profile(True)
         ctx.srand(1)
@@ -530,7 +532,6 @@ def main():
         # computeSurfaceNormals as a launch of its own (in the whole-map path with SIFT keypoints the normals ride on the first
         # octave's sorted lists and have no launch to time): map 0's filtered points through the stand-alone entry point, and
         # detectKeypoints stand-alone (no fused normals) to price what the fusion adds to the first octave
-        normals_alone = None
         try:
             ctx.profile_reset(); ctx.profile(True)
             nrm0 = ctx.computeSurfaceNormals(two[0].points, params.normal_radius)
@@ -959,6 +960,12 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", me
         fro_dbl = float(np.linalg.norm(T_dev - T_dbl))
         cpu_noise = float(np.linalg.norm(T - T_dbl))
         conf_rel = abs(float(rec["confidence"]) * score - 1.0)
+        # The confidence is 1 / transformScore(T): against the oracle's own value it inherits the CPU path's noise in T (at 1.6 M
+        # points T_oracle is 2e-3 from exact arithmetic and the score moves with it), which says nothing about the score kernel.
+        # The kernel is held to the CPU path's transformScore evaluated AT THE DEVICE'S TRANSFORM (1e-4 relative, measured ~1e-6);
+        # the raw difference is reported and bounded like the all-pairs test bounds it (1e-3).
+        score_at_dev_T = po.transform_score(f0, f1, T_dev, p.max_correspondence_distance)
+        conf_rel_same_T = abs(float(rec["confidence"]) * score_at_dev_T - 1.0)
         # THE stated pair-transform tolerance (oracle/pyoracle.py, BASELINE.md "Reported metrics"): BOTH
         # clauses must hold.  exact: within TOL_T_EXACT of the same ICP with its sums in double, equal iteration counts;
         # oracle: within transform_tolerance(n_src) of the CPU path, whose sequential float sums carry their own summation
@@ -977,16 +984,17 @@ def cpu_baseline(host, n_maps, n_pairs, gpu_sample, check, descriptor="FPFH", me
             "pair_transform_frobenius_vs_double_sums": round(fro_dbl, 9), "pair_transform_tolerance_vs_double_sums": po.TOL_T_EXACT,
             "cpu_path_own_noise_vs_double_sums": round(cpu_noise, 9),
             "clause_oracle_ok": bool(oracle_ok), "clause_exact_ok": bool(exact_ok),
-            "confidence_rel_err": round(conf_rel, 9), "confidence_tolerance": 1e-4,
+            "confidence_rel_err_at_the_device_transform": round(conf_rel_same_T, 9), "confidence_tolerance_at_the_device_transform": 1e-4,
+            "confidence_rel_err": round(conf_rel, 9), "confidence_tolerance": 1e-3,
             "icp_iterations": {"device": it_dev, "oracle": int(it), "double_sums": int(it_dbl)},
             "icp_last_iteration_correspondences": {"device": int(rec["icp_correspondences"]), "oracle": int(corr_oracle),
                                                    "double_sums": int(corr_dbl)},
             "all_pairs": "tests/test_gpu_baseline_configs.py::test_16x500k_all_120_pairs_within_the_stated_tolerance holds every pair of the "
-                         "headline job to the same two clauses (profiles/r04_all_pairs_tolerance.txt)",
+                         "headline job to the same two clauses (profiles/r05_all_pairs_tolerance.txt)",
             "oracle_threads_agree": bool(threads_agree),
         }
         parity["ok"] = bool(parity["filtered_points_bit_equal"] and parity["keypoints_bit_equal"] and parity["descriptors_bit_equal"]
-                            and oracle_ok and exact_ok and conf_rel <= 1e-4 and threads_agree)
+                            and oracle_ok and exact_ok and conf_rel_same_T <= 1e-4 and conf_rel <= 1e-3 and threads_agree)
     return b1, b2, parity, cpu_stages
 
 

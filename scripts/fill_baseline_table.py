@@ -28,7 +28,8 @@ for cfg in (1, 2, 3, 4, 5, "4indoor", "2lattice", "3lattice"):
     rows.append("| %s | %s | %.4g | %.4g (%d) | **%.4g** (%.1f ms/step) | n/a (driver) | %s | %s | %s | %s | %s | %s |" % (
         cfg, d["config"]["workload"], b1["value"], b2["value"], b2["cores"], d["value"], d["ms_per_step"],
         m.get("normals") if m.get("normals") is not None else ("fused into SIFT's first octave" if m.get("normals_fused") else None),
-        ("%.2f %%" % (100 * nb["hbm_frac"])) if "hbm_frac" in nb else "—",
+        ("%.2f %%" % (100 * nb["hbm_frac"])) if "hbm_frac" in nb else
+        (("%.2f %% (stand-alone launch)" % (100 * m["normals_alone"]["hbm_frac"])) if (m.get("normals_alone") or {}).get("hbm_frac") is not None else "—"),
         ("%.1f %%" % (100 * knn["mfma_frac"])) if "mfma_frac" in knn else "—", m.get("icp"),
         ("ok: T %.1e%s, conf %.1e" % (par["pair_transform_frobenius"],
                                       (" (vs double-sum ICP %.0e)" % par["pair_transform_frobenius_vs_double_sums"]) if "pair_transform_frobenius_vs_double_sums" in par else "",
