@@ -238,11 +238,39 @@ size_t ransac_transform(Context *c, const mm3d_cloud *skp_, const mm3d_cloud *tk
 // failures) and findSimilarFeatures (one draw per sample).  It depends on the SOURCE keypoints only
 // (a target with at least one descriptor is assumed), which is what lets the stream scheduler of
 // mm3d_estimate_maps_transforms position the generator for a pair before that pair's target exists.
+// "sqrtf(d2) < msd" without the square root: the smallest float t with sqrtf(t) >= msd, so that sqrtf(d2) < msd <=> d2 < t
+// (sqrtf is correctly rounded and monotone; a NaN d2 fails both tests)
+static float sq_threshold(float msd)
+{
+  if (!(msd > 0.0f)) return 0.0f;                       // nothing is nearer than a distance <= 0
+  float t = msd * msd;
+  while (sqrtf(t) >= msd && t > 0.0f) t = std::nextafterf(t, 0.0f);
+  while (sqrtf(t) < msd) t = std::nextafterf(t, INFINITY);
+  return t;
+}
+
+// The replay of SampleConsensusInitialAlignment's random stream for one pair (selectSamples + findSimilarFeatures' picks,
+// ia_ransac.hpp): it is sequential by nature -- a pair starts where the previous one left the generator -- and every rank /
+// device / worker of a sharded job needs it up to its last pair, so its speed is on the critical path of many small maps
+// (2 016 pairs per step) and of a rank that owns few pairs.  Round 5: the generator's state in locals and its two ring
+// indices wrapped by a compare instead of `% 31`, the distance test on the squared distance against an exactly equivalent
+// threshold: 18 -> 8.5 us per pair (scripts/micro/replay_bench.cpp), the same state after every pair.
 void sac_ia_draws(GlibcRand &rnd, const std::vector<float4> &skp, int ns, float min_sample_distance, int H, int kk, int *samp,
                   int *pick)
 {
   const int nr_samples = 3, k_corr = 10;
-  auto get_random_index = [&](int n) { return (int)(n * (rnd.next() / (2147483647 + 1.0))); };
+  uint32_t *ring = rnd.ring;
+  int f = rnd.f, b = rnd.b;
+  auto next = [&]() {                                   // GlibcRand::next
+    ring[f] += ring[b];
+    const uint32_t res = ring[f] >> 1;
+    if (++f == 31) f = 0;
+    if (++b == 31) b = 0;
+    return (int)res;
+  };
+  // getRandomIndex(n) = int(n * (rand() / (RAND_MAX + 1.0))): the division by 2^31 is an exact scaling
+  auto get_random_index = [&](int n) { return (int)(n * (next() * (1.0 / 2147483648.0))); };
+  float thr = sq_threshold(min_sample_distance);
   int scratch[3];
   for (int it = 0; it < H; ++it) {
     int *sample = samp ? &samp[(size_t)it * 3] : scratch;
@@ -253,15 +281,16 @@ void sac_ia_draws(GlibcRand &rnd, const std::vector<float4> &skp, int ns, float 
       while (cnt < nr_samples) {
         const int si = get_random_index(ns);
         bool valid = true;
+        const float4 a = skp[si];
         for (int i = 0; i < cnt; ++i) {
-          const float4 &a = skp[si], &b = skp[sample[i]];
-          const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-          const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-          if (si == sample[i] || dist < min_sample_distance) { valid = false; break; }
+          const float4 &o = skp[sample[i]];
+          const float dx = a.x - o.x, dy = a.y - o.y, dz = a.z - o.z;
+          const float d2 = dx * dx + dy * dy + dz * dz;         // euclideanDistance = sqrt of this, compared with `<`
+          if (si == sample[i] || d2 < thr) { valid = false; break; }
         }
         if (valid) { sample[cnt++] = si; without = 0; }
         else ++without;
-        if (without >= max_without) { min_sample_distance *= 0.5f; without = 0; }
+        if (without >= max_without) { min_sample_distance *= 0.5f; thr = sq_threshold(min_sample_distance); without = 0; }
       }
     }
     // findSimilarFeatures
@@ -271,6 +300,7 @@ void sac_ia_draws(GlibcRand &rnd, const std::vector<float4> &skp, int ns, float 
       if (pick) pick[(size_t)it * 3 + i] = rc;
     }
   }
+  rnd.f = f; rnd.b = b;
 }
 
 // the draws estimate_pair(method, source, non-empty target) consumes, without touching the device or the target
