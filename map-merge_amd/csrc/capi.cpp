@@ -1336,6 +1336,44 @@ void mm3d_shard_end(mm3d_shard *sh)
   delete sh;
 }
 
+// the reference's two loops on ONE stream, in the reference's order (mm3d_set_streams(ctx, 1), the default)
+static void estimate_maps_sequential(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, const mm3d_params *params, float *out_T,
+                                     size_t *n_out, mm3d_pair_result *pairs_out, size_t *n_pairs_out)
+{
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+  ctx->last_points.assign(n, 0);
+  ctx->last_keypoints.assign(n, 0);
+  std::vector<std::unique_ptr<mm3d_map, std::function<void(mm3d_map *)>>> maps;
+  auto del = [](mm3d_map *m) { if (m) { delete m->points; delete m->keypoints; delete m->desc; delete m; } };
+  for (size_t i = 0; i < n; ++i) {
+    // a null / empty map (robot subscribed but no message yet) counts as "no keypoints"
+    std::unique_ptr<mm3d_cloud> raw(cloud_from_memory(ctx, clouds[i].points, clouds[i].points ? clouds[i].n : 0,
+                                                      clouds[i].stride ? clouds[i].stride : 16,
+                                                      clouds[i].stride ? clouds[i].rgba_offset : 12));
+    maps.emplace_back(map_features_impl(ctx, raw.get(), params), del);
+    map_prepare_impl(ctx, maps.back().get(), params);   // search structures and k-NN target operands, once per map
+    ctx->last_points[i] = maps.back()->points->n;
+    ctx->last_keypoints[i] = maps.back()->keypoints->n;
+  }
+  ctx->last_features_s = since_start();
+  std::vector<mm3d_pair_result> pairs;
+  for (size_t i = 0; i + 1 < n; ++i)
+    for (size_t j = i + 1; j < n; ++j)
+      if (maps[i]->keypoints->n > 0 && maps[j]->keypoints->n > 0) {
+        mm3d_pair_result r;
+        std::memset(&r, 0, sizeof(r));
+        r.source_idx = i; r.target_idx = j;
+        pairs.push_back(r);
+      }
+  for (auto &r : pairs) pair_estimate_impl(ctx, maps[r.source_idx].get(), maps[r.target_idx].get(), params, true, &r);
+  if (pairs_out) std::memcpy(pairs_out, pairs.data(), pairs.size() * sizeof(mm3d_pair_result));
+  if (n_pairs_out) *n_pairs_out = pairs.size();
+  int st = global_transforms(pairs.data(), pairs.size(), params->confidence_threshold, n, out_T, n_out);
+  if (st != MM3D_OK) throw Error(st, "computeGlobalTransforms failed");
+  ctx->last_total_s = since_start();
+}
+
 // ---------------------------------------------------------------- the same job on N devices of ONE process
 // estimateMapsTransforms behind the reference's own entry point on a device list (mm3d_create_devices): the reference's
 // caller is one process -- a ROS timer callback, R/src/map_merge_node.cpp:133-153 -- and cannot be relaunched under torchrun.
@@ -1381,6 +1419,28 @@ static void estimate_maps_devices(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
   roots.insert(roots.end(), ctx->peers.begin(), ctx->peers.end());
   const size_t D = roots.size();
   const size_t max_pairs = n * (n - 1) / 2;
+  if (D == 1) {
+    // a list of one device: nothing to shard, so the job runs as on a plain context (pipelined over the streams, not in
+    // barriered stages) -- and its pair records still travel through the communicator's all-gather (a world of one), so that
+    // the collective of the path is exercised wherever a device list is used
+    std::vector<mm3d_pair_result> local(std::max<size_t>(max_pairs, 1));
+    size_t np = 0;
+    if (!ctx->helpers.empty()) estimate_maps_streams(ctx, clouds, n, params, out_T, n_out, local.data(), &np);
+    else estimate_maps_sequential(ctx, clouds, n, params, out_T, n_out, local.data(), &np);
+    const double t_before = ctx->last_total_s;
+    std::vector<std::vector<mm3d_pair_result>> send(1);
+    send[0].assign(local.begin(), local.begin() + (ptrdiff_t)np);
+    std::vector<mm3d_pair_result> gathered;
+    ctx->last_gather_s = gather_pair_records(ctx->device_set, roots, send, np, gathered);
+    ctx->last_exchange_s = ctx->last_features_s;
+    ctx->last_pairs_s = t_before;
+    if (pairs_out && np) std::memcpy(pairs_out, gathered.data(), np * sizeof(mm3d_pair_result));
+    if (n_pairs_out) *n_pairs_out = np;
+    const int st = global_transforms(gathered.data(), np, params->confidence_threshold, n, out_T, n_out);   // (from what the gather delivered)
+    if (st != MM3D_OK) throw Error(st, "computeGlobalTransforms failed");
+    ctx->last_total_s = t_before + ctx->last_gather_s;
+    return;
+  }
   const auto t_start = std::chrono::steady_clock::now();
   auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
   std::vector<std::unique_ptr<mm3d_shard>> sh(D);
@@ -1525,38 +1585,7 @@ int mm3d_estimate_maps_transforms(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
       estimate_maps_streams(ctx, clouds, n, params, out_T, n_out, pairs_out, n_pairs_out);
       return;
     }
-    const auto t_start = std::chrono::steady_clock::now();
-    auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
-    ctx->last_points.assign(n, 0);
-    ctx->last_keypoints.assign(n, 0);
-    std::vector<std::unique_ptr<mm3d_map, std::function<void(mm3d_map *)>>> maps;
-    auto del = [](mm3d_map *m) { if (m) { delete m->points; delete m->keypoints; delete m->desc; delete m; } };
-    for (size_t i = 0; i < n; ++i) {
-      // a null / empty map (robot subscribed but no message yet) counts as "no keypoints"
-      std::unique_ptr<mm3d_cloud> raw(cloud_from_memory(ctx, clouds[i].points, clouds[i].points ? clouds[i].n : 0,
-                                                        clouds[i].stride ? clouds[i].stride : 16,
-                                                        clouds[i].stride ? clouds[i].rgba_offset : 12));
-      maps.emplace_back(map_features_impl(ctx, raw.get(), params), del);
-      map_prepare_impl(ctx, maps.back().get(), params);   // search structures and k-NN target operands, once per map
-      ctx->last_points[i] = maps.back()->points->n;
-      ctx->last_keypoints[i] = maps.back()->keypoints->n;
-    }
-    ctx->last_features_s = since_start();
-    std::vector<mm3d_pair_result> pairs;
-    for (size_t i = 0; i + 1 < n; ++i)
-      for (size_t j = i + 1; j < n; ++j)
-        if (maps[i]->keypoints->n > 0 && maps[j]->keypoints->n > 0) {
-          mm3d_pair_result r;
-          std::memset(&r, 0, sizeof(r));
-          r.source_idx = i; r.target_idx = j;
-          pairs.push_back(r);
-        }
-    for (auto &r : pairs) pair_estimate_impl(ctx, maps[r.source_idx].get(), maps[r.target_idx].get(), params, true, &r);
-    if (pairs_out) std::memcpy(pairs_out, pairs.data(), pairs.size() * sizeof(mm3d_pair_result));
-    if (n_pairs_out) *n_pairs_out = pairs.size();
-    int st = global_transforms(pairs.data(), pairs.size(), params->confidence_threshold, n, out_T, n_out);
-    if (st != MM3D_OK) throw Error(st, "computeGlobalTransforms failed");
-    ctx->last_total_s = since_start();
+    estimate_maps_sequential(ctx, clouds, n, params, out_T, n_out, pairs_out, n_pairs_out);
   });
 }
 
