@@ -470,17 +470,20 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
     acc[15] = best;
     acc[16] = 1.0;
   }
+  // A wave none of whose points found a neighbour in range adds seventeen zeros: it writes them without the seventeen
+  // reductions (each six shuffle steps on a double).  With the headline's initial poses that is a good part of the waves.
+  const bool any_corr = ballot(valid && best <= max_d2) != 0ull;       // wave-uniform
   if (SPLIT == 4) {
 #pragma unroll
     for (int k = 0; k < kAcc; ++k) {
-      const double v = (MODE == 0 || k >= 15) ? wave_sum(acc[k]) : 0.0;
+      const double v = ((MODE == 0 || k >= 15) && any_corr) ? wave_sum(acc[k]) : 0.0;
       if (lane == 0) partials[(size_t)bid * kAcc + k] = v;
     }
     return;
   }
 #pragma unroll
   for (int k = (MODE == 0 ? 0 : 15); k < kAcc; ++k) {
-    const double v = wave_sum(acc[k]);
+    const double v = any_corr ? wave_sum(acc[k]) : 0.0;
     if (lane == 0) red[wave][k] = v;
   }
   __syncthreads();
