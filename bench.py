@@ -650,6 +650,15 @@ def main():
         out["nearest"] = max(((v, k[:-5]) for k, v in out.items()), default=(0, None))[1]
         return out
 
+    # Every rank empties its C stdio buffer now (RCCL's banner sits there on each of them, and torchrun merges the ranks'
+    # stdout into one pipe), and rank 0 prints behind a barrier: the JSON line is the LAST line of the job's output.
+    try:
+        C.CDLL(None).fflush(None)
+        sys.stdout.flush()
+    except Exception:
+        pass
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         n_pairs = stats["n_pairs"]
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
