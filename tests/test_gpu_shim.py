@@ -92,3 +92,32 @@ def test_shim_results_equal_the_c_abi(tmp_path, mm, synth):
     assert np.array_equal(bits(rd.arr(mm.POINT, rd.u64())), bits(merged.numpy()))
     assert rd.o == len(rd.d)
     ctx.close()
+
+
+def test_shim_on_a_device_list_writes_the_same_bytes(tmp_path, synth):
+    """MM3D_DEVICES makes the shim's estimation context a device-list one (mm3d_create_devices: estimateMapsTransforms sharded
+    inside the library, pair records through the RCCL all-gather) -- the way the ROS node gets several GPUs without a source
+    change.  Every result of the shim's check program must be byte for byte what the plain context writes:
+    with the one GPU of this box as the list [0], and as "all"."""
+    if not os.path.exists(EXE):
+        pytest.skip("shim_check was not built (no reference headers at build time)")
+    _, maps = synth.synth_maps(3, 12000)
+    raws = [synth.pack_points(x, c) for x, c, _ in maps]
+    inp = str(tmp_path / "in.bin")
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<Q", len(raws)))
+        for r in raws:
+            f.write(struct.pack("<Q", len(r)))
+            f.write(r.tobytes())
+    outs = []
+    for tag, env in (("plain", {}), ("list0", {"MM3D_DEVICES": "0"}), ("all", {"MM3D_DEVICES": "all"})):
+        outp = str(tmp_path / f"out_{tag}.bin")
+        e = dict(os.environ)
+        e.pop("MM3D_DEVICES", None)
+        e.update(env)
+        r = subprocess.run([EXE, "gpu", inp, outp], capture_output=True, text=True, timeout=600, env=e)
+        assert r.returncode == 0 and "shim_check gpu: ok" in r.stdout, (tag, r.stdout[-2000:] + r.stderr[-2000:])
+        if env:
+            assert "RCCL version" in r.stdout + r.stderr, "a device-list context creates RCCL communicators (its banner)"
+        outs.append(open(outp, "rb").read())
+    assert outs[0] == outs[1] == outs[2]
