@@ -1397,6 +1397,23 @@ __global__ void k_gather_desc_rows(const float *__restrict__ X, const int *__res
   out[e] = X[(size_t)rows[e / dim] * dim + e % dim];
 }
 
+// the same for up to kGatherMax sources in ONE launch (blockIdx.y = the source): a batch of pairs that share their target
+// used to cost a gather launch per source -- with many small maps nearly 2 000 of the step's launches
+constexpr int kGatherMax = 16;
+struct GatherSrcs {
+  const float *X[kGatherMax];
+  const int *rows[kGatherMax];
+  int n_rows[kGatherMax];
+  int first_row[kGatherMax];                           // where the source's rows start in the output
+};
+__global__ void k_gather_desc_rows_multi(GatherSrcs G, int dim, float *__restrict__ out)
+{
+  const int s = blockIdx.y;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)G.n_rows[s] * dim) return;
+  out[(size_t)G.first_row[s] * dim + e] = G.X[s][(size_t)G.rows[s][e / dim] * dim + e % dim];
+}
+
 // k-NN of a subset of A's rows (device index list); result row r belongs to rows[r]
 void desc_knn_rows(Context *c, const mm3d_desc *A, const int *rows_dev, int n_rows, const mm3d_desc *B, int k, DevBuf<int> &idx,
                    DevBuf<float> &d2)
@@ -1428,12 +1445,25 @@ void desc_knn_rows_multi(Context *c, const KnnRows *srcs, int n_srcs, const mm3d
   sub.n = total;
   sub.data = DevBuf<float>(c, total * sub.dim);
   size_t off = 0;
-  for (int i = 0; i < n_srcs; ++i) {
-    const int n_rows = srcs[i].n_rows;
-    if (n_rows > 0)
-      MM3D_LAUNCH(c, "desc_knn_prep", n_rows * sub.dim * 8.0, k_gather_desc_rows, dim3(div_up((size_t)n_rows * sub.dim, 256)), dim3(256), 0,
-                  (const float *)srcs[i].A->data.get(), srcs[i].rows_dev, n_rows, sub.dim, sub.data.get() + off * sub.dim);
-    off += (size_t)n_rows;
+  for (int i0 = 0; i0 < n_srcs; i0 += kGatherMax) {      // (a batch holds at most 16 pairs: one launch)
+    GatherSrcs G;
+    std::memset(&G, 0, sizeof(G));
+    const int cnt = std::min(kGatherMax, n_srcs - i0);
+    int max_rows = 0;
+    size_t rows_here = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const KnnRows &S = srcs[i0 + i];
+      G.X[i] = (const float *)S.A->data.get();
+      G.rows[i] = S.rows_dev;
+      G.n_rows[i] = S.n_rows;
+      G.first_row[i] = (int)off;
+      off += (size_t)S.n_rows;
+      rows_here += (size_t)S.n_rows;
+      max_rows = std::max(max_rows, S.n_rows);
+    }
+    if (max_rows > 0)
+      MM3D_LAUNCH(c, "desc_knn_prep", rows_here * sub.dim * 8.0, k_gather_desc_rows_multi, dim3(div_up((size_t)max_rows * sub.dim, 256), cnt), dim3(256), 0, G,
+                  sub.dim, sub.data.get());
   }
   desc_knn(c, &sub, B, k, idx, d2);
 }

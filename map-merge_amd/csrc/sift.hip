@@ -449,7 +449,8 @@ static SiftDogPending sift_dog_octave(Context *c, int oct, const mm3d_cloud *cur
     // largest tile a CU holds -- before anything is left to the global-memory lists; a cloud that is dense everywhere (thousands of items) goes to those directly (measured on
     // 8 x 2 M indoor points: the large configuration is no faster per neighbour there, and it runs one block per CU)
     std::shared_ptr<SnbLaunch<SiftCfgDense>> sl2;
-    if (!std::is_same<Cfg, SiftCfgDense>::value && n_overflow <= 256) {
+    static const int dense_max = [] { const char *e = getenv("MM3D_SIFT_DENSE_MAX"); return e ? atoi(e) : 256; }();   // A/B knob
+    if (!std::is_same<Cfg, SiftCfgDense>::value && n_overflow <= dense_max) {
       const size_t extra2 = sizeof(float) * 64 * (nrm ? 9 : kScales) + (nrm ? sizeof(int) * 64 : 0) + 256;
       sl2 = std::make_shared<SnbLaunch<SiftCfgDense>>(c, n_items, extra2);
       const dim3 grid2(std::min(sl2->blocks, (unsigned)n_overflow)), block2(64 * SiftCfgDense::kWaves);
