@@ -69,7 +69,15 @@ int main(void)
     b[i].x = cosf(yaw) * dx + sinf(yaw) * dy; b[i].y = -sinf(yaw) * dx + cosf(yaw) * dy; b[i].z = wz; b[i].rgba = colour(u, v);
   }
   mm3d_ctx *ctx = NULL;
-  if (mm3d_create(0, &ctx) != MM3D_OK) { fprintf(stderr, "mm3d_create failed (no GPU?)\n"); return 2; }
+  /* MM3D_DEMO_DEVICES=<n>: the same call on the first n GPUs of this ONE process (mm3d_create_devices: the job is sharded inside
+   * the library, the pair records travel through an RCCL all-gather); otherwise one GPU */
+  const char *nd = getenv("MM3D_DEMO_DEVICES");
+  if (nd && atoi(nd) > 0) {
+    int devs[64], k = atoi(nd) > 64 ? 64 : atoi(nd);
+    for (int i = 0; i < k; ++i) devs[i] = i;
+    if (mm3d_create_devices(devs, k, &ctx) != MM3D_OK) { fprintf(stderr, "mm3d_create_devices(%d GPUs) failed\n", k); return 2; }
+    printf("device list of %d, pair records through %s\n", mm3d_device_count(ctx), mm3d_devices_use_rccl(ctx) ? "ncclAllGather" : "host memory");
+  } else if (mm3d_create(0, &ctx) != MM3D_OK) { fprintf(stderr, "mm3d_create failed (no GPU?)\n"); return 2; }
   mm3d_params p;
   mm3d_params_default(&p);
   p.descriptor_type = MM3D_DESC_FPFH;
