@@ -100,7 +100,8 @@ int mm3d_create(int device, mm3d_ctx **out);
  * (hipMemcpyPeerAsync over xGMI), pairs by target owner, ONE RCCL all-gather (ncclAllGather, communicators from
  * ncclCommInitAll) of the 104-byte pair records, pose graph on the host -- with the bits of one device.  Every other entry
  * point of such a context works on its first device.  mm3d_set_streams applies to every device of the list.
- * Creating the communicators takes seconds (once, here).  A device listed twice is MM3D_EINVAL (test hook:
+ * Creating the communicators takes seconds (once, here); librccl.so.1 is loaded by this call (a context made by mm3d_create
+ * never needs it).  A device listed twice is MM3D_EINVAL (test hook:
  * MM3D_DEVICES_ALLOW_DUPLICATES=1 admits it, the records are then gathered through host memory instead of RCCL, which
  * refuses a device twice; mm3d_devices_use_rccl tells). */
 int mm3d_create_devices(const int *devices, int n_devices, mm3d_ctx **out);

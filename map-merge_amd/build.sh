@@ -21,6 +21,7 @@ for s in $SRCS; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-# librccl: the one collective of the path, the all-gather of the pair records between the devices of one process (devices.cpp)
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS -L/opt/rocm/lib -lrccl
+# (librccl -- the one collective of the path, the all-gather of the pair records between the devices of one process -- is bound
+# by csrc/devices.cpp on first use of mm3d_create_devices, not at load time: 570 MB that a one-GPU process never maps)
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS -ldl
 echo "built $(pwd)/$OUT"

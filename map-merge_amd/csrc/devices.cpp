@@ -8,10 +8,12 @@
 //     PULLED by every device that does not own the map with hipMemcpyPeerAsync -- point-to-point over xGMI, each device
 //     reading from up to seven peers at once on its own streams; no collective, no staging through the host;
 //   * the 104-byte pair records are all-gathered with RCCL (ncclAllGather inside one group, one communicator per device
-//     from ncclCommInitAll): the one collective north_star names ("only a final RCCL gather of the pairwise
+//     from ncclCommInitAll; librccl bound on first use, see rccl() below): the one collective north_star names ("only a final RCCL gather of the pairwise
 //     Eigen::Matrix4f over xGMI before the host-side pose-graph solve").  Latency-bound (120 records = 12.5 KB).
 // Host code only: it also compiles, unchanged, into the host sanitizer build (tests/host_san: fake HIP runtime + fake RCCL).
 #include <rccl/rccl.h>
+
+#include <dlfcn.h>
 
 #include <chrono>
 #include <set>
@@ -19,6 +21,45 @@
 #include "types.hpp"
 
 namespace mm3d {
+
+// librccl is bound on first use, not at load time: the library is 570 MB of device code, and a process that works on one GPU
+// (every context made by mm3d_create) should neither map it nor run its constructors -- on a cold machine that alone can take
+// longer than the whole job.  mm3d_create_devices resolves the six entry points it needs: from what the process has already
+// loaded (an application that links RCCL itself, PyTorch's bundled copy, the fake of tests/host_san), else from librccl.so.1.
+namespace {
+struct Rccl {
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;                                   // why it could not be bound (empty: bound)
+};
+const Rccl &rccl()
+{
+  static const Rccl R = [] {
+    Rccl r;
+    void *h = nullptr;
+    if (!dlsym(RTLD_DEFAULT, "ncclCommInitAll")) {
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+      }
+      if (!h) { r.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "?"); return r; }
+    }
+    auto sym = [&](const char *n) { void *p = h ? dlsym(h, n) : dlsym(RTLD_DEFAULT, n); if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + n; return p; };
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    return r;
+  }();
+  return R;
+}
+}  // namespace
 
 struct DeviceSet {
   std::vector<int> devices;
@@ -29,7 +70,7 @@ struct DeviceSet {
   do {                                                                                                                 \
     ncclResult_t r_ = (expr);                                                                                          \
     if (r_ != ncclSuccess)                                                                                             \
-      throw ::mm3d::Error(MM3D_EDEVICE, std::string(#expr) + ": " + ncclGetErrorString(r_) + " (" + __FILE__ + ":" +   \
+      throw ::mm3d::Error(MM3D_EDEVICE, std::string(#expr) + ": " + rccl().GetErrorString(r_) + " (" + __FILE__ + ":" + \
                                             std::to_string(__LINE__) + ")");                                           \
   } while (0)
 
@@ -62,8 +103,9 @@ DeviceSet *device_set_create(const int *devices, int n)
       }
     }
   }
+  if (!rccl().error.empty()) throw Error(MM3D_EDEVICE, "mm3d_create_devices: " + rccl().error);
   ds->comms.resize((size_t)n);
-  MM3D_NCCL(ncclCommInitAll(ds->comms.data(), n, devices));
+  MM3D_NCCL(rccl().CommInitAll(ds->comms.data(), n, devices));
   (void)hipSetDevice(devices[0]);
   return ds.release();
 }
@@ -71,7 +113,7 @@ DeviceSet *device_set_create(const int *devices, int n)
 void device_set_destroy(DeviceSet *ds)
 {
   if (!ds) return;
-  for (ncclComm_t c : ds->comms) (void)ncclCommDestroy(c);
+  for (ncclComm_t c : ds->comms) (void)rccl().CommDestroy(c);
   delete ds;
 }
 
@@ -145,12 +187,12 @@ double gather_pair_records(DeviceSet *ds, const std::vector<mm3d_ctx *> &roots, 
     MM3D_HIP(hipMemcpyAsync(sbuf[d].get(), h, bytes, hipMemcpyHostToDevice, c->stream));
   }
   // one thread, one group: the standard single-process form (every rank's call is enqueued on its own device's stream)
-  MM3D_NCCL(ncclGroupStart());
+  MM3D_NCCL(rccl().GroupStart());
   for (size_t d = 0; d < D; ++d) {
     MM3D_HIP(hipSetDevice(roots[d]->device));
-    MM3D_NCCL(ncclAllGather(sbuf[d].get(), rbuf[d].get(), bytes, ncclChar, ds->comms[d], roots[d]->stream));
+    MM3D_NCCL(rccl().AllGather(sbuf[d].get(), rbuf[d].get(), bytes, ncclChar, ds->comms[d], roots[d]->stream));
   }
-  MM3D_NCCL(ncclGroupEnd());
+  MM3D_NCCL(rccl().GroupEnd());
   // the host solves the pose graph once, from the first device's copy; with mm3d_set_debug every device's copy is read back
   // and must hold the same bytes
   const size_t n_read = roots[0]->debug ? D : 1;

@@ -20,5 +20,6 @@ for f in $CSRC/runtime.cpp $CSRC/capi.cpp $CSRC/host_pipeline.cpp $CSRC/linalg.c
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-$CLANG $SAN -o _build/san_$KIND $objs -lpthread
+# -rdynamic: devices.cpp binds RCCL with dlsym(RTLD_DEFAULT, ...) first -- the fake of fake_rccl.cpp must be visible to it
+$CLANG $SAN -rdynamic -o _build/san_$KIND $objs -lpthread -ldl
 echo "built $(pwd)/_build/san_$KIND"
