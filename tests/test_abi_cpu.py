@@ -39,6 +39,24 @@ def test_no_cpu_fallback(mm):
                 assert "liboracle" not in src and "pyoracle" not in src and "mm3d_oracle" not in src, f
 
 
+def test_rccl_is_bound_on_first_use_not_at_load_time(mm):
+    """The one collective of the path (the all-gather of the pair records between the devices of ONE process) is RCCL's, called
+    by the library itself -- but librccl.so is 570 MB, and a process that works on one GPU must not map it: libmm3d.so has no
+    load-time dependency on it (csrc/devices.cpp binds the six entry points on the first mm3d_create_devices), and a device
+    list is still refused loudly where there is no device."""
+    import subprocess
+    lib = os.path.join(ROOT, "map-merge_amd", "libmm3d.so")
+    needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+    assert "libamdhip64" in needed and "rccl" not in needed.lower(), needed
+    src = open(os.path.join(ROOT, "map-merge_amd", "csrc", "devices.cpp")).read()
+    for sym in ("ncclCommInitAll", "ncclAllGather", "ncclGroupStart", "ncclGroupEnd", "ncclCommDestroy"):
+        assert '"%s"' % sym in src, sym                     # resolved by name
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(mm.Mm3dError):
+            mm.Context(devices=[0])
+
+
 def test_params_default_and_command_line(mm):
     p = mm.MapMergingParams()
     # R/include/map_merge_3d/map_merging.h:28-44
