@@ -61,6 +61,9 @@ constexpr int kTile = MM3D_NN_TILE;   // staged target points per wave and tile 
 #ifndef MM3D_NN_LOWER_BOUND
 #define MM3D_NN_LOWER_BOUND 1
 #endif
+#ifndef MM3D_NN_CORNERS
+#define MM3D_NN_CORNERS 1
+#endif
 constexpr bool kPrefetch = MM3D_NN_PREFETCH != 0;
 constexpr int kRowsPerLane = MM3D_NN_ROWS_PER_LANE;   // row headers a lane reads per chunk
 constexpr int kRows = kWave * kRowsPerLane;           // rows of the box per chunk (power of two: the slot -> row search halves it)
@@ -174,12 +177,16 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
   const int cx = cell_floor(p.x, g.minx, g.inv), cy = cell_floor(p.y, g.miny, g.inv), cz = cell_floor(p.z, g.minz, g.inv);
   bool active = valid;
   int need = max_ring;          // radius (in cells around the lane's own cell) the lane wants scanned
+  float reach_cap = rmax;       // no target point of interest is farther: min(rmax, what the distance transform guarantees)
   if (active) {
     const bool inside = cx >= 0 && cx < g.dx && cy >= 0 && cy < g.dy && cz >= 0 && cz < g.dz;
     if (inside) {
       const int d0 = g.dt[((size_t)cz * g.dy + cy) * g.dx + cx];
       if (d0 > max_ring) active = false;          // nothing within range of this cell
       need = d0 > 1 ? d0 : 1;
+      // an occupied cell d0 cells away holds a point within sqrt(3) (d0 + 1) cells of this one (its farthest corner): an upper
+      // bound of the nearest-neighbour distance that needs no candidate (used when the corner filter below has dropped them)
+      if (MM3D_NN_CORNERS && d0 <= max_ring) reach_cap = fminf(rmax, 1.7321f * (float)(d0 + 1) * g.cell * 1.0001f + 1e-5f);
 #if MM3D_NN_LOWER_BOUND
       // The nearest occupied cell is d0 cells away along some axis, so no target point is nearer than (d0 - 1) cells plus the
       // way from this point to the nearest face of its own cell.  Where that already exceeds rmax the lane has no neighbour
@@ -243,6 +250,32 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
     const int z0 = max(bz0, 0), z1 = min(bz1, g.dz - 1);
     const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
     const int nrows = (x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
+    // What this pass's box proves for a lane -- every target point nearer than `guard` has been staged -- is known before the
+    // box is read (a face on the grid's own border proves everything beyond it).
+    float guard = 0.0f;
+    if (active) {
+      const float gx0 = (bx0 > 0) ? p.x - (g.minx + (float)bx0 * g.cell) : INFINITY;
+      const float gx1 = (bx1 < g.dx - 1) ? (g.minx + (float)(bx1 + 1) * g.cell) - p.x : INFINITY;
+      const float gy0 = (by0 > 0) ? p.y - (g.miny + (float)by0 * g.cell) : INFINITY;
+      const float gy1 = (by1 < g.dy - 1) ? (g.miny + (float)(by1 + 1) * g.cell) - p.y : INFINITY;
+      const float gz0 = (bz0 > 0) ? p.z - (g.minz + (float)bz0 * g.cell) : INFINITY;
+      const float gz1 = (bz1 < g.dz - 1) ? (g.minz + (float)(bz1 + 1) * g.cell) - p.z : INFINITY;
+      guard = fminf(fminf(fminf(gx0, gx1), fminf(gy0, gy1)), fminf(gz0, gz1)) * 0.9999f - 1e-5f;
+    }
+#if MM3D_NN_CORNERS
+    // Which candidates can matter is known too: none that is farther from a lane than the best that lane has (or, before it
+    // has one, than the distance transform's bound).  A candidate farther than the LARGEST such bound of the active lanes from
+    // the bounding box of their positions improves nobody's result and is dropped while its tile is staged: the corners of a
+    // later pass's box, whose radius is that very bound rounded up to cells.  (The bound must not be what this pass PROVES,
+    // `guard`: that drops more, a fifth of a headline ICP launch's candidates, but the next pass skips this pass's box on the
+    // ground that its lanes have seen ALL of it -- measured: wrong scores.)
+    const float far = active ? fminf(best < INFINITY ? sqrtf(best) : INFINITY, reach_cap) : 0.0f;
+    const float keep_r = wave_max_f(far) * 1.0001f + 1e-5f, keep_r2 = keep_r * keep_r;
+    const float plx = wave_min_f(active ? p.x : INFINITY), phx = wave_max_f(active ? p.x : -INFINITY);
+    const float ply = wave_min_f(active ? p.y : INFINITY), phy = wave_max_f(active ? p.y : -INFINITY);
+    const float plz = wave_min_f(active ? p.z : INFINITY), phz = wave_max_f(active ? p.z : -INFINITY);
+    const float edge = 1e-3f * g.cell + 1e-6f * (fabsf(g.miny) + fabsf(g.minz) + (float)(g.dy + g.dz) * g.cell);
+#endif
     // A later pass only looks at what the earlier ones have not shown its lanes: every lane that is still active scanned ALL
     // the candidates of the previous pass's box (every lane scans every staged candidate), and by induction of every box
     // before it.  So the part of the new box that lies inside the previous one is skipped: a row of the new box whose (y, z)
@@ -277,6 +310,23 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
             int xa = x0, xb = x1;
             if (second) xa = max(x0, ox1 + 1);
             else if (n_inner && y >= iy0 && y <= iy1 && z >= iz0 && z <= iz1) xb = min(x1, ox0 - 1);
+#if MM3D_NN_CORNERS
+            {
+              // the same bound at cell granularity: of this row only the cells that reach into the ball around the lanes'
+              // position box are read at all (`edge`: what the row's points may lie outside their cells' nominal faces)
+              const float ylo = g.miny + (float)y * g.cell, zlo = g.minz + (float)z * g.cell;
+              const float ey = fmaxf(fmaxf(fmaxf(ylo - phy, ply - (ylo + g.cell)), 0.0f) - edge, 0.0f);
+              const float ez = fmaxf(fmaxf(fmaxf(zlo - phz, plz - (zlo + g.cell)), 0.0f) - edge, 0.0f);
+              const float rem = keep_r2 - ey * ey - ez * ez;
+              if (rem < 0.0f) {
+                xb = xa - 1;
+              } else {
+                const float w = sqrtf(rem) * 1.0001f + edge;
+                xa = max(xa, cell_floor(plx - w, g.minx, g.inv));     // (cell_floor is monotone: exact in x)
+                xb = min(xb, cell_floor(phx + w, g.minx, g.inv));
+              }
+            }
+#endif
             if (xa <= xb) {
               const int row = (z * g.dy + y) * g.dx;
               hb[u] = g.cell_start[row + xa];
@@ -336,6 +386,27 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
       while (cnt > 0) {
         MM3D_TICK(t_stage);
         if (!kPrefetch) fetch_tile(t0, cnt);
+#if MM3D_NN_CORNERS
+        {
+          int kept = 0;                                  // wave-uniform
+#pragma unroll
+          for (int u = 0; u < kPer; ++u) {
+            const int s = lane + u * kWave;
+            const float ex = fmaxf(fmaxf(plx - stage[u].x, stage[u].x - phx), 0.0f), ey = fmaxf(fmaxf(ply - stage[u].y, stage[u].y - phy), 0.0f);
+            const float ez = fmaxf(fmaxf(plz - stage[u].z, stage[u].z - phz), 0.0f);
+            const bool keep = s < cnt && ex * ex + ey * ey + ez * ez <= keep_r2;
+            const unsigned long long m = ballot(keep);
+            const int d = kept + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (keep) {
+              s_cx[wave][d] = stage[u].x; s_cy[wave][d] = stage[u].y; s_cz[wave][d] = stage[u].z;
+              s_cw[wave][d] = __float_as_uint(stage[u].w);
+            }
+            kept += __popcll(m);
+          }
+          MM3D_STAT(38, cnt - kept);
+          cnt = kept;                                    // (the tile's next slot range was fixed above: t0n, cntn)
+        }
+#else
 #pragma unroll
         for (int u = 0; u < kPer; ++u) {
           const int s = lane + u * kWave;
@@ -344,6 +415,7 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
             s_cw[wave][s] = __float_as_uint(stage[u].w);
           }
         }
+#endif
         // pad to a multiple of four with points at infinity (distance +inf never wins)
         if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) {
           s_cx[wave][cnt + lane] = INFINITY; s_cy[wave][cnt + lane] = INFINITY; s_cz[wave][cnt + lane] = INFINITY;
@@ -415,18 +487,10 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
     // what the scanned box proves: every target point closer than `guard` to this lane has been seen
     best = MODE == 1 ? bestd : (((unsigned)bkey == 0xffffffffu) ? INFINITY : __uint_as_float((unsigned)(bkey >> 32)));
     if (active) {
-      // (a face of the box that lies on the grid's own border proves everything beyond it: there is nothing there)
-      const float gx0 = (bx0 > 0) ? p.x - (g.minx + (float)bx0 * g.cell) : INFINITY;
-      const float gx1 = (bx1 < g.dx - 1) ? (g.minx + (float)(bx1 + 1) * g.cell) - p.x : INFINITY;
-      const float gy0 = (by0 > 0) ? p.y - (g.miny + (float)by0 * g.cell) : INFINITY;
-      const float gy1 = (by1 < g.dy - 1) ? (g.miny + (float)(by1 + 1) * g.cell) - p.y : INFINITY;
-      const float gz0 = (bz0 > 0) ? p.z - (g.minz + (float)bz0 * g.cell) : INFINITY;
-      const float gz1 = (bz1 < g.dz - 1) ? (g.minz + (float)(bz1 + 1) * g.cell) - p.z : INFINITY;
-      const float guard = fminf(fminf(fminf(gx0, gx1), fminf(gy0, gy1)), fminf(gz0, gz1)) * 0.9999f - 1e-5f;
       if (guard >= rmax || best <= guard * guard) {
         active = false;
       } else {
-        const float reach = best < INFINITY ? fminf(sqrtf(best), rmax) : rmax;
+        const float reach = best < INFINITY ? fminf(sqrtf(best), reach_cap) : reach_cap;
         const int want = (int)ceilf(reach * g.inv * 1.001f + 0.01f);   // guard >= want*cell*0.9999 - 1e-5 >= reach
         // (at least one ring more than this lane had: best > guard^2 and guard >= need cells already make `want` that large;
         // with the common radius of rounds 1 - 4 it was E + 1, the wave's largest plus one)

@@ -29,4 +29,5 @@ for (a, b) in PAIRS:
     print("  hist log2(ticks):", {b: v[8 + b] for b in range(24) if v[8 + b]})
     print("  phase ticks: headers", v[32], "staging", v[33], "scan", v[34], " total wave ticks", v[7])
     print("  per ring size E: passes", v[40:48], " ticks", v[48:56])
+    print("  staged candidates dropped by the corner filter (no active lane can still use them):", v[38], "of", v[3])
     print("  lanes by the ring they ask for before the first pass (1..7, >=8):", v[56:64])
