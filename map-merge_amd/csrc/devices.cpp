@@ -43,7 +43,9 @@ const Rccl &rccl()
     void *h = nullptr;
     if (!dlsym(RTLD_DEFAULT, "ncclCommInitAll")) {
       for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // RTLD_LOCAL: a process that loads a second RCCL later (a Python test that imports torch, which ships its own) must not
+        // have that one's references bound to this one's symbols -- "double free or corruption" at exit, measured
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (h) break;
       }
       if (!h) { r.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "?"); return r; }

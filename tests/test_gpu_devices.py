@@ -116,3 +116,20 @@ def test_bad_lists_and_failures(mm, clouds):
         assert len(d) > 1000
     finally:
         c.close()
+
+
+def test_a_process_that_loads_a_second_rccl_afterwards_exits_cleanly():
+    """libmm3d.so binds RCCL on first use (dlopen, RTLD_LOCAL).  torch ships its own librccl.so: a process that imports torch
+    AFTER a device-list context existed used to abort at exit ("double free or corruption") while RCCL was opened RTLD_GLOBAL --
+    and `pytest -m gpu` with it, after all tests had passed.  (The other order binds torch's copy: one RCCL in the process.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for order in ("after", "before"):
+        code = ("import sys; sys.path.insert(0, %r)\n"
+                "%s"
+                "import __graft_entry__ as ge\nmm = ge.load()\nc = mm.Context(devices=[0]); assert c.uses_rccl; c.close()\n"
+                "%s"
+                "print('done', flush=True)\n") % (root, "import torch\n" if order == "before" else "",
+                                                  "import torch; torch.cuda.device_count()\n" if order == "after" else "")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "done" in r.stdout, (order, r.returncode, r.stdout[-500:], r.stderr[-1500:])
