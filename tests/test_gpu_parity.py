@@ -468,6 +468,31 @@ def test_transform_score(ctx, po, scene, synth):
     assert ctx.transformScore(ca, cb, z, 1.0) == pytest.approx(po.transform_score(a["filt"], b["filt"], z, 1.0), rel=1e-6)
 
 
+def test_nearest_neighbour_search_over_ranges(ctx, po, scene, synth):
+    """The ICP / score search's cells are a quarter of its range, so the range sets how many points a cell holds and how many
+    passes a lane needs (round 5: per-lane boxes, skipped shells, dropped corners, lanes that provably have nothing in range):
+    ranges from a twentieth of the point spacing's scale to the whole scene, poses from aligned to far off."""
+    a, b = scene
+    gt = synth.relative_gt(a["T"], b["T"]).astype(np.float32)
+    ca, cb = ctx.cloud(a["filt"]), ctx.cloud(b["filt"])
+    poses = (gt, (gt @ _small_rot(0.05, -0.03, 0.2, [0.6, -0.4, 0.2])).astype(np.float32),
+             (gt @ _small_rot(0.0, 0.0, 0.0, [3.0, 2.0, 0.5])).astype(np.float32))
+    for max_distance in (0.0025, 0.04, 0.25, 4.0, 100.0):          # compared with the SQUARED distance: ranges 0.05 m .. 10 m
+        for T in poses:
+            ref = po.transform_score(a["filt"], b["filt"], T, max_distance)
+            got = ctx.transformScore(ca, cb, T, max_distance)
+            if ref == np.finfo(np.float64).max:
+                assert got == ref, (max_distance, got)
+            else:
+                assert got == pytest.approx(ref, rel=1e-6), (max_distance, got, ref)
+    for max_corr in (0.1, 2.0):
+        guess = (gt @ _small_rot(0.02, -0.01, 0.04, [0.2, -0.1, 0.05])).astype(np.float32)
+        T_ref, it_ref = po.icp(a["filt"], b["filt"], guess, max_corr, 0.5, 30, 1e-6)
+        T = ctx.estimateTransformICP(ca, cb, guess, max_corr, 0.5, 30, 1e-6)
+        assert np.linalg.norm(T - T_ref) <= 1e-3, (max_corr, np.linalg.norm(T - T_ref))
+        assert ctx.last_icp_iterations == it_ref, (max_corr, ctx.last_icp_iterations, it_ref)
+
+
 def test_icp(ctx, po, scene, synth):
     a, b = scene
     gt = synth.relative_gt(a["T"], b["T"])
