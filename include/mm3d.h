@@ -300,9 +300,13 @@ int mm3d_global_transforms(const mm3d_pair_result *pairs, size_t n_pairs, double
  * its ranks (bench.py: torch.distributed over RCCL): one all-gather of feature bundles, one of pair records.
  *   1. mm3d_shard_begin: the per-cloud loop for the maps this rank owns (mm3d_shard_map_owner), on the
  *      context's streams (mm3d_set_streams), including the target-side search structures of those maps;
- *   2. mm3d_shard_bundle_sizes / mm3d_shard_pack: an owned map's bundle -- filtered points (16-byte records),
- *      keypoints (16-byte records), descriptors (rows of float) -- contiguously at `dst` (device or host);
- *      after the exchange mm3d_shard_unpack hands every other map's bundle over;
+ *   2. mm3d_shard_bundle_sizes / mm3d_shard_pack: an owned map's bundle -- a 256-byte header, filtered points
+ *      (16-byte records), keypoints (16-byte records), descriptors (rows of float), and both clouds once more in
+ *      the library's Hilbert query order with their work items (the source role of ICP / score / SAC-IA scoring
+ *      reads them in that order: the owner has it, a receiver would have to sort) -- contiguously at `dst`
+ *      (device or host; mm3d_shard_bundle_bytes(points, keypoints, descriptor) bytes: every part at the size the
+ *      two counts allow, opaque to the caller and only valid between ranks of one library build);
+ *      after the exchange mm3d_shard_unpack hands every other map's bundle over (copies and one wait, no kernel);
  *   3. mm3d_shard_pairs: every live pair in the reference's order with the pairs whose TARGET this rank owns
  *      estimated on the context's streams (mine[q] = 1), the others zero; the rand() stream of the
  *      reference's single sequential loop is replayed on every rank, so the union over the ranks equals the

@@ -1166,10 +1166,49 @@ int mm3d_shard_bundle_sizes(const mm3d_shard *sh, uint64_t *n_points, uint64_t *
   return MM3D_OK;
 }
 
+// A map's bundle (round 5: the source-side structures travel with it).  What a rank does with another rank's map is the SOURCE
+// role: ICP / score / SAC-IA scoring read the cloud in its Hilbert query order through its work items, the rand() replay reads
+// the keypoints on the host.  Until round 5 a rank rebuilt those orders from the points it had received (two Hilbert sorts and a
+// wait per map: 2.3 ms per rank and step at N = 8, with fourteen foreign maps); now the owner -- who has them -- sends them:
+//   header (256 B) | points 16 B x P | keypoints 16 B x K | descriptors 4 B x dim x K |
+//   points in Hilbert order 16 B x P | their work items 8 B x (P / 64 + 16 386) | the same two for the keypoints
+// Every part starts 16-byte aligned and is as large as P and K allow (the sizes are all a receiver knows before the exchange);
+// the header says how much of the Hilbert parts is meant, and carries the bounding boxes.  The order a pair's reductions run in
+// is then the owner's, i.e. the one-process run's, by construction.
+namespace {
+struct BundleHeader {
+  uint64_t magic, n_points, n_keypoints;
+  uint64_t p_finite, p_items, k_finite, k_items;
+  uint32_t p_have, k_have;                   // bounding box + Hilbert copy + items are in the bundle
+  float p_bmin[3], p_bmax[3], k_bmin[3], k_bmax[3];
+  unsigned char pad[256 - 7 * 8 - 2 * 4 - 12 * 4];
+};
+static_assert(sizeof(BundleHeader) == 256, "bundle header");
+constexpr uint64_t kBundleMagic = 0x6d6d33642d623032ull;          // "mm3d-b02"
+struct BundleLayout {
+  size_t pts, kp, desc, p_hil, p_items, k_hil, k_items, total, p_item_cap, k_item_cap;
+};
+size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+BundleLayout bundle_layout(uint64_t P, uint64_t K, int dim)
+{
+  BundleLayout L;
+  L.p_item_cap = (size_t)P / 64 + 16384 + 2;                        // cloud_hilbert's bound (grid.hip)
+  L.k_item_cap = (size_t)K / 64 + 16384 + 2;
+  L.pts = sizeof(BundleHeader);
+  L.kp = L.pts + (size_t)P * 16;
+  L.desc = L.kp + (size_t)K * 16;
+  L.p_hil = up16(L.desc + (size_t)K * (size_t)(dim > 0 ? dim : 0) * 4);
+  L.p_items = L.p_hil + (size_t)P * 16;
+  L.k_hil = up16(L.p_items + L.p_item_cap * sizeof(int2));
+  L.k_items = L.k_hil + (size_t)K * 16;
+  L.total = up16(L.k_items + L.k_item_cap * sizeof(int2));
+  return L;
+}
+}  // namespace
+
 size_t mm3d_shard_bundle_bytes(uint64_t n_points, uint64_t n_keypoints, int descriptor_type)
 {
-  const int dim = mm3d_descriptor_dim(descriptor_type);
-  return (size_t)n_points * 16 + (size_t)n_keypoints * 16 + (size_t)n_keypoints * (size_t)(dim > 0 ? dim : 0) * 4;
+  return bundle_layout(n_points, n_keypoints, mm3d_descriptor_dim(descriptor_type)).total;
 }
 
 int mm3d_shard_pack(mm3d_shard *sh, size_t map, void *dst)
@@ -1179,13 +1218,84 @@ int mm3d_shard_pack(mm3d_shard *sh, size_t map, void *dst)
   return guarded(ctx, [&] {
     const mm3d_map *m = sh->maps[map];
     char *d = static_cast<char *>(dst);
-    if (m->points->n) MM3D_HIP(hipMemcpyAsync(d, m->points->pts.get(), m->points->n * 16, hipMemcpyDefault, ctx->stream));
-    d += m->points->n * 16;
-    if (m->keypoints->n) MM3D_HIP(hipMemcpyAsync(d, m->keypoints->pts.get(), m->keypoints->n * 16, hipMemcpyDefault, ctx->stream));
-    d += m->keypoints->n * 16;
-    if (m->desc->n) MM3D_HIP(hipMemcpyAsync(d, m->desc->data.get(), m->desc->n * (size_t)m->desc->dim * 4, hipMemcpyDefault, ctx->stream));
+    const BundleLayout L = bundle_layout(m->points->n, m->keypoints->n, m->desc->dim);
+    // the query orders exist on the owner as soon as it has played the source role once; a map that has not is ordered now
+    if (m->points->n) cloud_hilbert(ctx, m->points);
+    if (m->keypoints->n) cloud_hilbert(ctx, m->keypoints);
+    // (ordinary memory: the pinned arena may wrap under the copies below, and 256 bytes need no pinning)
+    BundleHeader header;
+    BundleHeader *h = &header;
+    std::memset(h, 0, sizeof(*h));
+    h->magic = kBundleMagic; h->n_points = m->points->n; h->n_keypoints = m->keypoints->n;
+    auto side = [&](const mm3d_cloud *cl, uint64_t &fin, uint64_t &items, uint32_t &have, float *bmin, float *bmax, size_t off_hil,
+                    size_t off_items, size_t item_cap) {
+      have = (cl->n && cl->have_bbox && cl->hil_pts.get() && (size_t)cl->n_wave_items <= item_cap) ? 1u : 0u;
+      if (!have) return;
+      fin = cl->n_finite; items = (uint64_t)cl->n_wave_items;
+      for (int a = 0; a < 3; ++a) { bmin[a] = cl->bmin[a]; bmax[a] = cl->bmax[a]; }
+      if (cl->n_finite) MM3D_HIP(hipMemcpyAsync(d + off_hil, cl->hil_pts.get(), cl->n_finite * 16, hipMemcpyDefault, ctx->stream));
+      if (cl->n_wave_items)
+        MM3D_HIP(hipMemcpyAsync(d + off_items, cl->wave_items.get(), (size_t)cl->n_wave_items * sizeof(int2), hipMemcpyDefault, ctx->stream));
+    };
+    side(m->points, h->p_finite, h->p_items, h->p_have, h->p_bmin, h->p_bmax, L.p_hil, L.p_items, L.p_item_cap);
+    side(m->keypoints, h->k_finite, h->k_items, h->k_have, h->k_bmin, h->k_bmax, L.k_hil, L.k_items, L.k_item_cap);
+    MM3D_HIP(hipMemcpyAsync(d, h, sizeof(*h), hipMemcpyDefault, ctx->stream));
+    if (m->points->n) MM3D_HIP(hipMemcpyAsync(d + L.pts, m->points->pts.get(), m->points->n * 16, hipMemcpyDefault, ctx->stream));
+    if (m->keypoints->n) MM3D_HIP(hipMemcpyAsync(d + L.kp, m->keypoints->pts.get(), m->keypoints->n * 16, hipMemcpyDefault, ctx->stream));
+    if (m->desc->n) MM3D_HIP(hipMemcpyAsync(d + L.desc, m->desc->data.get(), m->desc->n * (size_t)m->desc->dim * 4, hipMemcpyDefault, ctx->stream));
     ctx->sync();
   });
+}
+
+// one received bundle -> a map in the source role, on context c (copies and ONE wait; no kernel unless the owner sent no orders)
+static mm3d_map *map_from_bundle(mm3d_ctx *c, const void *src, uint64_t n_points, uint64_t n_keypoints, int descriptor_type)
+{
+  const char *s = static_cast<const char *>(src);
+  const int dim = mm3d_descriptor_dim(descriptor_type);
+  const BundleLayout L = bundle_layout(n_points, n_keypoints, dim);
+  // (into ordinary memory: the pinned arena may wrap under cloud_host() below, and 256 bytes need no pinning)
+  BundleHeader header;
+  BundleHeader *h = &header;
+  std::memset(h, 0, sizeof(*h));
+  if (s) MM3D_HIP(hipMemcpyAsync(h, s, sizeof(*h), hipMemcpyDefault, c->stream));
+  std::unique_ptr<mm3d_cloud> pts(cloud_from_memory(c, n_points ? s + L.pts : nullptr, n_points, 16, 12));
+  std::unique_ptr<mm3d_cloud> kp(cloud_from_memory(c, n_keypoints ? s + L.kp : nullptr, n_keypoints, 16, 12));
+  std::unique_ptr<mm3d_desc> desc(desc_from_memory(c, reinterpret_cast<const float *>(s ? s + L.desc : nullptr), n_keypoints, descriptor_type));
+  // the Hilbert parts at their full size (how much of them is meant is in the header, which arrives with the same wait)
+  struct Side { DevBuf<float4> hil; DevBuf<int2> items; };
+  auto grab = [&](uint64_t n, size_t off_hil, size_t off_items, size_t item_cap) {
+    Side sd;
+    if (!n || !s) return sd;
+    sd.hil = DevBuf<float4>(c, n);
+    sd.items = DevBuf<int2>(c, item_cap);
+    MM3D_HIP(hipMemcpyAsync(sd.hil.get(), s + off_hil, (size_t)n * 16, hipMemcpyDefault, c->stream));
+    MM3D_HIP(hipMemcpyAsync(sd.items.get(), s + off_items, item_cap * sizeof(int2), hipMemcpyDefault, c->stream));
+    return sd;
+  };
+  Side ps = grab(n_points, L.p_hil, L.p_items, L.p_item_cap), ks = grab(n_keypoints, L.k_hil, L.k_items, L.k_item_cap);
+  (void)cloud_host(c, kp.get());                      // (the host copy of the keypoints: this is the wait)
+  c->sync();
+  if (s && (h->magic != kBundleMagic || h->n_points != n_points || h->n_keypoints != n_keypoints))
+    throw Error(MM3D_EINVAL, "mm3d_shard_unpack: not a bundle of this library version, or the sizes do not match it");
+  auto adopt = [&](mm3d_cloud *cl, Side &sd, uint32_t have, uint64_t fin, uint64_t items, const float *bmin, const float *bmax, size_t item_cap) {
+    if (!have || !cl->n || fin > cl->n || items > item_cap) return;
+    std::lock_guard<std::recursive_mutex> lk(cl->cache_mu);
+    cl->have_bbox = true;
+    cl->n_finite = (size_t)fin;
+    for (int a = 0; a < 3; ++a) { cl->bmin[a] = bmin[a]; cl->bmax[a] = bmax[a]; }
+    cl->hil_pts = std::move(sd.hil);
+    cl->wave_items = std::move(sd.items);
+    cl->n_wave_items = (int)items;
+  };
+  adopt(pts.get(), ps, h->p_have, h->p_finite, h->p_items, h->p_bmin, h->p_bmax, L.p_item_cap);
+  adopt(kp.get(), ks, h->k_have, h->k_finite, h->k_items, h->k_bmin, h->k_bmax, L.k_item_cap);
+  // (an owner that sent no orders -- an empty or all-NaN cloud -- leaves them to be built here, as before round 5)
+  if (pts->n) cloud_hilbert(c, pts.get());
+  if (kp->n) cloud_hilbert(c, kp.get());
+  c->sync();
+  auto *m = new mm3d_map();
+  m->points = pts.release(); m->keypoints = kp.release(); m->desc = desc.release();
+  return m;
 }
 
 int mm3d_shard_unpack(mm3d_shard *sh, size_t map, const void *src, uint64_t n_points, uint64_t n_keypoints)
@@ -1194,21 +1304,9 @@ int mm3d_shard_unpack(mm3d_shard *sh, size_t map, const void *src, uint64_t n_po
   if (sh->maps[map]) return MM3D_OK;               // an owned map is already here
   mm3d_ctx *ctx = sh->ctx;
   return guarded(ctx, [&] {
-    const char *s = static_cast<const char *>(src);
-    std::unique_ptr<mm3d_cloud> pts(cloud_from_memory(ctx, n_points ? s : nullptr, n_points, 16, 12));
-    s += n_points * 16;
-    std::unique_ptr<mm3d_cloud> kp(cloud_from_memory(ctx, n_keypoints ? s : nullptr, n_keypoints, 16, 12));
-    s += n_keypoints * 16;
-    std::unique_ptr<mm3d_desc> desc(desc_from_memory(ctx, reinterpret_cast<const float *>(s), n_keypoints, sh->params.descriptor_type));
     // source role only: the query orders of ICP / score and of SAC-IA's scoring, and the host copy of the
     // keypoints that the rand() replay reads; target-side structures are the owner's business
-    if (pts->n) cloud_hilbert(ctx, pts.get());
-    if (kp->n) cloud_hilbert(ctx, kp.get());
-    (void)cloud_host(ctx, kp.get());
-    ctx->sync();
-    auto *m = new mm3d_map();
-    m->points = pts.release(); m->keypoints = kp.release(); m->desc = desc.release();
-    sh->maps[map] = m;
+    sh->maps[map] = map_from_bundle(ctx, src, n_points, n_keypoints, sh->params.descriptor_type);
   });
 }
 
@@ -1228,20 +1326,9 @@ int mm3d_shard_unpack_many(mm3d_shard *sh, size_t count, const size_t *maps, con
         if (k >= count || failed.load()) break;
         const size_t i = maps[k];
         if (sh->maps[i]) continue;                    // an owned map is already here
-        const char *s = static_cast<const char *>(srcs[k]);
-        std::unique_ptr<mm3d_cloud> pts(cloud_from_memory(c, n_points[k] ? s : nullptr, n_points[k], 16, 12));
-        s += n_points[k] * 16;
-        std::unique_ptr<mm3d_cloud> kp(cloud_from_memory(c, n_keypoints[k] ? s : nullptr, n_keypoints[k], 16, 12));
-        s += n_keypoints[k] * 16;
-        std::unique_ptr<mm3d_desc> desc(desc_from_memory(c, reinterpret_cast<const float *>(s), n_keypoints[k], sh->params.descriptor_type));
-        c->private_objects = true;                    // nobody sees the map before this worker's wait below
-        if (pts->n) cloud_hilbert(c, pts.get());      // source role only, as in mm3d_shard_unpack
-        if (kp->n) cloud_hilbert(c, kp.get());
-        (void)cloud_host(c, kp.get());
+        c->private_objects = true;                    // nobody sees the map before this worker's waits
+        mm3d_map *m = map_from_bundle(c, srcs[k], n_points[k], n_keypoints[k], sh->params.descriptor_type);   // source role only, as in mm3d_shard_unpack
         c->private_objects = false;
-        c->sync();
-        auto *m = new mm3d_map();
-        m->points = pts.release(); m->keypoints = kp.release(); m->desc = desc.release();
         sh->maps[i] = m;                              // distinct slots
       }
     });
