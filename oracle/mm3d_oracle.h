@@ -89,6 +89,10 @@ void mo_normals(const mo_point *in, int n, double radius, mo_normal *out);
 int mo_keypoints_sift(const mo_point *in, int n, double min_scale,
                       int nr_octaves, int nr_scales_per_octave,
                       double min_contrast, mo_point **out, float **scales_out);
+/* test / evidence hook (o_sift.c): one octave's scale space laid open -- float DoG, the responses in double, the counts
+ * inside 3 sigma, the 25 nearest neighbours.  Everything malloc'ed (mo_free). */
+int mo_sift_octave_debug(const mo_point *in, int n, double min_scale, int octave, int nr_scales_per_octave,
+                         mo_point **cloud_out, int *n_out, float **dog_out, double **resp_out, int **cnt_out, int **knn_out);
 /* detectKeypoints(HARRIS): R/src/features.cpp:64-83 (o_harris.c).  Returns the count; keypoints (refined xyz,
  * rgba = 0) malloc'ed into *out; kept_idx (optional, malloc'ed) = the source indices; response_out
  * (optional, n floats) = the Harris response of every point. */

@@ -150,3 +150,88 @@ int mo_keypoints_sift(const mo_point *in, int n, double min_scale, int nr_octave
   if (scales_out) *scales_out = kv.scales; else free(kv.scales);
   return kv.n;
 }
+
+/* TEST / EVIDENCE HOOK (scripts/sift_price.py, tests/test_sift_bound.py): the scale space of ONE octave laid open.
+ * For octave `octave` of detectKeypoints(SIFT) on `in`: the octave's cloud (*cloud_out, *n_out, malloc'ed), and per point
+ *   dog[5]      the float DoG values of computeScaleSpace (the CPU path's bits),
+ *   resp_d[6]   the six responses evaluated in DOUBLE (weights exp() of the exact quotient, double sums): the "real value"
+ *               the error bound of the certified device path is stated against,
+ *   cnt[6]      the number of neighbours inside 3 sigma of every scale,
+ *   knn[25]     the 25 nearest neighbours in nearestKSearch's order (-1 padded).
+ * Returns 0, or -1 when the octave does not exist (fewer than 25 points). */
+int mo_sift_octave_debug(const mo_point *in, int n, double min_scale, int octave, int nr_scales_per_octave,
+                         mo_point **cloud_out, int *n_out, float **dog_out, double **resp_out, int **cnt_out, int **knn_out)
+{
+  mo_point *cloud = (mo_point *)malloc(sizeof(mo_point) * (size_t)(n > 0 ? n : 1));
+  memcpy(cloud, in, sizeof(mo_point) * (size_t)(n > 0 ? n : 0));
+  int cn = n;
+  float scale = (float)min_scale;
+  for (int oct = 0; oct <= octave; ++oct) {
+    const float s = 1.0f * scale;
+    mo_point *tmp = (mo_point *)malloc(sizeof(mo_point) * (size_t)(cn > 0 ? cn : 1));
+    int tn = mo_downsample(cloud, cn, (double)s, tmp);
+    free(cloud); cloud = tmp; cn = tn;
+    if (cn < 25) { free(cloud); return -1; }
+    if (oct < octave) scale *= 2;
+  }
+  const int ns = nr_scales_per_octave + 3, nd = ns - 1;
+  float scales[16];
+  for (int i = 0; i < ns; ++i) scales[i] = scale * powf(2.0f, (1.0f * (float)i - 1.0f) / (float)nr_scales_per_octave);
+  const float max_radius = 3.0f * scales[ns - 1];
+  const float r2 = (float)((double)max_radius * (double)max_radius);
+  mo_grid *g = mo_grid_build(cloud, cn, max_radius * 0.5f);
+  float *dog = (float *)malloc(sizeof(float) * (size_t)cn * (size_t)nd);
+  double *resp = (double *)malloc(sizeof(double) * (size_t)cn * (size_t)ns);
+  int *cnts = (int *)malloc(sizeof(int) * (size_t)cn * (size_t)ns);
+  int *knn = (int *)malloc(sizeof(int) * (size_t)cn * 25);
+#pragma omp parallel num_threads(mo_get_threads())
+  {
+  int cap = 4096;
+  int *idx = (int *)malloc(sizeof(int) * (size_t)cap);
+  float *d2 = (float *)malloc(sizeof(float) * (size_t)cap);
+#pragma omp for schedule(dynamic, 512)
+  for (int i = 0; i < cn; ++i) {
+    int cnt = mo_radius_search(g, cloud[i].x, cloud[i].y, cloud[i].z, r2, idx, d2, cap);
+    if (cnt > cap) {
+      cap = cnt * 2;
+      idx = (int *)realloc(idx, sizeof(int) * (size_t)cap);
+      d2 = (float *)realloc(d2, sizeof(float) * (size_t)cap);
+      cnt = mo_radius_search(g, cloud[i].x, cloud[i].y, cloud[i].z, r2, idx, d2, cap);
+    }
+    float filter_response = 0.0f, previous_filter_response;
+    for (int s = 0; s < ns; ++s) {
+      float sigma_sqr = powf(scales[s], 2.0f);
+      float numerator = 0.0f, denominator = 0.0f;
+      double nd_ = 0.0, dd_ = 0.0;
+      int m = 0;
+      for (int j = 0; j < cnt; ++j) {
+        float value = intensity(&cloud[idx[j]]);
+        float dist_sqr = d2[j];
+        if (dist_sqr <= 9 * sigma_sqr) {
+          float w = expf(-0.5f * dist_sqr / sigma_sqr);
+          numerator += value * w;
+          denominator += w;
+          double wd = exp(-0.5 * (double)dist_sqr / (double)sigma_sqr);
+          nd_ += (double)value * wd;
+          dd_ += wd;
+          ++m;
+        } else {
+          break;
+        }
+      }
+      previous_filter_response = filter_response;
+      filter_response = numerator / denominator;
+      if (s > 0) dog[(size_t)i * nd + (s - 1)] = filter_response - previous_filter_response;
+      resp[(size_t)i * ns + s] = nd_ / dd_;
+      cnts[(size_t)i * ns + s] = m;
+    }
+    int nn_idx[25]; float nn_d2[25];
+    int nr_nn = mo_knn_search(g, cloud[i].x, cloud[i].y, cloud[i].z, 25, INFINITY, nn_idx, nn_d2);
+    for (int j = 0; j < 25; ++j) knn[(size_t)i * 25 + j] = j < nr_nn ? nn_idx[j] : -1;
+  }
+  free(idx); free(d2);
+  }
+  mo_grid_free(g);
+  *cloud_out = cloud; *n_out = cn; *dog_out = dog; *resp_out = resp; *cnt_out = cnts; *knn_out = knn;
+  return 0;
+}

@@ -102,6 +102,28 @@ def keypoints_sift(pts, min_scale, nr_octaves=3, nr_scales=3, min_contrast=5.0):
     return kp, sc
 
 
+def sift_octave_debug(pts, min_scale, octave, nr_scales=3):
+    """One octave's scale space laid open (mo_sift_octave_debug): (cloud, dog[n,5] f32, resp[n,6] f64, cnt[n,6], knn[n,25]),
+    or None when the octave does not exist."""
+    pts = _pts(pts)
+    pc, pd, pr, pn, pk = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n = C.c_int(0)
+    rc = lib().mo_sift_octave_debug(_p(pts), len(pts), C.c_double(min_scale), int(octave), int(nr_scales), C.byref(pc), C.byref(n),
+                                    C.byref(pd), C.byref(pr), C.byref(pn), C.byref(pk))
+    if rc != 0:
+        return None
+    n = n.value
+    ns = nr_scales + 3
+    cloud = np.frombuffer((C.c_char * (16 * n)).from_address(pc.value), dtype=POINT).copy()
+    dog = np.frombuffer((C.c_char * (4 * n * (ns - 1))).from_address(pd.value), dtype=np.float32).reshape(n, ns - 1).copy()
+    resp = np.frombuffer((C.c_char * (8 * n * ns)).from_address(pr.value), dtype=np.float64).reshape(n, ns).copy()
+    cnt = np.frombuffer((C.c_char * (4 * n * ns)).from_address(pn.value), dtype=np.int32).reshape(n, ns).copy()
+    knn = np.frombuffer((C.c_char * (4 * n * 25)).from_address(pk.value), dtype=np.int32).reshape(n, 25).copy()
+    for p in (pc, pd, pr, pn, pk):
+        lib().mo_free(p)
+    return cloud, dog, resp, cnt, knn
+
+
 def keypoints_harris(pts, nrm, threshold, radius):
     """detectKeypoints(HARRIS): (keypoints, source indices, response of every point)."""
     pts = _pts(pts)
