@@ -127,6 +127,17 @@ int mm3d_debug_float_chain(mm3d_ctx *ctx, const float *incr, const unsigned *hit
 /* test hook: out[i] = the device's restatement of glibc's expf (fn 0), atanf (1), sinf (2), cosf (3) of x[i] or
  * atan2f(y[i], x[i]) (4) -- csrc/libm_exact.hpp, the functions the CPU path's PCL calls through libm */
 int mm3d_debug_libm(mm3d_ctx *ctx, int fn, const float *x, const float *y, int n, float *out);
+/* (fn 5: the raw v_exp_f32, 2^x, of the certified SIFT pass.)
+ * test hooks of the certified SIFT decision (csrc/sift_cert.hpp; the later octaves of detectKeypoints(SIFT),
+ * R/src/features.cpp:45-62): the unsorted scale space of octave `octave` (0-based) on `points` -- val[5 i + s] and
+ * bound[5 i + s] >= |the CPU path's float DoG - val| for point i of the octave's cloud -- *n_out = that cloud's size
+ * (nothing is written when it exceeds capacity; 0: no such octave); and process-wide counters since the last reset:
+ * out[0] octaves decided on the certified path, [1] their points, [2] points that took the exact sorted-list path,
+ * [3] points left open by the first pass, [4] octaves sent back to the sorted-list path, [5] bound violations (must be 0),
+ * [6] points still open after the second pass (must be 0), [7] work items the unsorted pass could not stage */
+int mm3d_debug_sift_cert_octave(mm3d_ctx *ctx, const mm3d_cloud *points, double min_scale, int octave, float *val, float *bound,
+                                size_t capacity, size_t *n_out);
+void mm3d_debug_sift_cert_stats(long long out[8], int reset);
 /* SAC-IA draws from libc rand() in the reference (process-global, glibc seed 1).  The context
  * carries its own replay of that generator; mm3d_srand re-seeds it (srand semantics). */
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed);

@@ -131,6 +131,14 @@ def _Tout(a):
     return np.asarray(a, dtype=np.float32).reshape(4, 4).T.copy()
 
 
+def sift_cert_stats(reset=False):
+    """Process-wide counters of the certified SIFT decision (mm3d_debug_sift_cert_stats): octaves, points, exact-path points,
+    open points, octaves sent back, bound violations, still-open points, unstaged items."""
+    out = (C.c_longlong * 8)()
+    lib().mm3d_debug_sift_cert_stats(out, 1 if reset else 0)
+    return list(out)
+
+
 class Context:
     """One registration engine on one GPU (mm3d_ctx) -- or, with `devices`, on a list of GPUs of this one process
     (mm3d_create_devices): estimateMapsTransforms then shards over them inside the library and gathers the pair
@@ -245,6 +253,19 @@ class Context:
                                              int(type), C.c_double(threshold), C.c_double(radius),
                                              C.c_double(resolution), C.byref(h)))
         return Cloud(self, h)
+
+    def siftCertOctave(self, points: "Cloud", min_scale: float, octave: int):
+        """Test hook (mm3d_debug_sift_cert_octave): the certified SIFT pass of one octave -- (val[n, 5], bound[n, 5]) with
+        bound >= |the CPU path's float DoG - val|, or None when the octave does not exist."""
+        n = C.c_size_t(0)
+        self._ck(lib().mm3d_debug_sift_cert_octave(self._h, points._h, C.c_double(min_scale), int(octave), None, None, C.c_size_t(0), C.byref(n)))
+        if n.value == 0:
+            return None
+        val = np.empty((n.value, 5), dtype=np.float32)
+        bound = np.empty((n.value, 5), dtype=np.float32)
+        self._ck(lib().mm3d_debug_sift_cert_octave(self._h, points._h, C.c_double(min_scale), int(octave), val.ctypes.data_as(C.c_void_p),
+                                                   bound.ctypes.data_as(C.c_void_p), C.c_size_t(n.value), C.byref(n)))
+        return val, bound
 
     def harrisResponse(self, points: "Cloud", normals: "Normals", radius: float) -> np.ndarray:
         """HarrisKeypoint3D::responseHarris of every point (what detectKeypoints(HARRIS) thresholds)."""

@@ -339,9 +339,16 @@ int mm3d_debug_float_chain(mm3d_ctx *ctx, const float *incr, const unsigned *hit
 }
 int mm3d_debug_libm(mm3d_ctx *ctx, int fn, const float *x, const float *y, int n, float *out)
 {
-  if (n < 0 || fn < 0 || fn > 4 || (n && (!x || !out || (fn == 4 && !y)))) return MM3D_EINVAL;
+  if (n < 0 || fn < 0 || fn > 5 || (n && (!x || !out || (fn == 4 && !y)))) return MM3D_EINVAL;
   return guarded(ctx, [&] { debug_libm(ctx, fn, x, y, n, out); });
 }
+int mm3d_debug_sift_cert_octave(mm3d_ctx *ctx, const mm3d_cloud *points, double min_scale, int octave, float *val, float *bound, size_t capacity,
+                                size_t *n_out)
+{
+  if (!points || !n_out || octave < 0 || (capacity && (!val || !bound))) return MM3D_EINVAL;
+  return guarded(ctx, [&] { *n_out = debug_sift_cert_octave(ctx, points, min_scale, octave, val, bound, capacity); });
+}
+void mm3d_debug_sift_cert_stats(long long out[8], int reset) { if (out) debug_sift_cert_stats(out, reset); }
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed) { if (ctx) ctx->rnd.seed(seed); }
 int mm3d_synchronize(mm3d_ctx *ctx) { return guarded(ctx, [&] { ctx->sync(); }); }
 

@@ -14,6 +14,7 @@ __global__ void k_debug_libm(int fn, const float *__restrict__ x, const float *_
     case 1: r = lm::atanf_glibc(x[i]); break;
     case 2: r = lm::sinf_glibc(x[i]); break;
     case 3: r = lm::cosf_glibc(x[i]); break;
+    case 5: r = __builtin_amdgcn_exp2f(x[i]); break;       // v_exp_f32 as the certified SIFT pass uses it (sift_cert.hpp)
     default: r = lm::atan2f_glibc(y[i], x[i]); break;
   }
   out[i] = r;

@@ -15,6 +15,7 @@
 // s" iff some neighbour q among its 25 nearest has DoG(q, s-1|s|s+1) < val: so it suffices to find
 // the NEAREST such violator (one min-reduction over (distance, index) keys) and count how many
 // points are closer than it (>= 25 <=> the violator is not among the 25 nearest).
+#include <atomic>
 #include <cfloat>
 #include <functional>
 #include <type_traits>
@@ -22,6 +23,7 @@
 
 #include "sorted_nb.hpp"
 #include "snb_lds.hpp"
+#include "sift_cert.hpp"
 
 namespace mm3d {
 
@@ -331,7 +333,7 @@ k_sift_dog_lds(const float4 *__restrict__ q_pts, const int2 *__restrict__ items,
         // A shorter list is left behind as well, with its length: its entries are the point's m nearest, and a
         // violator among them already decides the test (only a point that is still an extremum candidate after
         // its m < 25 nearest has to search for the others).  0 stays for a point whose list was not built here.
-        if (mine && m > 0) {
+        if (knn && mine && m > 0) {                   // (knn == nullptr: the certified path's exact launch wants the DoG only)
           const int self_q = __float_as_int(q.w);
           const int keep = m < kKnn ? m : kKnn;
           int *row = knn + (size_t)self_q * kKnn;
@@ -480,6 +482,7 @@ static SiftDogPending sift_dog_octave(Context *c, int oct, const mm3d_cloud *cur
   };
   return pend;
 }
+
 
 #ifdef MM3D_SN_STATS
 extern "C" void mm3d_debug_sn_stats_sift(unsigned long long *out, int reset)
@@ -826,6 +829,191 @@ __global__ void k_sift_emit(const float4 *__restrict__ pts, const int *__restric
   }
 }
 
+// ---- the certified octave (sift_cert.hpp) -----------------------------------------------------------------
+// process-wide statistics (mm3d_debug_sift_cert_stats): 0 octaves on the certified path, 1 their points, 2 points that took
+// the exact path, 3 points whose test was open after the first pass, 4 octaves sent back to the sorted-list path,
+// 5 bound violations, 6 points still open after the second pass, 7 items the fast kernel's tile could not hold
+static std::atomic<long long> g_cert_stats[8];
+
+void debug_sift_cert_stats(long long *out, int reset)
+{
+  for (int i = 0; i < 8; ++i) { out[i] = g_cert_stats[i].load(); if (reset) g_cert_stats[i].store(0); }
+}
+
+static SfScales cert_scales(const SiftScales &sc, float r2)
+{
+  SfScales fs;
+  const float r2p = nextafterf(r2, 0.0f);          // radiusSearch keeps d2 < r2: d2 <= pred(r2)
+  for (int i = 0; i < kScales; ++i) {
+    fs.T[i] = fminf(sc.thr9[i], r2p);
+    fs.c[i] = (float)(-0.5 * 1.4426950408889634074 / (double)sc.sigma_sqr[i]);
+  }
+  fs.TA = 0.5f * fs.T[0];
+  fs.TB = 0.25f * fs.T[0];
+  return fs;
+}
+
+template <class Cfg>
+struct SfLaunch {
+  DevBuf<int> ctl, ov_items;
+  unsigned blocks = 0;
+  SfLaunch(Context *c, int n_items)
+  {
+    const unsigned cap = (unsigned)snb_cu_count(c->device) * 2u;
+    blocks = (unsigned)std::max(1, std::min<int>(n_items, (int)cap));
+    ctl = DevBuf<int>(c, sizeof(SnbCtl) / sizeof(int));
+    ov_items = DevBuf<int>(c, (size_t)std::max(n_items, 1));
+    MM3D_HIP(hipMemsetAsync(ctl.get(), 0, sizeof(SnbCtl), c->stream));
+  }
+  SnbCtl *ctl_dev() const { return reinterpret_cast<SnbCtl *>(ctl.get()); }
+};
+
+static void sift_dog_fast_launch(Context *c, const mm3d_cloud *cur, const Grid &gr, int n_items, float max_radius, const SfScales &fs,
+                                 SfLaunch<SfCfgDefault> &fl, float *dogv, float *dogb, float *rlo2, float *rup2, unsigned char *need_exact)
+{
+  MM3D_LAUNCH(c, "sift_dog_fast", gr.n * 36.0, (k_sift_dog_fast<SfCfgDefault>), dim3(fl.blocks), dim3(64 * SfCfgDefault::kWaves), 0,
+              (const float4 *)cur->hil_pts.get(), (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float4 *)cur->pts.get(), max_radius, fs,
+              fl.ctl_dev(), fl.ov_items.get(), dogv, dogb, rlo2, rup2, need_exact);
+}
+
+// One octave's keypoint flags by certified decisions.  flags ([3 n + 1] ints, zeroed) receives them; returns false when the
+// octave has to be taken by the sorted-list path instead (flags may then hold partial results: the caller clears them).
+static bool sift_octave_certified(Context *c, const mm3d_cloud *cur, const Grid &gr, int n_items, float max_radius, float r2,
+                                  const SiftScales &sc, float min_contrast, int *flags, int *pos, int *h_keypoints /* pinned */)
+{
+  const int n = (int)cur->n;
+  const SfScales fs = cert_scales(sc, r2);
+  DevBuf<float> dogv(c, (size_t)n * kDog), dogb(c, (size_t)n * kDog), dog(c, (size_t)n * kDog);
+  DevBuf<float4> dogx(c, (size_t)n * 3);
+  DevBuf<unsigned char> cls(c, (size_t)n);
+  // zeroed: CertCounters | list lengths: marked, -, candidates, wide candidates, open, wide open, -, - | need_exact [n] | open_p [n]
+  const size_t z_head = sizeof(CertCounters) + 8 * sizeof(int);
+  DevBuf<unsigned char> zeroed(c, z_head + 2 * (size_t)n);
+  MM3D_HIP(hipMemsetAsync(zeroed.get(), 0, z_head + 2 * (size_t)n, c->stream));
+  CertCounters *ctr = reinterpret_cast<CertCounters *>(zeroed.get());
+  int *n_marked_dev = reinterpret_cast<int *>(zeroed.get() + sizeof(CertCounters));
+  unsigned char *need_exact = zeroed.get() + z_head, *open_p = need_exact + n;
+  // 1. the unsorted pass
+  SfLaunch<SfCfgDefault> fl(c, n_items);
+  DevBuf<float> rlo2(c, (size_t)n);
+  DevBuf<float> rup2(c, (size_t)n);
+  sift_dog_fast_launch(c, cur, gr, n_items, max_radius, fs, fl, dogv.get(), dogb.get(), rlo2.get(), rup2.get(), need_exact);
+  // 2. intervals and contrast classes
+  MM3D_LAUNCH(c, "sift_pack", n * 100.0, k_sift_pack_iv, dim3(div_up(n, 256)), dim3(256), 0, (const float *)dogv.get(), (const float *)dogb.get(), n,
+              min_contrast, dogx.get(), cls.get());
+  // 2b. most candidates leave here: a certain violator on both sides inside the ball that holds at most 25 points
+  static const bool use_reject = [] { const char *e = getenv("MM3D_SIFT_NO_REJECT"); return !(e && atoi(e)); }();   // A/B knob
+  DevBuf<int> rctl(c, sizeof(SnbCtl) / sizeof(int));
+  if (use_reject) {
+    MM3D_HIP(hipMemsetAsync(rctl.get(), 0, sizeof(SnbCtl), c->stream));
+    const unsigned rblocks = (unsigned)std::max(1, std::min<int>(n_items, snb_cu_count(c->device) * 2));
+    MM3D_LAUNCH(c, "sift_reject", 0.0, k_sift_reject, dim3(rblocks), dim3(64 * SrCfg::kWaves), 0, (const float4 *)cur->hil_pts.get(),
+                (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float *)rlo2.get(), (const float *)dogv.get(), (const float *)dogb.get(),
+                (const float4 *)dogx.get(), n, cls.get(), reinterpret_cast<SnbCtl *>(rctl.get()), ctr);
+  }
+  // 3. what is left: one wave per point where the unsorted pass knows a ball that holds the 25 nearest, ring growth for the
+  // few it does not (fewer than 25 points within 3 sigma_max)
+  DevBuf<int> cids(c, (size_t)n), oids2(c, (size_t)n);
+  DevBuf<float4> wq(c, (size_t)n), owq(c, (size_t)n);
+  DevBuf<int2> witems(c, (size_t)n), owitems(c, (size_t)n);
+  int *n_cids = n_marked_dev + 2, *n_wide = n_marked_dev + 3, *n_oids = n_marked_dev + 4, *n_owide = n_marked_dev + 5;
+  const unsigned one_blocks = (unsigned)snb_cu_count(c->device) * 4u;
+  MM3D_LAUNCH(c, "sift_collect", n * 5.0, k_sift_collect_split, dim3(div_up(n, 256)), dim3(256), 0, (const unsigned char *)cls.get(), 7u,
+              (const float *)rup2.get(), (const float4 *)cur->pts.get(), n, cids.get(), n_cids, wq.get(), witems.get(), n_wide);
+  MM3D_LAUNCH(c, "sift_extrema_one", 0.0, k_sift_extrema_one<false>, dim3(one_blocks), dim3(256), 0, (const int *)cids.get(), (const int *)n_cids,
+              (const float4 *)cur->pts.get(), gr.view(), (const float *)rup2.get(), (const float4 *)dogx.get(), n, (const float *)dogv.get(),
+              (const float *)dogb.get(), (const unsigned char *)cls.get(), flags, need_exact, open_p, ctr);
+  MM3D_LAUNCH(c, "sift_extrema_iv", 0.0, k_sift_extrema_iv<false>, dim3(256), dim3(256), 0,
+              (const float4 *)wq.get(), (const int2 *)witems.get(), (const int *)n_wide, gr.view(), (const float4 *)dogx.get(), n,
+              (const float *)dogv.get(), (const float *)dogb.get(), (const unsigned char *)cls.get(), flags, need_exact, open_p, ctr);
+  // 4. the marked points: exact DoG floats from the sorted lists (single-query items, the number known to the device only)
+  DevBuf<float4> mq(c, (size_t)n);
+  DevBuf<int2> mitems(c, (size_t)n);
+  DevBuf<int> mids(c, (size_t)n), mident(c, (size_t)n);
+  MM3D_LAUNCH(c, "sift_collect", n * 1.0, k_sift_collect, dim3(div_up(n, 256)), dim3(256), 0, (const unsigned char *)need_exact,
+              (const float4 *)cur->pts.get(), n, mq.get(), mitems.get(), mids.get(), mident.get(), n_marked_dev);
+  const size_t extra_lds = sizeof(float) * 64 * kScales + 256;
+  SnbLaunch<SiftCfgLarge> sl(c, n, extra_lds);
+  const unsigned exact_blocks = std::min(sl.blocks, 256u);
+  MM3D_LAUNCH(c, "sift_dog_exact", 0.0, (k_sift_dog_lds<SiftCfgLarge, false>), dim3(exact_blocks), dim3(64 * SiftCfgLarge::kWaves), 0,
+              (const float4 *)mq.get(), (const int2 *)mitems.get(), 0, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, sl.ctl_dev(),
+              sl.ov_items.get(), dog.get(), (int *)nullptr, (unsigned char *)nullptr, (const int *)mident.get(), (const int *)n_marked_dev, 0.0f,
+              (float4 *)nullptr);
+  MM3D_LAUNCH(c, "sift_pack", 0.0, k_sift_pack_marked, dim3(std::min(div_up(n, 256), 64u)), dim3(256), 0, (const int *)mids.get(), (const int *)n_marked_dev,
+              (const float *)dog.get(), dogv.get(), dogb.get(), n, min_contrast, dogx.get(), cls.get(), ctr);
+  // 5. the open points again, on the collapsed intervals
+  MM3D_LAUNCH(c, "sift_collect", n * 1.0, k_sift_collect_split, dim3(div_up(n, 256)), dim3(256), 0, (const unsigned char *)open_p, 1u,
+              (const float *)rup2.get(), (const float4 *)cur->pts.get(), n, oids2.get(), n_oids, owq.get(), owitems.get(), n_owide);
+  MM3D_LAUNCH(c, "sift_extrema_fin", 0.0, k_sift_extrema_one<true>, dim3(64), dim3(256), 0, (const int *)oids2.get(), (const int *)n_oids,
+              (const float4 *)cur->pts.get(), gr.view(), (const float *)rup2.get(), (const float4 *)dogx.get(), n, (const float *)dogv.get(),
+              (const float *)dogb.get(), (const unsigned char *)cls.get(), flags, need_exact, open_p, ctr);
+  MM3D_LAUNCH(c, "sift_extrema_fin", 0.0, k_sift_extrema_iv<true>, dim3(64), dim3(256), 0,
+              (const float4 *)owq.get(), (const int2 *)owitems.get(), (const int *)n_owide, gr.view(), (const float4 *)dogx.get(), n,
+              (const float *)dogv.get(), (const float *)dogb.get(), (const unsigned char *)cls.get(), flags, need_exact, open_p, ctr);
+  int *h = (int *)c->pin(64);      // [0..7] CertCounters, [8] marked, [9] exact launch's overflow, [10] fast launch's overflow items
+  MM3D_HIP(hipMemcpyAsync(h, ctr, sizeof(CertCounters), hipMemcpyDeviceToHost, c->stream));
+  MM3D_HIP(hipMemcpyAsync(h + 8, n_marked_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MM3D_HIP(hipMemcpyAsync(h + 9, &sl.ctl_dev()->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MM3D_HIP(hipMemcpyAsync(h + 10, &fl.ctl_dev()->ov_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  // the keypoint positions and their number ride on the same wait (thrown away when the octave is sent back)
+  exclusive_scan_int(c, flags, pos, (size_t)n * 3 + 1);
+  MM3D_HIP(hipMemcpyAsync(h_keypoints, pos + (size_t)n * 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  const CertCounters *hc = reinterpret_cast<const CertCounters *>(h);
+  g_cert_stats[0] += 1; g_cert_stats[1] += n; g_cert_stats[2] += h[8]; g_cert_stats[3] += hc->n_open;
+  g_cert_stats[5] += hc->violations; g_cert_stats[6] += hc->still_open; g_cert_stats[7] += h[10];
+  static const bool snb_debug = getenv("MM3D_SNB_DEBUG") != nullptr;
+  if (snb_debug)
+    fprintf(stderr, "sift certified octave: n=%d items=%d rejected=%d to-search=%d marked=%d open=%d still_open=%d violations=%d exact overflow=%d fast overflow items=%d\n", n, n_items,
+            hc->pad[0], hc->pad[1], h[8], hc->n_open, hc->still_open, hc->violations, h[9], h[10]);
+  const bool ok = hc->still_open == 0 && hc->violations == 0 && h[9] == 0;
+  if (!ok) g_cert_stats[4] += 1;
+  return ok;
+}
+
+
+// test hook: val* and B of one octave (0-based) of detectKeypoints(SIFT) on `points`, downloaded; returns the octave
+// cloud's size (0: the octave does not exist).  Nothing is written when the size exceeds `capacity`.
+size_t debug_sift_cert_octave(Context *c, const mm3d_cloud *points, double min_scale, int octave, float *val_host, float *bound_host, size_t capacity)
+{
+  std::unique_ptr<mm3d_cloud> cur;
+  const mm3d_cloud *input = points;
+  float scale = (float)min_scale;
+  for (int oct = 0; oct <= octave; ++oct) {
+    std::unique_ptr<mm3d_cloud> next(downsample(c, input, (double)scale));
+    cur = std::move(next);
+    input = cur.get();
+    if (cur->n < 25) return 0;
+    if (oct < octave) scale *= 2;
+  }
+  const mm3d_cloud *oc = cur.get();
+  float scales[kScales];
+  for (int i = 0; i < kScales; ++i) scales[i] = scale * powf(2.0f, (1.0f * (float)i - 1.0f) / 3.0f);
+  SiftScales sc;
+  for (int i = 0; i < kScales; ++i) {
+    sc.sigma_sqr[i] = powf(scales[i], 2.0f);
+    sc.thr9[i] = 9 * sc.sigma_sqr[i];
+    sc.rcp[i] = (float)(1.0 / (double)sc.sigma_sqr[i]);
+  }
+  const float max_radius = 3.0f * scales[kScales - 1];
+  const float r2 = (float)((double)max_radius * (double)max_radius);
+  const size_t n = oc->n;
+  if (n > capacity) return n;
+  cloud_hilbert(c, oc, 2.5f * scale);
+  const Grid &gr = cloud_grid(c, oc, max_radius * 0.5f);
+  DevBuf<float> dogv(c, n * kDog), dogb(c, n * kDog);
+  DevBuf<unsigned char> mark(c, n);
+  MM3D_HIP(hipMemsetAsync(mark.get(), 0, n, c->stream));
+  SfLaunch<SfCfgDefault> fl(c, oc->n_wave_items);
+  const SfScales fs = cert_scales(sc, r2);
+  DevBuf<float> rlo2(c, n), rup2(c, n);
+  sift_dog_fast_launch(c, oc, gr, oc->n_wave_items, max_radius, fs, fl, dogv.get(), dogb.get(), rlo2.get(), rup2.get(), mark.get());
+  MM3D_HIP(hipMemcpyAsync(val_host, dogv.get(), n * kDog * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  MM3D_HIP(hipMemcpyAsync(bound_host, dogb.get(), n * kDog * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  return n;
+}
+
 // normals_radius > 0 and normals_out: the caller also wants computeSurfaceNormals(points, normals_radius) (it is about to
 // describe the keypoints).  When the first octave works on `points` itself and normal_radius <= 3 sigma_max, the normals
 // come out of the first octave's scale-space launch (k_sift_dog_lds<., true>); otherwise compute_normals runs as usual.
@@ -906,6 +1094,22 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
       nrm_res->n = points->n;
       nrm_res->nrm = DevBuf<float4>(c, points->n);
     }
+    const DevPtr<int> flags{flags_p}, n_search{n_search_p};
+    const DevPtr<unsigned char> need_search{need_search_p};
+    DevBuf<int> pos(c, (size_t)n * 3 + 1);
+    const int nh = (int)octave_cloud->n_finite;
+    int *h = (int *)c->pin(64);                          // [0] keypoints, [1] points for the searching kernel
+    // Later octaves (round 6): the keypoint DECISION is certified from an unsorted scale space with an error bound, and only
+    // the points it leaves open get the sorted lists (sift_cert.hpp).  The first octave keeps its lists -- the fused normals
+    // ride on them.  MM3D_SIFT_CERT=0: every octave on the sorted lists (the A/B and the reference for the parity tests);
+    // MM3D_SIFT_CERT=2: the first octave certified too whenever no normals are fused into it.
+    static const int cert_mode = [] { const char *e = getenv("MM3D_SIFT_CERT"); return e ? atoi(e) : 1; }();
+    bool certified = false;
+    if (cert_mode > 0 && (oct >= 1 || (cert_mode >= 2 && !fused)) && octave_cloud->n_finite == octave_cloud->n) {
+      certified = sift_octave_certified(c, octave_cloud, gr, n_items, max_radius, r2, sc, (float)min_contrast, flags.get(), pos.get(), h);
+      if (!certified) zero_again = true;                   // (the flags hold the abandoned run's)
+    }
+    if (!certified) {
     // (measured, round 4: the sixteen-wave configuration is bit-equal and NOT faster -- octave 1 1.74 against 1.69 ms, octave 2
     // 0.88 against 0.78 -- every phase's ticks per query double with the waves: the kernel is bound by VALU issue, not by
     // latency; it stays behind this knob)
@@ -923,11 +1127,6 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     // for LDS behind the other streams' kernels).
     const Grid &gk = gr;
     DevBuf<float4> dogx(c, (size_t)n * 2);
-    const DevPtr<int> flags{flags_p}, n_search{n_search_p};
-    const DevPtr<unsigned char> need_search{need_search_p};
-    DevBuf<int> pos(c, (size_t)n * 3 + 1);
-    const int nh = (int)octave_cloud->n_finite;
-    int *h = (int *)c->pin(64);                          // [0] keypoints, [1] points for the searching kernel
     auto extremum_test = [&](bool search) {
       MM3D_LAUNCH(c, "sift_pack", n * 52.0, k_sift_dogx, dim3(div_up(n, 256)), dim3(256), 0, (const float *)dog.get(), n, dogx.get());
       if (zero_again) MM3D_HIP(hipMemsetAsync(flags.get(), 0, z_flags + sizeof(int) + (size_t)n, c->stream));
@@ -987,6 +1186,7 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
       extremum_test(false);
     }
     if (h[1] > 0) extremum_test(true);                    // some point's short list left it undecided: search for its 25 nearest
+    }
     const size_t nk = (size_t)h[0];
     DevBuf<float4> kp(c, nk);
     if (nk)

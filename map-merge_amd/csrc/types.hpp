@@ -196,6 +196,10 @@ mm3d_desc *compute_pfhrgb(Context *c, const mm3d_cloud *points, const mm3d_norma
 
 void debug_libm(Context *c, int fn, const float *x_host, const float *y_host, int n, float *out_host);
 void debug_float_chain(Context *c, const float *incr_host, const unsigned *hits_host, int n, float *out_host);
+// sift.hip, test hooks of the certified SIFT decision (sift_cert.hpp): the unsorted scale space of ONE octave -- val* and the
+// bound B per point and DoG column, [n][5] by the octave cloud's index -- and the process-wide statistics
+size_t debug_sift_cert_octave(Context *c, const mm3d_cloud *points, double min_scale, int octave, float *val_host, float *bound_host, size_t capacity);
+void debug_sift_cert_stats(long long *out, int reset);
 
 // rsd.hip
 mm3d_desc *compute_rsd(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,

@@ -143,6 +143,8 @@ mm3d_desc *compute_rsd(Context *c, const mm3d_cloud *, const mm3d_normals *, mm3
 mm3d_desc *compute_sc3d(Context *c, const mm3d_cloud *, const mm3d_normals *, mm3d_cloud *kp, double) { return fake_desc(c, kp, MM3D_DESC_SC3D, 1980); }
 mm3d_desc *compute_shot(Context *c, const mm3d_cloud *, const mm3d_normals *, mm3d_cloud *kp, double) { return fake_desc(c, kp, MM3D_DESC_SHOT, 1344); }
 void debug_libm(Context *, int, const float *x, const float *, int n, float *out) { for (int i = 0; i < n; ++i) out[i] = x[i]; }
+size_t debug_sift_cert_octave(Context *, const mm3d_cloud *, double, int, float *, float *, size_t) { return 0; }
+void debug_sift_cert_stats(long long *out, int) { for (int i = 0; i < 8; ++i) out[i] = 0; }
 void debug_float_chain(Context *, const float *incr, const unsigned *hits, int n, float *out)
 {
   for (int i = 0; i < n; ++i) { float v = 0.f; for (unsigned k = 0; k < hits[i]; ++k) v += incr[i]; out[i] = v; }

@@ -1,0 +1,106 @@
+"""The certified SIFT decision (csrc/sift_cert.hpp): detectKeypoints(SIFT) returns an index set (R/src/features.cpp:45-62),
+so the later octaves decide it from an UNSORTED scale space with a rigorous error bound and give only the points that
+leaves open the CPU path's exact float sums.  Here: the pieces the certificate rests on, against the CPU oracle.
+Run with `-m gpu` on the MI355X box; all calls go through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RES, R_DESC, R_NRM, MIN_NB = 0.1, 0.8, 0.6, 50
+
+
+def xyz(a):
+    return np.stack([a["x"], a["y"], a["z"]], axis=1)
+
+
+@pytest.fixture(scope="module")
+def big_scene(po, synth):
+    """One synthetic map large enough for three populated octaves (about 50 k filtered points)."""
+    world, maps = synth.synth_maps(2, 70000, overlap_step=0.35)
+    x, c, _ = maps[0]
+    raw = synth.pack_points(x, c)
+    return po.remove_outliers(po.downsample(raw, RES), R_DESC, MIN_NB)
+
+
+def test_v_exp_f32_is_within_two_ulp_on_the_weights_range(ctx, mm):
+    """The bound budgets 2 ulp for v_exp_f32.  Every float argument the pass can form lies in [-6.5, 0]: all 106 M floats of
+    [-6.6, -1e-3] and every 97th of (-1e-3, 0] against numpy's double exp2."""
+    lo, hi = np.float32(-1e-3).view(np.uint32), np.float32(-6.6).view(np.uint32)
+    worst = 0.0
+    chunk = 1 << 24
+    starts = list(range(int(lo), int(hi) + 1, chunk))
+    for a in starts:
+        bits = np.arange(a, min(a + chunk, int(hi) + 1), dtype=np.uint32)
+        x = bits.view(np.float32)
+        out = np.empty_like(x)
+        ctx._ck(mm.lib().mm3d_debug_libm(ctx._h, 5, x.ctypes.data_as(C.c_void_p), None, len(x), out.ctypes.data_as(C.c_void_p)))
+        true = np.exp2(x.astype(np.float64))
+        ulp = np.spacing(true.astype(np.float32)).astype(np.float64)
+        worst = max(worst, float(np.max(np.abs(out.astype(np.float64) - true) / ulp)))
+    bits = np.arange(0x80000000, int(lo), 97, dtype=np.uint32)
+    x = bits.view(np.float32)
+    out = np.empty_like(x)
+    ctx._ck(mm.lib().mm3d_debug_libm(ctx._h, 5, x.ctypes.data_as(C.c_void_p), None, len(x), out.ctypes.data_as(C.c_void_p)))
+    true = np.exp2(x.astype(np.float64))
+    worst = max(worst, float(np.max(np.abs(out.astype(np.float64) - true) / np.spacing(true.astype(np.float32)).astype(np.float64))))
+    print(f"v_exp_f32: worst error {worst:.3f} ulp")
+    assert worst <= 2.0
+
+
+def test_the_bound_holds_on_every_point(ctx, po, big_scene):
+    """|the CPU path's float DoG - val*| <= B for every point and DoG column of every octave, the octave clouds being the
+    oracle's; and the bound is tight enough to decide with (median B far below the contrast threshold of 5)."""
+    cloud = ctx.cloud(big_scene)
+    for octv in range(3):
+        r = po.sift_octave_debug(big_scene, RES, octv)
+        got = ctx.siftCertOctave(cloud, RES, octv)
+        assert r is not None and got is not None
+        oc, dog, resp, cnt, knn = r
+        val, bound = got
+        assert val.shape == dog.shape
+        err = np.abs(dog.astype(np.float64) - val.astype(np.float64))
+        assert np.isfinite(bound).all() and (bound > 0).all()
+        worst = float(np.max(err / bound))
+        print(f"octave {octv}: n {len(oc)}, worst |float DoG - val*| / B = {worst:.3f}, median B {np.median(bound):.5f}")
+        assert worst <= 1.0
+        assert np.median(bound) < 0.05
+        # and against the real value (double evaluation): the device's own share of the bound
+        real = resp[:, 1:] - resp[:, :-1]
+        assert float(np.max(np.abs(real - val.astype(np.float64)) / bound)) <= 1.0
+
+
+def test_certified_octaves_give_the_oracles_keypoints_and_say_what_they_did(ctx, po, mm, big_scene):
+    mm.sift_cert_stats(reset=True)
+    ref, _ = po.keypoints_sift(big_scene, RES, 3, 3, 5.0)
+    got = ctx.detectKeypoints(ctx.cloud(big_scene), None, 0, 5.0, R_NRM, RES).numpy()
+    assert len(got) == len(ref) > 500
+    assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
+    st = mm.sift_cert_stats()
+    print("certified SIFT statistics:", st)
+    assert st[0] == 2                      # octaves 1 and 2 were decided on the certified path
+    assert st[4] == 0 and st[5] == 0 and st[6] == 0
+    assert 0 < st[2] < 0.02 * st[1]        # a small share of their points needed the exact sums
+
+
+def test_ties_everywhere_send_every_point_to_the_exact_path(ctx, po, mm):
+    """The power-of-two step-edge lattice of test_sift_ties_across_scales_are_not_extrema with the contrast threshold at zero:
+    exact ties among the responses, so no interval comparison can be certain -- every candidate is left open, takes the exact
+    path, and the keypoints are still the oracle's."""
+    gx, gy = np.meshgrid(np.arange(-30, 31) * 0.1, np.arange(-30, 31) * 0.1)
+    pts = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], 1).astype(np.float32)
+    c = np.zeros(len(pts), dtype=po.POINT)
+    c["x"], c["y"], c["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    for rgba in (np.full(len(c), 0xFF808080, dtype=np.uint32), np.where(c["x"] < 0.0, 0xFF404040, 0xFF808080).astype(np.uint32)):
+        c["rgba"] = rgba
+        mm.sift_cert_stats(reset=True)
+        ref, _ = po.keypoints_sift(c, 0.1, 3, 3, 0.0)
+        got = ctx.detectKeypoints(ctx.cloud(c), None, 0, 0.0, R_NRM, 0.1).numpy()
+        st = mm.sift_cert_stats()
+        print("ties:", st, len(ref))
+        assert len(got) == len(ref)
+        assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
+        assert st[0] == 2 and st[4] == 0 and st[5] == 0 and st[6] == 0
+        assert st[2] > 0.5 * st[1]         # most points of the two octaves needed the exact sums
