@@ -51,44 +51,15 @@ VALU_PEAK_WINSTR_S = 8.4e11
 VALU_PEAK_NOMINAL_WINSTR_S = 256 * 4 * 2.4e9 / 2
 # profile name (MM3D_LAUNCH) of the kernels whose C++ symbol differs from it (scripts/pmc_summary.py prints symbols)
 KERNEL_OF_SYMBOL = {"k_sift_dog_lds": "sift_dog", "k_sift_dog_lds_dense": "sift_dog_dense", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_sift_extrema": "sift_extrema", "k_spfh": "spfh", "k_normals": "normals_radius_big",
-                    "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_sacia_seq_sum": "sacia_seq_sum",
+                    "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_seq_sum": "sacia_seq_sum", "k_sift_dog_fast": "sift_dog_fast", "k_sift_reject": "sift_reject",
+                    "k_sift_extrema_one": "sift_extrema_one",
                     "k_fpfh_weight": "fpfh_weight", "k_knn_mfma": "desc_knn_mfma", "k_knn_rerank": "desc_knn_rerank",
-                    "k_radius_outlier_count": "radius_outlier_count"}
+                    "k_radius_count": "radius_outlier_count"}
 
 
-# the sources a kernel's instruction stream comes from: the PMC / SQ figures under profiles/ carry the hashes of these
-# files as they were when the counters were collected (scripts/assemble_profiles.py); a figure whose files have changed
-# since is reported with "stale": true instead of passing for a measurement of the code that ran
-_CS = "map-merge_amd/csrc/"
-# root files per kernel; the hash covers their transitive local #includes too (device_util.hpp, common.hpp, types.hpp, ...),
-# plus grid.hip wherever a kernel reads a layout that file builds (neighbour-block lists, Hilbert items, cell tables)
-KERNEL_SOURCES = {
-    "sift_dog": ["sift.hip", "grid.hip"], "sift_extrema": ["sift.hip", "grid.hip"],
-    "normals_radius": ["normals.hip", "grid.hip"], "spfh": ["fpfh.hip", "grid.hip"],
-    "fpfh_weight": ["fpfh.hip", "grid.hip"], "fpfh_mark": ["fpfh.hip", "grid.hip"], "icp_corr_reduce": ["nn.hip", "grid.hip"],
-    "score_nn_reduce": ["nn.hip", "grid.hip"], "sacia_err": ["registration.hip", "grid.hip"], "sacia_seq_sum": ["registration.hip"],
-    "desc_knn_mfma": ["desc_knn.hip"], "desc_knn_rerank": ["desc_knn.hip"], "radius_outlier_count": ["filters.hip", "grid.hip"],
-    "voxel_centroid": ["filters.hip", "grid.hip"],
-}
-
-
-def _source_closure(roots):
-    """The root files and every local header they include, transitively (names relative to csrc/, sorted)."""
-    import re
-    seen, todo = set(), list(roots)
-    while todo:
-        f = todo.pop()
-        if f in seen:
-            continue
-        seen.add(f)
-        try:
-            with open(os.path.join(ROOT, _CS + f), "r", errors="replace") as fh:
-                for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), re.M):
-                    if os.path.exists(os.path.join(ROOT, _CS + m.group(1))):
-                        todo.append(m.group(1))
-        except OSError:
-            pass
-    return sorted(seen)
+# The PMC / SQ figures under profiles/ carry a hash of each kernel's MACHINE CODE as it was when the counters were collected
+# (scripts/assemble_profiles.py; kernel_source_hash below); a figure whose kernel has changed since is reported with
+# "stale": true instead of passing for a measurement of the code that ran.
 
 
 # registration_visualisation's stage boundaries (R/src/registration_visualisation.cpp:51-158): which stage a kernel's
@@ -122,19 +93,92 @@ def workload_signature(args):
             "window": float(args.window), "resolution": float(args.resolution), "sac_iterations": int(args.sac_iterations)}
 
 
+# Which device functions a profile name stands for (the names MM3D_LAUNCH gives its kernels -> the kernels' symbols in the
+# gfx950 code objects of libmm3d.so).  The staleness hash below covers these symbols' machine code.
+KERNEL_SYMBOLS = {
+    "sift_dog": r"k_sift_dog_lds", "sift_dog_fast": r"k_sift_dog_fast", "sift_reject": r"k_sift_reject",
+    "sift_extrema": r"k_sift_extremaI", "sift_extrema_one": r"k_sift_extrema_one", "normals_radius": r"k_normals_lds", "spfh": r"k_spfh", "fpfh_weight": r"k_fpfh_weight",
+    "fpfh_mark": r"k_fpfh_mark", "icp_corr_reduce": r"k_nn_waveILi0", "score_nn_reduce": r"k_nn_waveILi1", "sacia_err": r"k_sacia_err",
+    "sacia_seq_sum": r"k_seq_sum", "desc_knn_mfma": r"k_knn_(mfma|filter)", "desc_knn_rerank": r"k_knn_rerank",
+    "radius_outlier_count": r"k_radius_count", "voxel_centroid": r"k_voxel_centroid",
+}
+_ISA_CACHE = {}
+
+
+def _device_kernels(lib_path):
+    """{symbol name: machine code bytes} of every kernel in the gfx950 code objects of a HIP shared library, read with nothing
+    but struct: the .so carries one clang offload bundle per translation unit, each bundle a gfx950 ELF whose .symtab lists
+    the kernels as FUNC symbols inside .text."""
+    import struct
+    if lib_path in _ISA_CACHE:
+        return _ISA_CACHE[lib_path]
+    out = {}
+    try:
+        data = open(lib_path, "rb").read()
+    except OSError:
+        _ISA_CACHE[lib_path] = out
+        return out
+    magic, pos = b"__CLANG_OFFLOAD_BUNDLE__", 0
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            break
+        pos = i + len(magic)
+        try:
+            (n_ent,) = struct.unpack_from("<Q", data, i + 24)
+            off = i + 32
+            for _ in range(n_ent):
+                o, sz, ts = struct.unpack_from("<QQQ", data, off)
+                off += 24
+                triple = data[off:off + ts].decode("ascii", "replace")
+                off += ts
+                if "gfx950" not in triple or sz == 0:
+                    continue
+                elf = data[i + o:i + o + sz]
+                if elf[:4] != b"\x7fELF":
+                    continue
+                shoff, = struct.unpack_from("<Q", elf, 0x28)
+                shentsize, shnum, shstrndx = struct.unpack_from("<HHH", elf, 0x3A)
+                secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + k * shentsize) for k in range(shnum)]
+                for sec in secs:
+                    if sec[1] != 2:                    # SHT_SYMTAB
+                        continue
+                    strtab = secs[sec[6]]
+                    for k in range(sec[5] // 24):
+                        name_off, info, _other, shndx, value, size = struct.unpack_from("<IBBHQQ", elf, sec[4] + k * 24)
+                        if (info & 0xF) != 2 or size == 0 or shndx == 0 or shndx >= shnum:    # STT_FUNC, defined
+                            continue
+                        end = elf.index(b"\0", strtab[4] + name_off)
+                        name = elf[strtab[4] + name_off:end].decode("ascii", "replace")
+                        tsec = secs[shndx]
+                        start = tsec[4] + (value - tsec[3])
+                        out[name] = elf[start:start + size]
+        except (struct.error, ValueError, IndexError):
+            continue
+    _ISA_CACHE[lib_path] = out
+    return out
+
+
 def kernel_source_hash(kernel):
-    """sha256 over the kernel's source files (None for kernels without an entry in KERNEL_SOURCES)."""
+    """What makes a committed counter stale: sha256 over the MACHINE CODE of the kernel's device functions as libmm3d.so
+    carries them (None for kernels without an entry in KERNEL_SYMBOLS, or when the library cannot be read).  Round 5 hashed
+    the source files with their include closure, and a comment edited in include/mm3d.h turned every counter of the round
+    stale; the code object does not change with a comment."""
     import hashlib
-    files = KERNEL_SOURCES.get(kernel)
-    if not files:
+    import re
+    pat = KERNEL_SYMBOLS.get(kernel)
+    if not pat:
+        return None
+    lib = os.environ.get("MM3D_LIB") or os.path.join(ROOT, "map-merge_amd", "libmm3d.so")
+    ks = _device_kernels(lib)
+    rx = re.compile(pat)
+    names = sorted(n for n in ks if rx.search(n))
+    if not names:
         return None
     h = hashlib.sha256()
-    for f in _source_closure(files):
-        try:
-            with open(os.path.join(ROOT, _CS + f), "rb") as fh:
-                h.update(fh.read())
-        except OSError:
-            return None
+    for n in names:
+        h.update(n.encode())
+        h.update(ks[n])
     return h.hexdigest()[:16]
 
 
@@ -230,9 +274,21 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    if args.gpus != world and args.engine != "devices":
+    if world == 1 and args.gpus > 1 and args.engine != "devices":
+        # `python bench.py --gpus N` WITHOUT torchrun: one process, N devices -- the library's own multi-device driver
+        # (mm3d_create_devices: maps by owner, peer copies, pairs by target owner, ONE in-library ncclAllGather), never a silent
+        # one-GPU run under an N-GPU label.  (Under torchrun -- WORLD_SIZE = N -- the ranks use the shard engine as before.)
+        have = torch.cuda.device_count()
+        if have < args.gpus and not os.environ.get("MM3D_BENCH_DEVICES"):
+            raise SystemExit(f"bench.py: --gpus {args.gpus} without torchrun needs {args.gpus} visible GPUs, this box has {have} "
+                             "(launch with torch.distributed.run for one rank per GPU, or lower --gpus)")
+        if args.engine != "library":
+            raise SystemExit(f"bench.py: --gpus {args.gpus} without torchrun runs the one-process device-list engine; --engine {args.engine} is a one-GPU engine")
+        print(f"note: --gpus {args.gpus} without torchrun: using --engine devices (one process over {args.gpus} GPUs)", file=sys.stderr)
+        args.engine = "devices"
+    elif args.gpus != world and args.engine != "devices":
         if rank == 0:
-            print(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
+            print(f"note: --gpus {args.gpus} but WORLD_SIZE {world} (torchrun): one rank per GPU, {world} GPUs", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

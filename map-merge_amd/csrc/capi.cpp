@@ -1192,6 +1192,13 @@ struct BundleHeader {
 };
 static_assert(sizeof(BundleHeader) == 256, "bundle header");
 constexpr uint64_t kBundleMagic = 0x6d6d33642d623032ull;          // "mm3d-b02"
+// A stack object (a bundle header) is the source / destination of an asynchronous copy: nothing may unwind the frame while
+// that copy can still be in flight.  Armed until the function's own wait.
+struct DrainOnUnwind {
+  Context *c;
+  bool armed = true;
+  ~DrainOnUnwind() { if (armed) (void)stream_wait(c->stream); }
+};
 struct BundleLayout {
   size_t pts, kp, desc, p_hil, p_items, k_hil, k_items, total, p_item_cap, k_item_cap;
 };
@@ -1244,6 +1251,7 @@ int mm3d_shard_pack(mm3d_shard *sh, size_t map, void *dst)
       if (cl->n_wave_items)
         MM3D_HIP(hipMemcpyAsync(d + off_items, cl->wave_items.get(), (size_t)cl->n_wave_items * sizeof(int2), hipMemcpyDefault, ctx->stream));
     };
+    DrainOnUnwind drain{ctx};                 // (`header` is read by the copy queued below)
     side(m->points, h->p_finite, h->p_items, h->p_have, h->p_bmin, h->p_bmax, L.p_hil, L.p_items, L.p_item_cap);
     side(m->keypoints, h->k_finite, h->k_items, h->k_have, h->k_bmin, h->k_bmax, L.k_hil, L.k_items, L.k_item_cap);
     MM3D_HIP(hipMemcpyAsync(d, h, sizeof(*h), hipMemcpyDefault, ctx->stream));
@@ -1251,10 +1259,11 @@ int mm3d_shard_pack(mm3d_shard *sh, size_t map, void *dst)
     if (m->keypoints->n) MM3D_HIP(hipMemcpyAsync(d + L.kp, m->keypoints->pts.get(), m->keypoints->n * 16, hipMemcpyDefault, ctx->stream));
     if (m->desc->n) MM3D_HIP(hipMemcpyAsync(d + L.desc, m->desc->data.get(), m->desc->n * (size_t)m->desc->dim * 4, hipMemcpyDefault, ctx->stream));
     ctx->sync();
+    drain.armed = false;
   });
 }
 
-// one received bundle -> a map in the source role, on context c (copies and ONE wait; no kernel unless the owner sent no orders)
+// one received bundle -> a map in the source role, on context c (copies, a short wait for the 256-byte header and ONE for the rest; no kernel unless the owner sent no orders)
 static mm3d_map *map_from_bundle(mm3d_ctx *c, const void *src, uint64_t n_points, uint64_t n_keypoints, int descriptor_type)
 {
   const char *s = static_cast<const char *>(src);
@@ -1264,7 +1273,15 @@ static mm3d_map *map_from_bundle(mm3d_ctx *c, const void *src, uint64_t n_points
   BundleHeader header;
   BundleHeader *h = &header;
   std::memset(h, 0, sizeof(*h));
-  if (s) MM3D_HIP(hipMemcpyAsync(h, s, sizeof(*h), hipMemcpyDefault, c->stream));
+  // the header first, blocking (256 bytes), and checked BEFORE the large copies are queued at sizes the caller supplied
+  if (s) {
+    MM3D_HIP(hipMemcpyAsync(h, s, sizeof(*h), hipMemcpyDefault, c->stream));
+    DrainOnUnwind drain{c};
+    c->sync();
+    drain.armed = false;
+    if (h->magic != kBundleMagic || h->n_points != n_points || h->n_keypoints != n_keypoints)
+      throw Error(MM3D_EINVAL, "mm3d_shard_unpack: not a bundle of this library version, or the sizes do not match it");
+  }
   std::unique_ptr<mm3d_cloud> pts(cloud_from_memory(c, n_points ? s + L.pts : nullptr, n_points, 16, 12));
   std::unique_ptr<mm3d_cloud> kp(cloud_from_memory(c, n_keypoints ? s + L.kp : nullptr, n_keypoints, 16, 12));
   std::unique_ptr<mm3d_desc> desc(desc_from_memory(c, reinterpret_cast<const float *>(s ? s + L.desc : nullptr), n_keypoints, descriptor_type));
@@ -1282,8 +1299,6 @@ static mm3d_map *map_from_bundle(mm3d_ctx *c, const void *src, uint64_t n_points
   Side ps = grab(n_points, L.p_hil, L.p_items, L.p_item_cap), ks = grab(n_keypoints, L.k_hil, L.k_items, L.k_item_cap);
   (void)cloud_host(c, kp.get());                      // (the host copy of the keypoints: this is the wait)
   c->sync();
-  if (s && (h->magic != kBundleMagic || h->n_points != n_points || h->n_keypoints != n_keypoints))
-    throw Error(MM3D_EINVAL, "mm3d_shard_unpack: not a bundle of this library version, or the sizes do not match it");
   auto adopt = [&](mm3d_cloud *cl, Side &sd, uint32_t have, uint64_t fin, uint64_t items, const float *bmin, const float *bmax, size_t item_cap) {
     if (!have || !cl->n || fin > cl->n || items > item_cap) return;
     std::lock_guard<std::recursive_mutex> lk(cl->cache_mu);
@@ -1384,7 +1399,7 @@ static void shard_pairs_impl(mm3d_shard *sh, mm3d_pair_result *pairs, unsigned c
   // a stream runs dry: every map exists already, so the whole list can be cut up front
   const size_t S = ctx->helpers.size() + 1;
   const double share = pair_share_knob();                  // (as claim_pairs above)
-  const size_t take = std::min(kPairBatch, std::max<size_t>(1, (size_t)((double)todo.size() / (share * (double)S))));
+  const size_t take = std::min(pair_batch_knob(), std::max<size_t>(1, (size_t)((double)todo.size() / (share * (double)S))));
   std::stable_sort(todo.begin(), todo.end(), [&](size_t a, size_t b) { return live[a].second < live[b].second; });
   std::vector<std::pair<size_t, size_t>> batches;           // [first, last) into todo
   for (size_t a = 0; a < todo.size();) {

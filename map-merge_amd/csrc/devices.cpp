@@ -42,13 +42,21 @@ const Rccl &rccl()
     Rccl r;
     void *h = nullptr;
     if (!dlsym(RTLD_DEFAULT, "ncclCommInitAll")) {
-      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      // MM3D_RCCL_LIB: another file name for the library (a private build; the tests' "no RCCL on this box" case)
+      const char *override_name = getenv("MM3D_RCCL_LIB");
+      std::string tried;
+      for (const char *name : {override_name, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        if (!name || !*name) continue;
         // RTLD_LOCAL: a process that loads a second RCCL later (a Python test that imports torch, which ships its own) must not
         // have that one's references bound to this one's symbols -- "double free or corruption" at exit, measured
         h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (h) break;
+        // (dlerror() hands its message out ONCE and clears it: one call per failure, every name's reason kept)
+        const char *e = dlerror();
+        tried += std::string(tried.empty() ? "" : "; ") + name + ": " + (e ? e : "?");
+        if (override_name && name == override_name) break;    // an explicit name is not a hint: nothing else is tried
       }
-      if (!h) { r.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "?"); return r; }
+      if (!h) { r.error = "librccl could not be loaded (" + tried + ")"; return r; }
     }
     auto sym = [&](const char *n) { void *p = h ? dlsym(h, n) : dlsym(RTLD_DEFAULT, n); if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + n; return p; };
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
@@ -66,6 +74,7 @@ const Rccl &rccl()
 struct DeviceSet {
   std::vector<int> devices;
   std::vector<ncclComm_t> comms;       // one per list entry; empty for the duplicate-device test hook
+  bool broken = false;                 // a collective failed half-way: the communicators are not used again
 };
 
 #define MM3D_NCCL(expr)                                                                                                \
@@ -189,12 +198,26 @@ double gather_pair_records(DeviceSet *ds, const std::vector<mm3d_ctx *> &roots, 
     MM3D_HIP(hipMemcpyAsync(sbuf[d].get(), h, bytes, hipMemcpyHostToDevice, c->stream));
   }
   // one thread, one group: the standard single-process form (every rank's call is enqueued on its own device's stream)
+  if (ds->broken) throw Error(MM3D_EDEVICE, "gather_pair_records: an earlier collective on these communicators failed; make a new context");
   MM3D_NCCL(rccl().GroupStart());
-  for (size_t d = 0; d < D; ++d) {
-    MM3D_HIP(hipSetDevice(roots[d]->device));
-    MM3D_NCCL(rccl().AllGather(sbuf[d].get(), rbuf[d].get(), bytes, ncclChar, ds->comms[d], roots[d]->stream));
+  {
+    // nothing may leave this block with the group open: the group depth is the THREAD's, and a group left at depth 1 queues
+    // every later collective of the thread without ever launching it (the next call would wait for ever in sync()).  A failed
+    // enqueue closes the group, restores the first device and marks the communicators unusable before it is reported.
+    std::string failed;
+    for (size_t d = 0; d < D && failed.empty(); ++d) {
+      if (hipSetDevice(roots[d]->device) != hipSuccess) { failed = "hipSetDevice failed inside the RCCL group"; break; }
+      const ncclResult_t r = rccl().AllGather(sbuf[d].get(), rbuf[d].get(), bytes, ncclChar, ds->comms[d], roots[d]->stream);
+      if (r != ncclSuccess) failed = std::string("ncclAllGather: ") + rccl().GetErrorString(r);
+    }
+    const ncclResult_t re = rccl().GroupEnd();
+    if (failed.empty() && re != ncclSuccess) failed = std::string("ncclGroupEnd: ") + rccl().GetErrorString(re);
+    if (!failed.empty()) {
+      ds->broken = true;
+      (void)hipSetDevice(roots[0]->device);
+      throw Error(MM3D_EDEVICE, "gather_pair_records: " + failed);
+    }
   }
-  MM3D_NCCL(rccl().GroupEnd());
   // the host solves the pose graph once, from the first device's copy; with mm3d_set_debug every device's copy is read back
   // and must hold the same bytes
   const size_t n_read = roots[0]->debug ? D : 1;

@@ -196,7 +196,10 @@ k_nn_wave(const NnJob *__restrict__ jobs, float max_d2, float rmax)
       if (active && d0 >= 2) {
         const float fx = p.x - (g.minx + (float)cx * g.cell), fy = p.y - (g.miny + (float)cy * g.cell), fz = p.z - (g.minz + (float)cz * g.cell);
         const float mface = fmaxf(fminf(fminf(fminf(fx, g.cell - fx), fminf(fy, g.cell - fy)), fminf(fz, g.cell - fz)), 0.0f);
-        if ((float)(d0 - 1) * g.cell + mface * 0.999f - 1e-5f >= rmax) active = false;
+        // (the slack scales with the cell and with how far the grid lies from the origin, like the corner filter's `edge`: a
+        // point can sit outside its nominal cell faces by the rounding of minx + cx * cell, 3e-5 .. 6e-5 m a kilometre out)
+        const float lb_edge = 1e-3f * g.cell + 1e-6f * (fabsf(g.minx) + fabsf(g.miny) + fabsf(g.minz) + (float)(g.dx + g.dy + g.dz) * g.cell);
+        if ((float)(d0 - 1) * g.cell + mface * 0.999f - lb_edge >= rmax) active = false;
       }
 #endif
     } else {

@@ -906,7 +906,7 @@ static bool sift_octave_certified(Context *c, const mm3d_cloud *cur, const Grid 
   DevBuf<int> rctl(c, sizeof(SnbCtl) / sizeof(int));
   if (use_reject) {
     MM3D_HIP(hipMemsetAsync(rctl.get(), 0, sizeof(SnbCtl), c->stream));
-    const unsigned rblocks = (unsigned)std::max(1, std::min<int>(n_items, snb_cu_count(c->device) * 2));
+    const unsigned rblocks = (unsigned)std::max(1, std::min<int>(n_items, snb_cu_count(c->device) * 5));
     MM3D_LAUNCH(c, "sift_reject", 0.0, k_sift_reject, dim3(rblocks), dim3(64 * SrCfg::kWaves), 0, (const float4 *)cur->hil_pts.get(),
                 (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float *)rlo2.get(), (const float *)dogv.get(), (const float *)dogb.get(),
                 (const float4 *)dogx.get(), n, cls.get(), reinterpret_cast<SnbCtl *>(rctl.get()), ctr);

@@ -321,7 +321,8 @@ __device__ __forceinline__ void cert_interval(float v, float b, float &lo, float
 //   mnhi_s = min(hi_s, pred(min(hi_(s-1), hi_(s+1)))):  mnhi < lo_p  -> the neighbour CERTAINLY spoils the minimum
 //   mnlo_s = min(lo_s, pred(min(lo_(s-1), lo_(s+1)))):  mnlo < hi_p  -> it POSSIBLY does
 // (maxima mirrored: mxlo > hi_p certainly, mxhi > lo_p possibly).  With b = 0 both are k_sift_dogx's value.
-// dogx: [3][n] float4 = (mnhi1, mnhi2, mnhi3, mnlo1), (mnlo2, mnlo3, mxlo1, mxlo2), (mxlo3, mxhi1, mxhi2, mxhi3);
+// dogx: [3][n] float4 = (mnhi1, mnhi2, mnhi3, mxlo1), (mxlo2, mxlo3, mnlo1, mnlo2), (mnlo3, mxhi1, mxhi2, mxhi3) -- the certain
+// values first: k_sift_reject reads one row and a half;
 // cls: bit s = |DoG(s + 1)| may reach the contrast (candidate), bit 3 + s = it certainly does (live).
 __device__ __forceinline__ void cert_pack_point(const float *__restrict__ dogv, const float *__restrict__ dogb, int i, int n, float min_contrast,
                                                 float4 *__restrict__ dogx, unsigned char *__restrict__ cls)
@@ -340,9 +341,9 @@ __device__ __forceinline__ void cert_pack_point(const float *__restrict__ dogv, 
     if (hi[s] >= min_contrast || lo[s] <= -min_contrast) c |= 1u << (s - 1);
     if (lo[s] >= min_contrast || hi[s] <= -min_contrast) c |= 8u << (s - 1);
   }
-  dogx[i] = make_float4(mnhi[0], mnhi[1], mnhi[2], mnlo[0]);
-  dogx[(size_t)n + i] = make_float4(mnlo[1], mnlo[2], mxlo[0], mxlo[1]);
-  dogx[2 * (size_t)n + i] = make_float4(mxlo[2], mxhi[0], mxhi[1], mxhi[2]);
+  dogx[i] = make_float4(mnhi[0], mnhi[1], mnhi[2], mxlo[0]);
+  dogx[(size_t)n + i] = make_float4(mxlo[1], mxlo[2], mnlo[0], mnlo[1]);
+  dogx[2 * (size_t)n + i] = make_float4(mnlo[2], mxhi[0], mxhi[1], mxhi[2]);
   cls[i] = (unsigned char)c;
 }
 
@@ -363,7 +364,7 @@ struct CertCounters {
 // the near misses and everything open: a few per cent) goes to k_sift_extrema_iv.
 struct SrCfg {
   static constexpr int kWaves = 4;
-  static constexpr int kTileCap = 1536;
+  static constexpr int kTileCap = 640;      // (an item is a few hundred candidates; five blocks per CU hide the staging round trips)
 };
 struct alignas(16) SrLds {
   float4 ta[SrCfg::kTileCap + 4];            // x, y, z, -
@@ -443,10 +444,10 @@ k_sift_reject(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, 
             if (w_off[lo + step] <= slot) lo += step;
           const float4 cnd = g.pts[w_beg[lo] + (slot - w_off[lo])];
           const bool k = in && keep(cnd);
-          float4 x0v = make_float4(0.f, 0.f, 0.f, 0.f), x1v = x0v, x2v = x0v;
+          float4 x0v = make_float4(0.f, 0.f, 0.f, 0.f), x1v = x0v;
           if (k) {
             const int o = __float_as_int(cnd.w);
-            x0v = dogx[o]; x1v = dogx[(size_t)n_pts + o]; x2v = dogx[2 * (size_t)n_pts + o];
+            x0v = dogx[o]; x1v = dogx[(size_t)n_pts + o];
           }
           const unsigned long long m = ballot(k);
           if (m) {
@@ -456,8 +457,8 @@ k_sift_reject(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, 
             const int d = snb_mbcnt(m, base);
             if (k && d < SrCfg::kTileCap) {
               S.ta[d] = make_float4(cnd.x, cnd.y, cnd.z, 0.0f);
-              S.tb[d] = make_float4(x0v.x, x0v.y, x0v.z, x1v.z);     // mnhi1..3, mxlo1
-              S.tc[d] = make_float2(x1v.w, x2v.x);                   // mxlo2, mxlo3
+              S.tb[d] = x0v;                                         // mnhi1..3, mxlo1
+              S.tc[d] = make_float2(x1v.x, x1v.y);                   // mxlo2, mxlo3
             }
           }
         }
@@ -679,8 +680,8 @@ k_sift_extrema_one(const int *__restrict__ ids, const int *__restrict__ n_ids_de
           }
           if (idx == (unsigned)self) continue;
           const float4 a = dogx[idx], bq = dogx[(size_t)n_pts + idx], dq = dogx[2 * (size_t)n_pts + idx];
-          const float mnhi[3] = {a.x, a.y, a.z}, mnlo[3] = {a.w, bq.x, bq.y};
-          const float mxlo[3] = {bq.z, bq.w, dq.x}, mxhi[3] = {dq.y, dq.z, dq.w};
+          const float mnhi[3] = {a.x, a.y, a.z}, mxlo[3] = {a.w, bq.x, bq.y};
+          const float mnlo[3] = {bq.z, bq.w, dq.x}, mxhi[3] = {dq.y, dq.z, dq.w};
           if (pass == 0) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
@@ -890,8 +891,8 @@ k_sift_extrema_iv(const float4 *__restrict__ q_pts, const int2 *__restrict__ ite
         const unsigned idx = __float_as_uint(c.w);
         const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | idx;
         const bool other = idx != (unsigned)self;
-        const float mnhi[3] = {a.x, a.y, a.z}, mnlo[3] = {a.w, b.x, b.y};
-        const float mxlo[3] = {b.z, b.w, d.x}, mxhi[3] = {d.y, d.z, d.w};
+        const float mnhi[3] = {a.x, a.y, a.z}, mxlo[3] = {a.w, b.x, b.y};
+        const float mnlo[3] = {b.z, b.w, d.x}, mxhi[3] = {d.y, d.z, d.w};
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
           if (other && mnhi[s] < lo_p[s] && key < vc_min[s]) vc_min[s] = key;
@@ -1018,8 +1019,8 @@ k_sift_extrema_iv(const float4 *__restrict__ q_pts, const int2 *__restrict__ ite
             const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
             const unsigned idx = __float_as_uint(c.w);
             if (idx == (unsigned)self || !(d2 <= guard2 || whole)) continue;
-            const float mnhi[3] = {a.x, a.y, a.z}, mnlo[3] = {a.w, b.x, b.y};
-            const float mxlo[3] = {b.z, b.w, d.x}, mxhi[3] = {d.y, d.z, d.w};
+            const float mnhi[3] = {a.x, a.y, a.z}, mxlo[3] = {a.w, b.x, b.y};
+            const float mnlo[3] = {b.z, b.w, d.x}, mxhi[3] = {d.y, d.z, d.w};
             bool hit = false;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {

@@ -225,3 +225,22 @@ def test_sharded_pairs_gloo(tmp_path, world, mm):
     elif os.path.exists(ref_path):
         assert np.array_equal(np.load(ref_path).view(np.uint32), T0.view(np.uint32))
     assert T0.shape == (4, 4, 4) and np.any(T0)
+
+
+def test_committed_counters_belong_to_the_library_in_the_tree():
+    """The roofline of bench.py's line uses the PMC / SQ counters of the newest profiles/r*_traffic.json only for kernels whose
+    machine code in libmm3d.so is what the counters were collected on (bench.kernel_source_hash: a hash of the kernel's
+    device functions out of the library's gfx950 code objects).  Round 5 ended with a source commit AFTER its last profile and
+    the driver's line fell back to the HBM figure with every counter stale.  This test fails in that state: re-run
+    scripts/profile_round.sh + scripts/assemble_profiles.py as the last act after the last kernel change."""
+    import glob
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+    doc = json.load(open(latest))
+    hashes = doc.get("source_sha256", {})
+    assert hashes, f"{latest} carries no kernel hashes"
+    # a comment edit changes no hash: the hash is of the code object, not of the sources
+    stale = {k: (v, bench.kernel_source_hash(k)) for k, v in hashes.items() if bench.kernel_source_hash(k) != v}
+    assert not stale, f"counters of {os.path.basename(latest)} are stale for {sorted(stale)}: profile again (scripts/profile_round.sh)"

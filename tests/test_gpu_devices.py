@@ -133,3 +133,24 @@ def test_a_process_that_loads_a_second_rccl_afterwards_exits_cleanly():
                                                   "import torch; torch.cuda.device_count()\n" if order == "after" else "")
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "done" in r.stdout, (order, r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_a_box_without_rccl_gets_an_error_not_a_crash():
+    """mm3d_create_devices on a machine whose librccl cannot be loaded must return MM3D_EDEVICE with the loader's reason
+    (round 5 built the message from two dlerror() calls -- the second returns NULL -- and the process died in strlen).
+    MM3D_RCCL_LIB names the library to load; a file that does not exist is the "no RCCL here" case.  In a child process: the
+    binding is made once per process."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import __graft_entry__ as ge\nmm = ge.load()\n"
+            "try:\n    mm.Context(devices=[0])\n    print('created')\n"
+            "except mm.Mm3dError as e:\n    print('refused:', e)\n") % root
+    env = dict(os.environ, MM3D_RCCL_LIB="/nonexistent/librccl_missing.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert "refused:" in r.stdout and "librccl could not be loaded" in r.stdout and "librccl_missing" in r.stdout, r.stdout[-800:]
+    # and a one-device context made by mm3d_create never asks for the library at all
+    code2 = ("import sys; sys.path.insert(0, %r)\nimport __graft_entry__ as ge\nmm = ge.load()\nc = mm.Context(0); c.close(); print('plain ok')\n") % root
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "plain ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
