@@ -109,7 +109,7 @@ int mm3d_device_count(const mm3d_ctx *ctx);          /* 1 for a context made by 
 int mm3d_device_at(const mm3d_ctx *ctx, int i);      /* the i-th device of the list, or MM3D_EINVAL */
 int mm3d_devices_use_rccl(const mm3d_ctx *ctx);      /* 1: pair records travel through ncclAllGather; 0: plain context or the test hook */
 void mm3d_destroy(mm3d_ctx *ctx);
-const char *mm3d_last_error(const mm3d_ctx *ctx);
+const char *mm3d_last_error(const mm3d_ctx *ctx);   /* ctx == NULL: why this thread's last mm3d_create / mm3d_create_devices failed */
 /* diagnostics of the most recent ICP run on this context (pcl::Registration::nr_iterations_, converged_) */
 int mm3d_last_icp_iterations(const mm3d_ctx *ctx);
 int mm3d_last_icp_converged(const mm3d_ctx *ctx);

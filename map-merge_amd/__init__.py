@@ -151,8 +151,9 @@ class Context:
             arr = (C.c_int * max(len(devices), 1))(*devices)
             st = lib().mm3d_create_devices(arr, len(devices), C.byref(self._h))
             if st != 0:
-                raise Mm3dError(st, f"mm3d_create_devices({devices}) failed: bad list, a device twice, no such device, or RCCL could not "
-                                    "create its communicators (there is no CPU path)")
+                why = (lib().mm3d_last_error(None) or b"").decode()
+                raise Mm3dError(st, f"mm3d_create_devices({devices}) failed: {why or 'bad list, a device twice, no such device, or RCCL could not create its communicators'} "
+                                    "(there is no CPU path)")
             device = devices[0]
         else:
             st = lib().mm3d_create(int(device), C.byref(self._h))

@@ -183,13 +183,22 @@ size_t mm3d_params_to_string(const mm3d_params *p, char *buf, size_t cap)
 }
 
 // ---------------------------------------------------------------- context
+static std::string &create_error()
+{
+  static thread_local std::string e = "null context";
+  return e;
+}
+
 int mm3d_create(int device, mm3d_ctx **out)
 {
   if (!out) return MM3D_EINVAL;
   *out = nullptr;
   int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return MM3D_EDEVICE;
-  if (hipSetDevice(device) != hipSuccess) return MM3D_EDEVICE;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+    create_error() = "mm3d_create: no HIP device " + std::to_string(device) + " (" + std::to_string(count) + " visible)";
+    return MM3D_EDEVICE;
+  }
+  if (hipSetDevice(device) != hipSuccess) { create_error() = "mm3d_create: hipSetDevice failed"; return MM3D_EDEVICE; }
   auto *c = new (std::nothrow) mm3d_ctx();
   if (!c) return MM3D_ENOMEM;
   c->device = device;
@@ -218,8 +227,10 @@ int mm3d_create_devices(const int *devices, int n_devices, mm3d_ctx **out)
       root->device_set = device_set_create(devices, n_devices);
     } catch (const Error &e) {
       st = e.status;
+      create_error() = e.what();
     } catch (...) {
       st = MM3D_EDEVICE;
+      create_error() = "mm3d_create_devices: unknown failure";
     }
   }
   if (st != MM3D_OK) { mm3d_destroy(root); return st; }
@@ -284,7 +295,8 @@ void mm3d_destroy(mm3d_ctx *ctx)
   delete ctx;
 }
 
-const char *mm3d_last_error(const mm3d_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+// (a null context: why the calling thread's last mm3d_create / mm3d_create_devices failed -- there is no context to ask then)
+const char *mm3d_last_error(const mm3d_ctx *ctx) { return ctx ? ctx->err.c_str() : create_error().c_str(); }
 int mm3d_last_icp_iterations(const mm3d_ctx *ctx) { return ctx ? ctx->last_icp_iterations : 0; }
 int mm3d_last_icp_converged(const mm3d_ctx *ctx) { return ctx ? ctx->last_icp_converged : 0; }
 int mm3d_last_run_stage_seconds(const mm3d_ctx *ctx, double *features_s, double *total_s)

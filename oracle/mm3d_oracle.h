@@ -93,6 +93,13 @@ int mo_keypoints_sift(const mo_point *in, int n, double min_scale,
  * inside 3 sigma, the 25 nearest neighbours.  Everything malloc'ed (mo_free). */
 int mo_sift_octave_debug(const mo_point *in, int n, double min_scale, int octave, int nr_scales_per_octave,
                          mo_point **cloud_out, int *n_out, float **dog_out, double **resp_out, int **cnt_out, int **knn_out);
+/* exposure census of the audit list (o_audit.c; scripts/audit_exposure.py) */
+void mo_audit_radius_ties(const mo_point *pts, int n, double radius, long long out[4]);
+void mo_audit_desc_knn_unrolled(const float *a, int na, const float *b, int nb, int dim, int k, int *idx, float *d2);
+void mo_audit_umeyama_order(const float *src, const float *dst, int n, int order, float T[16]);
+int mo_audit_icp_correspondences(const mo_point *src, int ns, const mo_point *tgt, int nt, const float guess[16], double max_corr,
+                                 float *src_out, float *dst_out);
+void mo_umeyama_core_f32(const float sg[9], const float sm[3], const float dm[3], float one_over_n, float T[16]);
 /* detectKeypoints(HARRIS): R/src/features.cpp:64-83 (o_harris.c).  Returns the count; keypoints (refined xyz,
  * rgba = 0) malloc'ed into *out; kept_idx (optional, malloc'ed) = the source indices; response_out
  * (optional, n floats) = the Harris response of every point. */

@@ -124,6 +124,8 @@ static void umeyama_core(const double sigma[9], const double src_mean[3], const 
     t[i] = dst_mean[i] - (R[i * 3 + 0] * src_mean[0] + R[i * 3 + 1] * src_mean[1] + R[i * 3 + 2] * src_mean[2]);
 }
 
+void mo_umeyama_core_f32(const float sg[9], const float sm[3], const float dm[3], float one_over_n, float T[16]);
+
 /* float instantiation: means, demeaning and sigma accumulate in float, sequentially */
 void mo_umeyama_f32(const float *src, const float *dst, int n, float T[16])
 {
@@ -139,6 +141,12 @@ void mo_umeyama_f32(const float *src, const float *dst, int n, float T[16])
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) sg[r * 3 + c] += d[r] * s[c];
   }
+  mo_umeyama_core_f32(sg, sm, dm, one_over_n, T);
+}
+
+/* the algebra behind the float sums (also used by o_audit.c, which forms the sums in other orders) */
+void mo_umeyama_core_f32(const float sg[9], const float sm[3], const float dm[3], float one_over_n, float T[16])
+{
   double sigma[9], smd[3], dmd[3], R[9], t[3];
   for (int i = 0; i < 9; ++i) sigma[i] = (double)(sg[i] * one_over_n);
   for (int a = 0; a < 3; ++a) { smd[a] = sm[a]; dmd[a] = dm[a]; }
