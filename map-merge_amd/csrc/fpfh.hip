@@ -109,6 +109,92 @@ __device__ __forceinline__ int bin_of(double x)
   return h >= kBins ? kBins - 1 : h;
 }
 
+// ---- the three BINS of a pair, certified (round 6) ------------------------------------------------------------------
+// A pair's features only matter through floor(11 (f1 + pi) / (2 pi)), floor(11 (f2 + 1) / 2), floor(11 (f3 + 1) / 2) and
+// the "switch p1 and p2" decision acos|a1| > acos|a2|.  pair_features above reproduces the CPU path's floats -- restated
+// glibc atan2f, two square roots, five IEEE divisions, double bins: ~300 instructions.  This evaluates the same geometry
+// in plain f32 (v_rsq / v_rcp, fma dot products, a degree-15 odd polynomial for the arc tangent: ~150 instructions) TOGETHER
+// WITH a bound on how far each feature can lie from the CPU path's float, and answers only when no feature is within its
+// bound of a bin edge, the two angles are not within theirs of a tie, and nothing is near a degenerate exit.  Everything
+// else -- about one pair in 10^4 -- takes pair_features.  The bins it answers with are the CPU path's.
+//
+// Bounds (u = 2^-24; both chains against the REAL function of the same float inputs d = p2 - p1, n1, n2 -- the subtraction
+// is the same IEEE operation on both sides; |n1|, |n2| within 1 % of 1 is required; kappa = |d| |n1| / |d x n1| >= 1):
+//   a_k = n_k . d / |d|      CPU: 3 roundings in the dot product (<= 3 u |n||d|), sqrt of a 3-rounding sum 2.5 u, division 1 u
+//                            -> 6.5 u;  here: fma dot 3 u, v_rsq (1 ulp) of a 3 u sum 3.5 u, product 1 u -> 7.5 u;  sum 14 u
+//   v = d x n1               each component within 2 u |d||n1| on both sides: |dv| <= 3.5 u |d||n1| = 3.5 u kappa |v|
+//   f2 = v^ . n2             CPU: v^ within (7 kappa + 3.5) u, dot 3 u -> (10.5 kappa + 3) u;  here (7 kappa + 7.5) u
+//   y = n2 . (n1 x v^), x = n1 . n2     CPU within 17 kappa u and 3 u;  here within (7 kappa + 11) u and 3 u
+//   f1 = atan2(y, x)         a perturbation delta of (x, y) with delta <= rho / 2, rho = |(x, y)|, turns the angle by at most
+//                            1.6 delta / rho;  glibc's atan2f within 1 ulp (<= 5 u);  the polynomial arc tangent below within
+//                            10 u in all (fit 0.04 u, float evaluation, the two folds; tests/test_gpu_parity.py checks it)
+// The constants below are TWICE these sums.  In bin units t = 11 (f + c) / w the float evaluation of t adds <= 22 u.
+__device__ __forceinline__ float atan_poly01(float z)      // atan(z) on [0, 1]: z P(z^2), |error| < 4e-8 before rounding
+{
+  const float w = z * z;
+  float p = -0.004054537974298f;
+  p = fmaf(p, w, 0.02186284214258194f);
+  p = fmaf(p, w, -0.055912140756845474f);
+  p = fmaf(p, w, 0.09642181545495987f);
+  p = fmaf(p, w, -0.13908623158931732f);
+  p = fmaf(p, w, 0.19946563243865967f);
+  p = fmaf(p, w, -0.33329859375953674f);
+  p = fmaf(p, w, 0.9999993443489075f);
+  return p * z;
+}
+__device__ __forceinline__ float atan2_fast(float y, float x)
+{
+  const float ay = fabsf(y), ax = fabsf(x);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float r = atan_poly01(mn * __builtin_amdgcn_rcpf(mx));
+  r = ay > ax ? 1.57079637f - r : r;
+  r = x < 0.0f ? 3.14159274f - r : r;
+  return copysignf(r, y);
+}
+
+__device__ __forceinline__ bool pair_bins_fast(const float4 &p1, const float4 &n1, const float4 &p2, const float4 &n2, int &h1, int &h2, int &h3)
+{
+  constexpr float U = 0x1p-24f;
+  const float dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
+  const float s = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  const float inv = __builtin_amdgcn_rsqf(s);
+  const float A2 = fmaf(n1.z, n1.z, fmaf(n1.y, n1.y, n1.x * n1.x)), B2 = fmaf(n2.z, n2.z, fmaf(n2.y, n2.y, n2.x * n2.x));
+  const float a1 = fmaf(n1.z, dz, fmaf(n1.y, dy, n1.x * dx)) * inv, a2 = fmaf(n2.z, dz, fmaf(n2.y, dy, n2.x * dx)) * inv;
+  const float m1 = fabsf(a1), m2 = fabsf(a2);
+  // (every condition is of the form "value > bound": a NaN anywhere answers false)
+  bool ok = s > 1e-12f && s < 1e12f && A2 > 0.98f && A2 < 1.02f && B2 > 0.98f && B2 < 1.02f;
+  ok = ok && fabsf(m1 - m2) > 64.0f * U && fmaxf(m1, m2) < 1.0f - 1e-5f;
+  const bool sw = m1 < m2;                       // acos|a1| > acos|a2|: certain, by the margin
+  const float ax = sw ? n2.x : n1.x, ay = sw ? n2.y : n1.y, az = sw ? n2.z : n1.z;
+  const float bx = sw ? n1.x : n2.x, by = sw ? n1.y : n2.y, bz = sw ? n1.z : n2.z;
+  const float ex = sw ? -dx : dx, ey = sw ? -dy : dy, ez = sw ? -dz : dz;
+  const float f3 = sw ? -a2 : a1;
+  const float vx = fmaf(ey, az, -(ez * ay)), vy = fmaf(ez, ax, -(ex * az)), vz = fmaf(ex, ay, -(ey * ax));
+  const float v2 = fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+  ok = ok && v2 > s * 1e-6f;                     // kappa < 1000: far from the "v_norm == 0" exit
+  const float rv = __builtin_amdgcn_rsqf(v2);
+  const float kappa = (s * inv) * rv * 1.02f;    // |d| |n1| / |v|, |n1| <= 1.01
+  const float f2 = fmaf(vz, bz, fmaf(vy, by, vx * bx)) * rv;
+  const float wx = fmaf(ay, vz, -(az * vy)), wy = fmaf(az, vx, -(ax * vz)), wz = fmaf(ax, vy, -(ay * vx));
+  const float y = fmaf(wz, bz, fmaf(wy, by, wx * bx)) * rv;
+  const float x = fmaf(az, bz, fmaf(ay, by, ax * bx));
+  const float f1 = atan2_fast(y, x);
+  const float irho = __builtin_amdgcn_rsqf(fmaf(y, y, x * x));
+  // bin coordinates and their bounds
+  const float t1 = fmaf(f1, 1.75070429f, 5.5f);                    // 11 d_pi f1 + 11 d_pi pi, d_pi = float(1 / (2 pi_f))
+  const float t2 = fmaf(f2, 5.5f, 5.5f), t3 = fmaf(f3, 5.5f, 5.5f);
+  const float e1 = ((80.0f * kappa + 40.0f) * irho + 30.0f) * (1.76f * U) + 24.0f * U;
+  const float e2 = (220.0f * kappa + 144.0f) * U;
+  const float e3 = 192.0f * U;
+  const float g1 = floorf(t1), g2 = floorf(t2), g3 = floorf(t3);
+  const float r1 = t1 - g1, r2 = t2 - g2, r3 = t3 - g3;
+  ok = ok && fminf(r1, 1.0f - r1) > e1 && fminf(r2, 1.0f - r2) > e2 && fminf(r3, 1.0f - r3) > e3;
+  h1 = min(max((int)g1, 0), kBins - 1);
+  h2 = min(max((int)g2, 0), kBins - 1);
+  h3 = min(max((int)g3, 0), kBins - 1);
+  return ok;
+}
+
 // 2. SPFH, wave-cooperative: a wave owns one compact patch of the surface (<= 64 points in Hilbert
 // order, the lanes that belong to the support set are live), streams the box of cells those lanes
 // can reach through LDS together with the candidates' normals, and bins the pairs inside every live
@@ -142,11 +228,16 @@ constexpr int kSpfhPool = MM3D_SPFH_POOL;
 #endif
 constexpr int kSpfhWaves = MM3D_SPFH_WAVES;
 #ifdef MM3D_SPFH_STATS
-__device__ unsigned long long g_spfh_stats[8];   // 0 waves, 1 candidates tested per wave, 2 in-radius hits, 3 pooled hits, 4 second votes, 5 ties, 6 live points
+__device__ unsigned long long g_spfh_stats[16];  // 0 waves, 1 candidates tested per wave, 2 in-radius hits, 3 pooled hits, 4 second votes, 5 ties, 6 live points,
+                                                 // 7 pooled hits the certified bins refused, 8 (-DMM3D_SPFH_VERIFY) certified bins that differ from the exact ones
 #define MM3D_SPFH_STAT(i_, v_) atomicAdd(&g_spfh_stats[i_], (unsigned long long)(v_))
 #else
 #define MM3D_SPFH_STAT(i_, v_)
 #endif
+#ifndef MM3D_SPFH_FAST
+#define MM3D_SPFH_FAST 1
+#endif
+constexpr bool kSpfhFast = MM3D_SPFH_FAST != 0;   // 0: every pair through pair_features (the A/B)
 constexpr int kSpfhT = 64 * kSpfhWaves;       // points per block
 constexpr int kSpfhNone = 0xFFFF;             // a candidate that is not a live point of the block: above every offset
 __global__ void __launch_bounds__(kSpfhT)
@@ -265,18 +356,38 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
             const int per = (n + kWave - 1) / kWave;
             for (int i = 0; i < per; ++i) {
               const int e = lane * per + i;
-              if (e < n) {
-                const unsigned ent = pool[e];
-                const int o = wave_off0 + (int)(ent >> 6), k = (int)(ent & 63u);
-                const float4 qo = s_q[o], no = s_nq[o];
-                const float4 p = sp[k], np = sn[k];
-                const int c = __float_as_int(p.w);
-                float f1, f2, f3;
-                bool sym;
-                pair_features(qo, no, p, np, f1, f2, f3, &sym);
-                int h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
-                int h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
-                int h3 = bin_of(kBins * (((double)f3 + 1.0) * 0.5));
+              const bool act = e < n;
+              const unsigned ent = act ? pool[e] : 0u;
+              const int o = wave_off0 + (int)(ent >> 6), k = (int)(ent & 63u);
+              const float4 qo = s_q[o], no = s_nq[o];
+              const float4 p = sp[k], np = sn[k];
+              const int c = __float_as_int(p.w);
+              // the certified bins where they can be had (nearly always); a lane that is refused one evaluates the CPU path's
+              // floats (the wave waits for it: about one iteration in a hundred)
+              int h1, h2, h3;
+              bool sym = true;                       // (certified: the angles are clear of a tie, so the exchanged call gives the same bits)
+              bool ok = true;
+              if (kSpfhFast) ok = pair_bins_fast(qo, no, p, np, h1, h2, h3);
+              else ok = false;
+              MM3D_SPFH_STAT(7, (act && !ok) ? 1 : 0);
+#ifdef MM3D_SPFH_VERIFY
+              const bool cert = ok;
+              const int c1 = h1, c2 = h2, c3 = h3;
+              ok = false;
+#endif
+              if (ballot(act && !ok)) {
+                if (act && !ok) {
+                  float f1, f2, f3;
+                  pair_features(qo, no, p, np, f1, f2, f3, &sym);
+                  h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
+                  h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
+                  h3 = bin_of(kBins * (((double)f3 + 1.0) * 0.5));
+                }
+              }
+#ifdef MM3D_SPFH_VERIFY
+              if (act && cert && (c1 != h1 || c2 != h2 || c3 != h3 || !sym)) MM3D_SPFH_STAT(8, 1);
+#endif
+              if (act) {
                 const unsigned one = 1u << ((o & 1) << 4);
                 atomicAdd(&hist[h1][o >> 1], one);
                 atomicAdd(&hist[kBins + h2][o >> 1], one);
@@ -285,6 +396,7 @@ k_spfh(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_i
                   MM3D_SPFH_STAT(4, 1);
                   if (!sym) {
                     MM3D_SPFH_STAT(5, 1);
+                    float f1, f2, f3;
                     pair_features(p, np, qo, no, f1, f2, f3);
                     h1 = bin_of(kBins * (((double)f1 + 3.14159265358979323846) * (double)d_pi));
                     h2 = bin_of(kBins * (((double)f2 + 1.0) * 0.5));
@@ -512,7 +624,7 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
 extern "C" void mm3d_debug_spfh_stats(unsigned long long *out, int reset)
 {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mm3d::g_spfh_stats), sizeof(unsigned long long) * 8);
-  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mm3d::g_spfh_stats), z, sizeof(z)); }
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mm3d::g_spfh_stats), sizeof(unsigned long long) * 16);     // (out: 16 words)
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mm3d::g_spfh_stats), z, sizeof(z)); }
 }
 #endif
