@@ -1533,42 +1533,30 @@ struct FailBarrier {
 };
 }  // namespace
 
-static void estimate_maps_devices(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, const mm3d_params *params, float *out_T,
-                                  size_t *n_out, mm3d_pair_result *pairs_out, size_t *n_pairs_out)
+// ---- one process, several devices --------------------------------------------------------------------------------------
+// What every device of a run shares on the host (one process: one address space).
+struct DevicesRun {
+  std::vector<mm3d_ctx *> roots;
+  size_t D = 0, n = 0;
+  std::vector<std::unique_ptr<mm3d_shard>> sh;            // per device: its own maps and its copies of the others'
+  std::vector<std::vector<mm3d_pair_result>> rec;         // per device, by live-pair number
+  std::vector<std::vector<unsigned char>> mine;
+  std::vector<size_t> np;
+  std::vector<double> t_feat, t_exch, t_pairs;
+  std::chrono::steady_clock::time_point t_start;
+  double since_start() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); }
+};
+
+// Round 5's form: three lock-step stages -- every device's features, barrier, every device pulls every other map, every
+// device replays the WHOLE rand() stream for itself and runs its pairs, barrier.  Kept as the fallback of the pipelined form
+// below (a map without keypoints falsifies its assumptions) and as its A/B (MM3D_DEVICES_STAGED=1).
+static void devices_run_staged(mm3d_ctx *ctx, DevicesRun &R, const mm3d_cloud_view *clouds, const mm3d_params *params, size_t max_pairs)
 {
-  std::vector<mm3d_ctx *> roots{ctx};
-  roots.insert(roots.end(), ctx->peers.begin(), ctx->peers.end());
-  const size_t D = roots.size();
-  const size_t max_pairs = n * (n - 1) / 2;
-  if (D == 1) {
-    // a list of one device: nothing to shard, so the job runs as on a plain context (pipelined over the streams, not in
-    // barriered stages) -- and its pair records still travel through the communicator's all-gather (a world of one), so that
-    // the collective of the path is exercised wherever a device list is used
-    std::vector<mm3d_pair_result> local(std::max<size_t>(max_pairs, 1));
-    size_t np = 0;
-    if (!ctx->helpers.empty()) estimate_maps_streams(ctx, clouds, n, params, out_T, n_out, local.data(), &np);
-    else estimate_maps_sequential(ctx, clouds, n, params, out_T, n_out, local.data(), &np);
-    const double t_before = ctx->last_total_s;
-    std::vector<std::vector<mm3d_pair_result>> send(1);
-    send[0].assign(local.begin(), local.begin() + (ptrdiff_t)np);
-    std::vector<mm3d_pair_result> gathered;
-    ctx->last_gather_s = gather_pair_records(ctx->device_set, roots, send, np, gathered);
-    ctx->last_exchange_s = ctx->last_features_s;
-    ctx->last_pairs_s = t_before;
-    if (pairs_out && np) std::memcpy(pairs_out, gathered.data(), np * sizeof(mm3d_pair_result));
-    if (n_pairs_out) *n_pairs_out = np;
-    const int st = global_transforms(gathered.data(), np, params->confidence_threshold, n, out_T, n_out);   // (from what the gather delivered)
-    if (st != MM3D_OK) throw Error(st, "computeGlobalTransforms failed");
-    ctx->last_total_s = t_before + ctx->last_gather_s;
-    return;
-  }
-  const auto t_start = std::chrono::steady_clock::now();
-  auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
-  std::vector<std::unique_ptr<mm3d_shard>> sh(D);
-  std::vector<std::vector<mm3d_pair_result>> rec(D, std::vector<mm3d_pair_result>(max_pairs));
-  std::vector<std::vector<unsigned char>> mine(D, std::vector<unsigned char>(max_pairs, 0));
-  std::vector<size_t> np(D, 0);
-  std::vector<double> t_feat(D, 0.0), t_exch(D, 0.0), t_pairs(D, 0.0);
+  std::vector<mm3d_ctx *> &roots = R.roots;
+  const size_t D = R.D, n = R.n;
+  auto &sh = R.sh; auto &rec = R.rec; auto &mine = R.mine; auto &np = R.np;
+  auto &t_feat = R.t_feat; auto &t_exch = R.t_exch; auto &t_pairs = R.t_pairs;
+  auto since_start = [&] { return R.since_start(); };
   FailBarrier bar(D);
   std::mutex err_mu;
   std::exception_ptr first_error;
@@ -1615,6 +1603,9 @@ static void estimate_maps_devices(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
       t_exch[d] = since_start();
       shard_pairs_impl(sh[d].get(), rec[d].data(), mine[d].data(), max_pairs, &np[d]);
       t_pairs[d] = since_start();
+      static const bool dbg = [] { const char *e = getenv("MM3D_DEVICES_DEBUG"); return e && atoi(e); }();
+      if (dbg) fprintf(stderr, "mm3d devices (staged): dev%zu features %.2f ms, pulls done %.2f ms, pairs done %.2f ms (its own replay of every pair inside)\n", d,
+                       1e3 * t_feat[d], 1e3 * t_exch[d], 1e3 * t_pairs[d]);
       // an owner's maps are read by its peers' pulls: nobody leaves (and nothing is freed) before everybody has pulled
       bar.wait();
     } catch (...) {
@@ -1639,6 +1630,309 @@ static void estimate_maps_devices(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
     (void)hipSetDevice(ctx->device);
     std::rethrow_exception(first_error);
   }
+}
+
+// Round 6: the same split -- features by owner, pairs by target owner, peer copies in between -- WITHOUT the lock-step and
+// WITHOUT D private replays of the rand() stream:
+//   * ONE table of generator states (state_at[q] = the state before pair q of the reference's loop), filled once by one host
+//     thread as the sources' keypoints appear (the draws of a pair depend on its source keypoints only) and read by every
+//     device.  Before, each device replayed all n (n - 1) / 2 pairs itself: 8.5 us x 2 016 pairs = 17 ms of serial host work
+//     per device on 64 x 50 k maps, the size of a device's whole pair stage at N = 8 ("host RNG replay dominates").
+//   * per-map readiness: a map is published (a flag under the run's mutex, behind its owner's full stream wait) the moment its
+//     owner has finished it; any device pulls it then (hipMemcpyPeerAsync on its own stream) and starts a pair as soon as the
+//     pair's two maps are on the device and the pair's state is in the table.  Only the end of the call waits for everybody
+//     (an owner's maps are read by its peers' pulls until then).
+// The table assumes that a target which does not exist yet will have keypoints (as estimate_maps_streams does); the
+// assumptions are checked when every map exists.  Returns false when one was wrong: the caller runs the staged form.
+static bool devices_run_pipelined(mm3d_ctx *ctx, DevicesRun &R, const mm3d_cloud_view *clouds, const mm3d_params *params)
+{
+  std::vector<mm3d_ctx *> &roots = R.roots;
+  const size_t D = R.D, n = R.n;
+  std::vector<std::pair<size_t, size_t>> all;
+  for (size_t i = 0; i + 1 < n; ++i)
+    for (size_t j = i + 1; j < n; ++j) all.emplace_back(i, j);
+  const size_t P = all.size();
+  for (size_t d = 0; d < D; ++d) {
+    R.sh[d].reset(new mm3d_shard());
+    R.sh[d]->ctx = roots[d]; R.sh[d]->rank = (int)d; R.sh[d]->world = (int)D; R.sh[d]->n = n; R.sh[d]->params = *params;
+    R.sh[d]->maps.assign(n, nullptr);
+  }
+  std::mutex mu;                                          // guards everything below but the table
+  std::condition_variable cv;
+  std::vector<char> ready(n, 0);                          // map i is published by its owner
+  std::vector<std::vector<char>> pull_claimed(D, std::vector<char>(n, 0)), have(D, std::vector<char>(n, 0));
+  std::vector<char> claimed(P, 0);
+  std::vector<std::vector<size_t>> own_maps(D), todo(D);  // per device: the maps it owns; the pairs whose target it owns
+  std::vector<size_t> next_own(D, 0);
+  for (size_t i = 0; i < n; ++i) own_maps[(size_t)mm3d_shard_map_owner(i, (int)D)].push_back(i);
+  for (size_t q = 0; q < P; ++q) todo[(size_t)mm3d_shard_map_owner(all[q].second, (int)D)].push_back(q);
+  bool abort = false;
+  std::exception_ptr first_error;
+  std::vector<mm3d_pair_result> rec_all(P);
+  std::vector<char> done(P, 0);
+  // the table
+  std::vector<GlibcRand> state_at(P + 1, ctx->rnd);
+  std::vector<char> assumed_live(P, 0);
+  std::atomic<size_t> known_upto{0};                      // state_at[0 .. known_upto] are final
+  double fill_busy_s = 0.0, fill_done_s = 0.0;            // (the filler thread's alone until it is joined)
+  auto fill_table = [&] {
+    try {
+      for (size_t q = 0; q < P; ++q) {
+        const size_t a = all[q].first, b = all[q].second;
+        const mm3d_map *ma = nullptr;
+        bool live = false;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return abort || ready[a]; });
+          if (abort) return;
+          ma = R.sh[(size_t)mm3d_shard_map_owner(a, (int)D)]->maps[a];
+          live = ma->keypoints->n > 0;
+          if (live) {
+            if (ready[b]) live = R.sh[(size_t)mm3d_shard_map_owner(b, (int)D)]->maps[b]->keypoints->n > 0;
+            else assumed_live[q] = 1;
+          }
+        }
+        GlibcRand r = state_at[q];
+        const auto tb = std::chrono::steady_clock::now();
+        // (the host copy of an owner's keypoints was made when the map was prepared: no device is touched here)
+        if (live) pair_rand_replay(r, params->estimation_method, cloud_host(roots[(size_t)mm3d_shard_map_owner(a, (int)D)], ma->keypoints),
+                                   params->inlier_threshold, params->max_iterations);
+        fill_busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count();
+        fill_done_s = R.since_start();
+        state_at[q + 1] = r;
+        known_upto.store(q + 1, std::memory_order_release);
+        if ((q & 7) == 7 || q + 1 == P) { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!first_error) first_error = std::current_exception();
+      abort = true;
+      cv.notify_all();
+    }
+  };
+  struct MapFree {
+    void operator()(mm3d_map *x) const { delete x->points; delete x->keypoints; delete x->desc; delete x; }
+  };
+  auto device_body = [&](size_t d) {
+    mm3d_ctx *root = roots[d];
+    std::unique_lock<std::mutex> peer_lock;
+    if (d > 0) peer_lock = std::unique_lock<std::mutex>(root->mu);
+    const size_t S = root->helpers.size() + 1;
+    try {
+      if (hipSetDevice(root->device) != hipSuccess) throw Error(MM3D_EDEVICE, "hipSetDevice failed");
+      on_streams(root, [&](size_t, mm3d_ctx *c, const std::atomic<bool> &failed) {
+        // 1. this device's own maps, in index order
+        for (;;) {
+          size_t i;
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (abort || failed.load() || next_own[d] >= own_maps[d].size()) break;
+            i = own_maps[d][next_own[d]++];
+          }
+          std::unique_ptr<mm3d_cloud> raw(cloud_from_memory(c, clouds[i].points, clouds[i].points ? clouds[i].n : 0,
+                                                            clouds[i].stride ? clouds[i].stride : 16,
+                                                            clouds[i].stride ? clouds[i].rgba_offset : 12));
+          c->private_objects = true;
+          std::unique_ptr<mm3d_map, MapFree> held(map_features_impl(c, raw.get(), params));
+          raw.reset();
+          map_prepare_impl(c, held.get(), params);          // this device is the map's target-side owner
+          c->private_objects = false;
+          c->sync();                                        // complete in this device's memory BEFORE anybody is told
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            R.sh[d]->maps[i] = held.release();
+            have[d][i] = 1;
+            ready[i] = 1;
+            R.t_feat[d] = std::max(R.t_feat[d], R.since_start());
+          }
+          cv.notify_all();
+        }
+        // 2. pulls and pairs, whatever can start
+        std::vector<size_t> batch;
+        std::vector<PairWork> work;
+        for (;;) {
+          size_t pull = n;
+          batch.clear();
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+              if (abort || failed.load()) return;
+              // a published map this device does not hold yet: first, it unlocks pairs
+              for (size_t i = 0; i < n && pull == n; ++i)
+                if (ready[i] && !have[d][i] && !pull_claimed[d][i]) pull = i;
+              if (pull != n) { pull_claimed[d][pull] = 1; break; }
+              // pairs of this device whose two maps are here and whose state is in the table: a batch shares its target
+              const size_t known = known_upto.load(std::memory_order_acquire);
+              size_t avail = 0, left = 0;
+              for (size_t q : todo[d]) {
+                if (claimed[q]) continue;
+                ++left;
+                if (q <= known && have[d][all[q].first] && have[d][all[q].second]) ++avail;
+              }
+              if (avail) {
+                const size_t take = std::min(pair_batch_knob(), std::max<size_t>(1, (size_t)((double)avail / (pair_share_knob() * (double)S))));
+                size_t target = n;
+                for (size_t q : todo[d]) {
+                  if (batch.size() >= take) break;
+                  if (claimed[q] || q > known || !have[d][all[q].first] || !have[d][all[q].second]) continue;
+                  if (target != n && all[q].second != target) continue;
+                  target = all[q].second;
+                  claimed[q] = 1;
+                  batch.push_back(q);
+                }
+                break;
+              }
+              bool pulls_left = false;
+              for (size_t i = 0; i < n; ++i) pulls_left = pulls_left || (!have[d][i] && !pull_claimed[d][i]);
+              if (!left && !pulls_left) return;           // nothing more for this worker, ever
+              cv.wait(lk);
+            }
+          }
+          if (pull != n) {
+            const size_t o = (size_t)mm3d_shard_map_owner(pull, (int)D);
+            const mm3d_map *src = R.sh[o]->maps[pull];    // (published: complete, and not freed before every thread has joined)
+            const int src_dev = roots[o]->device;
+            c->private_objects = true;
+            std::unique_ptr<mm3d_cloud> pts(cloud_clone_from_peer(c, src->points, src_dev));
+            std::unique_ptr<mm3d_cloud> kp(cloud_clone_from_peer(c, src->keypoints, src_dev));
+            std::unique_ptr<mm3d_desc> desc(desc_clone_from_peer(c, src->desc, src_dev));
+            if (pts->n) cloud_hilbert(c, pts.get());
+            if (kp->n) cloud_hilbert(c, kp.get());
+            (void)cloud_host(c, kp.get());
+            c->private_objects = false;
+            c->sync();
+            auto *m = new mm3d_map();
+            m->points = pts.release(); m->keypoints = kp.release(); m->desc = desc.release();
+            {
+              std::lock_guard<std::mutex> lk(mu);
+              R.sh[d]->maps[pull] = m;
+              have[d][pull] = 1;
+              R.t_exch[d] = std::max(R.t_exch[d], R.since_start());
+            }
+            cv.notify_all();
+            continue;
+          }
+          work.clear();
+          for (size_t q : batch) {
+            const mm3d_map *ms = R.sh[d]->maps[all[q].first], *mt = R.sh[d]->maps[all[q].second];
+            if (ms->keypoints->n > 0 && mt->keypoints->n > 0) {
+              rec_all[q].source_idx = all[q].first;
+              rec_all[q].target_idx = all[q].second;
+              work.push_back(PairWork{ms, mt, &rec_all[q], state_at[q]});
+              done[q] = 1;                                // (distinct q per worker; read after the joins)
+            }
+          }
+          if (!work.empty()) pairs_estimate_batch(c, work.data(), work.size(), params);
+          { std::lock_guard<std::mutex> lk(mu); R.t_pairs[d] = std::max(R.t_pairs[d], R.since_start()); }
+        }
+      });
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!first_error) first_error = std::current_exception();
+      abort = true;
+      cv.notify_all();
+    }
+  };
+  {
+    std::thread filler(fill_table);
+    std::vector<std::thread> threads;
+    for (size_t d = 1; d < D; ++d) threads.emplace_back(device_body, d);
+    device_body(0);
+    for (auto &t : threads) t.join();
+    { std::lock_guard<std::mutex> lk(mu); if (first_error) abort = true; }
+    cv.notify_all();
+    filler.join();
+  }
+  (void)hipSetDevice(ctx->device);
+  if (first_error) {
+    for (size_t d = 0; d < D; ++d) {                      // drain before the shards (and their maps) go
+      (void)hipSetDevice(roots[d]->device);
+      (void)stream_wait(roots[d]->stream);
+      for (mm3d_ctx *h : roots[d]->helpers) (void)stream_wait(h->stream);
+    }
+    (void)hipSetDevice(ctx->device);
+    std::rethrow_exception(first_error);
+  }
+  static const bool dbg = [] { const char *e = getenv("MM3D_DEVICES_DEBUG"); return e && atoi(e); }();
+  if (dbg) {
+    fprintf(stderr, "mm3d devices (pipelined): %zu devices, %zu maps, %zu pairs; ONE rand() table: %.2f ms of replay on one host thread, complete %.2f ms into the call "
+            "(0 ms of replay on the devices' threads);", D, n, P, 1e3 * fill_busy_s, 1e3 * fill_done_s);
+    for (size_t d = 0; d < D; ++d) fprintf(stderr, " dev%zu last map %.2f last pull %.2f last pair %.2f ms;", d, 1e3 * R.t_feat[d], 1e3 * R.t_exch[d], 1e3 * R.t_pairs[d]);
+    fprintf(stderr, "\n");
+  }
+  // every map exists: were the table's assumptions right?
+  for (size_t q = 0; q < P; ++q)
+    if (assumed_live[q] && R.sh[0]->maps[all[q].second]->keypoints->n == 0) return false;
+  ctx->rnd = state_at[P];                                 // where the reference's sequential loop leaves the generator
+  // the live pairs in the reference's order, per executing device (what the gather sends)
+  size_t nl = 0;
+  for (size_t q = 0; q < P; ++q) {
+    if (!done[q]) continue;
+    const size_t d = (size_t)mm3d_shard_map_owner(all[q].second, (int)D);
+    for (size_t e = 0; e < D; ++e) {
+      R.rec[e][nl] = mm3d_pair_result{};
+      R.rec[e][nl].source_idx = all[q].first; R.rec[e][nl].target_idx = all[q].second;
+      R.mine[e][nl] = e == d ? 1 : 0;
+    }
+    R.rec[d][nl] = rec_all[q];
+    ++nl;
+  }
+  for (size_t d = 0; d < D; ++d) R.np[d] = nl;
+  return true;
+}
+
+static void estimate_maps_devices(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, size_t n, const mm3d_params *params, float *out_T,
+                                  size_t *n_out, mm3d_pair_result *pairs_out, size_t *n_pairs_out)
+{
+  std::vector<mm3d_ctx *> roots{ctx};
+  roots.insert(roots.end(), ctx->peers.begin(), ctx->peers.end());
+  const size_t D = roots.size();
+  const size_t max_pairs = n * (n - 1) / 2;
+  if (D == 1) {
+    // a list of one device: nothing to shard, so the job runs as on a plain context (pipelined over the streams, not in
+    // barriered stages) -- and its pair records still travel through the communicator's all-gather (a world of one), so that
+    // the collective of the path is exercised wherever a device list is used
+    std::vector<mm3d_pair_result> local(std::max<size_t>(max_pairs, 1));
+    size_t np = 0;
+    if (!ctx->helpers.empty()) estimate_maps_streams(ctx, clouds, n, params, out_T, n_out, local.data(), &np);
+    else estimate_maps_sequential(ctx, clouds, n, params, out_T, n_out, local.data(), &np);
+    const double t_before = ctx->last_total_s;
+    std::vector<std::vector<mm3d_pair_result>> send(1);
+    send[0].assign(local.begin(), local.begin() + (ptrdiff_t)np);
+    std::vector<mm3d_pair_result> gathered;
+    ctx->last_gather_s = gather_pair_records(ctx->device_set, roots, send, np, gathered);
+    ctx->last_exchange_s = ctx->last_features_s;
+    ctx->last_pairs_s = t_before;
+    if (pairs_out && np) std::memcpy(pairs_out, gathered.data(), np * sizeof(mm3d_pair_result));
+    if (n_pairs_out) *n_pairs_out = np;
+    const int st = global_transforms(gathered.data(), np, params->confidence_threshold, n, out_T, n_out);   // (from what the gather delivered)
+    if (st != MM3D_OK) throw Error(st, "computeGlobalTransforms failed");
+    ctx->last_total_s = t_before + ctx->last_gather_s;
+    return;
+  }
+  DevicesRun R;
+  R.roots = roots; R.D = D; R.n = n;
+  R.sh.resize(D);
+  R.rec.assign(D, std::vector<mm3d_pair_result>(max_pairs));
+  R.mine.assign(D, std::vector<unsigned char>(max_pairs, 0));
+  R.np.assign(D, 0);
+  R.t_feat.assign(D, 0.0); R.t_exch.assign(D, 0.0); R.t_pairs.assign(D, 0.0);
+  R.t_start = std::chrono::steady_clock::now();
+  static const bool staged_only = [] { const char *e = getenv("MM3D_DEVICES_STAGED"); return e && atoi(e); }();
+  const GlibcRand rnd0 = ctx->rnd;
+  bool ran = false;
+  if (!staged_only) {
+    ran = devices_run_pipelined(ctx, R, clouds, params);
+    if (!ran) {                                           // a map without keypoints: the table was positioned wrongly after it
+      for (size_t d = 0; d < D; ++d) { (void)hipSetDevice(roots[d]->device); R.sh[d].reset(); }
+      (void)hipSetDevice(ctx->device);
+      ctx->rnd = rnd0;
+    }
+  }
+  if (!ran) devices_run_staged(ctx, R, clouds, params, max_pairs);
+  auto &sh = R.sh; auto &rec = R.rec; auto &mine = R.mine; auto &np = R.np;
+  auto &t_feat = R.t_feat; auto &t_exch = R.t_exch; auto &t_pairs = R.t_pairs;
+  auto since_start = [&] { return R.since_start(); };
   ctx->last_points.assign(n, 0);
   ctx->last_keypoints.assign(n, 0);
   for (size_t i = 0; i < n; ++i) {

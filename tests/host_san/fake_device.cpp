@@ -5,6 +5,8 @@
 // (tests/test_host_sanitizers.py).  The stages compute cheap deterministic placeholders of the right
 // shapes; their numbers mean nothing, only that they depend on nothing but their inputs -- which lets the driver check that
 // sixteen worker threads give the bits of one.  "Device" memory is host memory (fake_hip.cpp).  Nothing here is product code.
+#include <thread>
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -114,6 +116,9 @@ void normals_of_items(Context *, const mm3d_cloud *, const Grid &, double, const
 mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double, int, int, double, double normals_radius, mm3d_normals **normals_out, float)
 {
   if (normals_out) *normals_out = compute_normals(c, points, normals_radius);
+  // TEST KNOB: the map whose filtered cloud has this many points is LATE (its owner publishes it long after the others)
+  if (const char *e = getenv("MM3D_FAKE_LATE_POINTS"))
+    if ((size_t)atol(e) == points->n) std::this_thread::sleep_for(std::chrono::milliseconds(60));
   mm3d_cloud *kp = every(c, points, 23, 5);
   for (size_t i = 0; i < kp->n; ++i) kp->pts.get()[i].w = 0.0f;
   return kp;
