@@ -138,6 +138,11 @@ int mm3d_debug_libm(mm3d_ctx *ctx, int fn, const float *x, const float *y, int n
 int mm3d_debug_sift_cert_octave(mm3d_ctx *ctx, const mm3d_cloud *points, double min_scale, int octave, float *val, float *bound,
                                 size_t capacity, size_t *n_out);
 void mm3d_debug_sift_cert_stats(long long out[8], int reset);
+/* test / study hook: the descriptor k-NN of findFeatureCorrespondences (R/src/matching.cpp:50-75) on raw rows of width `dim`
+ * -- the widths of the reference's descriptors (2, 33, 125, 250, 1344, 1980) and 352, pcl::SHOT352's shape, which the reference
+ * does not bind (dispatch_descriptors.h:44-46 binds SHOT1344) but BASELINE.json configs[3] names: idx / d2 receive na x k
+ * nearest target rows in FLANN's (distance, index) order, exact */
+int mm3d_debug_desc_knn(mm3d_ctx *ctx, const float *a, size_t na, const float *b, size_t nb, int dim, int k, int *idx, float *d2);
 /* SAC-IA draws from libc rand() in the reference (process-global, glibc seed 1).  The context
  * carries its own replay of that generator; mm3d_srand re-seeds it (srand semantics). */
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed);

@@ -454,6 +454,27 @@ static mm3d_desc *desc_from_memory(mm3d_ctx *ctx, const float *data, size_t n, i
   return r.release();
 }
 
+int mm3d_debug_desc_knn(mm3d_ctx *ctx, const float *a, size_t na, const float *b, size_t nb, int dim, int k, int *idx, float *d2)
+{
+  if (!a || !b || !idx || !d2 || na == 0 || nb == 0 || dim < 1 || k < 1) return MM3D_EINVAL;
+  return guarded(ctx, [&] {
+    auto make = [&](const float *data, size_t n) {
+      std::unique_ptr<mm3d_desc> r(new mm3d_desc());
+      r->n = n; r->dim = dim; r->type = -1;
+      r->data = DevBuf<float>(ctx, n * (size_t)dim);
+      MM3D_HIP(hipMemcpyAsync(r->data.get(), data, n * (size_t)dim * sizeof(float), hipMemcpyDefault, ctx->stream));
+      return r;
+    };
+    std::unique_ptr<mm3d_desc> A = make(a, na), B = make(b, nb);
+    DevBuf<int> di;
+    DevBuf<float> dd;
+    desc_knn(ctx, A.get(), B.get(), k, di, dd);
+    MM3D_HIP(hipMemcpyAsync(idx, di.get(), na * (size_t)k * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MM3D_HIP(hipMemcpyAsync(d2, dd.get(), na * (size_t)k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+  });
+}
+
 int mm3d_desc_create(mm3d_ctx *ctx, const float *data, size_t n, int descriptor_type, mm3d_desc **out)
 {
   if (!out || (!data && n)) return MM3D_EINVAL;

@@ -25,6 +25,8 @@
 
 namespace mm3d {
 
+int snb_cu_count(int device);                    // grid.hip
+
 constexpr int kMaxK = 16;
 // The kernels are templates on the descriptor dimension kD: 33 (FPFH) and 125 (PFH) are instantiated.
 // padded contraction length (dimension + the two augmentation columns, even): 36 / 128
@@ -819,6 +821,207 @@ k_knn_mfma_wide(const float *__restrict__ Ap, int na, int na_tiles, const float 
   }
 }
 
+// ---- the wide selector on split-bf16 MFMA (round 6) ------------------------------------------------------------------
+// k_knn_mfma_wide only SELECTS candidates for the exact re-rank below, and it did so on the f32 matrix cores (157 TF/s
+// peak) of a part whose bf16 cores do 2.5 PF/s.  A float splits into two bf16 halves, x = hi + lo + r with |r| <= 2^-18 |x|,
+// and a product into hi hi + hi lo + lo hi (+ terms of 3 * 2^-18 |x y| at most): three v_mfma_f32_32x32x16_bf16 per 16
+// contraction steps instead of eight v_mfma_f32_32x32x2f32, at a sixteenth of the time each -- and the same operand bytes
+// (two bf16 per float).  The error of the approximation against the f32 expansion, <= 3 * 2^-18 |a - mu| |2 (b - mu)| <=
+// 1.2e-5 (|a - mu|^2 + rho^2), is added (doubled and rounded up: 5e-5) to the certificate's epsilon (k_knn_rerank_wide:
+// eps_add); the squared norms ride in three bf16 pieces each against exact ones, so they lose nothing.
+// Operand layout: Xp[((tile * kChunks + chunk) * 64 + lane) * 2 + {0: hi, 1: lo}] = 8 bf16 (16 bytes): row tile * 32 +
+// (lane & 31), contraction indices 16 chunk + 8 (lane >> 5) + 0..7 -- the A / B register layout of the instruction.
+constexpr int knn_kp16(int d) { return (d + 6 + 15) / 16 * 16; }      // + three norm pieces + three ones
+typedef __bf16 knn_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned knn_bf16_rn(float x)               // round to nearest even (finite inputs)
+{
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float knn_bf16_f(unsigned h) { return __uint_as_float(h << 16); }
+
+template <int kD>
+__global__ void k_knn_rownorm_c(const float *__restrict__ X, int n, const float *__restrict__ colsum, float inv_nb, float *__restrict__ nrm)
+{
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  float acc = 0.0f;
+  for (int d = lane; d < kD; d += kWave) { const float xc = X[(size_t)row * kD + d] - colsum[d] * inv_nb; acc = fmaf(xc, xc, acc); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+  if (lane == 0) nrm[row] = acc;
+}
+
+template <int kD>
+__global__ void k_knn_prep_bf(const float *__restrict__ X, int n, int ntiles, int is_target, const float *__restrict__ colsum, float inv_nb,
+                              const float *__restrict__ nrm, uint4 *__restrict__ Xp)
+{
+  constexpr int kChunks = knn_kp16(kD) / 16;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)ntiles * kChunks * 64) return;
+  const int lane = (int)(e & 63);
+  const int chunk = (int)((e >> 6) % kChunks);
+  const int tile = (int)(e / (64 * kChunks));
+  const int row = tile * 32 + (lane & 31);
+  const int k0 = 16 * chunk + 8 * (lane >> 5);
+  unsigned hi[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int kk = k0 + j;
+    float v = 0.0f;
+    bool exact_piece = false;
+    if (row < n) {
+      if (kk < kD) {
+        const float xc = X[(size_t)row * kD + kk] - colsum[kk] * inv_nb;
+        v = is_target ? -2.0f * xc : xc;
+      } else if (kk < kD + 6) {
+        // query: [norm pieces x 3, 1, 1, 1]; target: [1, 1, 1, norm pieces x 3]
+        const int slot = kk - kD;
+        const bool norm_slot = is_target ? slot >= 3 : slot < 3;
+        if (norm_slot) {
+          const float nv = nrm[row];
+          const float p0 = knn_bf16_f(knn_bf16_rn(nv)), p1 = knn_bf16_f(knn_bf16_rn(nv - p0)), p2 = knn_bf16_f(knn_bf16_rn((nv - p0) - p1));
+          const int piece = slot % 3;
+          v = piece == 0 ? p0 : (piece == 1 ? p1 : p2);
+        } else {
+          v = 1.0f;
+        }
+        exact_piece = true;
+      }
+    } else if (is_target) {
+      v = (kk == kD + 3) ? 1e30f : 0.0f;            // padding targets: a'.b' = 1e30, never ahead of a real row
+      exact_piece = true;
+    }
+    const unsigned h = knn_bf16_rn(v);
+    hi[j] = h;
+    lo[j] = exact_piece ? 0u : knn_bf16_rn(v - knn_bf16_f(h));
+  }
+  uint4 H, L;
+  H.x = hi[0] | (hi[1] << 16); H.y = hi[2] | (hi[3] << 16); H.z = hi[4] | (hi[5] << 16); H.w = hi[6] | (hi[7] << 16);
+  L.x = lo[0] | (lo[1] << 16); L.y = lo[2] | (lo[3] << 16); L.z = lo[4] | (lo[5] << 16); L.w = lo[6] | (lo[7] << 16);
+  Xp[e * 2] = H;
+  Xp[e * 2 + 1] = L;
+}
+
+union KnnBfReg { uint4 u; knn_bf16x8 v; };
+
+#ifndef MM3D_KNN_BF_WPE
+#define MM3D_KNN_BF_WPE 1
+#endif
+template <int kD>
+__global__ void __launch_bounds__(256, MM3D_KNN_BF_WPE)
+k_knn_mfma_wide_bf(const uint4 *__restrict__ Ap, int na, int na_tiles, const uint4 *__restrict__ Bp, int nb, int nb_tiles,
+                   float *__restrict__ cand_d, int *__restrict__ cand_i)
+{
+  constexpr int kChunks = knn_kp16(kD) / 16;
+  const int lane = threadIdx.x & 63;
+  const int slice = threadIdx.x >> 6;
+  const int tile_a0 = blockIdx.x * kWideQT;
+  const uint4 *ap[kWideQT];
+#pragma unroll
+  for (int q = 0; q < kWideQT; ++q) ap[q] = Ap + ((size_t)min(tile_a0 + q, na_tiles - 1) * kChunks * 64 + lane) * 2;
+  float ld[kWideQT][kListLen];
+  int li[kWideQT][kListLen];
+#pragma unroll
+  for (int q = 0; q < kWideQT; ++q)
+#pragma unroll
+    for (int s = 0; s < kListLen; ++s) { ld[q][s] = INFINITY; li[q][s] = -1; }
+  // TWO target tiles per wave and pass (round 6: the query operands of a chunk feed eight MFMA chains instead of four -- the
+  // kernel was bound by the L1 traffic of its operands, 10 KB per wave and chunk for twelve instructions)
+  const int part = blockIdx.y, stride = kSlices * (int)gridDim.y;
+  for (int c0 = part * kSlices + slice; c0 < nb_tiles; c0 += 2 * stride) {
+    const int c1 = c0 + stride;
+    const bool two = c1 < nb_tiles;                       // wave-uniform
+    const uint4 *bp0 = Bp + ((size_t)c0 * kChunks * 64 + lane) * 2;
+    const uint4 *bp1 = Bp + ((size_t)(two ? c1 : c0) * kChunks * 64 + lane) * 2;
+    f32x16 acc[2][kWideQT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < kWideQT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][q][r] = 0.0f;
+    // two operand sets in turn (no register copies): set 1 - p of chunk ch + 1 is in flight while set p of chunk ch is multiplied
+    KnnBfReg bh[2][2], bl[2][2], ah[2][kWideQT], al[2][kWideQT];
+    auto load_set = [&](int p, int ch) {
+      bh[p][0].u = bp0[(size_t)ch * 128]; bl[p][0].u = bp0[(size_t)ch * 128 + 1];
+      bh[p][1].u = bp1[(size_t)ch * 128]; bl[p][1].u = bp1[(size_t)ch * 128 + 1];
+#pragma unroll
+      for (int q = 0; q < kWideQT; ++q) { ah[p][q].u = ap[q][(size_t)ch * 128]; al[p][q].u = ap[q][(size_t)ch * 128 + 1]; }
+    };
+    auto mul_set = [&](int p) {
+      // targets as rows (first operand), queries as columns; the three products of an accumulator are eight instructions apart
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < kWideQT; ++q) acc[t][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[p][t].v, ah[p][q].v, acc[t][q], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < kWideQT; ++q) acc[t][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[p][t].v, al[p][q].v, acc[t][q], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < kWideQT; ++q) acc[t][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[p][t].v, ah[p][q].v, acc[t][q], 0, 0, 0);
+    };
+    load_set(0, 0);
+    int ch = 0;
+    for (; ch + 2 <= kChunks; ch += 2) {
+      load_set(1, ch + 1);
+      mul_set(0);
+      load_set(0, ch + 2 < kChunks ? ch + 2 : ch + 1);
+      mul_set(1);
+    }
+    if (ch < kChunks) mul_set(0);                  // an odd number of chunks: the last one sits in set 0
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t == 1 && !two) break;
+      const int rbase = (t == 0 ? c0 : c1) * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int q = 0; q < kWideQT; ++q) {
+        float tmin = acc[t][q][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmin = fminf(tmin, acc[t][q][r]);
+        if (__any(tmin < ld[q][kListLen - 1]))
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[t][q][r];
+            if (v < ld[q][kListLen - 1]) {
+              float cd = v;
+              int ci = rbase + (r & 3) + 8 * (r >> 2);
+              bool carrying = false;
+#pragma unroll
+              for (int s2 = 0; s2 < kListLen; ++s2) {
+                const bool sw = carrying || cd < ld[q][s2];
+                carrying = sw;
+                const float td = ld[q][s2];
+                const int ti = li[q][s2];
+                ld[q][s2] = sw ? cd : td; li[q][s2] = sw ? ci : ti;
+                cd = sw ? td : cd; ci = sw ? ti : ci;
+              }
+            }
+          }
+      }
+    }
+  }
+  const int n_lists = kLists * (int)gridDim.y;
+  const int list = part * kLists + (lane >> 5) * kSlices + slice;
+#pragma unroll
+  for (int q = 0; q < kWideQT; ++q) {
+    const int a = (tile_a0 + q) * 32 + (lane & 31);
+    if (a >= na) continue;
+    float *od = cand_d + ((size_t)a * n_lists + list) * kListLen;
+    int *oi = cand_i + ((size_t)a * n_lists + list) * kListLen;
+#pragma unroll
+    for (int s = 0; s < kListLen; ++s) {
+      const bool real = li[q][s] >= 0 && li[q][s] < nb;
+      od[s] = real ? ld[q][s] : INFINITY;
+      oi[s] = real ? li[q][s] : -1;
+    }
+  }
+}
+
 // FLANN's L2_Simple between the row staged in LDS (broadcast reads) and target row b (this lane's);
 // rows are read 4 floats at a time when their length allows 16-byte alignment (1344), else 2 (250)
 template <int kD>
@@ -883,7 +1086,8 @@ template <int kD>
 __global__ void __launch_bounds__(256)
 k_knn_rerank_wide(const float *__restrict__ A, int na, const float *__restrict__ B, int nb, int k, int n_lists,
                   const float *__restrict__ cand_d, const int *__restrict__ cand_i, const float *__restrict__ colsum, float inv_nb,
-                  int *__restrict__ idx, float *__restrict__ d2out, int *__restrict__ fb_rows, int *__restrict__ fb_count)
+                  int *__restrict__ idx, float *__restrict__ d2out, int *__restrict__ fb_rows, int *__restrict__ fb_count,
+                  float eps_mul /* 1: the f32 selector */, float eps_add /* x (|a - mu|^2 + rho^2): the split-bf16 selector's own error */)
 {
   constexpr int kMaxCand = 64 * 32;                 // parts <= 32
   __shared__ __attribute__((aligned(16))) float s_x[4][kD];
@@ -937,7 +1141,7 @@ k_knn_rerank_wide(const float *__restrict__ A, int na, const float *__restrict__
   const float U = n_first >= k ? wave_max_f(first_d) : INFINITY;
   // 2. every candidate that can still be among the k nearest
   const float rho_u = (sqrtf(na2) + sqrtf(U)) * 1.001f + 1e-3f;
-  const float eps_u = (2e-5f * (na2 + rho_u * rho_u) + 1e-5f * U) * ((float)knn_kp(kD) / 36.0f);
+  const float eps_u = (2e-5f * (na2 + rho_u * rho_u) + 1e-5f * U) * ((float)knn_kp(kD) / 36.0f) * eps_mul + eps_add * (na2 + rho_u * rho_u);
   const float thr = U + eps_u;                      // +inf when fewer than k candidates exist
   int n_sel = 0;
   for (int e0 = 0; e0 < n_cand; e0 += kWave) {
@@ -988,7 +1192,7 @@ k_knn_rerank_wide(const float *__restrict__ A, int na, const float *__restrict__
     }
   }
   const float rho = (sqrtf(na2) + sqrtf(kth)) * 1.001f + 1e-3f;
-  const float eps = (2e-5f * (na2 + rho * rho) + 1e-5f * kth) * ((float)knn_kp(kD) / 36.0f);
+  const float eps = (2e-5f * (na2 + rho * rho) + 1e-5f * kth) * ((float)knn_kp(kD) / 36.0f) * eps_mul + eps_add * (na2 + rho * rho);
   const bool certified = !(tau < INFINITY) || (kth < tau - eps);
   if (!certified && lane == 0 && live) fb_rows[atomicAdd(fb_count, 1)] = a;
 }
@@ -1093,6 +1297,14 @@ k_knn_exact_wide(const float *__restrict__ A, const float *__restrict__ B, int n
 }
 
 // column sums and MFMA-ordered operands of a TARGET set
+// wide rows (more than 128 floats): the selector runs on split-bf16 MFMA (k_knn_mfma_wide_bf); MM3D_KNN_WIDE_BF16=0 restores
+// the f32 one (the A/B).  Read once: the cached target operands of a descriptor set are laid out for one of the two.
+static bool knn_wide_bf16()
+{
+  static const bool v = [] { const char *e = getenv("MM3D_KNN_WIDE_BF16"); return !(e && !atoi(e)); }();
+  return v;
+}
+
 template <int kD>
 static void knn_target_operands(Context *c, const mm3d_desc *B, DevBuf<float> &colsum, DevBuf<float> &Bp)
 {
@@ -1100,6 +1312,23 @@ static void knn_target_operands(Context *c, const mm3d_desc *B, DevBuf<float> &c
   const int nb = (int)B->n, nb_tiles = (nb + 31) / 32;
   constexpr int kCols = kD > 128 ? kD : 128;
   colsum = DevBuf<float>(c, kCols);
+  if constexpr (kD > 128) {
+    if (knn_wide_bf16()) {
+      constexpr int kChunks = knn_kp16(kD) / 16;
+      MM3D_HIP(hipMemsetAsync(colsum.get(), 0, kCols * sizeof(float), c->stream));
+      MM3D_LAUNCH(c, "desc_knn_prep", nb * kD * 4.0, k_knn_colsum_wide, dim3(div_up(kD, 256), 64), dim3(256), 0, (const float *)B->data.get(), nb,
+                  kD, colsum.get());
+      DevBuf<float> nrm(c, (size_t)nb);
+      MM3D_LAUNCH(c, "desc_knn_prep", nb * kD * 4.0, (k_knn_rownorm_c<kD>), dim3(div_up(nb, 4)), dim3(256), 0, (const float *)B->data.get(), nb,
+                  (const float *)colsum.get(), 1.0f / (float)nb, nrm.get());
+      Bp = DevBuf<float>(c, (size_t)nb_tiles * kChunks * 64 * 8);          // 32 bytes per lane and chunk
+      MM3D_LAUNCH(c, "desc_knn_prep", nb * (kD + kKP) * 4.0, (k_knn_prep_bf<kD>), dim3(div_up((size_t)nb_tiles * kChunks * 64, 256)), dim3(256), 0,
+                  (const float *)B->data.get(), nb, nb_tiles, 1, (const float *)colsum.get(), 1.0f / (float)nb, (const float *)nrm.get(),
+                  reinterpret_cast<uint4 *>(Bp.get()));
+      c->settle();                                   // (nrm goes out of scope)
+      return;
+    }
+  }
   Bp = DevBuf<float>(c, (size_t)nb_tiles * kSteps * 64);
   MM3D_HIP(hipMemsetAsync(colsum.get(), 0, kCols * sizeof(float), c->stream));
   if constexpr (kD <= 128)
@@ -1227,7 +1456,7 @@ static void desc_knn_impl(Context *c, const mm3d_desc *A, const mm3d_desc *B, in
     if constexpr (kD >= 64)
       MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * 8 + 32 * kD * 4), (k_knn_rerank_wide<kD>), dim3(div_up(na, 4)), dim3(256), 0,
                   Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
-                  idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1));
+                  idx.get(), d2.get(), fb_rows.get(), (int *)(meta.get() + 1), 1.0f, 0.0f);
     else
       MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * (kD * 4 + 8) + kD * 4), (k_knn_rerank<kD>), dim3(div_up(na, 4)), dim3(256), 0,
                   Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb,
@@ -1272,7 +1501,9 @@ static void desc_knn_wide_impl(Context *c, const mm3d_desc *A, const mm3d_desc *
     return;
   }
   const int na_tiles = (na + 31) / 32, nb_tiles = (nb + 31) / 32;
-  DevBuf<float> Ap(c, (size_t)na_tiles * kSteps * 64);
+  const bool bf = knn_wide_bf16();
+  constexpr int kChunks = knn_kp16(kD) / 16;
+  DevBuf<float> Ap(c, bf ? (size_t)na_tiles * kChunks * 64 * 8 : (size_t)na_tiles * kSteps * 64);
   MM3D_HIP(hipMemsetAsync(meta.get(), 0, 16, c->stream));
   DevBuf<float> colsum_tmp, Bp_tmp;
   const float *colsum = B->knn_colsum.get(), *Bp = B->knn_Bp.get();
@@ -1282,19 +1513,41 @@ static void desc_knn_wide_impl(Context *c, const mm3d_desc *A, const mm3d_desc *
     Bp = Bp_tmp.get();
   }
   const float inv_nb = 1.0f / (float)nb;
-  MM3D_LAUNCH(c, "desc_knn_prep", na * (kD + kKP) * 4.0, (k_knn_prep<kD>), dim3(div_up((size_t)na_tiles * kSteps * 64, 256)), dim3(256), 0, Ad, na,
-              na_tiles, 0, colsum, inv_nb, Ap.get());
+  DevBuf<float> nrm_a;
+  if (bf) {
+    nrm_a = DevBuf<float>(c, (size_t)na);
+    MM3D_LAUNCH(c, "desc_knn_prep", na * kD * 4.0, (k_knn_rownorm_c<kD>), dim3(div_up(na, 4)), dim3(256), 0, Ad, na, colsum, inv_nb, nrm_a.get());
+    MM3D_LAUNCH(c, "desc_knn_prep", na * (kD + kKP) * 4.0, (k_knn_prep_bf<kD>), dim3(div_up((size_t)na_tiles * kChunks * 64, 256)), dim3(256), 0, Ad, na,
+                na_tiles, 0, colsum, inv_nb, (const float *)nrm_a.get(), reinterpret_cast<uint4 *>(Ap.get()));
+  } else {
+    MM3D_LAUNCH(c, "desc_knn_prep", na * (kD + kKP) * 4.0, (k_knn_prep<kD>), dim3(div_up((size_t)na_tiles * kSteps * 64, 256)), dim3(256), 0, Ad, na,
+                na_tiles, 0, colsum, inv_nb, Ap.get());
+  }
   const int a_blocks = div_up(na_tiles, kWideQT);
   int parts = 1;
-  while (parts < 32 && a_blocks * parts < 512 && nb_tiles / (kSlices * parts * 2) >= 2) parts *= 2;
+  if (bf) {
+    // one resident block per CU (its registers): at most one round of blocks, and at least four target tiles per wave
+    static const int cus = snb_cu_count(c->device);
+    parts = std::max(1, std::min(std::min(32, cus / std::max(a_blocks, 1)), nb_tiles / (kSlices * 4)));     // (any number: a part is eight lists)
+  } else {
+    while (parts < 32 && a_blocks * parts < 512 && nb_tiles / (kSlices * parts * 2) >= 2) parts *= 2;
+  }
   const int n_lists = kLists * parts;
   DevBuf<float> cand_d(c, (size_t)na * n_lists * kListLen);
   DevBuf<int> cand_i(c, (size_t)na * n_lists * kListLen);
-  MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, (k_knn_mfma_wide<kD>), dim3(a_blocks, parts),
-              dim3(256), 0, (const float *)Ap.get(), na, na_tiles, Bp, nb, nb_tiles, cand_d.get(), cand_i.get());
+  // (the profile's flops are the f32-equivalent ones of the product either way: 2 na nb kKP)
+  if (bf)
+    MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, (k_knn_mfma_wide_bf<kD>), dim3(a_blocks, parts),
+                dim3(256), 0, reinterpret_cast<const uint4 *>(Ap.get()), na, na_tiles, reinterpret_cast<const uint4 *>(Bp), nb, nb_tiles, cand_d.get(),
+                cand_i.get());
+  else
+    MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, (k_knn_mfma_wide<kD>), dim3(a_blocks, parts),
+                dim3(256), 0, (const float *)Ap.get(), na, na_tiles, Bp, nb, nb_tiles, cand_d.get(), cand_i.get());
+  // the split-bf16 selector: three accumulation chains instead of one (x 1.5), and its own approximation error (5e-5, see
+  // k_knn_mfma_wide_bf)
   MM3D_LAUNCH(c, "desc_knn_rerank", na * (double)(n_lists * kListLen * 8 + 32 * kD * 4), (k_knn_rerank_wide<kD>), dim3(div_up(na, 4)), dim3(256), 0,
               Ad, na, Bd, nb, k, n_lists, (const float *)cand_d.get(), (const int *)cand_i.get(), colsum, inv_nb, idx.get(), d2.get(),
-              fb_rows.get(), (int *)(meta.get() + 1));
+              fb_rows.get(), (int *)(meta.get() + 1), bf ? 1.5f : 1.0f, bf ? 5e-5f : 0.0f);
   MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, (k_knn_exact_wide<kD>), dim3(fb_groups < 64 ? fb_groups : 64, kFbParts), dim3(64), 0, Ad, Bd, nb, k,
               (const int *)fb_rows.get(), (const int *)(meta.get() + 1), 0, part_keys.get());
   MM3D_LAUNCH(c, "desc_knn_fallback", 0.0, k_knn_merge_parts, dim3(div_up(na, 64)), dim3(64), 0,
@@ -1385,6 +1638,7 @@ void desc_knn(Context *c, const mm3d_desc *A, const mm3d_desc *B, int k, DevBuf<
   else if (A->dim == 125) desc_knn_impl<125>(c, A, B, k, idx, d2);   // PFHSignature125
   else if (A->dim == 250) desc_knn_wide_impl<250>(c, A, B, k, idx, d2);     // PFHRGBSignature250
   else if (A->dim == 1344) desc_knn_wide_impl<1344>(c, A, B, k, idx, d2);   // SHOT1344
+  else if (A->dim == 352) desc_knn_wide_impl<352>(c, A, B, k, idx, d2);     // SHOT352's shape only (mm3d_debug_desc_knn: the reference binds SHOT1344)
   else if (A->dim == 1980) desc_knn_wide_impl<1980>(c, A, B, k, idx, d2);   // ShapeContext1980
   else throw Error(MM3D_EUNSUPPORTED, "descriptor k-NN is built for RSD (2), FPFH (33), PFH (125), PFHRGB (250), SHOT (1344) and SC3D (1980) rows");
 }

@@ -1034,6 +1034,38 @@ def test_sc3d(ctx, po, mm, scene):
     assert pairs[0]["confidence"] == pytest.approx(ref_pairs[0]["confidence"], rel=1e-3)
 
 
+
+def test_desc_knn_dim352_shape_exact(ctx, po, mm):
+    """pcl::SHOT352's width (BASELINE.json configs[3] names it; the reference binds SHOT1344, so the width has no descriptor
+    type and goes through mm3d_debug_desc_knn): the wide path -- split-bf16 MFMA selector, exact re-rank, certificate -- against
+    the oracle's FLANN-order k-NN, indices and distance bits, with duplicate rows and few fallbacks."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    centres = np.abs(rng.normal(0, 1, (40, 352))).astype(np.float32)
+
+    def rows(n):
+        X = centres[rng.integers(0, 40, n)] + np.abs(rng.normal(0, 0.05, (n, 352))).astype(np.float32)
+        return (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+
+    A, B = rows(900), rows(2100)
+    B[50:70] = B[150:170]
+    A[:10] = B[300:310]
+    L = mm.lib()
+    L.mm3d_debug_knn_fallback_rows.restype = L.mm3d_debug_knn_rows.restype = C.c_longlong
+    L.mm3d_set_debug(ctx._h, 1)
+    r0, f0 = L.mm3d_debug_knn_rows(ctx._h), L.mm3d_debug_knn_fallback_rows(ctx._h)
+    for k in (1, 5, 10):
+        gi, gd = np.empty((len(A), k), dtype=np.int32), np.empty((len(A), k), dtype=np.float32)
+        ctx._ck(L.mm3d_debug_desc_knn(ctx._h, A.ctypes.data_as(C.c_void_p), C.c_size_t(len(A)), B.ctypes.data_as(C.c_void_p), C.c_size_t(len(B)), 352, k,
+                                      gi.ctypes.data_as(C.c_void_p), gd.ctypes.data_as(C.c_void_p)))
+        ri, rd = po.desc_knn(A, B, k)
+        assert np.array_equal(gi, ri), k
+        assert np.array_equal(gd.view(np.uint32), rd.view(np.uint32)), k
+    rows_, fb = L.mm3d_debug_knn_rows(ctx._h) - r0, L.mm3d_debug_knn_fallback_rows(ctx._h) - f0
+    L.mm3d_set_debug(ctx._h, 0)
+    assert rows_ > 0 and fb <= 0.05 * rows_, (rows_, fb)
+
+
 def test_float_chain_replay_is_exact(ctx, mm):
     """PFH bins are counted in integers and the float chain "0 + incr + incr + ..." is replayed once per bin, binade by
     binade (device_util.hpp::float_chain_sum); the skip must give the bits of the plain loop."""
