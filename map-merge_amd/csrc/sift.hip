@@ -1101,9 +1101,10 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     int *h = (int *)c->pin(64);                          // [0] keypoints, [1] points for the searching kernel
     // Later octaves (round 6): the keypoint DECISION is certified from an unsorted scale space with an error bound, and only
     // the points it leaves open get the sorted lists (sift_cert.hpp).  The first octave keeps its lists -- the fused normals
-    // ride on them.  MM3D_SIFT_CERT=0: every octave on the sorted lists (the A/B and the reference for the parity tests);
-    // MM3D_SIFT_CERT=2: the first octave certified too whenever no normals are fused into it.
-    static const int cert_mode = [] { const char *e = getenv("MM3D_SIFT_CERT"); return e ? atoi(e) : 1; }();
+    // ride on them; where they do not (a normals ball wider than the first octave's 3 sigma_max: the dense indoor workload at
+    // resolution 0.05) the first octave is certified too.  MM3D_SIFT_CERT=0: every octave on the sorted lists (the A/B);
+    // MM3D_SIFT_CERT=1: the later octaves only.
+    static const int cert_mode = [] { const char *e = getenv("MM3D_SIFT_CERT"); return e ? atoi(e) : 2; }();
     bool certified = false;
     if (cert_mode > 0 && (oct >= 1 || (cert_mode >= 2 && !fused)) && octave_cloud->n_finite == octave_cloud->n) {
       certified = sift_octave_certified(c, octave_cloud, gr, n_items, max_radius, r2, sc, (float)min_contrast, flags.get(), pos.get(), h);

@@ -80,74 +80,12 @@ __device__ __forceinline__ float sf_intensity(float w)
   return lm::fdiv_const((float)(299 * r + 587 * g + 114 * b), 1000.0f, 0.001f);     // (sift.hip::intensity_of: the CPU path's float)
 }
 
-// stages the box of q_pts[first .. first + count) into S.tile (as snb_stage_queries; candidates as float4 with the
-// intensity in .w).  All threads; begins and ends with a block barrier.  Returns the number of kept candidates.
-template <class Cfg>
-__device__ __forceinline__ int sf_stage_queries(const GridView &g, SfLds<Cfg> &S, const float4 *__restrict__ q_pts, int first, int count,
-                                                float ri, int epoch, const float4 *__restrict__ pts)
-{
-  constexpr int T = 64 * Cfg::kWaves;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) S.n_tile[epoch & 1] = 0;
-  __syncthreads();
-  const bool live = lane < count;
-  const float4 qa = q_pts[first + (live ? lane : 0)];
-  if (wave == 0) S.qpts[lane] = live ? qa : make_float4(kSnbFar, kSnbFar, kSnbFar, 0.0f);
-  const float lx = snb_min_f_dpp(live ? qa.x : INFINITY), hx = snb_max_f_dpp(live ? qa.x : -INFINITY);
-  const float ly = snb_min_f_dpp(live ? qa.y : INFINITY), hy = snb_max_f_dpp(live ? qa.y : -INFINITY);
-  const float lz = snb_min_f_dpp(live ? qa.z : INFINITY), hz = snb_max_f_dpp(live ? qa.z : -INFINITY);
-  const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
-  const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
-  const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
-  const KeepNearBox keep{lx, hx, ly, hy, lz, hz, ri * ri};
-  int *n_tile = &S.n_tile[epoch & 1];
-  const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
-  const int nrows = (x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
-  int *w_off = S.off[wave], *w_beg = S.beg[wave];
-  for (int r0 = 0; r0 < nrows; r0 += kWave) {
-    const int r = r0 + lane;
-    int b = 0, len = 0;
-    if (r < nrows) {
-      const int z = z0 + r / ny, y = y0 + r % ny;
-      const int row = (z * g.dy + y) * g.dx;
-      b = g.cell_start[row + x0];
-      len = g.cell_start[row + x1 + 1] - b;
-    }
-    const int incl = snb_scan_dpp(len);
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    wave_lds_fence();
-    w_off[lane] = incl - len;
-    w_beg[lane] = b;
-    wave_lds_fence();
-    for (int t0 = wave * kWave; t0 < total; t0 += T) {
-      const int s = t0 + lane;
-      const bool in = s < total;
-      const int slot = in ? s : t0;
-      int lo = 0;
-#pragma unroll
-      for (int step = 32; step > 0; step >>= 1)
-        if (w_off[lo + step] <= slot) lo += step;
-      const float4 cnd = g.pts[w_beg[lo] + (slot - w_off[lo])];
-      const bool k = in && keep(cnd);
-      float pv = 0.0f;
-      if (k) pv = sf_intensity(pts[__float_as_int(cnd.w)].w);
-      const unsigned long long m = ballot(k);
-      if (m) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(n_tile, __popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const int d = snb_mbcnt(m, base);
-        if (k && d < Cfg::kTileCap) S.tile[d] = make_float4(cnd.x, cnd.y, cnd.z, pv);
-      }
-    }
-  }
-  __syncthreads();
-  return S.n_tile[epoch & 1];
-}
-
-// the certified scale space of one octave: val* and B for every point (by original index, [n][5]).  An item the tile
-// cannot hold even in eight parts is listed (ov_items / ctl->ov_count) and its points are marked for the exact path
-// (need_exact) with an interval of everything.
+// the certified scale space of one octave: val* and B for every point (by original index, [n][5]), the reject radius and the
+// search radius (rlo2, rup2).  A block owns one work item (<= 64 queries, lane = query); the box of cells the item can reach
+// is STREAMED through the tile: staged up to the tile's capacity (coalesced gathers, every wave a share of the slots), scanned
+// by the eight waves (each a share of the candidates, broadcast LDS reads), staged again -- an unsorted pass needs no
+// candidate twice, so no box is too large for it (round 6, second half: a first version staged the whole box at once and gave
+// the items of a dense cloud -- 8 x 2 M indoor points: most of them -- up to the exact path, 56 map-pairs/s against 76).
 template <class Cfg>
 __global__ void __launch_bounds__(64 * Cfg::kWaves, 2 * Cfg::kWaves / 4)
 k_sift_dog_fast(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* .w = original index */,
@@ -156,36 +94,36 @@ k_sift_dog_fast(const float4 *__restrict__ q_pts, const int2 *__restrict__ items
                 unsigned char *__restrict__ need_exact)
 {
   __shared__ SfLds<Cfg> S;
-  constexpr int W = Cfg::kWaves;
+  constexpr int W = Cfg::kWaves, T = 64 * W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float ri = radius * 1.0001f + 1e-4f;
-  int epoch = 0;
+  (void)ov_items; (void)need_exact;
   for (;;) {
-    if (threadIdx.x == 0) S.item = snb_claim_item(ctl->item_ctr, n_items);
+    if (threadIdx.x == 0) { S.item = snb_claim_item(ctl->item_ctr, n_items); S.n_tile[0] = 0; }
     __syncthreads();
     if (S.item < 0) break;
-    const int item = S.item;
-    const int2 it = items[item];
-    int parts = 1;
-    bool failed = false;
-    for (int part = 0; part < parts; ++epoch) {
-      const int lo = (int)((long long)it.y * part / parts), hi = (int)((long long)it.y * (part + 1) / parts);
-      if (hi == lo) { ++part; continue; }
-      const int n_tile = sf_stage_queries<Cfg>(g, S, q_pts, it.x + lo, hi - lo, ri, epoch, pts);
-      if (n_tile > Cfg::kTileCap) {                // block-uniform
-        if (hi - lo == 1 || parts >= kSnbMaxParts) { failed = true; break; }
-        parts *= 2;
-        part *= 2;
-        continue;
-      }
+    const int2 it = items[S.item];
+    const bool live = lane < it.y;
+    const float4 q = live ? q_pts[it.x + lane] : make_float4(kSnbFar, kSnbFar, kSnbFar, 0.0f);
+    const float lx = snb_min_f_dpp(live ? q.x : INFINITY), hx = snb_max_f_dpp(live ? q.x : -INFINITY);
+    const float ly = snb_min_f_dpp(live ? q.y : INFINITY), hy = snb_max_f_dpp(live ? q.y : -INFINITY);
+    const float lz = snb_min_f_dpp(live ? q.z : INFINITY), hz = snb_max_f_dpp(live ? q.z : -INFINITY);
+    const int x0 = max(cell_floor(lx - ri, g.minx, g.inv), 0), x1 = min(cell_floor(hx + ri, g.minx, g.inv), g.dx - 1);
+    const int y0 = max(cell_floor(ly - ri, g.miny, g.inv), 0), y1 = min(cell_floor(hy + ri, g.miny, g.inv), g.dy - 1);
+    const int z0 = max(cell_floor(lz - ri, g.minz, g.inv), 0), z1 = min(cell_floor(hz + ri, g.minz, g.inv), g.dz - 1);
+    const KeepNearBox keep{lx, hx, ly, hy, lz, hz, ri * ri};
+    const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    const int nrows = (x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
+    float num[kCertScales], den[kCertScales];
+    int cnt[kCertScales], cnt_a = 0, cnt_b = 0;
+#pragma unroll
+    for (int s = 0; s < kCertScales; ++s) { num[s] = 0.0f; den[s] = 0.0f; cnt[s] = 0; }
+    // the pass over what the tile holds: lane = query, the wave's share of the candidates four at a time
+    auto scan_tile = [&]() {
+      __syncthreads();                               // the staged candidates and their number are visible
+      const int n_tile = S.n_tile[0];
       if (threadIdx.x < 4) S.tile[n_tile + threadIdx.x] = make_float4(kSnbFar, kSnbFar, kSnbFar, 0.0f);   // pad to a multiple of four
       __syncthreads();
-      // ---- the pass: lane = query, the wave's share of the candidates four at a time (broadcast LDS reads) -------
-      const float4 q = S.qpts[lane];
-      float num[kCertScales], den[kCertScales];
-      int cnt[kCertScales], cnt_a = 0, cnt_b = 0;
-#pragma unroll
-      for (int s = 0; s < kCertScales; ++s) { num[s] = 0.0f; den[s] = 0.0f; cnt[s] = 0; }
       const int n4 = (n_tile + 3) >> 2;            // groups of four
       const int per = (n4 + W - 1) / W;
       const int g0 = wave * per, g1 = min(n4, g0 + per);
@@ -216,83 +154,120 @@ k_sift_dog_fast(const float4 *__restrict__ q_pts, const int2 *__restrict__ items
           }
         }
       }
-      __syncthreads();                             // every wave is done with the tile: its memory takes the partial sums
-      float *red = reinterpret_cast<float *>(S.tile);
-      int *redi = reinterpret_cast<int *>(S.tile);
-#pragma unroll
-      for (int s = 0; s < kCertScales; ++s) {
-        red[(wave * Cfg::kVals + s) * 64 + lane] = num[s];
-        red[(wave * Cfg::kVals + kCertScales + s) * 64 + lane] = den[s];
-        redi[(wave * Cfg::kVals + 2 * kCertScales + s) * 64 + lane] = cnt[s];
-      }
-      redi[(wave * Cfg::kVals + 3 * kCertScales) * 64 + lane] = cnt_a;
-      redi[(wave * Cfg::kVals + 3 * kCertScales + 1) * 64 + lane] = cnt_b;
+      __syncthreads();                               // every wave is done with the tile
+      if (threadIdx.x == 0) S.n_tile[0] = 0;
       __syncthreads();
-      if (wave < kCertScales) {                    // wave s: the response of scale s and its bound, per query
-        const int s = wave;
-        float N = 0.0f, D = 0.0f;
-        int n = 0, kmax = 0;
+    };
+    // stage, scan whenever the next slice might not fit (an upper bound that ignores the near-box filter: block-uniform
+    // without looking at the counter)
+    int *w_off = S.off[wave], *w_beg = S.beg[wave];
+    int ub = 0;
+    for (int r0 = 0; r0 < nrows; r0 += kWave) {
+      const int r = r0 + lane;
+      int b = 0, len = 0;
+      if (r < nrows) {
+        const int z = z0 + r / ny, y = y0 + r % ny;
+        const int row = (z * g.dy + y) * g.dx;
+        b = g.cell_start[row + x0];
+        len = g.cell_start[row + x1 + 1] - b;
+      }
+      const int incl = snb_scan_dpp(len);
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      wave_lds_fence();
+      w_off[lane] = incl - len;
+      w_beg[lane] = b;
+      wave_lds_fence();
+      for (int tb = 0; tb < total; tb += T) {
+        const int m = min(T, total - tb);
+        if (ub + m > Cfg::kTileCap) { scan_tile(); ub = 0; }
+        ub += m;
+        const int sl = tb + wave * kWave + lane;
+        const bool in = sl < total;
+        const int slot = in ? sl : 0;
+        int lo = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < W; ++w2) {
-          N += red[(w2 * Cfg::kVals + s) * 64 + lane];
-          D += red[(w2 * Cfg::kVals + kCertScales + s) * 64 + lane];
-          const int c2 = redi[(w2 * Cfg::kVals + 2 * kCertScales + s) * 64 + lane];
-          n += c2;
-          kmax = max(kmax, c2);
+        for (int step = 32; step > 0; step >>= 1)
+          if (w_off[lo + step] <= slot) lo += step;
+        const float4 cnd = g.pts[w_beg[lo] + (slot - w_off[lo])];
+        const bool k = in && keep(cnd);
+        float pv = 0.0f;
+        if (k) pv = sf_intensity(pts[__float_as_int(cnd.w)].w);
+        const unsigned long long mk = ballot(k);
+        if (mk) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&S.n_tile[0], __popcll(mk));
+          base = __builtin_amdgcn_readfirstlane(base);
+          const int d = snb_mbcnt(mk, base);
+          if (k) S.tile[d] = make_float4(cnd.x, cnd.y, cnd.z, pv);
         }
-        const float R = N / D;
-        const float e = (float)(2 * n + 2 * (kmax + W) + 48) * 0x1p-24f * 1.015625f;
-        S.resp[s][lane] = R;
-        S.bres[s][lane] = R * e;
-        S.ntot[s][lane] = n;
-      } else {                                     // waves 6, 7: the two small-ball counts
-        int n = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < W; ++w2) n += redi[(w2 * Cfg::kVals + 3 * kCertScales + (wave - kCertScales)) * 64 + lane];
-        S.ntot[wave][lane] = n;
       }
-      __syncthreads();
-      if (wave == 0 && lane < hi - lo) {
-        const int self = __float_as_int(q.w);
-#pragma unroll
-        for (int s = 0; s < kCertDog; ++s) {
-          const float v = S.resp[s + 1][lane] - S.resp[s][lane];
-          const float b = (S.bres[s + 1][lane] + S.bres[s][lane] + 0x1p-14f) * (1.0f + 0x1p-18f);
-          dogv[(size_t)self * kCertDog + s] = v;
-          dogb[(size_t)self * kCertDog + s] = b;
-        }
-        // the reject radius: the widest of five balls that holds at most 25 points (the point itself included) -- every
-        // point inside it is one of the 25 nearest, whatever their order (k_sift_reject); 0: even the smallest holds more
-        float r = 0.0f;
-        if (S.ntot[kCertScales + 1][lane] <= kCertKnn) r = sc.TB;
-        if (S.ntot[kCertScales][lane] <= kCertKnn) r = sc.TA;
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-          if (S.ntot[s][lane] <= kCertKnn) r = sc.T[s];
-        rlo2[self] = r;
-        // ... and the search radius: the narrowest of the eight balls that holds at least 25 points -- the 25 nearest all lie
-        // inside it (k_sift_extrema_one); +inf: even the 3 sigma_max ball holds fewer (k_sift_extrema_iv grows rings)
-        float ru = INFINITY;
-#pragma unroll
-        for (int s = kCertScales - 1; s >= 0; --s)
-          if (S.ntot[s][lane] >= kCertKnn) ru = sc.T[s];
-        if (S.ntot[kCertScales][lane] >= kCertKnn) ru = sc.TA;
-        if (S.ntot[kCertScales + 1][lane] >= kCertKnn) ru = sc.TB;
-        rup2[self] = ru;
-      }
-      ++part;
     }
-    if (failed) {                                  // block-uniform: a dense spot -- its points take the exact path
-      if (wave == 0 && lane < it.y) {
-        const int self = __float_as_int(q_pts[it.x + lane].w);
+    scan_tile();
+    // the waves' partial sums meet in the tile's memory
+    float *red = reinterpret_cast<float *>(S.tile);
+    int *redi = reinterpret_cast<int *>(S.tile);
 #pragma unroll
-        for (int s = 0; s < kCertDog; ++s) { dogv[(size_t)self * kCertDog + s] = 0.0f; dogb[(size_t)self * kCertDog + s] = INFINITY; }
-        rlo2[self] = 0.0f;
-        rup2[self] = INFINITY;
-        need_exact[self] = 1;
-      }
-      if (threadIdx.x == 0) ov_items[atomicAdd(&ctl->ov_count, 1)] = item;
+    for (int s = 0; s < kCertScales; ++s) {
+      red[(wave * Cfg::kVals + s) * 64 + lane] = num[s];
+      red[(wave * Cfg::kVals + kCertScales + s) * 64 + lane] = den[s];
+      redi[(wave * Cfg::kVals + 2 * kCertScales + s) * 64 + lane] = cnt[s];
     }
+    redi[(wave * Cfg::kVals + 3 * kCertScales) * 64 + lane] = cnt_a;
+    redi[(wave * Cfg::kVals + 3 * kCertScales + 1) * 64 + lane] = cnt_b;
+    __syncthreads();
+    if (wave < kCertScales) {                    // wave s: the response of scale s and its bound, per query
+      const int s = wave;
+      float N = 0.0f, D = 0.0f;
+      int n = 0, kmax = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < W; ++w2) {
+        N += red[(w2 * Cfg::kVals + s) * 64 + lane];
+        D += red[(w2 * Cfg::kVals + kCertScales + s) * 64 + lane];
+        const int c2 = redi[(w2 * Cfg::kVals + 2 * kCertScales + s) * 64 + lane];
+        n += c2;
+        kmax = max(kmax, c2);
+      }
+      const float R = N / D;
+      const float e = (float)(2 * n + 2 * (kmax + W) + 48) * 0x1p-24f * 1.015625f;
+      S.resp[s][lane] = R;
+      S.bres[s][lane] = R * e;
+      S.ntot[s][lane] = n;
+    } else {                                     // waves 6, 7: the two small-ball counts
+      int n = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < W; ++w2) n += redi[(w2 * Cfg::kVals + 3 * kCertScales + (wave - kCertScales)) * 64 + lane];
+      S.ntot[wave][lane] = n;
+    }
+    __syncthreads();
+    if (wave == 0 && live) {
+      const int self = __float_as_int(q.w);
+#pragma unroll
+      for (int s = 0; s < kCertDog; ++s) {
+        const float v = S.resp[s + 1][lane] - S.resp[s][lane];
+        const float b = (S.bres[s + 1][lane] + S.bres[s][lane] + 0x1p-14f) * (1.0f + 0x1p-18f);
+        dogv[(size_t)self * kCertDog + s] = v;
+        dogb[(size_t)self * kCertDog + s] = b;
+      }
+      // the reject radius: the widest of five balls that holds at most 25 points (the point itself included) -- every
+      // point inside it is one of the 25 nearest, whatever their order (k_sift_reject); 0: even the smallest holds more
+      float r = 0.0f;
+      if (S.ntot[kCertScales + 1][lane] <= kCertKnn) r = sc.TB;
+      if (S.ntot[kCertScales][lane] <= kCertKnn) r = sc.TA;
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        if (S.ntot[s][lane] <= kCertKnn) r = sc.T[s];
+      rlo2[self] = r;
+      // ... and the search radius: the narrowest of the eight balls that holds at least 25 points -- the 25 nearest all lie
+      // inside it (k_sift_extrema_one); +inf: even the 3 sigma_max ball holds fewer (k_sift_extrema_iv grows rings)
+      float ru = INFINITY;
+#pragma unroll
+      for (int s = kCertScales - 1; s >= 0; --s)
+        if (S.ntot[s][lane] >= kCertKnn) ru = sc.T[s];
+      if (S.ntot[kCertScales][lane] >= kCertKnn) ru = sc.TA;
+      if (S.ntot[kCertScales + 1][lane] >= kCertKnn) ru = sc.TB;
+      rup2[self] = ru;
+    }
+    __syncthreads();                               // (the next item's claim rewrites S.item, its staging the tile)
   }
 }
 

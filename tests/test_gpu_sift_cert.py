@@ -73,6 +73,12 @@ def test_the_bound_holds_on_every_point(ctx, po, big_scene):
 
 
 def test_certified_octaves_give_the_oracles_keypoints_and_say_what_they_did(ctx, po, mm, big_scene):
+    """Without normals to fuse into it the first octave is certified too (three octaves); with them (the reference's call: the
+    descriptors need the normals) it keeps its sorted lists and the later two are certified."""
+    mm.sift_cert_stats(reset=True)
+    m = ctx.mapFeatures(ctx.cloud(big_scene), mm.MapMergingParams(descriptor_type=mm.Descriptor.FPFH, estimation_method=mm.EstimationMethod.SAC_IA))
+    assert mm.sift_cert_stats()[0] == 2 and len(m.keypoints) > 500      # the map's feature chain fuses the normals into the first octave
+    m.free()
     mm.sift_cert_stats(reset=True)
     ref, _ = po.keypoints_sift(big_scene, RES, 3, 3, 5.0)
     got = ctx.detectKeypoints(ctx.cloud(big_scene), None, 0, 5.0, R_NRM, RES).numpy()
@@ -80,7 +86,7 @@ def test_certified_octaves_give_the_oracles_keypoints_and_say_what_they_did(ctx,
     assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
     st = mm.sift_cert_stats()
     print("certified SIFT statistics:", st)
-    assert st[0] == 2                      # octaves 1 and 2 were decided on the certified path
+    assert st[0] == 3                      # all three octaves were decided on the certified path (no normals asked for: nothing is fused into the first)
     assert st[4] == 0 and st[5] == 0 and st[6] == 0
     assert 0 < st[2] < 0.02 * st[1]        # a small share of their points needed the exact sums
 
@@ -102,5 +108,5 @@ def test_ties_everywhere_send_every_point_to_the_exact_path(ctx, po, mm):
         print("ties:", st, len(ref))
         assert len(got) == len(ref)
         assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
-        assert st[0] == 2 and st[4] == 0 and st[5] == 0 and st[6] == 0
-        assert st[2] > 0.5 * st[1]         # most points of the two octaves needed the exact sums
+        assert st[0] == 3 and st[4] == 0 and st[5] == 0 and st[6] == 0
+        assert st[2] > 0.5 * st[1]         # most points of the octaves needed the exact sums
