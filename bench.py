@@ -687,6 +687,25 @@ def main():
         pass
     if not counters_apply:
         valu_insts, sq_ratios = {}, {}
+        # another workload than the headline: its own SQ counters, if a pass was made for it (scripts/profile_counters.sh +
+        # assemble_counters.py write one profiles/r*_counters_<name>.json per workload, with the kernels' machine-code hashes)
+        try:
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters_*.json")), reverse=True):
+                with open(path) as f:
+                    doc = json.load(f)
+                if doc.get("workload") != workload_signature(args):
+                    continue
+                pmc_hashes = doc.get("source_sha256", {})
+                for name, v in doc.get("kernels", {}).items():
+                    valu_insts[name] = v["valu_wave_instructions_per_dispatch"]
+                    sq_ratios[name] = {"stall": v.get("stall"), "lds_conflict": v.get("lds_conflict"),
+                                       "valu_active_per_wave_cycle": v.get("valu_active_per_wave_cycle")}
+                valu_source = doc.get("source")
+                counters_workload = doc["workload"]
+                counters_apply = True
+                break
+        except Exception:
+            pass
 
     def bound_of(name, launch_ms, work):
         """Which ceiling the kernel is nearest to, from what can be known here: algorithmic bytes (or flops) per launch
