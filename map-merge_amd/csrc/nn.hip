@@ -839,7 +839,8 @@ void icp_score_batch(Context *c, IcpScoreJob *jobs, int n_jobs, bool run_icp, do
   // that runs sixteen streams: its blocks still queue for 20 KB of LDS and 128 registers behind the other streams'
   // kernels before they can find that out.  So the first look comes after ONE iteration (a batch of one or two
   // pairs is then usually finished), later ones after two.
-  const int min_chunk = B <= 2 ? 1 : 2;
+  static const int first_chunk_knob = [] { const char *e = getenv("MM3D_ICP_FIRST_CHUNK"); return e ? atoi(e) : 0; }();   // A/B knob (1 or 2; 0: by batch size)
+  const int min_chunk = first_chunk_knob > 0 ? std::min(first_chunk_knob, 2) : (B <= 2 ? 1 : 2);
   for (int round = 0;; ++round) {
     const int chunk = round == 0 ? min_chunk : 2;
     if (run_icp) {
