@@ -10,6 +10,10 @@ def short(name):
         # tiny launches) apart from the launches that work whole octaves, so that "per dispatch" means per octave
         if m.group(1) == "k_sift_dog_lds" and re.search(r"SnbCfg<8, *3584", name):
             return "k_sift_dog_lds_dense"
+        # (round 6) the later octaves' configuration now only serves the certified path's exact launches on the handful of
+        # marked points (single-query items): apart from the first octave's launch, which is what "sift_dog" means in the step
+        if m.group(1) == "k_sift_dog_lds" and re.search(r"SnbCfg<8, *2816", name):
+            return "k_sift_dog_lds_exact"
         return m.group(1) + ("<%s>" % m.group(2) if m.group(1) == "k_nn_wave" and m.group(2) else "")
     m = re.search(r"(\w+)<", name)
     return (m.group(1) if m else name)[:40]

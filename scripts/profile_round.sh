@@ -30,7 +30,7 @@ with_retries() {
 
 # (nothing behind the timed steps in this run: trace_concurrency.py looks at the last 60 % of the traced window)
 export MM3D_BENCH_NO_ISOLATED=1
-with_retries 3 /tmp/prof_kt -- rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 bench.py --steps 5 --warmup 1 --no-pcie --no-pair-stage \
+with_retries 3 /tmp/prof_kt -- rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 bench.py --steps 5 --warmup 3 --no-pcie --no-pair-stage \
     --no-cpu-baseline --kernel-table "$R/gpurun_out/${TAG}_hip_event_table.csv" || fail "kernel trace"
 cp /tmp/prof_kt/*/*kernel_stats.csv "gpurun_out/${TAG}_kernel_stats.csv" || fail "no kernel_stats.csv"
 need "gpurun_out/${TAG}_kernel_stats.csv"; need "gpurun_out/${TAG}_hip_event_table.csv"
