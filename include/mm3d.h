@@ -138,6 +138,8 @@ int mm3d_debug_libm(mm3d_ctx *ctx, int fn, const float *x, const float *y, int n
 int mm3d_debug_sift_cert_octave(mm3d_ctx *ctx, const mm3d_cloud *points, double min_scale, int octave, float *val, float *bound,
                                 size_t capacity, size_t *n_out);
 void mm3d_debug_sift_cert_stats(long long out[8], int reset);
+/* test hook: octaves of at least n points take the certified path (default 15 000, MM3D_SIFT_CERT_MIN; n < 0 restores it) */
+void mm3d_debug_sift_cert_min(int n);
 /* test / study hook: the descriptor k-NN of findFeatureCorrespondences (R/src/matching.cpp:50-75) on raw rows of width `dim`
  * -- the widths of the reference's descriptors (2, 33, 125, 250, 1344, 1980) and 352, pcl::SHOT352's shape, which the reference
  * does not bind (dispatch_descriptors.h:44-46 binds SHOT1344) but BASELINE.json configs[3] names: idx / d2 receive na x k

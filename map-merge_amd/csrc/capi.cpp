@@ -361,6 +361,7 @@ int mm3d_debug_sift_cert_octave(mm3d_ctx *ctx, const mm3d_cloud *points, double 
   return guarded(ctx, [&] { *n_out = debug_sift_cert_octave(ctx, points, min_scale, octave, val, bound, capacity); });
 }
 void mm3d_debug_sift_cert_stats(long long out[8], int reset) { if (out) debug_sift_cert_stats(out, reset); }
+void mm3d_debug_sift_cert_min(int n) { debug_sift_cert_min(n); }
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed) { if (ctx) ctx->rnd.seed(seed); }
 int mm3d_synchronize(mm3d_ctx *ctx) { return guarded(ctx, [&] { ctx->sync(); }); }
 

@@ -834,6 +834,8 @@ __global__ void k_sift_emit(const float4 *__restrict__ pts, const int *__restric
 // the exact path, 3 points whose test was open after the first pass, 4 octaves sent back to the sorted-list path,
 // 5 bound violations, 6 points still open after the second pass, 7 items the fast kernel's tile could not hold
 static std::atomic<long long> g_cert_stats[8];
+static std::atomic<int> g_cert_min_override{-1};
+void debug_sift_cert_min(int n) { g_cert_min_override.store(n); }
 
 void debug_sift_cert_stats(long long *out, int reset)
 {
@@ -1105,8 +1107,13 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     // resolution 0.05) the first octave is certified too.  MM3D_SIFT_CERT=0: every octave on the sorted lists (the A/B);
     // MM3D_SIFT_CERT=1: the later octaves only.
     static const int cert_mode = [] { const char *e = getenv("MM3D_SIFT_CERT"); return e ? atoi(e) : 2; }();
+    // (a small octave is cheaper on the sorted lists: the certified path is sixteen launches against five, and below a few
+    // ten thousand points every launch is latency -- measured interleaved, octaves under 15 000 points on the lists: 2 x 10 k 232 against
+    // 220 map-pairs/s, 64 x 50 k 12 650 against 12 320, 4 x 200 k and the headline unchanged; MM3D_SIFT_CERT_MIN moves the line)
+    static const int cert_min_env = [] { const char *e = getenv("MM3D_SIFT_CERT_MIN"); return e ? atoi(e) : 15000; }();
+    const int cert_min = g_cert_min_override.load() >= 0 ? g_cert_min_override.load() : cert_min_env;     // (test hook: debug_sift_cert_min)
     bool certified = false;
-    if (cert_mode > 0 && (oct >= 1 || (cert_mode >= 2 && !fused)) && octave_cloud->n_finite == octave_cloud->n) {
+    if (cert_mode > 0 && (oct >= 1 || (cert_mode >= 2 && !fused)) && octave_cloud->n_finite == octave_cloud->n && n >= cert_min) {
       certified = sift_octave_certified(c, octave_cloud, gr, n_items, max_radius, r2, sc, (float)min_contrast, flags.get(), pos.get(), h);
       if (!certified) zero_again = true;                   // (the flags hold the abandoned run's)
     }

@@ -200,6 +200,7 @@ void debug_float_chain(Context *c, const float *incr_host, const unsigned *hits_
 // bound B per point and DoG column, [n][5] by the octave cloud's index -- and the process-wide statistics
 size_t debug_sift_cert_octave(Context *c, const mm3d_cloud *points, double min_scale, int octave, float *val_host, float *bound_host, size_t capacity);
 void debug_sift_cert_stats(long long *out, int reset);
+void debug_sift_cert_min(int n);     // test hook: octaves of at least n points are certified (< 0: the default / MM3D_SIFT_CERT_MIN)
 
 // rsd.hip
 mm3d_desc *compute_rsd(Context *c, const mm3d_cloud *points, const mm3d_normals *normals,

@@ -16,6 +16,15 @@ def xyz(a):
     return np.stack([a["x"], a["y"], a["z"]], axis=1)
 
 
+@pytest.fixture(autouse=True)
+def every_octave_certified(mm):
+    """The product certifies octaves of at least 15 000 points (smaller ones are cheaper on the sorted lists); these tests want
+    the certified path on their small scenes too."""
+    mm.lib().mm3d_debug_sift_cert_min(0)
+    yield
+    mm.lib().mm3d_debug_sift_cert_min(-1)
+
+
 @pytest.fixture(scope="module")
 def big_scene(po, synth):
     """One synthetic map large enough for three populated octaves (about 50 k filtered points)."""
@@ -110,3 +119,36 @@ def test_ties_everywhere_send_every_point_to_the_exact_path(ctx, po, mm):
         assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
         assert st[0] == 3 and st[4] == 0 and st[5] == 0 and st[6] == 0
         assert st[2] > 0.5 * st[1]         # most points of the octaves needed the exact sums
+
+
+def test_the_hard_scenes_of_the_parity_suite_on_the_certified_path(ctx, po, big_scene):
+    """tests/test_gpu_parity.py holds these scenes to the oracle on the sorted-list path (their octaves are under the 15 000
+    points from which the product certifies); here the same scenes with every octave certified: a cloud thinned to a fifth (most
+    3 sigma_max balls of the first octave hold fewer than 25 points: the search radius is unknown and the ring-growing interval
+    search serves them), a solid block of points inside an ordinary scene (boxes far larger than the tile: the unsorted pass
+    streams them), and the single-blob lattice (one keypoint, on the blob)."""
+    rng = np.random.default_rng(5)
+    thin = big_scene[np.sort(rng.choice(len(big_scene), len(big_scene) // 5, replace=False))].copy()
+    ref, _ = po.keypoints_sift(thin, RES, 3, 3, 1.0)
+    got = ctx.detectKeypoints(ctx.cloud(thin), None, 0, 1.0, R_NRM, RES).numpy()
+    assert len(got) == len(ref) > 20 and np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
+    c0 = xyz(big_scene).mean(axis=0)
+    blob = np.zeros(9000, dtype=big_scene.dtype)
+    p = rng.uniform(-0.75, 0.75, (9000, 3)).astype(np.float32) + c0.astype(np.float32)
+    blob["x"], blob["y"], blob["z"] = p[:, 0], p[:, 1], p[:, 2]
+    blob["rgba"] = rng.integers(0, 1 << 24, 9000).astype(np.uint32)
+    cloud = np.concatenate([big_scene, blob])
+    ref, _ = po.keypoints_sift(cloud, RES, 3, 3, 5.0)
+    got = ctx.detectKeypoints(ctx.cloud(cloud), None, 0, 5.0, R_NRM, RES).numpy()
+    assert len(got) == len(ref) > 100 and np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
+    gx, gy = np.meshgrid(np.arange(-40, 41) * 0.1, np.arange(-40, 41) * 0.1)
+    pts = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], 1).astype(np.float32)
+    for amplitude, sigma, expect in ((150.0, 0.25, 1), (-55.0, 0.4, 1), (4.0, 0.4, 0)):
+        c = np.zeros(len(pts), dtype=po.POINT)
+        c["x"], c["y"], c["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+        g = amplitude * np.exp(-((pts[:, 0] - 0.33) ** 2 + (pts[:, 1] + 0.21) ** 2) / (2 * sigma * sigma))
+        lum = np.clip(60.0 + g, 0, 255).astype(np.uint32)
+        c["rgba"] = (0xFF << 24) | (lum << 16) | (lum << 8) | lum
+        got = ctx.detectKeypoints(ctx.cloud(c), None, 0, 5.0, R_NRM, 0.1).numpy()
+        ref, _ = po.keypoints_sift(c, 0.1, 3, 3, 5.0)
+        assert len(got) == len(ref) == expect and np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
