@@ -861,7 +861,7 @@ struct SfLaunch {
   unsigned blocks = 0;
   SfLaunch(Context *c, int n_items)
   {
-    const unsigned cap = (unsigned)snb_cu_count(c->device) * 2u;
+    const unsigned cap = (unsigned)snb_cu_count(c->device) * (unsigned)MM3D_SF_BLOCKS;
     blocks = (unsigned)std::max(1, std::min<int>(n_items, (int)cap));
     ctl = DevBuf<int>(c, sizeof(SnbCtl) / sizeof(int));
     ov_items = DevBuf<int>(c, (size_t)std::max(n_items, 1));

@@ -14,9 +14,14 @@
 //      B(i, s) >= |CPU path's float DoG - val*| (derivation below).
 //   2. k_sift_pack_iv: intervals [val* - B, val* + B] per point and scale; contrast classes: certainly below the
 //      contrast (no candidate), certainly above (live), open.
-//   3. k_sift_extrema_iv: the 25 nearest by the exact search of k_sift_extrema (nearest violator + count of closer points,
-//      ring by ring), with intervals: a neighbour CERTAINLY below decides "no", no neighbour POSSIBLY below-or-equal
-//      decides "yes", anything else is open -- the point and the neighbours whose comparison is open are marked.
+//   3. k_sift_reject: a (point, scale) that is no extremum has many neighbours below AND above it, and ONE certain violator
+//      per side decides "no" if it is among the 25 nearest -- which every point inside the widest ball that the unsorted pass
+//      counted at most 25 points in is.  97 % of the candidates end here.  What is left -- the keypoints themselves, near misses,
+//      open comparisons -- gets the exact 25-nearest test of k_sift_extrema (nearest certain / possible violator as (distance,
+//      index) keys, then the number of closer points) on intervals: k_sift_extrema_one, one wave per point inside the narrowest
+//      counted ball with at least 25 points (k_sift_extrema_iv grows rings for the points whose 3 sigma_max ball holds fewer):
+//      a neighbour CERTAINLY below decides "no", no neighbour POSSIBLY below-or-equal decides "yes", anything else is open --
+//      the point and the neighbours whose comparison is open are marked.
 //   4. the marked points (0.05 - 0.1 % of an octave on the headline maps, scripts/sift_price.py) get the CPU path's exact
 //      DoG floats from k_sift_dog_lds on single-query items; their intervals collapse to points and the test of the open
 //      points is taken again: every comparison that was open is now exact against exact, every other one stays decided
@@ -60,16 +65,21 @@ struct SfCfg {
   static_assert(WAVES_ == 8, "the reduction deals its eight sums to eight waves");
   static_assert(TILE_CAP_ * 16 >= WAVES_ * (3 * kCertScales + 2) * 64 * 4, "the partial sums reuse the tile's memory");
 };
-using SfCfgDefault = SfCfg<8, 2816>;
+#ifndef MM3D_SF_TILE
+#define MM3D_SF_TILE 2816
+#endif
+#ifndef MM3D_SF_BLOCKS
+#define MM3D_SF_BLOCKS 2
+#endif
+using SfCfgDefault = SfCfg<8, MM3D_SF_TILE>;
 
 template <class Cfg>
 struct alignas(16) SfLds {
   float4 tile[Cfg::kTileCap + 4];            // staged candidates: x, y, z, intensity (then: the waves' partial sums)
   int off[Cfg::kWaves][64], beg[Cfg::kWaves][64];
-  float4 qpts[64];
   float resp[kCertScales][64], bres[kCertScales][64];
   int ntot[kCertScales + 2][64];             // neighbours inside T[0..5], TA, TB
-  int n_tile[2];
+  int n_tile[1];
   int item;
 };
 
@@ -87,7 +97,7 @@ __device__ __forceinline__ float sf_intensity(float w)
 // candidate twice, so no box is too large for it (round 6, second half: a first version staged the whole box at once and gave
 // the items of a dense cloud -- 8 x 2 M indoor points: most of them -- up to the exact path, 56 map-pairs/s against 76).
 template <class Cfg>
-__global__ void __launch_bounds__(64 * Cfg::kWaves, 2 * Cfg::kWaves / 4)
+__global__ void __launch_bounds__(64 * Cfg::kWaves, MM3D_SF_BLOCKS * Cfg::kWaves / 4)
 k_sift_dog_fast(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, int n_items, GridView g /* .w = original index */,
                 const float4 *__restrict__ pts /* original order: rgba */, float radius, SfScales sc, SnbCtl *ctl, int *__restrict__ ov_items,
                 float *__restrict__ dogv, float *__restrict__ dogb, float *__restrict__ rlo2, float *__restrict__ rup2,
@@ -525,13 +535,6 @@ __global__ void k_sift_collect(const unsigned char *__restrict__ mark, const flo
   items[k] = make_int2(k, 1);
   ids[k] = i;
   ident[k] = k;
-}
-
-__global__ void k_sift_live_iv(const float4 *__restrict__ hil, int n, const unsigned char *__restrict__ cls, int *__restrict__ flag /* [n + 1] */)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > n) return;
-  flag[j] = (j < n && (cls[__float_as_int(hil[j].w)] & 7u)) ? 1 : 0;
 }
 
 // the points with sel[i] & mask as work for the two extremum kernels: a point whose search radius is known (rup2 finite) goes
