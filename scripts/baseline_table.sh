@@ -26,4 +26,4 @@ run 4indoor --maps 8 --points 2000000 --descriptor SHOT --window 30 --resolution
 run 2lattice --maps 4 --points 200000 --scenes lattice --overlap-step 0.25 --sac-iterations 20000 --steps 3 --warmup 1
 # the headline size on the 'lattice' family with 20 000 hypotheses: poses worth refining, so "Mpoints/s (ICP)" is measured on an ICP
 # that iterates (CPU baselines + parity_check on a sample of two maps and ONE pair: a pair with 20 000 hypotheses is ~ 50 s of one core)
-run 3lattice --maps 16 --points 500000 --scenes lattice --overlap-step 0.25 --sac-iterations 20000 --steps 2 --warmup 1
+run 3lattice --maps 16 --points 500000 --scenes lattice --overlap-step 0.25 --sac-iterations 20000 --steps 3 --warmup 2
