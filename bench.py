@@ -40,7 +40,10 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA (v_mfma_f32_32x32x2_f32)
-MFMA_KERNELS = {"desc_knn_mfma"}   # kernels whose profile "bytes" field carries FLOPs (csrc/desc_knn.hip)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), measured 2495
+# kernels whose profile "bytes" field carries the FLOPs they execute (csrc/desc_knn.hip), and the matrix peak they run against:
+# the f32 selector on the f32 cores, the split-bf16 selector of the wide rows (three bf16 products per float product) on the bf16 ones
+MFMA_KERNELS = {"desc_knn_mfma": MFMA_F32_PEAK_TFLOPS, "desc_knn_mfma_bf16": MFMA_BF16_PEAK_TFLOPS}
 # VALU issue peak, wave-instructions per second over the chip.  MEASURED: independent v_fma_f32 streams at 4 and 8 waves per
 # SIMD on all 256 CUs sustain 8.4e11 (scripts/micro/valu_rate.hip, profiles/r04_valu_rate.txt; v_add_f32 / v_mul_f32 /
 # integer adds and logic 6.5 - 8.3e11; v_max / v_cvt / shifts / v_mbcnt / packed f32 / DPP adds / f64 4.2 - 5.0e11;
@@ -53,7 +56,7 @@ VALU_PEAK_NOMINAL_WINSTR_S = 256 * 4 * 2.4e9 / 2
 KERNEL_OF_SYMBOL = {"k_sift_dog_lds": "sift_dog", "k_sift_dog_lds_dense": "sift_dog_dense", "k_sift_dog_lds_exact": "sift_dog_exact", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_sift_extrema": "sift_extrema", "k_spfh": "spfh", "k_normals": "normals_radius_big",
                     "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_seq_sum": "sacia_seq_sum", "k_sift_dog_fast": "sift_dog_fast", "k_sift_reject": "sift_reject",
                     "k_sift_extrema_one": "sift_extrema_one",
-                    "k_fpfh_weight": "fpfh_weight", "k_knn_mfma": "desc_knn_mfma", "k_knn_rerank": "desc_knn_rerank",
+                    "k_fpfh_weight": "fpfh_weight", "k_knn_mfma": "desc_knn_mfma", "k_knn_mfma_wide_bf": "desc_knn_mfma_bf16", "k_knn_rerank": "desc_knn_rerank",
                     "k_radius_count": "radius_outlier_count"}
 
 
@@ -99,7 +102,7 @@ KERNEL_SYMBOLS = {
     "sift_dog": r"k_sift_dog_lds", "sift_dog_exact": r"k_sift_dog_lds", "sift_dog_fast": r"k_sift_dog_fast", "sift_reject": r"k_sift_reject",
     "sift_extrema": r"k_sift_extremaI", "sift_extrema_one": r"k_sift_extrema_one", "normals_radius": r"k_normals_lds", "spfh": r"k_spfh", "fpfh_weight": r"k_fpfh_weight",
     "fpfh_mark": r"k_fpfh_mark", "icp_corr_reduce": r"k_nn_waveILi0", "score_nn_reduce": r"k_nn_waveILi1", "sacia_err": r"k_sacia_err",
-    "sacia_seq_sum": r"k_seq_sum", "desc_knn_mfma": r"k_knn_(mfma|filter)", "desc_knn_rerank": r"k_knn_rerank",
+    "sacia_seq_sum": r"k_seq_sum", "desc_knn_mfma": r"k_knn_(mfma|filter)", "desc_knn_mfma_bf16": r"k_knn_mfma_wide_bf", "desc_knn_rerank": r"k_knn_rerank",
     "radius_outlier_count": r"k_radius_count", "voxel_centroid": r"k_voxel_centroid",
 }
 _ISA_CACHE = {}
@@ -715,7 +718,7 @@ def main():
         if launch_ms <= 0:
             return out
         if name in MFMA_KERNELS:
-            out["mfma_frac"] = round(work / (launch_ms * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12), 5)
+            out["mfma_frac"] = round(work / (launch_ms * 1e-3) / (MFMA_KERNELS[name] * 1e12), 5)
         else:
             out["hbm_frac"] = round(work / (launch_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 5)
         if name in valu_insts and not stale(name):
@@ -747,8 +750,9 @@ def main():
             work_per_launch = k["bytes"] / max(k["launches"], 1)   # bytes, or FLOPs for the MFMA kernel
             rate = work_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
             if dom[0] in MFMA_KERNELS:
-                roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(rate / 1e12, 4), "peak": MFMA_F32_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(rate / 1e12 / MFMA_F32_PEAK_TFLOPS, 6), "traffic": None,
+                roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(rate / 1e12, 4), "peak": MFMA_KERNELS[dom[0]],
+                            "unit": "TFLOP/s", "frac": round(rate / 1e12 / MFMA_KERNELS[dom[0]], 6), "traffic": None,
+                            "mfma_dtype": "bf16 (split: three products per f32 product)" if dom[0].endswith("_bf16") else "f32",
                             "avg_launch_us": round(avg_ms * 1e3, 3), "launches_per_step": k["launches"] / max(args.steps, 1),
                             "algorithmic_flops_per_launch": round(work_per_launch, 1)}
             else:
@@ -768,7 +772,7 @@ def main():
             if dom[0] in iso and iso[dom[0]]["launches"]:
                 iso_ms = iso[dom[0]]["ms"] / iso[dom[0]]["launches"]
                 iso_work = iso[dom[0]]["bytes"] / iso[dom[0]]["launches"]
-                peak = MFMA_F32_PEAK_TFLOPS * 1e12 if dom[0] in MFMA_KERNELS else HBM_PEAK_GBS * 1e9
+                peak = MFMA_KERNELS[dom[0]] * 1e12 if dom[0] in MFMA_KERNELS else HBM_PEAK_GBS * 1e9
                 roofline["isolated_avg_launch_us"] = round(iso_ms * 1e3, 3)
                 roofline["isolated_frac"] = round(iso_work / (iso_ms * 1e-3) / peak, 6) if iso_ms > 0 else None
             iso_us = roofline.get("isolated_avg_launch_us")

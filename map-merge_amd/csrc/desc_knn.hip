@@ -1535,9 +1535,10 @@ static void desc_knn_wide_impl(Context *c, const mm3d_desc *A, const mm3d_desc *
   const int n_lists = kLists * parts;
   DevBuf<float> cand_d(c, (size_t)na * n_lists * kListLen);
   DevBuf<int> cand_i(c, (size_t)na * n_lists * kListLen);
-  // (the profile's flops are the f32-equivalent ones of the product either way: 2 na nb kKP)
+  // (its own profile name, and the flops it EXECUTES: three bf16 products per padded contraction step -- against the bf16 MFMA
+  // peak in bench.py; the f32-equivalent figure, 2 na nb kKP, is a third of it less the padding)
   if (bf)
-    MM3D_LAUNCH(c, "desc_knn_mfma", 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * kKP, (k_knn_mfma_wide_bf<kD>), dim3(a_blocks, parts),
+    MM3D_LAUNCH(c, "desc_knn_mfma_bf16", 3.0 * 2.0 * (double)na_tiles * 32 * (double)nb_tiles * 32 * knn_kp16(kD), (k_knn_mfma_wide_bf<kD>), dim3(a_blocks, parts),
                 dim3(256), 0, reinterpret_cast<const uint4 *>(Ap.get()), na, na_tiles, reinterpret_cast<const uint4 *>(Bp), nb, nb_tiles, cand_d.get(),
                 cand_i.get());
   else

@@ -52,6 +52,9 @@ for dim in dims:
             if ms / tot < 0.02:
                 continue
             extra = f"  {b / ms * 1e3 / 1e12:.1f} TF/s" if name == "desc_knn_mfma" else ""
+            if name == "desc_knn_mfma_bf16":        # the profile carries the bf16 flops the selector executes (3 products, padded K)
+                kp, kp16 = (dim + 9) // 8 * 8, (dim + 6 + 15) // 16 * 16
+                extra = f"  {b / ms * 1e3 / 1e12:.0f} TF/s of bf16 MFMA executed = {b / 3 * kp / kp16 / ms * 1e3 / 1e12:.1f} TF/s f32-equivalent"
             print(f"   {name:22s} {n:4d} launches  {ms / n * 1e3:9.1f} us avg{extra}")
         if dim in TYPE:
             da.free(); db.free()
