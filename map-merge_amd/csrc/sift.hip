@@ -913,21 +913,14 @@ static bool sift_octave_certified(Context *c, const mm3d_cloud *cur, const Grid 
                 (const int2 *)cur->wave_items.get(), n_items, gr.view(), (const float *)rlo2.get(), (const float *)dogv.get(), (const float *)dogb.get(),
                 (const float4 *)dogx.get(), n, cls.get(), reinterpret_cast<SnbCtl *>(rctl.get()), ctr);
   }
-  // 3. what is left: one wave per point where the unsorted pass knows a ball that holds the 25 nearest, ring growth for the
-  // few it does not (fewer than 25 points within 3 sigma_max)
+  // 3. what is left: one wave per point, inside the ball the unsorted pass counted the 25 nearest in
   DevBuf<int> cids(c, (size_t)n), oids2(c, (size_t)n);
-  DevBuf<float4> wq(c, (size_t)n), owq(c, (size_t)n);
-  DevBuf<int2> witems(c, (size_t)n), owitems(c, (size_t)n);
-  int *n_cids = n_marked_dev + 2, *n_wide = n_marked_dev + 3, *n_oids = n_marked_dev + 4, *n_owide = n_marked_dev + 5;
+  int *n_cids = n_marked_dev + 2, *n_oids = n_marked_dev + 4;
   const unsigned one_blocks = (unsigned)snb_cu_count(c->device) * 4u;
-  MM3D_LAUNCH(c, "sift_collect", n * 5.0, k_sift_collect_split, dim3(div_up(n, 256)), dim3(256), 0, (const unsigned char *)cls.get(), 7u,
-              (const float *)rup2.get(), (const float4 *)cur->pts.get(), n, cids.get(), n_cids, wq.get(), witems.get(), n_wide);
+  MM3D_LAUNCH(c, "sift_collect", n * 5.0, k_sift_collect_ids, dim3(div_up(n, 256)), dim3(256), 0, (const unsigned char *)cls.get(), 7u, n, cids.get(), n_cids);
   MM3D_LAUNCH(c, "sift_extrema_one", 0.0, k_sift_extrema_one<false>, dim3(one_blocks), dim3(256), 0, (const int *)cids.get(), (const int *)n_cids,
-              (const float4 *)cur->pts.get(), gr.view(), (const float *)rup2.get(), (const float4 *)dogx.get(), n, (const float *)dogv.get(),
+              (const float4 *)cur->pts.get(), gr.view(), (const float *)rup2.get(), fs.T[kScales - 1], (const float4 *)dogx.get(), n, (const float *)dogv.get(),
               (const float *)dogb.get(), (const unsigned char *)cls.get(), flags, need_exact, open_p, ctr);
-  MM3D_LAUNCH(c, "sift_extrema_iv", 0.0, k_sift_extrema_iv<false>, dim3(256), dim3(256), 0,
-              (const float4 *)wq.get(), (const int2 *)witems.get(), (const int *)n_wide, gr.view(), (const float4 *)dogx.get(), n,
-              (const float *)dogv.get(), (const float *)dogb.get(), (const unsigned char *)cls.get(), flags, need_exact, open_p, ctr);
   // 4. the marked points: exact DoG floats from the sorted lists (single-query items, the number known to the device only)
   DevBuf<float4> mq(c, (size_t)n);
   DevBuf<int2> mitems(c, (size_t)n);
@@ -936,6 +929,8 @@ static bool sift_octave_certified(Context *c, const mm3d_cloud *cur, const Grid 
               (const float4 *)cur->pts.get(), n, mq.get(), mitems.get(), mids.get(), mident.get(), n_marked_dev);
   const size_t extra_lds = sizeof(float) * 64 * kScales + 256;
   SnbLaunch<SiftCfgLarge> sl(c, n, extra_lds);
+  // (a few hundred single-query items, a block each: 64 blocks of four items measured slower inside the step -- 410 against 270 us per
+  // launch -- although every block of this configuration waits for a whole CU's LDS)
   const unsigned exact_blocks = std::min(sl.blocks, 256u);
   MM3D_LAUNCH(c, "sift_dog_exact", 0.0, (k_sift_dog_lds<SiftCfgLarge, false>), dim3(exact_blocks), dim3(64 * SiftCfgLarge::kWaves), 0,
               (const float4 *)mq.get(), (const int2 *)mitems.get(), 0, gr.view(), (const float4 *)cur->pts.get(), max_radius, r2, sc, sl.ctl_dev(),
@@ -944,14 +939,10 @@ static bool sift_octave_certified(Context *c, const mm3d_cloud *cur, const Grid 
   MM3D_LAUNCH(c, "sift_pack", 0.0, k_sift_pack_marked, dim3(std::min(div_up(n, 256), 64u)), dim3(256), 0, (const int *)mids.get(), (const int *)n_marked_dev,
               (const float *)dog.get(), dogv.get(), dogb.get(), n, min_contrast, dogx.get(), cls.get(), ctr);
   // 5. the open points again, on the collapsed intervals
-  MM3D_LAUNCH(c, "sift_collect", n * 1.0, k_sift_collect_split, dim3(div_up(n, 256)), dim3(256), 0, (const unsigned char *)open_p, 1u,
-              (const float *)rup2.get(), (const float4 *)cur->pts.get(), n, oids2.get(), n_oids, owq.get(), owitems.get(), n_owide);
+  MM3D_LAUNCH(c, "sift_collect", n * 1.0, k_sift_collect_ids, dim3(div_up(n, 256)), dim3(256), 0, (const unsigned char *)open_p, 1u, n, oids2.get(), n_oids);
   MM3D_LAUNCH(c, "sift_extrema_fin", 0.0, k_sift_extrema_one<true>, dim3(64), dim3(256), 0, (const int *)oids2.get(), (const int *)n_oids,
-              (const float4 *)cur->pts.get(), gr.view(), (const float *)rup2.get(), (const float4 *)dogx.get(), n, (const float *)dogv.get(),
+              (const float4 *)cur->pts.get(), gr.view(), (const float *)rup2.get(), fs.T[kScales - 1], (const float4 *)dogx.get(), n, (const float *)dogv.get(),
               (const float *)dogb.get(), (const unsigned char *)cls.get(), flags, need_exact, open_p, ctr);
-  MM3D_LAUNCH(c, "sift_extrema_fin", 0.0, k_sift_extrema_iv<true>, dim3(64), dim3(256), 0,
-              (const float4 *)owq.get(), (const int2 *)owitems.get(), (const int *)n_owide, gr.view(), (const float4 *)dogx.get(), n,
-              (const float *)dogv.get(), (const float *)dogb.get(), (const unsigned char *)cls.get(), flags, need_exact, open_p, ctr);
   int *h = (int *)c->pin(64);      // [0..7] CertCounters, [8] marked, [9] exact launch's overflow, [10] fast launch's overflow items
   MM3D_HIP(hipMemcpyAsync(h, ctr, sizeof(CertCounters), hipMemcpyDeviceToHost, c->stream));
   MM3D_HIP(hipMemcpyAsync(h + 8, n_marked_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -19,7 +19,7 @@
 //      counted at most 25 points in is.  97 % of the candidates end here.  What is left -- the keypoints themselves, near misses,
 //      open comparisons -- gets the exact 25-nearest test of k_sift_extrema (nearest certain / possible violator as (distance,
 //      index) keys, then the number of closer points) on intervals: k_sift_extrema_one, one wave per point inside the narrowest
-//      counted ball with at least 25 points (k_sift_extrema_iv grows rings for the points whose 3 sigma_max ball holds fewer):
+//      counted ball with at least 25 points (a point whose 3 sigma_max ball holds fewer doubles its radius until the ball does):
 //      a neighbour CERTAINLY below decides "no", no neighbour POSSIBLY below-or-equal decides "yes", anything else is open --
 //      the point and the neighbours whose comparison is open are marked.
 //   4. the marked points (0.05 - 0.1 % of an octave on the headline maps, scripts/sift_price.py) get the CPU path's exact
@@ -268,7 +268,7 @@ k_sift_dog_fast(const float4 *__restrict__ q_pts, const int2 *__restrict__ items
         if (S.ntot[s][lane] <= kCertKnn) r = sc.T[s];
       rlo2[self] = r;
       // ... and the search radius: the narrowest of the eight balls that holds at least 25 points -- the 25 nearest all lie
-      // inside it (k_sift_extrema_one); +inf: even the 3 sigma_max ball holds fewer (k_sift_extrema_iv grows rings)
+      // inside it (k_sift_extrema_one); +inf: even the 3 sigma_max ball holds fewer (the search doubles the radius)
       float ru = INFINITY;
 #pragma unroll
       for (int s = kCertScales - 1; s >= 0; --s)
@@ -537,21 +537,11 @@ __global__ void k_sift_collect(const unsigned char *__restrict__ mark, const flo
   ident[k] = k;
 }
 
-// the points with sel[i] & mask as work for the two extremum kernels: a point whose search radius is known (rup2 finite) goes
-// on the id list of k_sift_extrema_one, the others become single-query items of k_sift_extrema_iv
-__global__ void k_sift_collect_split(const unsigned char *__restrict__ sel, unsigned mask, const float *__restrict__ rup2, const float4 *__restrict__ pts, int n,
-                                     int *__restrict__ ids, int *__restrict__ n_ids, float4 *__restrict__ wq, int2 *__restrict__ witems, int *__restrict__ n_wide)
+// the points with sel[i] & mask, as the id list of k_sift_extrema_one
+__global__ void k_sift_collect_ids(const unsigned char *__restrict__ sel, unsigned mask, int n, int *__restrict__ ids, int *__restrict__ n_ids)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !(sel[i] & mask)) return;
-  if (rup2[i] < INFINITY) {
-    ids[atomicAdd(n_ids, 1)] = i;
-  } else {
-    const int k = atomicAdd(n_wide, 1);
-    const float4 p = pts[i];
-    wq[k] = make_float4(p.x, p.y, p.z, __int_as_float(i));
-    witems[k] = make_int2(k, 1);
-  }
+  if (i < n && (sel[i] & mask)) ids[atomicAdd(n_ids, 1)] = i;
 }
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
@@ -571,11 +561,17 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // passes.  Here the radius is KNOWN: the unsorted pass counted at least 25 points inside rup2(p), so the 25 nearest all lie
 // in that ball and one look at the cells that cover it is enough -- nearest certain / possible violator per (scale, side)
 // as (distance, index) keys over the ball's points (every lane its share, one wave reduction), then the number of points
-// closer than each; the decisions are k_sift_extrema_iv's.  No LDS tile: a candidate is read by one lane, once per pass.
+// closer than each.  Per side: a certain violator among the 25 nearest -> not an extremum; else a possible one among them ->
+// OPEN; else an extremum.  A (point, scale) is decided when both sides say no, or the contrast is certain and a side says yes;
+// what is open marks the point (open_p, need_exact) and, in a third look at the same candidates, every neighbour whose
+// comparison on an open side is possible but not certain (need_exact).  kFinal: nothing may be open (counted).
+// A point whose 3 sigma_max ball holds fewer than 25 points (rup2 = +inf: the border of a sparse cloud) first doubles its
+// radius until the ball does.  No LDS tile: a candidate is read by one lane, once per pass.
 template <bool kFinal>
 __global__ void __launch_bounds__(256)
 k_sift_extrema_one(const int *__restrict__ ids, const int *__restrict__ n_ids_dev, const float4 *__restrict__ pts /* original order */, GridView g /* .w = original index */,
-                   const float *__restrict__ rup2, const float4 *__restrict__ dogx /* [3][n_pts] */, int n_pts, const float *__restrict__ dogv,
+                   const float *__restrict__ rup2, float r2_max /* the 3 sigma_max ball */, const float4 *__restrict__ dogx /* [3][n_pts] */, int n_pts,
+                   const float *__restrict__ dogv,
                    const float *__restrict__ dogb, const unsigned char *__restrict__ cls, int *__restrict__ flags /* [n*3] */,
                    unsigned char *__restrict__ need_exact, unsigned char *__restrict__ open_p, CertCounters *__restrict__ ctr)
 {
@@ -588,10 +584,37 @@ k_sift_extrema_one(const int *__restrict__ ids, const int *__restrict__ n_ids_de
   for (int k = (int)blockIdx.x * 4 + wave; k < n_ids; k += n_waves) {
     const int self = ids[k];
     const float4 q = pts[self];
-    const float r2q = rup2[self];
+    float r2q = rup2[self];
     const unsigned c = cls[self];
     const unsigned cand = c & 7u, live = (c >> 3) & 7u;
     if (!cand) continue;                         // wave-uniform
+    if (!(r2q < INFINITY)) {                     // wave-uniform: grow the ball until it holds the 25 nearest
+      const int kk0 = g.n < kCertKnn ? g.n : kCertKnn;
+      float r2 = r2_max;
+      for (int grow = 0; grow < 48; ++grow) {
+        r2 *= 4.0f;
+        const float rg = sqrtf(r2) * 1.0001f + 1e-4f;
+        const int bx0 = max(cell_floor(q.x - rg, g.minx, g.inv), 0), bx1 = min(cell_floor(q.x + rg, g.minx, g.inv), g.dx - 1);
+        const int by0 = max(cell_floor(q.y - rg, g.miny, g.inv), 0), by1 = min(cell_floor(q.y + rg, g.miny, g.inv), g.dy - 1);
+        const int bz0 = max(cell_floor(q.z - rg, g.minz, g.inv), 0), bz1 = min(cell_floor(q.z + rg, g.minz, g.inv), g.dz - 1);
+        if (bx0 == 0 && by0 == 0 && bz0 == 0 && bx1 == g.dx - 1 && by1 == g.dy - 1 && bz1 == g.dz - 1) { r2 = 3.0e38f; break; }   // the whole cloud
+        int cnt = 0;
+        const int bny = by1 - by0 + 1, brows = (bx0 <= bx1 && bny > 0 && bz1 >= bz0) ? bny * (bz1 - bz0 + 1) : 0;
+        for (int r = 0; r < brows; ++r) {        // (rare points: one row at a time, the lanes over its span)
+          const int z = bz0 + r / bny, y = by0 + r % bny;
+          const int row = (z * g.dy + y) * g.dx;
+          const int b = g.cell_start[row + bx0], e = g.cell_start[row + bx1 + 1];
+          for (int j = b + lane; j < e; j += kWave) {
+            const float4 cd = g.pts[j];
+            cnt += dist2(q.x, q.y, q.z, cd.x, cd.y, cd.z) <= r2 ? 1 : 0;
+          }
+        }
+        cnt = wave_sum(cnt);
+        cnt = __shfl(cnt, 0, 64);
+        if (cnt >= kk0) break;
+      }
+      r2q = r2;
+    }
     float lo[kCertDog], hi[kCertDog];
 #pragma unroll
     for (int s = 0; s < kCertDog; ++s) cert_interval(dogv[(size_t)self * kCertDog + s], dogb[(size_t)self * kCertDog + s], lo[s], hi[s]);
@@ -729,312 +752,6 @@ k_sift_extrema_one(const int *__restrict__ ids, const int *__restrict__ n_ids_de
       if (lane == 0) { need_exact[self] = 1; open_p[self] = 1; atomicAdd(&ctr->n_open, 1); }
       if (!(open_min | open_max)) break;         // only the contrast is open: no neighbour to mark
     }
-  }
-}
-
-// findScaleSpaceExtrema on intervals.  q_pts = the candidate points (compacted runs, or the open points as single-query
-// items), one item per BLOCK: the four waves hold the same <= 64 points and each scans a quarter of a tile's candidates
-// (k_sift_extrema<4> in sift.hip is the exact-value original of this kernel; its comments describe the search).
-// Per (point, scale, side) the scan keeps the nearest CERTAIN violator and the nearest POSSIBLE one as (distance, index)
-// keys, then counts the points closer than each:
-//   a certain violator among the 25 nearest                      -> not an extremum on that side
-//   else, the 25 nearest proven and no possible violator there   -> an extremum on that side
-//   else, the 25 nearest proven                                  -> OPEN
-// A (point, scale) is decided when both sides say no, or the contrast is certain and a side says yes.  What is open marks
-// the point (open_p, need_exact) and, in a third look at the same candidates, every neighbour inside the proven zone whose
-// comparison on an open side is possible but not certain (need_exact).  final: nothing may be open (counted).
-constexpr int kCertTile = 256;
-template <bool kFinal>
-__global__ void __launch_bounds__(256)
-k_sift_extrema_iv(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, const int *__restrict__ n_items_dev, GridView g /* .w = original index */,
-                  const float4 *__restrict__ dogx /* [3][n_pts] */, int n_pts, const float *__restrict__ dogv, const float *__restrict__ dogb,
-                  const unsigned char *__restrict__ cls, int *__restrict__ flags /* [n*3] */, unsigned char *__restrict__ need_exact,
-                  unsigned char *__restrict__ open_p, CertCounters *__restrict__ ctr)
-{
-  __shared__ float4 s_pts[4][kCertTile];
-  __shared__ float4 s_x[4][3 * kCertTile];
-  __shared__ int s_off[4][64];
-  __shared__ int s_beg[4][64];
-  const int n_items = *n_items_dev;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int item = (int)blockIdx.x; item < n_items; item += (int)gridDim.x) {
-  const int2 it = items[item];
-  const bool valid = lane < it.y;
-  if (it.y == 0) continue;                    // block-uniform
-  const float4 q = q_pts[it.x + (valid ? lane : 0)];
-  const int self = __float_as_int(q.w);
-  const unsigned long long key_self = (unsigned long long)(unsigned)self;      // distance 0
-  // own intervals at the three tested scales; the point itself at the adjacent scales (it is its own nearest neighbour:
-  // the same-scale comparison with itself never spoils anything and is left out of the scans)
-  float lo_p[3], hi_p[3];
-  bool self_cmin[3], self_pmin[3], self_cmax[3], self_pmax[3];
-  unsigned cand = 0, live = 0;
-  {
-    float lo[kCertDog], hi[kCertDog];
-#pragma unroll
-    for (int s = 0; s < kCertDog; ++s) {
-      lo[s] = 0.0f; hi[s] = 0.0f;
-      if (valid) cert_interval(dogv[(size_t)self * kCertDog + s], dogb[(size_t)self * kCertDog + s], lo[s], hi[s]);
-    }
-    const unsigned c = valid ? cls[self] : 0u;
-    cand = c & 7u;
-    live = (c >> 3) & 7u;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      lo_p[s] = lo[s + 1]; hi_p[s] = hi[s + 1];
-      self_cmin[s] = cert_pred(fminf(hi[s], hi[s + 2])) < lo_p[s];
-      self_pmin[s] = cert_pred(fminf(lo[s], lo[s + 2])) < hi_p[s];
-      self_cmax[s] = cert_succ(fmaxf(lo[s], lo[s + 2])) > hi_p[s];
-      self_pmax[s] = cert_succ(fmaxf(hi[s], hi[s + 2])) > lo_p[s];
-    }
-  }
-  bool todo = cand != 0;
-  // per (scale, side): 0 no, 1 yes, 2 open
-  int st_min[3] = {0, 0, 0}, st_max[3] = {0, 0, 0};
-  const int cx = cell_floor(q.x, g.minx, g.inv), cy = cell_floor(q.y, g.miny, g.inv), cz = cell_floor(q.z, g.minz, g.inv);
-  const int n_total = g.n;
-  const int max_e = max(max(g.dx, g.dy), g.dz) + 1;
-  const float4 *sp = s_pts[wave];
-  const float4 *sx = s_x[wave];
-  for (int grp = 0; grp < 64; ++grp) {
-  const unsigned long long open_l = ballot(todo);
-  if (!open_l) break;
-  const int leader = __ffsll((long long)open_l) - 1;
-  const int ldx = cx - __shfl(cx, leader, 64), ldy = cy - __shfl(cy, leader, 64), ldz = cz - __shfl(cz, leader, 64);
-  bool active = todo && abs(ldx) <= 8 && abs(ldy) <= 8 && abs(ldz) <= 8;
-  todo = todo && !active;
-  int need = 1;
-  for (int pass = 0; pass < 4096; ++pass) {
-    if (!ballot(active)) break;
-    const int E = wave_max_int(active ? need : 0);
-    const int lx = wave_min_int(active ? cx : 0x7fffffff), hx = wave_max_int(active ? cx : -0x7fffffff);
-    const int ly = wave_min_int(active ? cy : 0x7fffffff), hy = wave_max_int(active ? cy : -0x7fffffff);
-    const int lz = wave_min_int(active ? cz : 0x7fffffff), hz = wave_max_int(active ? cz : -0x7fffffff);
-    const int x0 = max(lx - E, 0), x1 = min(hx + E, g.dx - 1);
-    const int y0 = max(ly - E, 0), y1 = min(hy + E, g.dy - 1);
-    const int z0 = max(lz - E, 0), z1 = min(hz + E, g.dz - 1);
-    const float gx0 = (lx - E > 0) ? q.x - (g.minx + (float)(lx - E) * g.cell) : INFINITY;
-    const float gx1 = (hx + E < g.dx - 1) ? (g.minx + (float)(hx + E + 1) * g.cell) - q.x : INFINITY;
-    const float gy0 = (ly - E > 0) ? q.y - (g.miny + (float)(ly - E) * g.cell) : INFINITY;
-    const float gy1 = (hy + E < g.dy - 1) ? (g.miny + (float)(hy + E + 1) * g.cell) - q.y : INFINITY;
-    const float gz0 = (lz - E > 0) ? q.z - (g.minz + (float)(lz - E) * g.cell) : INFINITY;
-    const float gz1 = (hz + E < g.dz - 1) ? (g.minz + (float)(hz + E + 1) * g.cell) - q.z : INFINITY;
-    const float guard = fmaxf(fminf(fminf(fminf(gx0, gx1), fminf(gy0, gy1)), fminf(gz0, gz1)) * 0.9999f - 1e-5f, 0.0f);
-    const float guard2 = guard * guard;
-    const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dx - 1 && y1 == g.dy - 1 && z1 == g.dz - 1;
-    // nearest certain / possible violators, seeded with the point itself at the adjacent scales
-    unsigned long long vc_min[3], vp_min[3], vc_max[3], vp_max[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      vc_min[s] = self_cmin[s] ? key_self : ~0ull; vp_min[s] = self_pmin[s] ? key_self : ~0ull;
-      vc_max[s] = self_cmax[s] ? key_self : ~0ull; vp_max[s] = self_pmax[s] ? key_self : ~0ull;
-    }
-    int cc_min[3] = {0, 0, 0}, cp_min[3] = {0, 0, 0}, cc_max[3] = {0, 0, 0}, cp_max[3] = {0, 0, 0}, cg = 0;
-    auto my_range = [&](int cnt, int &k0, int &k1) {
-      const int qn = (cnt + 3) >> 2;
-      k0 = min(cnt, wave * qn);
-      k1 = min(cnt, k0 + qn);
-    };
-    auto merge_violators = [&]() {
-      unsigned long long *mine = reinterpret_cast<unsigned long long *>(s_x[wave]);
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        mine[s * 64 + lane] = vc_min[s]; mine[(3 + s) * 64 + lane] = vp_min[s];
-        mine[(6 + s) * 64 + lane] = vc_max[s]; mine[(9 + s) * 64 + lane] = vp_max[s];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) {
-        const unsigned long long *other = reinterpret_cast<const unsigned long long *>(s_x[w2]);
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const unsigned long long a = other[s * 64 + lane], b = other[(3 + s) * 64 + lane];
-          const unsigned long long c2 = other[(6 + s) * 64 + lane], d2 = other[(9 + s) * 64 + lane];
-          vc_min[s] = a < vc_min[s] ? a : vc_min[s];
-          vp_min[s] = b < vp_min[s] ? b : vp_min[s];
-          vc_max[s] = c2 < vc_max[s] ? c2 : vc_max[s];
-          vp_max[s] = d2 < vp_max[s] ? d2 : vp_max[s];
-        }
-      }
-      __syncthreads();
-    };
-    auto find_violators = [&](int cnt) {
-      if (!active) return;
-      int k0, k1;
-      my_range(cnt, k0, k1);
-      for (int k = k0; k < k1; ++k) {
-        const float4 c = sp[k];
-        const float4 a = sx[k], b = sx[kCertTile + k], d = sx[2 * kCertTile + k];
-        const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
-        const unsigned idx = __float_as_uint(c.w);
-        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | idx;
-        const bool other = idx != (unsigned)self;
-        const float mnhi[3] = {a.x, a.y, a.z}, mxlo[3] = {a.w, b.x, b.y};
-        const float mnlo[3] = {b.z, b.w, d.x}, mxhi[3] = {d.y, d.z, d.w};
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          if (other && mnhi[s] < lo_p[s] && key < vc_min[s]) vc_min[s] = key;
-          if (other && mnlo[s] < hi_p[s] && key < vp_min[s]) vp_min[s] = key;
-          if (other && mxlo[s] > hi_p[s] && key < vc_max[s]) vc_max[s] = key;
-          if (other && mxhi[s] > lo_p[s] && key < vp_max[s]) vp_max[s] = key;
-        }
-      }
-    };
-    auto count_closer = [&](int cnt) {
-      if (!active) return;
-      int k0, k1;
-      my_range(cnt, k0, k1);
-      for (int k = k0; k < k1; ++k) {
-        const float4 c = sp[k];
-        const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
-        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_uint(c.w);
-        cg += (d2 <= guard2) ? 1 : 0;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          cc_min[s] += (key < vc_min[s]) ? 1 : 0;
-          cp_min[s] += (key < vp_min[s]) ? 1 : 0;
-          cc_max[s] += (key < vc_max[s]) ? 1 : 0;
-          cp_max[s] += (key < vp_max[s]) ? 1 : 0;
-        }
-      }
-    };
-    auto load_x = [&](int j, float4 (&out)[3]) {
-      const int o = __float_as_int(g.pts[j].w);
-      out[0] = dogx[o]; out[1] = dogx[(size_t)n_pts + o]; out[2] = dogx[2 * (size_t)n_pts + o];
-    };
-    bool counted = false;                       // block-uniform
-    wave_stream_box<kCertTile, 3>(g, x0, x1, y0, y1, z0, z1, s_pts[wave], s_x[wave], s_off[wave], s_beg[wave], lane, load_x,
-                                  [&](int cnt, bool whole_box) {
-                                    find_violators(cnt);
-                                    if (whole_box) {
-                                      // (the exchange runs through the tile's interval half: save nothing -- the count needs only s_pts)
-                                      merge_violators();
-                                      count_closer(cnt);
-                                      counted = true;
-                                    }
-                                  });
-    if (!counted) {
-      merge_violators();
-      wave_stream_box<kCertTile, 0>(g, x0, x1, y0, y1, z0, z1, s_pts[wave], (float4 *)nullptr, s_off[wave], s_beg[wave], lane,
-                                    [](int, float4 (&)[1]) {}, count_closer);
-    }
-    {       // the quarters' counts
-      int *mine = reinterpret_cast<int *>(s_x[wave]);
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        mine[s * 64 + lane] = cc_min[s]; mine[(3 + s) * 64 + lane] = cp_min[s];
-        mine[(6 + s) * 64 + lane] = cc_max[s]; mine[(9 + s) * 64 + lane] = cp_max[s];
-      }
-      mine[12 * 64 + lane] = cg;
-      __syncthreads();
-#pragma unroll
-      for (int s = 0; s < 3; ++s) { cc_min[s] = 0; cp_min[s] = 0; cc_max[s] = 0; cp_max[s] = 0; }
-      cg = 0;
-#pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) {
-        const int *other = reinterpret_cast<const int *>(s_x[w2]);
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          cc_min[s] += other[s * 64 + lane]; cp_min[s] += other[(3 + s) * 64 + lane];
-          cc_max[s] += other[(6 + s) * 64 + lane]; cp_max[s] += other[(9 + s) * 64 + lane];
-        }
-        cg += other[12 * 64 + lane];
-      }
-      __syncthreads();
-    }
-    bool mark_pass = false;
-    unsigned open_min = 0, open_max = 0;        // sides open at this (final) pass
-    if (active) {
-      const int kk = n_total < kCertKnn ? n_total : kCertKnn;
-      const bool proven = cg >= kk || whole;     // the 25 nearest all lie inside the staged, proven zone
-      bool all_done = true;
-      auto side = [&](unsigned long long vc, unsigned long long vp, int cc, int cp, int &st) {
-        const float vcd2 = __uint_as_float((unsigned)(vc >> 32)), vpd2 = __uint_as_float((unsigned)(vp >> 32));
-        if (vc != ~0ull && (vcd2 <= guard2 || whole) && cc < kk) st = 0;                      // a certain violator among the 25 nearest
-        else if (proven) st = (vp != ~0ull && (vpd2 <= guard2 || whole) && cp < kk) ? 2 : 1;  // a possible one among them: open
-        else all_done = false;
-      };
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        if (!(cand & (1u << s))) continue;
-        side(vc_min[s], vp_min[s], cc_min[s], cp_min[s], st_min[s]);
-        side(vc_max[s], vp_max[s], cc_max[s], cp_max[s], st_max[s]);
-      }
-      if (all_done) {
-        active = false;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          if (!(cand & (1u << s))) continue;
-          const bool decided = (st_min[s] == 0 && st_max[s] == 0) || ((live & (1u << s)) && (st_min[s] == 1 || st_max[s] == 1));
-          if (!decided) {
-            if (st_min[s] == 2) open_min |= 1u << s;
-            if (st_max[s] == 2) open_max |= 1u << s;
-            mark_pass = true;
-          }
-        }
-      } else {
-        need = min(E + 1 + (E >> 1), max_e);
-      }
-    }
-    // the neighbours of the open comparisons: one more look at the same candidates (rare: block-uniform vote through LDS)
-    if (!kFinal) {
-      int *vote = reinterpret_cast<int *>(s_x[0]);
-      if (threadIdx.x == 0) vote[0] = 0;
-      __syncthreads();
-      if (ballot(mark_pass && (open_min | open_max)) && lane == 0) vote[0] = 1;
-      __syncthreads();
-      const bool any = vote[0] != 0;
-      __syncthreads();
-      if (any) {
-        const bool me = mark_pass && (open_min | open_max);
-        auto mark = [&](int cnt) {
-          if (!me) return;
-          int k0, k1;
-          my_range(cnt, k0, k1);
-          for (int k = k0; k < k1; ++k) {
-            const float4 c = sp[k];
-            const float4 a = sx[k], b = sx[kCertTile + k], d = sx[2 * kCertTile + k];
-            const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
-            const unsigned idx = __float_as_uint(c.w);
-            if (idx == (unsigned)self || !(d2 <= guard2 || whole)) continue;
-            const float mnhi[3] = {a.x, a.y, a.z}, mxlo[3] = {a.w, b.x, b.y};
-            const float mnlo[3] = {b.z, b.w, d.x}, mxhi[3] = {d.y, d.z, d.w};
-            bool hit = false;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-              if ((open_min & (1u << s)) && mnlo[s] < hi_p[s] && !(mnhi[s] < lo_p[s])) hit = true;
-              if ((open_max & (1u << s)) && mxhi[s] > lo_p[s] && !(mxlo[s] > hi_p[s])) hit = true;
-            }
-            if (hit) need_exact[idx] = 1;
-          }
-        };
-        wave_stream_box<kCertTile, 3>(g, x0, x1, y0, y1, z0, z1, s_pts[wave], s_x[wave], s_off[wave], s_beg[wave], lane, load_x, mark);
-        __syncthreads();
-      }
-    }
-    if (mark_pass && wave == 0) {
-      if (kFinal) atomicAdd(&ctr->still_open, 1);
-      else { need_exact[self] = 1; open_p[self] = 1; atomicAdd(&ctr->n_open, 1); }
-    }
-  }
-  }
-  if (valid && wave == 0) {
-    bool open_any = false;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      if (!(cand & (1u << s))) continue;
-      const bool no = st_min[s] == 0 && st_max[s] == 0;
-      const bool yes = (live & (1u << s)) && (st_min[s] == 1 || st_max[s] == 1);
-      if (!no && !yes) open_any = true;
-    }
-    // an open point's flags are written by the second pass (all three scales again, on exact values)
-    if (!open_any || kFinal) {
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-        if (cand & (1u << s)) flags[(size_t)self * 3 + s] = ((live & (1u << s)) && (st_min[s] == 1 || st_max[s] == 1)) ? 1 : 0;
-    }
-  }
-  __syncthreads();            // the next item reuses the tiles
   }
 }
 
