@@ -346,7 +346,7 @@ struct CertCounters {
 // the ball rlo2(p) is (the unsorted pass counted at most 25 points in it).  So: one unsorted look at the candidates within
 // the item's largest reject radius, no keys, no counts: per (query, candidate) the distance, the ball test and six
 // comparisons.  A scale with a certain violator on both sides loses its candidate bit in cls; what survives (the keypoints,
-// the near misses and everything open: a few per cent) goes to k_sift_extrema_iv.
+// the near misses and everything open: a few per cent) goes to k_sift_extrema_one.
 struct SrCfg {
   static constexpr int kWaves = 4;
   static constexpr int kTileCap = 640;      // (an item is a few hundred candidates; five blocks per CU hide the staging round trips)
