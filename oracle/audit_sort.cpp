@@ -84,3 +84,45 @@ extern "C" void ma_voxel_sort(const Pt *in, int n, double resolution, long long 
     b = e;
   }
 }
+
+// pcl::VoxelGrid as o_filters.c::mo_downsample restates it, but with the points of a voxel taken in the order THIS libstdc++'s
+// std::sort leaves them in (PCL's own call) instead of input order: what the first stage of the path would hand on if PCL 1.8.1's
+// libstdc++ orders equal keys like this one.  scripts/audit_exposure.py runs the rest of the oracle on both clouds and counts
+// what changes downstream.  out has room for n points; returns the number of voxels.
+extern "C" int ma_downsample_stdsort(const Pt *in, int n, double resolution, Pt *out)
+{
+  const float leaf = (float)resolution, inv = 1.0f / leaf;
+  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  bool any = false;
+  for (int i = 0; i < n; ++i) {
+    if (!std::isfinite(in[i].x) || !std::isfinite(in[i].y) || !std::isfinite(in[i].z)) continue;
+    const float v[3] = {in[i].x, in[i].y, in[i].z};
+    for (int a = 0; a < 3; ++a) { if (!any || v[a] < mn[a]) mn[a] = v[a]; if (!any || v[a] > mx[a]) mx[a] = v[a]; }
+    any = true;
+  }
+  if (!any) return 0;
+  int min_b[3], div_b[3];
+  for (int a = 0; a < 3; ++a) { min_b[a] = (int)floorf(mn[a] * inv); div_b[a] = (int)floorf(mx[a] * inv) - min_b[a] + 1; }
+  const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+  std::vector<Rec> rec;
+  rec.reserve((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    if (!std::isfinite(in[i].x) || !std::isfinite(in[i].y) || !std::isfinite(in[i].z)) continue;
+    const int i0 = (int)(floorf(in[i].x * inv) - (float)min_b[0]), i1 = (int)(floorf(in[i].y * inv) - (float)min_b[1]),
+              i2 = (int)(floorf(in[i].z * inv) - (float)min_b[2]);
+    rec.push_back(Rec{(unsigned)(i0 + i1 * mul1 + i2 * mul2), (unsigned)i});
+  }
+  std::sort(rec.begin(), rec.end(), std::less<Rec>());
+  int nout = 0;
+  for (size_t b = 0; b < rec.size();) {
+    size_t e = b + 1;
+    while (e < rec.size() && rec[e].idx == rec[b].idx) ++e;
+    float c[3];
+    uint32_t rgba;
+    centroid(in, &rec[b], &rec[e - 1] + 1, c, &rgba);
+    out[nout].x = c[0]; out[nout].y = c[1]; out[nout].z = c[2]; out[nout].rgba = rgba;
+    ++nout;
+    b = e;
+  }
+  return nout;
+}

@@ -132,5 +132,75 @@ def census(ci):
     print(f"  ({time.time() - t0:.0f} s)", flush=True)
 
 
-for ci in ([int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4]):
-    census(ci)
+if os.environ.get("MM3D_AUDIT_CENSUS", "1") != "0":       # (MM3D_AUDIT_CENSUS=0: only the downstream part below)
+    for ci in ([int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4]):
+        census(ci)
+
+
+def downstream_of_the_voxel_order(ci):
+    """Row 2 followed downstream: the oracle's feature chain on the VoxelGrid output in input order (the oracle's, the device's)
+    against the same chain on the output in libstdc++'s std::sort order (ma_downsample_stdsort).  The two clouds have the same
+    voxels in the same order, so point i corresponds to point i."""
+    cfg = CONFIGS[ci]
+    if cfg["descriptor"] != "FPFH":
+        return
+    host, _, _ = bench.make_workload_gt(cfg["maps"], cfg["points"], window=cfg["window"])
+    P = po.params_default()
+    A.ma_downsample_stdsort.restype = C.c_int
+    for mi in range(min(cfg["take"], 2)):
+        raw = host[mi]
+        d0 = po.downsample(raw, P.resolution)
+        d1 = np.empty(len(raw), dtype=raw.dtype)
+        n1 = A.ma_downsample_stdsort(p(raw), len(raw), C.c_double(P.resolution), p(d1))
+        d1 = d1[:n1].copy()
+        assert n1 == len(d0)
+        xyz_diff = int((np.stack([d0["x"], d0["y"], d0["z"]], 1).view(np.uint32) != np.stack([d1["x"], d1["y"], d1["z"]], 1).view(np.uint32)).any(1).sum())
+
+        def keep_mask(full, kept):                 # the filter preserves order: which points of `full` are in `kept`
+            m = np.zeros(len(full), dtype=bool)
+            fb, kb = full.view(np.uint8).reshape(len(full), -1), kept.view(np.uint8).reshape(len(kept), -1)
+            j = 0
+            for i in range(len(full)):
+                if j < len(kept) and np.array_equal(fb[i], kb[j]):
+                    m[i] = True
+                    j += 1
+            return m
+        f0 = po.remove_outliers(d0, P.descriptor_radius, P.outliers_min_neighbours)
+        f1 = po.remove_outliers(d1, P.descriptor_radius, P.outliers_min_neighbours)
+        m0, m1 = keep_mask(d0, f0), keep_mask(d1, f1)
+        flips = int((m0 != m1).sum())
+        k0, _ = po.keypoints_sift(f0, P.resolution, 3, 3, P.keypoint_threshold)
+        k1, _ = po.keypoints_sift(f1, P.resolution, 3, 3, P.keypoint_threshold)
+
+        def key(k):                                # keypoints are octave-cloud points: compare them to a tenth of a millimetre
+            return set(map(tuple, np.round(np.stack([k["x"], k["y"], k["z"]], 1).astype(np.float64) * 1e4).astype(np.int64)))
+        s0, s1 = key(k0), key(k1)
+        only0, only1 = len(s0 - s1), len(s1 - s0)
+        b0 = set(map(bytes, np.stack([k0["x"], k0["y"], k0["z"]], 1).astype(np.float32)))
+        b1 = set(map(bytes, np.stack([k1["x"], k1["y"], k1["z"]], 1).astype(np.float32)))
+        bits_moved = len(b0 - b1)
+        # FPFH rows of the keypoints the two runs share to 0.1 mm, in the first run's order
+        n0, n1 = po.normals(f0, P.normal_radius), po.normals(f1, P.normal_radius)
+        kk0, e0 = po.descriptors_fpfh(f0, n0, k0, P.descriptor_radius)
+        kk1, e1 = po.descriptors_fpfh(f1, n1, k1, P.descriptor_radius)
+        pos1 = {tuple(v): i for i, v in enumerate(np.round(np.stack([kk1["x"], kk1["y"], kk1["z"]], 1).astype(np.float64) * 1e4).astype(np.int64))}
+        rows_bits = rows_1e3 = shared = 0
+        for i, v in enumerate(np.round(np.stack([kk0["x"], kk0["y"], kk0["z"]], 1).astype(np.float64) * 1e4).astype(np.int64)):
+            j = pos1.get(tuple(v))
+            if j is None:
+                continue
+            shared += 1
+            if e0[i].tobytes() != e1[j].tobytes():
+                rows_bits += 1
+                rows_1e3 += int(np.max(np.abs(e0[i] - e1[j])) > 1e-3)
+        print(f"  map {mi} row 2 followed downstream (std::sort's order inside the voxels instead of input order): {xyz_diff} of {len(d0)} voxel centroids differ in "
+              f"their bits; the outlier filter then keeps {int(m0.sum())} / {int(m1.sum())} points ({flips} decisions flip); SIFT finds {len(k0)} / {len(k1)} keypoints, "
+              f"{only0} only with input order and {only1} only with std::sort's order ({100.0 * (only0 + only1) / max(len(k0), 1):.2f} % of the keypoints move by more than 0.1 mm or "
+              f"appear / disappear; {bits_moved} keypoints have other coordinate bits); of the {shared} FPFH rows of shared keypoints {rows_bits} differ in some bit, "
+              f"{rows_1e3} by more than 1e-3 in a bin (a bin is a percentage: 0 .. 100)", flush=True)
+
+
+if os.environ.get("MM3D_AUDIT_DOWNSTREAM", "1") != "0":
+    print("== row 2, downstream")
+    for ci in ([int(a) for a in sys.argv[1:]] or [0, 1, 2, 4]):
+        downstream_of_the_voxel_order(ci)

@@ -244,3 +244,14 @@ def test_committed_counters_belong_to_the_library_in_the_tree():
     # a comment edit changes no hash: the hash is of the code object, not of the sources
     stale = {k: (v, bench.kernel_source_hash(k)) for k, v in hashes.items() if bench.kernel_source_hash(k) != v}
     assert not stale, f"counters of {os.path.basename(latest)} are stale for {sorted(stale)}: profile again (scripts/profile_round.sh)"
+
+
+def test_bench_never_measures_one_gpu_under_an_n_gpu_label():
+    """`python bench.py --gpus N` without torchrun selects the one-process device-list engine -- and refuses, loudly, when the box has
+    fewer than N GPUs (round 5 printed a note and measured ONE GPU).  Here: no GPU at all, so --gpus 2 must end with that refusal
+    and no JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MM3D_BENCH_DEVICES")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "needs 2 visible GPUs" in (r.stderr + r.stdout)
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
