@@ -152,3 +152,38 @@ def test_the_hard_scenes_of_the_parity_suite_on_the_certified_path(ctx, po, big_
         got = ctx.detectKeypoints(ctx.cloud(c), None, 0, 5.0, R_NRM, 0.1).numpy()
         ref, _ = po.keypoints_sift(c, 0.1, 3, 3, 5.0)
         assert len(got) == len(ref) == expect and np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_on_the_certified_path(ctx, po, seed):
+    """Eight seeded scenes of different character -- textured sheets, clumps with empty space between them, sparse scatter, a
+    jittered lattice with duplicated points, other resolutions and thresholds -- through the certified octaves against the
+    oracle's keypoints, bit for bit."""
+    rng = np.random.default_rng(100 + seed)
+    kind = seed % 4
+    n = int(rng.integers(6000, 40000))
+    if kind == 0:        # an undulating textured sheet
+        xy = rng.uniform(-8, 8, (n, 2))
+        z = 0.3 * np.sin(xy[:, 0]) * np.cos(0.7 * xy[:, 1]) + rng.normal(0, 0.01, n)
+        p = np.column_stack([xy, z])
+    elif kind == 1:      # clumps of very different density, empty space between them
+        c = rng.uniform(-10, 10, (12, 3)) * np.array([1, 1, 0.2])
+        p = c[rng.integers(0, 12, n)] + rng.normal(0, 1, (n, 3)) * rng.uniform(0.1, 1.2, (n, 1))
+    elif kind == 2:      # sparse scatter in a slab
+        p = rng.uniform(-15, 15, (n, 3)) * np.array([1, 1, 0.05])
+    else:                # a jittered lattice, a tenth of the points duplicated
+        g = np.stack(np.meshgrid(np.arange(-60, 60), np.arange(-60, 60)), -1).reshape(-1, 2)[:n] * 0.11
+        p = np.column_stack([g, np.zeros(len(g))]) + rng.normal(0, 0.004, (len(g), 3))
+        p = np.concatenate([p, p[rng.integers(0, len(p), len(p) // 10)]])
+    c = np.zeros(len(p), dtype=po.POINT)
+    c["x"], c["y"], c["z"] = p[:, 0].astype(np.float32), p[:, 1].astype(np.float32), p[:, 2].astype(np.float32)
+    tex = 128 + 90 * np.sin(1.7 * p[:, 0] + 0.3 * seed) * np.cos(2.3 * p[:, 1]) + rng.normal(0, 12, len(p))
+    lum = np.clip(tex, 0, 255).astype(np.uint32)
+    c["rgba"] = (0xFF << 24) | (lum << 16) | (np.clip(lum + rng.integers(-20, 20, len(p)), 0, 255).astype(np.uint32) << 8) | lum
+    res = (0.1, 0.1, 0.2, 0.05)[seed % 4] if seed < 4 else 0.1
+    thr = (5.0, 1.0, 0.2, 12.0)[(seed // 2) % 4]
+    cloud = po.downsample(c, res)
+    ref, _ = po.keypoints_sift(cloud, res, 3, 3, thr)
+    got = ctx.detectKeypoints(ctx.cloud(cloud), None, 0, thr, R_NRM, res).numpy()
+    assert len(got) == len(ref), (seed, len(got), len(ref))
+    assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32)), seed
