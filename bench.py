@@ -53,7 +53,7 @@ MFMA_KERNELS = {"desc_knn_mfma": MFMA_F32_PEAK_TFLOPS, "desc_knn_mfma_bf16": MFM
 VALU_PEAK_WINSTR_S = 8.4e11
 VALU_PEAK_NOMINAL_WINSTR_S = 256 * 4 * 2.4e9 / 2
 # profile name (MM3D_LAUNCH) of the kernels whose C++ symbol differs from it (scripts/pmc_summary.py prints symbols)
-KERNEL_OF_SYMBOL = {"k_sift_dog_lds": "sift_dog", "k_sift_dog_lds_dense": "sift_dog_dense", "k_sift_dog_lds_exact": "sift_dog_exact", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_sift_extrema": "sift_extrema", "k_spfh": "spfh", "k_normals": "normals_radius_big",
+KERNEL_OF_SYMBOL = {"k_sift_dog_lds": "sift_dog", "k_sift_dog_lds_dense": "sift_dog_dense", "k_sift_dog_lds_exact": "sift_dog_exact", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_spfh": "spfh", "k_normals": "normals_radius_big",
                     "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_seq_sum": "sacia_seq_sum", "k_sift_dog_fast": "sift_dog_fast", "k_sift_reject": "sift_reject",
                     "k_sift_extrema_one": "sift_extrema_one",
                     "k_fpfh_weight": "fpfh_weight", "k_knn_mfma": "desc_knn_mfma", "k_knn_mfma_wide_bf": "desc_knn_mfma_bf16", "k_knn_rerank": "desc_knn_rerank",
@@ -100,7 +100,7 @@ def workload_signature(args):
 # gfx950 code objects of libmm3d.so).  The staleness hash below covers these symbols' machine code.
 KERNEL_SYMBOLS = {
     "sift_dog": r"k_sift_dog_lds", "sift_dog_exact": r"k_sift_dog_lds", "sift_dog_fast": r"k_sift_dog_fast", "sift_reject": r"k_sift_reject",
-    "sift_extrema": r"k_sift_extremaI", "sift_extrema_one": r"k_sift_extrema_one", "normals_radius": r"k_normals_lds", "spfh": r"k_spfh", "fpfh_weight": r"k_fpfh_weight",
+    "sift_extrema_one": r"k_sift_extrema_one", "normals_radius": r"k_normals_lds", "spfh": r"k_spfh", "fpfh_weight": r"k_fpfh_weight",
     "fpfh_mark": r"k_fpfh_mark", "icp_corr_reduce": r"k_nn_waveILi0", "score_nn_reduce": r"k_nn_waveILi1", "sacia_err": r"k_sacia_err",
     "sacia_seq_sum": r"k_seq_sum", "desc_knn_mfma": r"k_knn_(mfma|filter)", "desc_knn_mfma_bf16": r"k_knn_mfma_wide_bf", "desc_knn_rerank": r"k_knn_rerank",
     "radius_outlier_count": r"k_radius_count", "voxel_centroid": r"k_voxel_centroid",

@@ -645,7 +645,8 @@ int mm3d_transform_score(mm3d_ctx *ctx, const mm3d_cloud *source, const mm3d_clo
 }
 
 // ---------------------------------------------------------------- map bundles
-static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const mm3d_params *p)
+// wait = false: the caller goes on in the same stream (map_prepare_impl) and waits once, there
+static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const mm3d_params *p, bool wait = true)
 {
   if (p->keypoint_type != MM3D_KP_SIFT && p->keypoint_type != MM3D_KP_HARRIS) throw Error(MM3D_EINVAL, "invalid keypoint type");
   if (p->descriptor_type < 0 || p->descriptor_type >= 6) throw Error(MM3D_EINVAL, "unknown descriptor type");   // dispatch_descriptors.h:63
@@ -675,7 +676,7 @@ static mm3d_map *map_features_impl(mm3d_ctx *ctx, const mm3d_cloud *raw, const m
                                   : p->descriptor_type == MM3D_DESC_PFHRGB ? compute_pfhrgb(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                   : p->descriptor_type == MM3D_DESC_SHOT ? compute_shot(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius)
                                                                          : compute_fpfh(ctx, filt.get(), nrm.get(), kp.get(), p->descriptor_radius));
-  ctx->sync();
+  if (wait) ctx->sync();
   auto *m = new mm3d_map();
   m->points = filt.release();
   m->keypoints = kp.release();
@@ -708,9 +709,9 @@ static void map_prepare_impl(mm3d_ctx *ctx, mm3d_map *m, const mm3d_params *p)
 {
   prepare_pair_search(ctx, m->points, p->max_correspondence_distance, p->max_correspondence_distance);
   if (p->estimation_method == MM3D_EST_SAC_IA) prepare_sacia_target(ctx, m->keypoints, (float)p->max_correspondence_distance);
-  (void)cloud_host(ctx, m->keypoints);
   desc_knn_prepare_target(ctx, m->desc);
-  ctx->sync();
+  (void)cloud_host(ctx, m->keypoints, false);       // (the keypoints' host copy rides on the wait below)
+  ctx->sync();                                       // everything complete, the error flags the kernels left looked at
 }
 
 int mm3d_map_prepare(mm3d_ctx *ctx, mm3d_map *m, const mm3d_params *p)
@@ -1018,11 +1019,10 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
         // the map is this worker's alone until it is published: no waits for other contexts' sake while it is built
         // (Context::settle), one full wait -- which also looks at the recorded error flags -- before it is published
         c->private_objects = true;
-        std::unique_ptr<mm3d_map, MapFree> held(map_features_impl(c, raw.get(), params));
+        std::unique_ptr<mm3d_map, MapFree> held(map_features_impl(c, raw.get(), params, false));
+        map_prepare_impl(c, held.get(), params);        // (ends in that wait)
         raw.reset();
-        map_prepare_impl(c, held.get(), params);
         c->private_objects = false;
-        c->sync();
         {
           std::lock_guard<std::mutex> lk(mu);
           mm3d_map *m = held.release();
@@ -1051,7 +1051,9 @@ static void estimate_maps_streams(mm3d_ctx *ctx, const mm3d_cloud_view *clouds, 
         for (size_t p : mine)
           if (maps[all[p].first]->keypoints->n > 0 && maps[all[p].second]->keypoints->n > 0) done[p] = 1;
       }
-      c->sync();
+      // (every map and every batch of pairs ended in a wait that brought its results to the host: nothing is in flight here
+      // unless a kernel left an error flag to be looked at)
+      if (!c->deferred.empty()) c->sync();
     } catch (...) {
       std::lock_guard<std::mutex> lk(mu);
       if (!first_error) first_error = std::current_exception();
@@ -1178,11 +1180,10 @@ static mm3d_shard *shard_begin_impl(mm3d_ctx *ctx, const mm3d_cloud_view *clouds
                                                         clouds[i].stride ? clouds[i].rgba_offset : 12));
       // nobody else sees the map before on_streams has drained every stream: no waits for other contexts' sake
       c->private_objects = true;
-      mm3d_map *m = map_features_impl(c, raw.get(), params);
+      mm3d_map *m = map_features_impl(c, raw.get(), params, false);
       sh->maps[i] = m;                         // (distinct slots: no lock needed; the shard owns it from here)
-      map_prepare_impl(c, m, params);          // this rank is the map's target-side owner
-      c->private_objects = false;
-      c->sync();                               // also looks at the error flags the kernels left
+      map_prepare_impl(c, m, params);          // this rank is the map's target-side owner; ends in a full wait, which also
+      c->private_objects = false;              // looks at the error flags the kernels left
     }
   });
   return sh.release();
@@ -1755,11 +1756,10 @@ static bool devices_run_pipelined(mm3d_ctx *ctx, DevicesRun &R, const mm3d_cloud
                                                             clouds[i].stride ? clouds[i].stride : 16,
                                                             clouds[i].stride ? clouds[i].rgba_offset : 12));
           c->private_objects = true;
-          std::unique_ptr<mm3d_map, MapFree> held(map_features_impl(c, raw.get(), params));
-          raw.reset();
-          map_prepare_impl(c, held.get(), params);          // this device is the map's target-side owner
+          std::unique_ptr<mm3d_map, MapFree> held(map_features_impl(c, raw.get(), params, false));
+          map_prepare_impl(c, held.get(), params);          // this device is the map's target-side owner; ends in a full wait:
+          raw.reset();                                      // the map is complete in this device's memory BEFORE anybody is told
           c->private_objects = false;
-          c->sync();                                        // complete in this device's memory BEFORE anybody is told
           {
             std::lock_guard<std::mutex> lk(mu);
             R.sh[d]->maps[i] = held.release();

@@ -188,6 +188,8 @@ struct Context {
     if (!private_objects) sync();
   }
   int prof_slot(const char *name);
+  // a launch whose algorithmic bytes were still on the device when it was enqueued (MM3D_LAUNCH with 0) gets them here
+  void prof_add_bytes(const char *name, double bytes) { if (prof_on) prof[prof_slot(name)].bytes += bytes; }
   void prof_resolve();
 };
 

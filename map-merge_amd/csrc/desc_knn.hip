@@ -1351,7 +1351,7 @@ static void knn_norm_order(Context *c, const mm3d_desc *B, DevBuf<uint32_t> &nso
   MM3D_LAUNCH(c, "desc_knn_prep", nb * kD * 4.0, (k_knn_norms<kD>), dim3(div_up(nb, 256)), dim3(256), 0, (const float *)B->data.get(), nb,
               keys.get(), vals.get());
   sort_pairs_u32(c, keys.get(), nsort.get(), vals.get(), nperm.get(), (size_t)nb, 32);
-  c->sync();                                   // keys / vals go out of scope
+  c->settle();                                 // keys / vals go out of scope
 }
 
 void desc_knn_prepare_target(Context *c, const mm3d_desc *B_)

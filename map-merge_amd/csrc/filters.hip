@@ -46,7 +46,7 @@ struct VoxelStartStore {
   int n; int *starts; int *n_voxels;
   __device__ __forceinline__ void operator()(size_t j, int prefix, int v) const
   {
-    if (j == (size_t)n) { *n_voxels = prefix; return; }
+    if (j == (size_t)n) { n_voxels[0] = prefix; n_voxels[1] = 0; return; }      // ([1]: k_voxel_centroid's "a centroid strayed" word)
     if (v) starts[prefix] = (int)j;
   }
   __device__ __forceinline__ void done() const {}
@@ -56,8 +56,8 @@ struct VoxelStartStore {
 // float in that order: bit-identical to CentroidPoint on the CPU restatement.
 __global__ void __launch_bounds__(256)
 k_voxel_centroid(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, const int *__restrict__ starts,
-                 const int *__restrict__ nvox_dev, const int *__restrict__ unsorted, int nvalid, float4 *__restrict__ out,
-                 unsigned *__restrict__ box)
+                 int *__restrict__ nvox_dev /* [1]: set when a centroid lies farther than two leaves from its voxel's first member */,
+                 const int *__restrict__ unsorted, int nvalid, float two_leaves, float4 *__restrict__ out, unsigned *__restrict__ box)
 {
   // (the grid is sized by the bound -- one thread per finite input point --: the number of voxels is still on the device
   // when this is launched; the centroids' bounding box is reduced on the way out, scan_fused.hpp::BoxAcc)
@@ -70,9 +70,11 @@ k_voxel_centroid(const float4 *__restrict__ pts, const uint32_t *__restrict__ or
   for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += gridDim.x * blockDim.x) {
     int b = starts[v], e = (v + 1 < nvox) ? starts[v + 1] : nvalid;
     float sx = 0.f, sy = 0.f, sz = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f;
+    float fx = 0.f, fy = 0.f, fz = 0.f;
     for (int j = b; j < e; ++j) {
       float4 p = pts[order[j]];
       unsigned c = __float_as_uint(p.w);
+      if (j == b) { fx = p.x; fy = p.y; fz = p.z; }
       sx += p.x; sy += p.y; sz += p.z;
       sr += (float)((c >> 16) & 255u);
       sg += (float)((c >> 8) & 255u);
@@ -87,6 +89,9 @@ k_voxel_centroid(const float4 *__restrict__ pts, const uint32_t *__restrict__ or
     o.w = __uint_as_float(rgba);
     out[v] = o;
     acc.add(o);
+    // The true mean lies inside the voxel, within one leaf of every member; the float sums of a voxel with very many points far
+    // from the origin can carry it away.  mm3d_cloud::voxel_leaf promises the grids that it has not gone far.
+    if (!(fabsf(o.x - fx) <= two_leaves && fabsf(o.y - fy) <= two_leaves && fabsf(o.z - fz) <= two_leaves)) nvox_dev[1] = 1;
   }
   acc.flush_slot(box);
 }
@@ -200,8 +205,8 @@ mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
     scan_fused(c, "voxel_starts", n * 12.0, (size_t)n + 1, VoxelHeadLoad{keys2.get(), n}, VoxelStartStore{n, starts.get(), (int *)ctl.get()});
     // 16 B read per raw point + 16 B written per voxel
     MM3D_LAUNCH(c, "voxel_centroid", in->n_finite * 32.0, k_voxel_centroid, dim3(cblocks), dim3(256), 0, in->pts.get(),
-                (const uint32_t *)vals2.get(), (const int *)starts.get(), (const int *)ctl.get(), attempt == 0 ? (const int *)too_long.get() : (const int *)nullptr, (int)in->n_finite, out.get(),
-                ctl.get() + 16);
+                (const uint32_t *)vals2.get(), (const int *)starts.get(), (int *)ctl.get(), attempt == 0 ? (const int *)too_long.get() : (const int *)nullptr, (int)in->n_finite, 2.0f * leaf,
+                out.get(), ctl.get() + 16);
     MM3D_HIP(hipMemcpyAsync(h + 16, ctl.get(), ctl_bytes, hipMemcpyDeviceToHost, c->stream));
     MM3D_HIP(hipMemcpyAsync(h + 15, too_long.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
     c->sync();
@@ -224,6 +229,7 @@ mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
   unsigned box[8];
   box_of_slots(h + 32, cblocks, box);
   cloud_set_bbox(res, box);
+  if (h[17] == 0) res->voxel_leaf = leaf;              // every centroid stayed with its voxel (types.hpp: what cloud_grid makes of it)
   c->settle();
   return res;
 }
@@ -281,6 +287,7 @@ mm3d_cloud *remove_outliers(Context *c, const mm3d_cloud *in, double radius, int
   }
   mm3d_cloud *res = cloud_from_device(c, std::move(out), m);
   cloud_set_bbox(res, box);
+  res->voxel_leaf = in->voxel_leaf;                    // a subset of a voxel grid's centroids
   return res;
 }
 

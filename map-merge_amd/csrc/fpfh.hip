@@ -546,14 +546,14 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
   MM3D_LAUNCH(c, "fpfh_mark", nk * 16.0, k_fpfh_mark, dim3(div_up(nk, 4)), dim3(256), 0, keypoints->pts.get(), nk, g.view(),
               (float)radius, r2, in_set.get());
   exclusive_scan_int(c, in_set.get(), pos.get(), (size_t)n + 1);
+  // The size of the support set (the points within the radius of some keypoint: six in ten on the headline) stays on the
+  // device: the SPFH rows are sized by their bound, one per point, and the number comes back with the pruning's wait below --
+  // one wait per map less than asking for it here (round 6); the kernels' algorithmic bytes are entered then.
   int *h = (int *)c->pin(64);
-  MM3D_HIP(hipMemcpyAsync(h, pos.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  c->sync();
-  const int ns = h[0];
   DevBuf<int> row_of(c, g.n);
   DevBuf<float4> nrm_sorted(c, g.n);
   DevBuf<int> hil_pos;
-  if (ns > 0) {
+  {
     cloud_hilbert(c, points);                            // query order + wave work items (shared with ICP / score)
     hil_pos = DevBuf<int>(c, (size_t)n + 1);
     MM3D_LAUNCH(c, "fpfh_support", points->n_finite * 20.0, k_hil_inverse, dim3(div_up(points->n_finite, 256)), dim3(256), 0,
@@ -561,13 +561,13 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
   }
   MM3D_LAUNCH(c, "fpfh_support", g.n * 44.0, k_fpfh_support, dim3(div_up(g.n, 256)), dim3(256), 0, g.sorted.get(), g.n,
               in_set.get(), pos.get(), row_of.get(), normals->nrm.get(), (const int *)hil_pos.get(), nrm_sorted.get());
-  DevBuf<float> spfh(c, (size_t)(ns > 0 ? ns : 1) * kDim);
+  DevBuf<float> spfh(c, (size_t)g.n * kDim);
   int *hse = nullptr;                                   // the SPFH kernel's error word, looked at with the weighting's below
-  if (ns > 0) {
-    const int n_items = points->n_wave_items;
+  const int n_items = points->n_wave_items;
+  if (n_items > 0) {
     DevBuf<int> spfh_err(c, 1);
     MM3D_HIP(hipMemsetAsync(spfh_err.get(), 0, sizeof(int), c->stream));
-    MM3D_LAUNCH(c, "spfh", ns * 156.0, k_spfh, dim3(div_up(n_items, kSpfhWaves)), dim3(kSpfhT), 0, (const float4 *)points->hil_pts.get(),
+    MM3D_LAUNCH(c, "spfh", 0.0, k_spfh, dim3(div_up(n_items, kSpfhWaves)), dim3(kSpfhT), 0, (const float4 *)points->hil_pts.get(),
                 (const int2 *)points->wave_items.get(), n_items, g.view(), (const float4 *)normals->nrm.get(),
                 (const float4 *)nrm_sorted.get(), (const int *)in_set.get(), (const int *)pos.get(), (float)radius, r2, spfh.get(), spfh_err.get());
     hse = (int *)c->pin(64);
@@ -580,7 +580,7 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
     SnLaunch<float2> sn(c, nki * 4, points->n);
     SnScratch scr{sn.tmp.get(), sn.fin.get(), sn.ctr.get(), sn.error()};
     if (keypoints->n_finite)
-      MM3D_LAUNCH(c, "fpfh_weight", (double)ns * 132.0 + nk * 132.0, k_fpfh_weight, dim3(sn.blocks), dim3(256), 0,
+      MM3D_LAUNCH(c, "fpfh_weight", nk * 132.0, k_fpfh_weight, dim3(sn.blocks), dim3(256), 0,
                   (const float4 *)keypoints->hil_pts.get(), (const int2 *)keypoints->wave_items.get(), nki, g.view(),
                   (const float4 *)points->pts.get(), (const int *)pos.get(), (const float *)spfh.get(), (float)radius, r2, scr, raw.get(), valid.get());
     int *he = (int *)c->pin(64);
@@ -592,8 +592,11 @@ mm3d_desc *compute_fpfh(Context *c, const mm3d_cloud *points, const mm3d_normals
   DevBuf<int> vpos(c, (size_t)nk + 1);
   exclusive_scan_int(c, valid.get(), vpos.get(), (size_t)nk + 1);
   MM3D_HIP(hipMemcpyAsync(h, vpos.get() + nk, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MM3D_HIP(hipMemcpyAsync(h + 1, pos.get() + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   c->sync();
-  const int nv = h[0];
+  const int nv = h[0], ns = h[1];
+  if (n_items > 0) c->prof_add_bytes("spfh", ns * 156.0);          // per point of the support set
+  if (keypoints->n_finite) c->prof_add_bytes("fpfh_weight", (double)ns * 132.0);
   res->n = (size_t)nv;
   if (nv == nk) {
     res->data = std::move(raw);

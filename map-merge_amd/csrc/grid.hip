@@ -200,7 +200,7 @@ void cloud_download(Context *c, const mm3d_cloud *cl, void *dst, size_t stride, 
   c->sync();
 }
 
-const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl)
+const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl, bool wait)
 {
   auto *m = const_cast<mm3d_cloud *>(cl);
   std::lock_guard<std::recursive_mutex> lk(m->cache_mu);
@@ -208,7 +208,7 @@ const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl)
     m->host.resize(m->n);
     if (m->n) {
       MM3D_HIP(hipMemcpyAsync(m->host.data(), m->pts.get(), m->n * 16, hipMemcpyDeviceToHost, c->stream));
-      c->sync();
+      if (wait) c->sync();
     }
   }
   return m->host;
@@ -303,9 +303,10 @@ __global__ void k_cell_keys(const float4 *__restrict__ pts, int n, float minx, f
 // is exactly the stable sort by (cell, original index), with three small kernels and the scan.
 // Cells longer than kCellSortMax (degenerate clouds) leave that to the rocPRIM path.
 constexpr int kCellSortMax = 4096;
+constexpr int kCellSortSmall = 32768;     // clouds up to this size never leave the counting sort (cloud_grid)
 
 __global__ void k_cell_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ ranks, const int *__restrict__ cell_start,
-                               int n, uint32_t invalid_key, int *__restrict__ slots, int *__restrict__ too_long)
+                               int n, uint32_t invalid_key, int max_len, int *__restrict__ slots, int *__restrict__ too_long)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -313,7 +314,7 @@ __global__ void k_cell_scatter(const uint32_t *__restrict__ keys, const uint32_t
   if (key == invalid_key) return;
   const int b = cell_start[key];
   slots[b + (int)ranks[i]] = i;
-  if (cell_start[key + 1] - b > kCellSortMax) *too_long = 1;
+  if (cell_start[key + 1] - b > max_len) *too_long = 1;
 }
 
 __global__ void k_cell_place(const float4 *__restrict__ pts, const uint32_t *__restrict__ keys, const int *__restrict__ cell_start,
@@ -393,15 +394,30 @@ const Grid &cloud_grid(Context *c, const mm3d_cloud *cl_, float cell)
     exclusive_scan_int(c, counts.get(), g->cell_start.get(), ncell + 1);
     g->sorted = DevBuf<float4>(c, nfin);
     DevBuf<int> slots(c, nfin);
+    // (a small cloud -- a map's keypoints -- is placed by counting whatever its cells hold: n^2 slot reads at worst, a
+    // millisecond at 32 k points, and no question to ask)
+    const bool small = n <= kCellSortSmall;
     MM3D_LAUNCH(c, "grid_cell_sort", n * 16.0, k_cell_scatter, dim3(div_up(n, 256)), dim3(256), 0, (const uint32_t *)keys.get(),
-                (const uint32_t *)ranks.get(), (const int *)g->cell_start.get(), n, invalid, slots.get(), too_long);
+                (const uint32_t *)ranks.get(), (const int *)g->cell_start.get(), n, invalid, small ? n : kCellSortMax, slots.get(), too_long);
     MM3D_LAUNCH(c, "grid_cell_sort", n * 40.0, k_cell_place, dim3(div_up(n, 256)), dim3(256), 0, cl->pts.get(),
                 (const uint32_t *)keys.get(), (const int *)g->cell_start.get(), (const int *)slots.get(), n, invalid,
                 (const int *)too_long, g->sorted.get());
+    // Can a cell have outgrown the counting sort?  Not when the cloud is a voxel grid's output and the cell spans few leaves
+    // (types.hpp: voxel_leaf), nor when the cloud is small -- every grid of the map pipeline: the answer is known without asking
+    // the device, which saves the wait (six per map); the word is still copied and looked at with the next wait, an
+    // invariant rather than a case.
+    // A caller's raw cloud can hold thousands of points in a cell, and its grid waits for the answer.
+    bool bounded = small;
+    if (!bounded && cl->voxel_leaf > 0.f) {
+      const double per_axis = std::floor((double)g->cell / (double)cl->voxel_leaf) + 6.0;
+      bounded = per_axis * per_axis * per_axis <= (double)kCellSortMax;
+    }
     int *h_long = (int *)c->pin(64);
+    *h_long = 0;
     MM3D_HIP(hipMemcpyAsync(h_long, too_long, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    c->sync();
-    if (*h_long) {
+    if (bounded) c->check_later(h_long, MM3D_EDEVICE, "grid: a cell of a voxel-filtered cloud holds more points than its leaf allows");
+    else c->sync();
+    if (!bounded && *h_long) {
       // a cell with thousands of points: stable radix sort of (cell, index) instead
       DevBuf<uint32_t> vals(c, n), keys2(c, n), vals2(c, n);
       MM3D_LAUNCH(c, "grid_cell_keys", n * 8.0, k_iota_u32, dim3(div_up(n, 256)), dim3(256), 0, vals.get(), n);

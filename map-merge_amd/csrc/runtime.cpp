@@ -6,7 +6,13 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <execinfo.h>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <sys/prctl.h>
 #include <thread>
 
@@ -97,11 +103,42 @@ hipError_t stream_wait(hipStream_t stream)
   return e;
 }
 
+// MM3D_WAIT_TRACE=1: every host wait is counted under the address it was called from; the table goes to stderr when the
+// process ends (scripts/one_map_latency.py reads it: which function makes a map wait, how often, how long).
+namespace {
+struct WaitSites {
+  std::mutex mu;
+  std::map<void *, std::pair<long long, long long>> sites;       // caller -> (waits, ns)
+  ~WaitSites()
+  {
+    for (auto &kv : sites) {
+      void *a = kv.first;
+      char **sym = backtrace_symbols(&a, 1);
+      fprintf(stderr, "wait site %-90s %8lld waits %10.3f ms\n", sym ? sym[0] : "?", kv.second.first, kv.second.second * 1e-6);
+      free(sym);
+    }
+  }
+};
+WaitSites *wait_sites()
+{
+  static std::unique_ptr<WaitSites> w(getenv("MM3D_WAIT_TRACE") ? new WaitSites() : nullptr);
+  return w.get();
+}
+}  // namespace
+
 void Context::sync()
 {
   const auto t0 = std::chrono::steady_clock::now();
   MM3D_HIP(stream_wait(stream));
   ++waits;
+  if (WaitSites *w = wait_sites()) {
+    void *bt[3] = {nullptr, nullptr, nullptr};
+    const int got = backtrace(bt, 3);
+    const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> lk(w->mu);
+    auto &e = w->sites[got >= 2 ? bt[1] : nullptr];
+    e.first += 1; e.second += ns;
+  }
   wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
   if (!deferred.empty()) {
     std::vector<Deferred> d;

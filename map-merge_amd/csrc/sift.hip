@@ -30,15 +30,6 @@ namespace mm3d {
 constexpr int kScales = 6;      // nr_scales_per_octave (3) + 3
 constexpr int kDog = 5;
 constexpr int kKnn = 25;
-#ifndef MM3D_EXT_TILE
-#define MM3D_EXT_TILE 256
-#endif
-#ifdef MM3D_EXT_WPE
-#define MM3D_EXT_ATTR __attribute__((amdgpu_waves_per_eu(MM3D_EXT_WPE, MM3D_EXT_WPE)))
-#else
-#define MM3D_EXT_ATTR
-#endif
-constexpr int kSiftTile = MM3D_EXT_TILE;
 
 struct SiftScales {
   float sigma_sqr[kScales];
@@ -493,43 +484,17 @@ extern "C" void mm3d_debug_sn_stats_sift(unsigned long long *out, int reset)
 }
 #endif
 
-// the next float below / above x (NaN and the infinity on that side stay; -0 and +0 count as one zero)
-__device__ __forceinline__ float float_pred(float x)
-{
-  const unsigned u = __float_as_uint(x);
-  if ((u & 0x7fffffffu) > 0x7f800000u || u == 0xff800000u) return x;          // NaN, -inf
-  if ((u & 0x7fffffffu) == 0u) return __uint_as_float(0x80000001u);            // +-0 -> the smallest negative number
-  return __uint_as_float((u & 0x80000000u) ? u + 1u : u - 1u);
-}
-__device__ __forceinline__ float float_succ(float x) { return -float_pred(-x); }
-
-// per point, by original index, two float4: (mn1, mn2, mn3, mx1) and (mx2, mx3, -, -)
-__global__ void k_sift_dogx(const float *__restrict__ dog, int n, float4 *__restrict__ dogx)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float *d = dog + (size_t)i * kDog;
-  // What a neighbour contributes to the extremum tests of scale s = 1, 2, 3 (computed once per point instead of once per
-  // (query, neighbour)).  SIFTKeypoint::findScaleSpaceExtrema asks of a minimum `val == min_val[s] && val < min_val[s - 1] &&
-  // val < min_val[s + 1]`: the point's own scale with equality, the ADJACENT scales strictly.  A neighbour therefore spoils
-  // a minimum v when its DoG at s is below v, or its DoG at s - 1 or s + 1 is below OR EQUAL to v -- and "a <= v" is
-  // "pred(a) < v" (no float lies between a and the one below it).  One value per scale and one strict comparison in the
-  // kernels below, as before: mn_s = min(d_s, pred(min(d_{s-1}, d_{s+1}))); maxima mirrored.
-  // (Rounds 1 - 4 compared the adjacent scales with <=, >=: the same keypoints unless two DoG values tie exactly.)
-  dogx[i] = make_float4(fminf(d[1], float_pred(fminf(d[0], d[2]))), fminf(d[2], float_pred(fminf(d[1], d[3]))), fminf(d[3], float_pred(fminf(d[2], d[4]))),
-                        fmaxf(d[1], float_succ(fmaxf(d[0], d[2]))));
-  dogx[n + i] = make_float4(fmaxf(d[2], float_succ(fmaxf(d[1], d[3]))), fmaxf(d[3], float_succ(fmaxf(d[2], d[4]))), 0.f, 0.f);
-}
-
 // findScaleSpaceExtrema from the neighbours the scale-space kernel left behind (knn, knn_ok = how many: 25, or
 // fewer when the 3 sigma_max ball holds fewer, or 0 when the point's list was not built there): one thread per point
 // of the octave, in Hilbert order.  A point is a minimum at scale s iff none of its 25 nearest (itself included)
-// has a DoG below its own at s-1, s or s+1; a maximum likewise.  With fewer than 25 neighbours at hand a violator
-// among them still decides "no"; a point they leave undecided is marked for the searching kernel and counted.
+// has a DoG below its own at s-1, s or s+1; a maximum likewise (dogx: what a neighbour contributes per scale and side,
+// sift_cert.hpp::cert_pack_point on the exact values; its first row and a half are read here).  With fewer than 25
+// neighbours at hand a violator among them still decides "no"; a point they leave undecided goes onto the list of
+// k_sift_extrema_one, which searches the grid for its 25 nearest (borders and sparse places: a handful per map).
 __global__ void __launch_bounds__(256)
 k_sift_extrema_knn(const float4 *__restrict__ hil, int nh, int n, const float *__restrict__ dog, const float4 *__restrict__ dogx,
                    const int *__restrict__ knn, const unsigned char *__restrict__ knn_ok, float min_contrast, int *__restrict__ flags /* [n*3] */,
-                   unsigned char *__restrict__ need_search /* [n], zeroed */, int *__restrict__ n_search)
+                   int *__restrict__ search_ids /* [n] */, int *__restrict__ n_search /* zeroed */)
 {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nh) return;
@@ -560,262 +525,11 @@ k_sift_extrema_knn(const float4 *__restrict__ hil, int nh, int n, const float *_
     bool open = false;                         // still a candidate at some scale that passes the contrast test
 #pragma unroll
     for (int s = 0; s < 3; ++s) open = open || ((live & (1u << s)) && (is_min[s] || is_max[s]));
-    if (open) { need_search[self] = 1; atomicAdd(n_search, 1); return; }
+    if (open) { search_ids[atomicAdd(n_search, 1)] = self; return; }
   }
 #pragma unroll
   for (int s = 0; s < 3; ++s)
     if (live & (1u << s)) flags[(size_t)self * 3 + s] = (is_min[s] || is_max[s]) ? 1 : 0;
-}
-
-// The extremum test only concerns points whose DoG passes the contrast test at some scale (about a
-// quarter of them): they are compacted, in Hilbert order, into dense runs of 64 so that a wave's
-// lanes all have work (k_sift_live + scan + k_sift_live_compact), instead of idling through the box
-// scans of their item's few live points.
-__global__ void k_sift_live(const float4 *__restrict__ hil, int n, const float *__restrict__ dog, float min_contrast,
-                            const unsigned char *__restrict__ need_search, int *__restrict__ flag /* [n + 1] */)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > n) return;
-  int f = 0;
-  if (j < n) {
-    const int self = __float_as_int(hil[j].w);
-#pragma unroll
-    for (int s = 0; s < 3; ++s) f |= fabsf(dog[(size_t)self * kDog + s + 1]) >= min_contrast ? 1 : 0;
-    if (!need_search[self]) f = 0;             // k_sift_extrema_knn has decided it
-  }
-  flag[j] = f;
-}
-
-__global__ void k_sift_live_compact(const float4 *__restrict__ hil, const uint32_t *__restrict__ keys, int n, const int *__restrict__ flag,
-                                    const int *__restrict__ pos, float4 *__restrict__ out, uint32_t *__restrict__ out_keys)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n && flag[j]) { out[pos[j]] = hil[j]; out_keys[pos[j]] = keys[j]; }
-}
-
-// work items over the live points: runs of at most 64 that stay inside one 2 m x 2 m column block of the
-// Hilbert order (key >> 16), like the items of the full cloud (grid.hip): where few points are live a
-// run of 64 would otherwise wander over many blocks and its wave would work them one after the other
-__global__ void k_sift_live_heads(const uint32_t *__restrict__ keys, const int *__restrict__ n_live_dev, int n_max, int *__restrict__ heads)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > n_max) return;
-  const int n = *n_live_dev;
-  heads[j] = (j < n && (j == 0 || (keys[j] >> 16) != (keys[j - 1] >> 16) || (j & 63) == 0)) ? 1 : 0;
-}
-
-__global__ void k_sift_live_items(const int *__restrict__ heads, const int *__restrict__ pos, const int *__restrict__ n_live_dev,
-                                  int2 *__restrict__ items)
-{
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = *n_live_dev;
-  if (j >= n || !heads[j]) return;
-  int cnt = 1;
-  while (cnt < 64 && j + cnt < n && !heads[j + cnt]) ++cnt;
-  items[pos[j]] = make_int2(j, cnt);
-}
-
-// findScaleSpaceExtrema.  q_pts = the live points (k_sift_live_compact); items = their runs
-// (k_sift_live_items), *n_items_dev of them, one per wave.
-constexpr int kExtremaSpan = 8;   // a run that still jumps farther than this many cells is worked in several groups
-
-// SPLIT 1: one work item per wave, four per block.  SPLIT 4: one item per BLOCK -- the four waves hold the same 64
-// points and boxes, every wave stages the tile but scans only a quarter of its candidates, and the nearest
-// violators / the counts meet in LDS.  The live points of an octave are a few hundred to two thousand items, far
-// fewer than the chip has SIMDs, and an item's passes are a long dependent chain: the split shortens the chain.
-template <int SPLIT>
-__global__ void __launch_bounds__(256) MM3D_EXT_ATTR
-k_sift_extrema(const float4 *__restrict__ q_pts, const int2 *__restrict__ items, const int *__restrict__ n_items_dev,
-               GridView g /* .w = original index */,
-               const float4 *__restrict__ dogx /* by original index, [2][n_pts] */, int n_pts, const float *__restrict__ dog, float min_contrast,
-               int *__restrict__ flags /* [n*3] */)
-{
-  __shared__ float4 s_pts[4][kSiftTile];
-  __shared__ float4 s_x[4][2 * kSiftTile];
-  __shared__ int s_off[4][64];
-  __shared__ int s_beg[4][64];
-  const int n_items = *n_items_dev;
-  const int n_blocks = SPLIT == 4 ? n_items : (n_items + 3) >> 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the number of items is only known on the device (normally a handful: the points k_sift_extrema_knn could not
-  // take): a modest grid walks them, instead of a worst-case grid of blocks that find nothing to do
-  for (int vb = (int)blockIdx.x; vb < n_blocks; vb += (int)gridDim.x) {
-  const int item = SPLIT == 4 ? vb : vb * 4 + wave;
-  const int2 it = item < n_items ? items[item] : make_int2(0, 0);
-  const bool valid = lane < it.y;
-  if (it.y == 0) continue;                    // wave-uniform (SPLIT 4: block-uniform)
-  const float4 q = q_pts[it.x + (valid ? lane : 0)];
-  const int self = __float_as_int(q.w);
-  float v[3];
-  unsigned live = 0;                          // bit s-1: |DoG(self, s)| passes the contrast test
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    v[s] = valid ? dog[(size_t)self * kDog + s + 1] : 0.0f;
-    if (valid && fabsf(v[s]) >= min_contrast) live |= 1u << s;
-  }
-  bool todo = live != 0;
-  bool is_min[3] = {false, false, false}, is_max[3] = {false, false, false};
-  const int cx = cell_floor(q.x, g.minx, g.inv), cy = cell_floor(q.y, g.miny, g.inv), cz = cell_floor(q.z, g.minz, g.inv);
-  const int n_total = g.n;
-  const int max_e = max(max(g.dx, g.dy), g.dz) + 1;
-  const float4 *sp = s_pts[wave];
-  const float4 *sx = s_x[wave];
-  // a run of live points is normally one compact patch; where the Hilbert curve leaves the occupied
-  // area and re-enters far away it is worked group by group (lanes near the first open lane)
-  for (int grp = 0; grp < 64; ++grp) {
-  const unsigned long long open = ballot(todo);
-  if (!open) break;
-  const int leader = __ffsll((long long)open) - 1;
-  const int ldx = cx - __shfl(cx, leader, 64), ldy = cy - __shfl(cy, leader, 64), ldz = cz - __shfl(cz, leader, 64);
-  bool active = todo && abs(ldx) <= kExtremaSpan && abs(ldy) <= kExtremaSpan && abs(ldz) <= kExtremaSpan;
-  todo = todo && !active;
-  int need = 1;                 // most lanes are decided by the first ring; starting wider measured slower
-  for (int pass = 0; pass < 4096; ++pass) {
-    if (!ballot(active)) break;
-    const int E = wave_max_int(active ? need : 0);
-    const int lx = wave_min_int(active ? cx : 0x7fffffff), hx = wave_max_int(active ? cx : -0x7fffffff);
-    const int ly = wave_min_int(active ? cy : 0x7fffffff), hy = wave_max_int(active ? cy : -0x7fffffff);
-    const int lz = wave_min_int(active ? cz : 0x7fffffff), hz = wave_max_int(active ? cz : -0x7fffffff);
-    const int x0 = max(lx - E, 0), x1 = min(hx + E, g.dx - 1);
-    const int y0 = max(ly - E, 0), y1 = min(hy + E, g.dy - 1);
-    const int z0 = max(lz - E, 0), z1 = min(hz + E, g.dz - 1);
-    // what this box proves for the lane: every point closer than `guard` has been staged
-    const float gx0 = (lx - E > 0) ? q.x - (g.minx + (float)(lx - E) * g.cell) : INFINITY;
-    const float gx1 = (hx + E < g.dx - 1) ? (g.minx + (float)(hx + E + 1) * g.cell) - q.x : INFINITY;
-    const float gy0 = (ly - E > 0) ? q.y - (g.miny + (float)(ly - E) * g.cell) : INFINITY;
-    const float gy1 = (hy + E < g.dy - 1) ? (g.miny + (float)(hy + E + 1) * g.cell) - q.y : INFINITY;
-    const float gz0 = (lz - E > 0) ? q.z - (g.minz + (float)(lz - E) * g.cell) : INFINITY;
-    const float gz1 = (hz + E < g.dz - 1) ? (g.minz + (float)(hz + E + 1) * g.cell) - q.z : INFINITY;
-    const float guard = fmaxf(fminf(fminf(fminf(gx0, gx1), fminf(gy0, gy1)), fminf(gz0, gz1)) * 0.9999f - 1e-5f, 0.0f);
-    const float guard2 = guard * guard;
-    // scan 1: nearest violator of every live (scale, min|max) test
-    unsigned long long vmin[3], vmax[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) { vmin[s] = ~0ull; vmax[s] = ~0ull; }
-    // scan 2 (below): how many points are closer than each nearest violator, and how many lie within guard
-    int cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0}, cg = 0;
-    // SPLIT 4: this wave's quarter of a tile's candidates
-    auto my_range = [&](int cnt, int &k0, int &k1) {
-      k0 = 0; k1 = cnt;
-      if (SPLIT == 4) { const int qn = (cnt + 3) >> 2; k0 = min(cnt, wave * qn); k1 = min(cnt, k0 + qn); }
-    };
-    // SPLIT 4: the four waves' nearest violators -> every wave holds the block's (own tile memory carries the exchange:
-    // nobody reads the DoG half of a tile once its scan is over)
-    auto merge_violators = [&]() {
-      if (SPLIT != 4) return;
-      unsigned long long *mine = reinterpret_cast<unsigned long long *>(s_x[wave]);
-#pragma unroll
-      for (int s = 0; s < 3; ++s) { mine[s * 64 + lane] = vmin[s]; mine[(3 + s) * 64 + lane] = vmax[s]; }
-      __syncthreads();
-#pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) {
-        const unsigned long long *other = reinterpret_cast<const unsigned long long *>(s_x[w2]);
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const unsigned long long a = other[s * 64 + lane], b = other[(3 + s) * 64 + lane];
-          vmin[s] = a < vmin[s] ? a : vmin[s];
-          vmax[s] = b < vmax[s] ? b : vmax[s];
-        }
-      }
-      __syncthreads();
-    };
-    auto count_closer = [&](int cnt) {
-      if (!active) return;
-      int k0, k1;
-      my_range(cnt, k0, k1);
-      for (int k = k0; k < k1; ++k) {
-        const float4 c = sp[k];
-        const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
-        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_uint(c.w);
-        cg += (d2 <= guard2) ? 1 : 0;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          cmin[s] += (key < vmin[s]) ? 1 : 0;
-          cmax[s] += (key < vmax[s]) ? 1 : 0;
-        }
-      }
-    };
-    bool counted = false;                       // wave-uniform
-    wave_stream_box<kSiftTile, 2>(
-        g, x0, x1, y0, y1, z0, z1, s_pts[wave], s_x[wave], s_off[wave], s_beg[wave], lane,
-        [&](int j, float4 (&out)[2]) { const int o = __float_as_int(g.pts[j].w); out[0] = dogx[o]; out[1] = dogx[n_pts + o]; },
-        [&](int cnt, bool whole_box) {
-          int k0, k1;
-          my_range(cnt, k0, k1);
-          if (active)
-            for (int k = k0; k < k1; ++k) {
-              const float4 c = sp[k];
-              const float4 a = sx[k];
-              const float4 b = sx[kSiftTile + k];
-              const float d2 = dist2(q.x, q.y, q.z, c.x, c.y, c.z);
-              const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_uint(c.w);
-              // min / max of the candidate's DoG over scales s-1, s, s+1 for s = 1, 2, 3 (k_sift_dogx)
-              const float mn[3] = {a.x, a.y, a.z};
-              const float mx[3] = {a.w, b.x, b.y};
-#pragma unroll
-              for (int s = 0; s < 3; ++s) {
-                if (mn[s] < v[s] && key < vmin[s]) vmin[s] = key;
-                if (mx[s] > v[s] && key < vmax[s]) vmax[s] = key;
-              }
-            }
-          // the usual case: the whole box was this one tile, so the counting scan reads it from LDS again
-          if (whole_box) { merge_violators(); count_closer(cnt); counted = true; }
-        });
-    if (!counted) merge_violators();
-    if (!counted)
-      wave_stream_box<kSiftTile, 0>(g, x0, x1, y0, y1, z0, z1, s_pts[wave], (float4 *)nullptr, s_off[wave], s_beg[wave], lane,
-                                    [](int, float4 (&)[1]) {}, count_closer);
-    if (SPLIT == 4) {       // the quarters' counts
-      int *mine = reinterpret_cast<int *>(s_x[wave]);
-#pragma unroll
-      for (int s = 0; s < 3; ++s) { mine[s * 64 + lane] = cmin[s]; mine[(3 + s) * 64 + lane] = cmax[s]; }
-      mine[6 * 64 + lane] = cg;
-      __syncthreads();
-#pragma unroll
-      for (int s = 0; s < 3; ++s) { cmin[s] = 0; cmax[s] = 0; }
-      cg = 0;
-#pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) {
-        const int *other = reinterpret_cast<const int *>(s_x[w2]);
-#pragma unroll
-        for (int s = 0; s < 3; ++s) { cmin[s] += other[s * 64 + lane]; cmax[s] += other[(3 + s) * 64 + lane]; }
-        cg += other[6 * 64 + lane];
-      }
-      __syncthreads();
-    }
-    if (active) {
-      const int kk = n_total < kKnn ? n_total : kKnn;
-      const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dx - 1 && y1 == g.dy - 1 && z1 == g.dz - 1;
-      bool all_done = true;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        if (!(live & (1u << s))) continue;
-        // minimum test
-        {
-          const float vd2 = __uint_as_float((unsigned)(vmin[s] >> 32));
-          if (vmin[s] != ~0ull && (vd2 <= guard2 || whole)) is_min[s] = cmin[s] >= kk;   // violator seen in the proven zone
-          else if (cg >= kk || whole) is_min[s] = true;                                  // 25 proven-nearest, none violates
-          else all_done = false;
-        }
-        {
-          const float vd2 = __uint_as_float((unsigned)(vmax[s] >> 32));
-          if (vmax[s] != ~0ull && (vd2 <= guard2 || whole)) is_max[s] = cmax[s] >= kk;
-          else if (cg >= kk || whole) is_max[s] = true;
-          else all_done = false;
-        }
-      }
-      if (all_done) active = false;
-      else need = min(E + 1 + (E >> 1), max_e);   // sparse places: grow the ring by half each time (stragglers set the kernel time)
-    }
-  }
-  }
-  if (valid && !(SPLIT == 4 && wave != 0)) {
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-      if (live & (1u << s)) flags[(size_t)self * 3 + s] = (is_min[s] || is_max[s]) ? 1 : 0;
-  }
-  if (SPLIT == 4) __syncthreads();            // the next item reuses the tiles
-  }
 }
 
 __global__ void k_sift_emit(const float4 *__restrict__ pts, const int *__restrict__ flags, const int *__restrict__ pos,
@@ -1069,14 +783,16 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
     DevBuf<float> dog(c, (size_t)n * kDog);
     DevBuf<int> knn(c, (size_t)n * kKnn);
     // everything the octave wants zeroed lies in ONE buffer -- knn_ok [n bytes, padded to 4] | flags [3 n + 1 ints] | n_search
-    // [1 int] | need_search [n bytes] -- and is cleared by one fill dispatch (a second extremum test clears from flags on)
+    // [1 int] | the searching kernel's counters -- and is cleared by one fill dispatch (a second extremum test clears from
+    // flags on)
     const size_t z_knn = ((size_t)n + 3) & ~(size_t)3, z_flags = ((size_t)n * 3 + 1) * sizeof(int);
-    DevBuf<unsigned char> zeroed(c, z_knn + z_flags + sizeof(int) + (size_t)n);
-    MM3D_HIP(hipMemsetAsync(zeroed.get(), 0, z_knn + z_flags + sizeof(int) + (size_t)n, c->stream));
+    const size_t z_tail = sizeof(int) + sizeof(CertCounters);
+    DevBuf<unsigned char> zeroed(c, z_knn + z_flags + z_tail);
+    MM3D_HIP(hipMemsetAsync(zeroed.get(), 0, z_knn + z_flags + z_tail, c->stream));
     unsigned char *const knn_ok_p = zeroed.get();
     int *const flags_p = reinterpret_cast<int *>(zeroed.get() + z_knn);
     int *const n_search_p = flags_p + (size_t)n * 3 + 1;
-    unsigned char *const need_search_p = reinterpret_cast<unsigned char *>(n_search_p + 1);
+    CertCounters *const search_ctr = reinterpret_cast<CertCounters *>(n_search_p + 1);
     bool zero_again = false;                             // (the first extremum test finds its words cleared by the fill above)
     const DevPtr<unsigned char> knn_ok{knn_ok_p};
     // the normals ride on the first octave when it works on `points` itself and their ball is inside the scale space's
@@ -1088,10 +804,9 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
       nrm_res->nrm = DevBuf<float4>(c, points->n);
     }
     const DevPtr<int> flags{flags_p}, n_search{n_search_p};
-    const DevPtr<unsigned char> need_search{need_search_p};
     DevBuf<int> pos(c, (size_t)n * 3 + 1);
     const int nh = (int)octave_cloud->n_finite;
-    int *h = (int *)c->pin(64);                          // [0] keypoints, [1] points for the searching kernel
+    int *h = (int *)c->pin(64);                          // [0] keypoints, [1] points for the searching kernel, [2] points it left open (none)
     // Later octaves (round 6): the keypoint DECISION is certified from an unsorted scale space with an error bound, and only
     // the points it leaves open get the sorted lists (sift_cert.hpp).  The first octave keeps its lists -- the fused normals
     // ride on them; where they do not (a normals ball wider than the first octave's 3 sigma_max: the dense indoor workload at
@@ -1118,50 +833,35 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
                                    : (large16 ? sift_dog_octave<SiftCfgLarge16>(c, oct, octave_cloud, gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get())
                                               : sift_dog_octave<SiftCfgLarge>(c, oct, octave_cloud, gr, n_items, max_radius, r2, sc, dog.get(), knn.get(), knn_ok.get()));
     // The extremum test: the points whose list held 25 neighbours read them back (k_sift_extrema_knn, nearly all
-    // of them); the others -- borders and sparse places, where the 25 nearest reach beyond 3 sigma_max -- search the
-    // same grid (k_sift_extrema over their compacted runs).  Both rare cases -- scale-space items left to the
-    // global-memory lists, points for the searching kernel -- are COUNTED by the kernels of the first pass; the octave
-    // ends with a host look at the keypoint count anyway, and only if one of the two counts is not zero the launches
-    // that serve them run and the test is taken again (a launch that finds nothing to do is not free here: it queues
-    // for LDS behind the other streams' kernels).
+    // of them); the others -- borders and sparse places, where the 25 nearest reach beyond 3 sigma_max: a handful per map --
+    // are listed by that kernel and searched for in the same grid, a wave per point (k_sift_extrema_one on the exact values:
+    // every interval a point, every ball grown until it holds 25).  Until round 6 that second kernel was a second PASS: the
+    // first one counted the points, the host looked at the count at the octave's wait, and two maps in three then ran a
+    // dozen launches for their two or three stray points and waited once more.  The scale-space items left to the
+    // global-memory lists are still COUNTED by the first pass and served after the octave's wait, the test taken again (a
+    // launch that finds nothing to do is not free here: it queues for LDS behind the other streams' kernels).
     const Grid &gk = gr;
-    DevBuf<float4> dogx(c, (size_t)n * 2);
-    auto extremum_test = [&](bool search) {
-      MM3D_LAUNCH(c, "sift_pack", n * 52.0, k_sift_dogx, dim3(div_up(n, 256)), dim3(256), 0, (const float *)dog.get(), n, dogx.get());
-      if (zero_again) MM3D_HIP(hipMemsetAsync(flags.get(), 0, z_flags + sizeof(int) + (size_t)n, c->stream));
+    DevBuf<float4> dogx(c, (size_t)n * 3);
+    DevBuf<unsigned char> cls(c, (size_t)n);
+    DevBuf<int> search_ids(c, (size_t)n);
+    auto extremum_test = [&]() {
+      MM3D_LAUNCH(c, "sift_pack", n * 69.0, k_sift_pack_iv, dim3(div_up(n, 256)), dim3(256), 0, (const float *)dog.get(), (const float *)nullptr, n,
+                  (float)min_contrast, dogx.get(), cls.get());
+      if (zero_again) MM3D_HIP(hipMemsetAsync(flags.get(), 0, z_flags + z_tail, c->stream));
       zero_again = true;
       MM3D_LAUNCH(c, "sift_extrema_knn", nh * 16.0 + n * 0.25 * (kKnn * 36.0 + 20.0), k_sift_extrema_knn, dim3(div_up(nh, 256)), dim3(256), 0,
                   (const float4 *)octave_cloud->hil_pts.get(), nh, n, (const float *)dog.get(), (const float4 *)dogx.get(), (const int *)knn.get(),
-                  (const unsigned char *)knn_ok.get(), (float)min_contrast, flags.get(), need_search.get(), n_search.get());
-      if (search) {
-        DevBuf<int> lflag(c, (size_t)nh + 1), lpos(c, (size_t)nh + 1);
-        DevBuf<float4> lpts(c, (size_t)nh);
-        DevBuf<uint32_t> lkeys(c, (size_t)nh);
-        DevBuf<int> lheads(c, (size_t)nh + 1), lipos(c, (size_t)nh + 1);
-        const int max_items = 2 * n_items + 4;                // a block's live run splits at most once more than its full run
-        DevBuf<int2> litems(c, (size_t)max_items);
-        MM3D_LAUNCH(c, "sift_live", nh * 28.0, k_sift_live, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const float4 *)octave_cloud->hil_pts.get(), nh,
-                    (const float *)dog.get(), (float)min_contrast, (const unsigned char *)need_search.get(), lflag.get());
-        exclusive_scan_int(c, lflag.get(), lpos.get(), (size_t)nh + 1);
-        MM3D_LAUNCH(c, "sift_live", nh * 32.0, k_sift_live_compact, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const float4 *)octave_cloud->hil_pts.get(),
-                    (const uint32_t *)octave_cloud->hil_keys.get(), nh, (const int *)lflag.get(), (const int *)lpos.get(), lpts.get(), lkeys.get());
-        MM3D_LAUNCH(c, "sift_live", nh * 8.0, k_sift_live_heads, dim3(div_up((size_t)nh + 1, 256)), dim3(256), 0, (const uint32_t *)lkeys.get(),
-                    (const int *)(lpos.get() + nh), nh, lheads.get());
-        exclusive_scan_int(c, lheads.get(), lipos.get(), (size_t)nh + 1);
-        MM3D_LAUNCH(c, "sift_live", nh * 12.0, k_sift_live_items, dim3(div_up((size_t)nh, 256)), dim3(256), 0, (const int *)lheads.get(),
-                    (const int *)lipos.get(), (const int *)(lpos.get() + nh), litems.get());
-        // one item per block (measured on MI355X, three octaves of one map: 1.69 -> 1.05 ms at 500 k points, 1.28 -> 0.45 ms
-        // at 50 k; four items per block, k_sift_extrema<1>, is the same code with one wave per item)
-        MM3D_LAUNCH(c, "sift_extrema", 0.0, k_sift_extrema<4>, dim3((unsigned)std::min(max_items, 1024)), dim3(256), 0,
-                    (const float4 *)lpts.get(), (const int2 *)litems.get(), (const int *)(lipos.get() + nh), gk.view(), (const float4 *)dogx.get(), n,
-                    (const float *)dog.get(), (float)min_contrast, flags.get());
-      }
+                  (const unsigned char *)knn_ok.get(), (float)min_contrast, flags.get(), search_ids.get(), n_search.get());
+      MM3D_LAUNCH(c, "sift_extrema_one", 0.0, k_sift_extrema_one<true>, dim3(64), dim3(256), 0, (const int *)search_ids.get(), (const int *)n_search.get(),
+                  (const float4 *)octave_cloud->pts.get(), gk.view(), (const float *)nullptr, r2, (const float4 *)dogx.get(), n, (const float *)dog.get(),
+                  (const float *)nullptr, (const unsigned char *)cls.get(), flags.get(), (unsigned char *)nullptr, (unsigned char *)nullptr, search_ctr);
       exclusive_scan_int(c, flags.get(), pos.get(), (size_t)n * 3 + 1);
       MM3D_HIP(hipMemcpyAsync(h, pos.get() + (size_t)n * 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
       MM3D_HIP(hipMemcpyAsync(h + 1, n_search.get(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      MM3D_HIP(hipMemcpyAsync(h + 2, &search_ctr->still_open, sizeof(int), hipMemcpyDeviceToHost, c->stream));
       c->sync();
     };
-    extremum_test(false);
+    extremum_test();
 #ifdef MM3D_SNB_STATS
     {   // instrumentation build: the phase ticks of this octave alone (scripts/snb_stats.py prints the sum over the octaves)
       unsigned long long v[32];
@@ -1182,9 +882,9 @@ mm3d_cloud *detect_keypoints_sift(Context *c, const mm3d_cloud *points, double m
       // the items the first pass left out get their scale space now (and, from the large LDS configuration, their
       // neighbour lists): the test is taken again on the complete values
       pend.fallback(*pend.h_overflow);
-      extremum_test(false);
+      extremum_test();
     }
-    if (h[1] > 0) extremum_test(true);                    // some point's short list left it undecided: search for its 25 nearest
+    MM3D_REQUIRE(h[2] == 0, "SIFT: the extremum search left a point undecided on exact values");
     }
     const size_t nk = (size_t)h[0];
     DevBuf<float4> kp(c, nk);

@@ -301,20 +301,24 @@ __device__ __forceinline__ void cert_interval(float v, float b, float &lo, float
 
 // What a point contributes to its neighbours' extremum tests, and its own contrast classes.
 // findScaleSpaceExtrema asks of a minimum at scale s: val == min over the 25 nearest at s, val < min at s - 1, val < min at
-// s + 1.  A neighbour spoils it when its DoG at s is below val or its DoG at s - 1 / s + 1 is below OR EQUAL (k_sift_dogx
-// in sift.hip: "a <= v" is "pred(a) < v").  With intervals there are two such values per (scale, side):
+// s + 1: the point's own scale with equality, the ADJACENT scales strictly.  A neighbour therefore spoils a minimum val
+// when its DoG at s is below val, or its DoG at s - 1 or s + 1 is below OR EQUAL -- and "a <= v" is "pred(a) < v" (no float
+// lies between a and the one below it): one value per (neighbour, scale) and one strict comparison per (query, neighbour),
+// computed once per point instead of once per pair.  (Rounds 1 - 4 compared the adjacent scales with <=, >=: the same
+// keypoints unless two DoG values tie exactly.)  With intervals there are two such values per (scale, side):
 //   mnhi_s = min(hi_s, pred(min(hi_(s-1), hi_(s+1)))):  mnhi < lo_p  -> the neighbour CERTAINLY spoils the minimum
 //   mnlo_s = min(lo_s, pred(min(lo_(s-1), lo_(s+1)))):  mnlo < hi_p  -> it POSSIBLY does
-// (maxima mirrored: mxlo > hi_p certainly, mxhi > lo_p possibly).  With b = 0 both are k_sift_dogx's value.
+// (maxima mirrored: mxlo > hi_p certainly, mxhi > lo_p possibly).  With b = 0 the two coincide.
 // dogx: [3][n] float4 = (mnhi1, mnhi2, mnhi3, mxlo1), (mxlo2, mxlo3, mnlo1, mnlo2), (mnlo3, mxhi1, mxhi2, mxhi3) -- the certain
 // values first: k_sift_reject reads one row and a half;
 // cls: bit s = |DoG(s + 1)| may reach the contrast (candidate), bit 3 + s = it certainly does (live).
+// dogb == nullptr: dogv holds the CPU path's floats themselves (the octaves on the sorted lists, sift.hip).
 __device__ __forceinline__ void cert_pack_point(const float *__restrict__ dogv, const float *__restrict__ dogb, int i, int n, float min_contrast,
                                                 float4 *__restrict__ dogx, unsigned char *__restrict__ cls)
 {
   float lo[kCertDog], hi[kCertDog];
 #pragma unroll
-  for (int s = 0; s < kCertDog; ++s) cert_interval(dogv[(size_t)i * kCertDog + s], dogb[(size_t)i * kCertDog + s], lo[s], hi[s]);
+  for (int s = 0; s < kCertDog; ++s) cert_interval(dogv[(size_t)i * kCertDog + s], dogb ? dogb[(size_t)i * kCertDog + s] : 0.0f, lo[s], hi[s]);
   float mnhi[3], mnlo[3], mxlo[3], mxhi[3];
   unsigned c = 0;
 #pragma unroll
@@ -567,6 +571,8 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // comparison on an open side is possible but not certain (need_exact).  kFinal: nothing may be open (counted).
 // A point whose 3 sigma_max ball holds fewer than 25 points (rup2 = +inf: the border of a sparse cloud) first doubles its
 // radius until the ball does.  No LDS tile: a candidate is read by one lane, once per pass.
+// The octaves on the sorted lists (sift.hip) use the kFinal form on exact values for the few points whose list is shorter
+// than 25: dogb == nullptr (every interval is a point, nothing can be open), rup2 == nullptr (every ball is grown).
 template <bool kFinal>
 __global__ void __launch_bounds__(256)
 k_sift_extrema_one(const int *__restrict__ ids, const int *__restrict__ n_ids_dev, const float4 *__restrict__ pts /* original order */, GridView g /* .w = original index */,
@@ -584,7 +590,7 @@ k_sift_extrema_one(const int *__restrict__ ids, const int *__restrict__ n_ids_de
   for (int k = (int)blockIdx.x * 4 + wave; k < n_ids; k += n_waves) {
     const int self = ids[k];
     const float4 q = pts[self];
-    float r2q = rup2[self];
+    float r2q = rup2 ? rup2[self] : INFINITY;
     const unsigned c = cls[self];
     const unsigned cand = c & 7u, live = (c >> 3) & 7u;
     if (!cand) continue;                         // wave-uniform
@@ -617,7 +623,7 @@ k_sift_extrema_one(const int *__restrict__ ids, const int *__restrict__ n_ids_de
     }
     float lo[kCertDog], hi[kCertDog];
 #pragma unroll
-    for (int s = 0; s < kCertDog; ++s) cert_interval(dogv[(size_t)self * kCertDog + s], dogb[(size_t)self * kCertDog + s], lo[s], hi[s]);
+    for (int s = 0; s < kCertDog; ++s) cert_interval(dogv[(size_t)self * kCertDog + s], dogb ? dogb[(size_t)self * kCertDog + s] : 0.0f, lo[s], hi[s]);
     float lo_p[3], hi_p[3];
     const unsigned long long key_self = (unsigned long long)(unsigned)self;
     unsigned long long vc_min[3], vp_min[3], vc_max[3], vp_max[3];

@@ -95,6 +95,11 @@ struct mm3d_cloud {
   mm3d::DevBuf<uint32_t> hil_keys;                     // their sort keys: (Hilbert index of the 0.25 m column << 10) | z cell
   mm3d::DevBuf<int2> wave_items;                       // {first point, count <= 64}: one compact patch per wave
   int n_wave_items = 0;
+  // > 0: the points are centroids of distinct voxels of a VoxelGrid with this leaf (downsample made the cloud, or a filter kept
+  // a subset of such a cloud), none farther than two leaves from a member of its voxel (checked on the device where the
+  // centroids were formed).  A grid cell of side C then holds at most (floor(C / leaf) + 6)^3 of them, and cloud_grid need not
+  // ask the device whether a cell outgrew its counting sort.  0: unknown (a caller's raw cloud, a copy from a peer).
+  float voxel_leaf = 0.f;
   // the points were replaced (descriptor pruning): everything derived from them goes
   void reset_caches()
   {
@@ -148,7 +153,8 @@ void cloud_hilbert(Context *c, const mm3d_cloud *cl, float min_cell = 0.25f);
 mm3d_cloud *cloud_from_device(Context *c, DevBuf<float4> &&pts, size_t n);
 mm3d_cloud *cloud_from_memory(Context *c, const void *src, size_t n, size_t stride, size_t rgba_off);
 void cloud_download(Context *c, const mm3d_cloud *cl, void *dst, size_t stride, size_t rgba_off);
-const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl);
+// wait = false: the copy is enqueued and the caller waits for the stream itself before the vector is read (by anybody)
+const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl, bool wait = true);
 // ordered compaction: keeps in[i] where flags[i] != 0, preserving order; returns kept count
 size_t compact_points(Context *c, const float4 *in, const int *flags, size_t n, DevBuf<float4> &out, unsigned *box_host = nullptr);   // box_host: 7 words for cloud_set_bbox
 void cloud_set_bbox(mm3d_cloud *cl, const unsigned box[7]);

@@ -11,7 +11,7 @@ host, _, _ = bench.make_workload_gt(16, PTS)
 dev = torch.device("cuda", 0)
 ctx = mm.Context(0)
 P = mm.MapMergingParams(descriptor_type=2, estimation_method=1)
-names = ("sift_dog", "sift_dog_oct0", "sift_dog_oct1", "sift_dog_oct2", "normals_radius", "spfh", "sift_extrema")
+names = ("sift_dog", "sift_dog_oct0", "sift_dog_oct1", "sift_dog_oct2", "normals_radius", "spfh", "sift_extrema_one")
 for rep in range(2):
     for i in range(N):
         raw_t = torch.from_numpy(host[i].view(np.uint8).reshape(-1, 16)).to(dev)

@@ -52,7 +52,7 @@ void cloud_download(Context *, const mm3d_cloud *cl, void *dst, size_t stride, s
     std::memcpy(p + rgba_off, &cl->pts.get()[i].w, 4);
   }
 }
-const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl)
+const std::vector<float4> &cloud_host(Context *c, const mm3d_cloud *cl, bool)
 {
   auto *m = const_cast<mm3d_cloud *>(cl);
   std::lock_guard<std::recursive_mutex> lk(m->cache_mu);

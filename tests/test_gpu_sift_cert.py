@@ -154,11 +154,9 @@ def test_the_hard_scenes_of_the_parity_suite_on_the_certified_path(ctx, po, big_
         assert len(got) == len(ref) == expect and np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32))
 
 
-@pytest.mark.parametrize("seed", range(8))
-def test_random_scenes_on_the_certified_path(ctx, po, seed):
+def random_scene(po, seed):
     """Eight seeded scenes of different character -- textured sheets, clumps with empty space between them, sparse scatter, a
-    jittered lattice with duplicated points, other resolutions and thresholds -- through the certified octaves against the
-    oracle's keypoints, bit for bit."""
+    jittered lattice with duplicated points, other resolutions and thresholds: (downsampled cloud, resolution, threshold)."""
     rng = np.random.default_rng(100 + seed)
     kind = seed % 4
     n = int(rng.integers(6000, 40000))
@@ -182,8 +180,29 @@ def test_random_scenes_on_the_certified_path(ctx, po, seed):
     c["rgba"] = (0xFF << 24) | (lum << 16) | (np.clip(lum + rng.integers(-20, 20, len(p)), 0, 255).astype(np.uint32) << 8) | lum
     res = (0.1, 0.1, 0.2, 0.05)[seed % 4] if seed < 4 else 0.1
     thr = (5.0, 1.0, 0.2, 12.0)[(seed // 2) % 4]
-    cloud = po.downsample(c, res)
+    return po.downsample(c, res), res, thr
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_on_the_certified_path(ctx, po, seed):
+    """The eight scenes through the certified octaves against the oracle's keypoints, bit for bit."""
+    cloud, res, thr = random_scene(po, seed)
     ref, _ = po.keypoints_sift(cloud, res, 3, 3, thr)
     got = ctx.detectKeypoints(ctx.cloud(cloud), None, 0, thr, R_NRM, res).numpy()
+    assert len(got) == len(ref), (seed, len(got), len(ref))
+    assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32)), seed
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_on_the_sorted_lists(ctx, po, mm, seed):
+    """The same scenes with every octave on the sorted neighbour lists (what the product does below 15 000 points): the points
+    whose 3 sigma_max ball holds fewer than 25 neighbours -- most of the clumps' outskirts and of the sparse slab -- are decided
+    by k_sift_extrema_one on the exact values, in the same pass as the others."""
+    cloud, res, thr = random_scene(po, seed)
+    mm.lib().mm3d_debug_sift_cert_min(1 << 30)
+    mm.sift_cert_stats(reset=True)
+    ref, _ = po.keypoints_sift(cloud, res, 3, 3, thr)
+    got = ctx.detectKeypoints(ctx.cloud(cloud), None, 0, thr, R_NRM, res).numpy()
+    assert mm.sift_cert_stats()[0] == 0          # no octave took the certified path
     assert len(got) == len(ref), (seed, len(got), len(ref))
     assert np.array_equal(xyz(got).view(np.uint32), xyz(ref).view(np.uint32)), seed
