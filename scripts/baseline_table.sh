@@ -26,4 +26,6 @@ run 4indoor --maps 8 --points 2000000 --descriptor SHOT --window 30 --resolution
 run 2lattice --maps 4 --points 200000 --scenes lattice --overlap-step 0.25 --sac-iterations 20000 --steps 3 --warmup 1
 # the headline size on the 'lattice' family with 20 000 hypotheses: poses worth refining, so "Mpoints/s (ICP)" is measured on an ICP
 # that iterates (CPU baselines + parity_check on a sample of two maps and ONE pair: a pair with 20 000 hypotheses is ~ 50 s of one core)
-run 3lattice --maps 16 --points 500000 --scenes lattice --overlap-step 0.25 --sac-iterations 20000 --steps 3 --warmup 2
+# (four warm-up steps: a step moves 1.26 GB of hypothesis errors per pair through the memory pools, which keep growing through the
+# first three -- with two warm-up steps the row scattered between 131 and 188 map-pairs/s, with four it is 186 - 187)
+run 3lattice --maps 16 --points 500000 --scenes lattice --overlap-step 0.25 --sac-iterations 20000 --steps 3 --warmup 4
