@@ -140,6 +140,10 @@ int mm3d_debug_sift_cert_octave(mm3d_ctx *ctx, const mm3d_cloud *points, double 
 void mm3d_debug_sift_cert_stats(long long out[8], int reset);
 /* test hook: octaves of at least n points take the certified path (default 15 000, MM3D_SIFT_CERT_MIN; n < 0 restores it) */
 void mm3d_debug_sift_cert_min(int n);
+/* test hook: the leaf of the VoxelGrid whose centroids the cloud's points are known to be (downSample's output and
+ * removeOutliers' subset of it, R/src/features.cpp:19-40; every centroid within two leaves of a member of its voxel), 0 when
+ * nothing is known -- what lets a grid build on the cloud skip its "did a cell outgrow the counting sort" wait */
+float mm3d_debug_cloud_voxel_leaf(const mm3d_cloud *cloud);
 /* test / study hook: the descriptor k-NN of findFeatureCorrespondences (R/src/matching.cpp:50-75) on raw rows of width `dim`
  * -- the widths of the reference's descriptors (2, 33, 125, 250, 1344, 1980) and 352, pcl::SHOT352's shape, which the reference
  * does not bind (dispatch_descriptors.h:44-46 binds SHOT1344) but BASELINE.json configs[3] names: idx / d2 receive na x k

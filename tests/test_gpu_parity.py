@@ -72,6 +72,52 @@ def test_downsample_edge_cases(ctx, po, mm):
                           po.downsample(nf, 0.1).view(np.uint32))
 
 
+def test_what_a_voxel_filtered_cloud_promises_its_grids(ctx, po, mm):
+    """downSample's output carries the leaf of its voxel grid (every centroid within two leaves of a member of its voxel), and
+    removeOutliers' subset inherits it: a grid build on such a cloud need not ask the device whether a cell outgrew the
+    counting sort (csrc/types.hpp: voxel_leaf).  A caller's raw cloud promises nothing, the int32-overflow pass-through promises
+    nothing -- and neither does a filter whose float sums carried a centroid away: 4 000 points per voxel 300 km from the origin
+    (ulp 0.03 m, partial sums of 1e9 with an ulp of 64 - 128) put centroids metres from their voxels, the CPU path's bits all
+    the same, and the filters after it (their grid asks the device again) still agree with the oracle bit for bit."""
+    import ctypes as C
+    leaf_of = mm.lib().mm3d_debug_cloud_voxel_leaf
+    leaf_of.restype = C.c_float
+    leaf_of.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(9)
+    a = np.zeros(60000, dtype=mm.POINT)
+    a["x"], a["y"], a["z"] = rng.uniform(-6, 6, 60000), rng.uniform(-6, 6, 60000), rng.uniform(0, 0.3, 60000)
+    a["rgba"] = 0xFF000000 | rng.integers(0, 1 << 24, 60000).astype(np.uint32)
+    raw = ctx.cloud(a)
+    assert leaf_of(raw._h) == 0.0
+    down = ctx.downSample(raw, 0.1)
+    assert leaf_of(down._h) == np.float32(0.1)
+    filt = ctx.removeOutliers(down, 0.8, 50)
+    assert leaf_of(filt._h) == np.float32(0.1) and 0 < len(filt) <= len(down)
+    ref = po.remove_outliers(po.downsample(a, 0.1), 0.8, 50)
+    assert np.array_equal(filt.numpy().view(np.uint32), ref.view(np.uint32))
+    far = np.zeros(3, dtype=mm.POINT); far["x"] = [0, 1000, 2000]; far["y"] = [0, 1500, 3000]; far["z"] = [0, 500, 900]
+    assert leaf_of(ctx.downSample(ctx.cloud(far), 0.001)._h) == 0.0
+    # centroids carried away by their own float sums
+    n_vox, per = 24, 4000
+    b = np.zeros(n_vox * per, dtype=mm.POINT)
+    base = np.float32(3.0e5)
+    cells = rng.integers(0, 40, (n_vox, 3)).astype(np.float32) * np.float32(0.8)
+    p = np.repeat(cells, per, axis=0) + rng.uniform(0, 0.09, (n_vox * per, 3)).astype(np.float32)
+    order = rng.permutation(len(p))
+    b["x"], b["y"], b["z"] = (base + p[order, 0]).astype(np.float32), (base + p[order, 1]).astype(np.float32), p[order, 2]
+    b["rgba"] = 0xFF000000 | rng.integers(0, 1 << 24, len(b)).astype(np.uint32)
+    ref = po.downsample(b, 0.1)
+    got = ctx.downSample(ctx.cloud(b), 0.1)
+    assert np.array_equal(got.numpy().view(np.uint32), ref.view(np.uint32))
+    # (some centroid of the oracle's lies farther than two leaves from every input point of its voxel's neighbourhood)
+    d = np.abs(ref["x"][:, None].astype(np.float64) - b["x"][None, ::97].astype(np.float64)).min(axis=1)
+    assert d.max() > 0.2, d.max()
+    assert leaf_of(got._h) == 0.0
+    ref2 = po.remove_outliers(ref, 0.8, 0)
+    got2 = ctx.removeOutliers(got, 0.8, 0)
+    assert leaf_of(got2._h) == 0.0 and np.array_equal(got2.numpy().view(np.uint32), ref2.view(np.uint32))
+
+
 def test_remove_outliers_exact(ctx, scene):
     for m in scene:
         got = ctx.removeOutliers(ctx.cloud(m["down"]), R_DESC, MIN_NB).numpy()
