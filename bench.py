@@ -54,7 +54,7 @@ VALU_PEAK_WINSTR_S = 8.4e11
 VALU_PEAK_NOMINAL_WINSTR_S = 256 * 4 * 2.4e9 / 2
 # profile name (MM3D_LAUNCH) of the kernels whose C++ symbol differs from it (scripts/pmc_summary.py prints symbols)
 KERNEL_OF_SYMBOL = {"k_sift_dog_lds": "sift_dog", "k_sift_dog_lds_dense": "sift_dog_dense", "k_sift_dog_lds_exact": "sift_dog_exact", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_spfh": "spfh", "k_normals": "normals_radius_big",
-                    "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_seq_sum": "sacia_seq_sum", "k_sift_dog_fast": "sift_dog_fast", "k_sift_reject": "sift_reject",
+                    "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_sacia_chain": "sacia_seq_sum", "k_sacia_select": "sacia_select", "k_sift_dog_fast": "sift_dog_fast", "k_sift_reject": "sift_reject",
                     "k_sift_extrema_one": "sift_extrema_one",
                     "k_fpfh_weight": "fpfh_weight", "k_knn_mfma": "desc_knn_mfma", "k_knn_mfma_wide_bf": "desc_knn_mfma_bf16", "k_knn_rerank": "desc_knn_rerank",
                     "k_radius_count": "radius_outlier_count"}
@@ -102,7 +102,7 @@ KERNEL_SYMBOLS = {
     "sift_dog": r"k_sift_dog_lds", "sift_dog_exact": r"k_sift_dog_lds", "sift_dog_fast": r"k_sift_dog_fast", "sift_reject": r"k_sift_reject",
     "sift_extrema_one": r"k_sift_extrema_one", "normals_radius": r"k_normals_lds", "spfh": r"k_spfh", "fpfh_weight": r"k_fpfh_weight",
     "fpfh_mark": r"k_fpfh_mark", "icp_corr_reduce": r"k_nn_waveILi0", "score_nn_reduce": r"k_nn_waveILi1", "sacia_err": r"k_sacia_err",
-    "sacia_seq_sum": r"k_seq_sum", "desc_knn_mfma": r"k_knn_(mfma|filter)", "desc_knn_mfma_bf16": r"k_knn_mfma_wide_bf", "desc_knn_rerank": r"k_knn_rerank",
+    "sacia_seq_sum": r"k_sacia_chain", "sacia_select": r"k_sacia_select", "desc_knn_mfma": r"k_knn_(mfma|filter)", "desc_knn_mfma_bf16": r"k_knn_mfma_wide_bf", "desc_knn_rerank": r"k_knn_rerank",
     "radius_outlier_count": r"k_radius_count", "voxel_centroid": r"k_voxel_centroid",
 }
 _ISA_CACHE = {}
@@ -534,6 +534,11 @@ def main():
                 "cgroup_throttled_ms_per_step": round((cgroup_throttle() - thr0) / 1e3 / max(args.steps, 1), 2)}
     if w0 and w1:
         host_cpu["stream_waits_per_step"] = round((w1[0] - w0[0]) / max(args.steps, 1), 1)
+    sacia_certified = None
+    if os.environ.get("MM3D_SACIA_STATS"):                 # (a study run: the collection costs a wait per batch of pairs)
+        st = mm.sacia_stats()
+        sacia_certified = {"pairs": st[0], "decided_without_a_chain": st[1], "candidates_left": st[2], "float_chains_run": st[3],
+                           "what": "SAC-IA's pick certified from the error sums in double (csrc/registration.hip::k_sacia_select), all steps of this run"}
     for c in ctxs:
         c.profile(False)
     # N = 1: the same step with the clouds handed over the way the reference's callers hold them -- host arrays of
@@ -883,6 +888,7 @@ def main():
             "maps_estimated": stats["n_estimated"],
             "icp_iterations_histogram": {str(k): int(v) for k, v in zip(*np.unique(stats["icp_iters"], return_counts=True))},
             "host_cpu": host_cpu,                           # the box's CPU quota bounds how many host threads can wait at once
+            **({"sacia_certified": sacia_certified} if sacia_certified else {}),
             "pair_transforms_crc32": stats["crc"],          # same job, same bits: independent of --gpus / --streams
             **({"rccl_gather_us": stats["rccl_gather_us"]} if "rccl_gather_us" in stats else {}),
             "roofline": roofline,

@@ -144,6 +144,12 @@ void mm3d_debug_sift_cert_min(int n);
  * removeOutliers' subset of it, R/src/features.cpp:19-40; every centroid within two leaves of a member of its voxel), 0 when
  * nothing is known -- what lets a grid build on the cloud skip its "did a cell outgrow the counting sort" wait */
 float mm3d_debug_cloud_voxel_leaf(const mm3d_cloud *cloud);
+/* test / study hook of SAC-IA's certified pick (csrc/registration.hip::k_sacia_select; R/src/matching.cpp:142-194 ->
+ * SampleConsensusInitialAlignment keeps the hypothesis of the lowest error sum): process-wide counters since the last reset --
+ * out[0] pairs scored, [1] pairs whose winner the sums in double decided (no float chain was run), [2] candidate hypotheses
+ * the intervals left, [3] float chains run.  collect = 1 / 0 switches the collection on / off (it costs a wait per batch;
+ * MM3D_SACIA_STATS in the environment switches it on for the whole process), collect < 0 leaves it as it is */
+void mm3d_debug_sacia_stats(long long out[4], int reset, int collect);
 /* test / study hook: the descriptor k-NN of findFeatureCorrespondences (R/src/matching.cpp:50-75) on raw rows of width `dim`
  * -- the widths of the reference's descriptors (2, 33, 125, 250, 1344, 1980) and 352, pcl::SHOT352's shape, which the reference
  * does not bind (dispatch_descriptors.h:44-46 binds SHOT1344) but BASELINE.json configs[3] names: idx / d2 receive na x k

@@ -139,6 +139,14 @@ def sift_cert_stats(reset=False):
     return list(out)
 
 
+def sacia_stats(reset=False, collect=-1):
+    """Process-wide counters of SAC-IA's certified pick (mm3d_debug_sacia_stats): pairs scored, pairs decided without a float
+    chain, candidate hypotheses the intervals left, chains run.  collect = 1 / 0 switches the collection on / off."""
+    out = (C.c_longlong * 4)()
+    lib().mm3d_debug_sacia_stats(out, 1 if reset else 0, int(collect))
+    return list(out)
+
+
 class Context:
     """One registration engine on one GPU (mm3d_ctx) -- or, with `devices`, on a list of GPUs of this one process
     (mm3d_create_devices): estimateMapsTransforms then shards over them inside the library and gathers the pair

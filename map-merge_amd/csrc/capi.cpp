@@ -363,6 +363,7 @@ int mm3d_debug_sift_cert_octave(mm3d_ctx *ctx, const mm3d_cloud *points, double 
 void mm3d_debug_sift_cert_stats(long long out[8], int reset) { if (out) debug_sift_cert_stats(out, reset); }
 void mm3d_debug_sift_cert_min(int n) { debug_sift_cert_min(n); }
 float mm3d_debug_cloud_voxel_leaf(const mm3d_cloud *cloud) { return cloud ? cloud->voxel_leaf : 0.0f; }
+void mm3d_debug_sacia_stats(long long out[4], int reset, int collect) { if (out) debug_sacia_stats(out, reset, collect); }
 void mm3d_srand(mm3d_ctx *ctx, unsigned seed) { if (ctx) ctx->rnd.seed(seed); }
 int mm3d_synchronize(mm3d_ctx *ctx) { return guarded(ctx, [&] { ctx->sync(); }); }
 

@@ -9,7 +9,9 @@
 // hypothesis in one launch with exactly the float predicate / float summation order of the
 // sequential CPU loop, so the host's replay of the accept logic picks the same hypothesis.
 // (ICP and transformScore live in nn.hip.)
+#include <atomic>
 #include <cfloat>
+#include <cstdlib>
 
 #include "device_util.hpp"
 #include "linalg_shared.hpp"
@@ -68,7 +70,14 @@ struct SacJob {
   float *E;                      // [H][ns_pad]
   float *err;                    // [H]
   float *T_best;                 // [16]
+  // the certified pick (below): per hypothesis the terms' sum in double and the number of terms that are not 1.0f (both
+  // zeroed), its class (0 out, 1 the chain decides, 2 its float sum is known), and the pair's verdict
+  double *S;                     // [H]
+  int *n_part;                   // [H]
+  unsigned char *cls;            // [H]
+  struct SacCtl *ctl;
 };
+struct SacCtl { int n_cand, decided, winner, n_chain; };
 
 __global__ void k_sacia_models(const SacJob *__restrict__ jobs, int H)
 {
@@ -106,13 +115,16 @@ k_sacia_err(const SacJob *__restrict__ jobs, int h_first, float thresh, float ra
   const GridView g = J.g;
   const float *__restrict__ T_all = J.T_all;
   float *__restrict__ E = J.E;
+  if ((int)(blockIdx.x * blockDim.x) >= ns) return;   // (the grid is as wide as the batch's largest pair)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ns) return;
+  const bool valid = i < ns;
   const int h = h_first + (int)blockIdx.y;            // uniform: the model sits in scalar registers
   const float *T = T_all + (size_t)h * 16;
   float Tl[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) Tl[k] = T[k];
+  float e_term = 0.0f;
+  if (valid) {
   const float4 s = skp[i];
   const float3 p = xform(Tl, s.x, s.y, s.z);
   float best = INFINITY;
@@ -157,80 +169,123 @@ k_sacia_err(const SacJob *__restrict__ jobs, int h_first, float thresh, float ra
   // the queries run in the source keypoints' Hilbert order (neighbouring lanes land in neighbouring target
   // cells: similar span lengths, shared cache lines); the summation order is the keypoint index order
   const int slot = permuted ? __float_as_int(s.w) : i;
-  E[(size_t)h * ns_pad + slot] = (best <= thresh) ? best / thresh : 1.0f;
+  e_term = (best <= thresh) ? best / thresh : 1.0f;
+  E[(size_t)h * ns_pad + slot] = e_term;
+  }
+  // for the certified pick: the terms' sum in double (any order) and how many terms are not exactly 1.0f
+  __shared__ double s_sum[4];
+  __shared__ int s_part[4];
+  const double ws = wave_sum((double)e_term);
+  const int part = __popcll(ballot(valid && e_term != 1.0f));
+  if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = ws; s_part[threadIdx.x >> 6] = part; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&J.S[h], (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
+    const int pt = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (pt) atomicAdd(&J.n_part[h], pt);
+  }
 }
 
-// error += e in source-keypoint order, float: the same chain the CPU path evaluates, bit for bit.
-// A block owns kSumRows hypotheses; all 256 threads stream the rows' tiles into LDS with coalesced
-// 16-byte loads (double buffered), the first kSumRows lanes walk their row out of LDS sequentially.
-constexpr int kSumRows = 8;
-constexpr int kSumTile = 1024;
-constexpr int kSumPad = 36;
-__global__ void __launch_bounds__(256) k_seq_sum(const SacJob *__restrict__ jobs, int H)
+// The certified pick.  SampleConsensusInitialAlignment keeps the hypothesis with the lowest error sum -- "if (i_iter == 0 ||
+// error < lowest_error)", ia_ransac.hpp -- and hands on that hypothesis' TRANSFORM; the sum itself leaves the stage nowhere.
+// The sum is a float chain in keypoint order (15.7 k dependent additions per hypothesis on the headline), and rounds 2 - 5
+// reproduced every hypothesis' chain (k_seq_sum: 200 us per launch inside the step, all of it latency).  What has to be the CPU
+// path's is the DECISION.  Every term lies in [0, 1], so the chain's partial sums never exceed the real sum R of the n float
+// terms, and its result F satisfies |F - R| <= (n - 1) u R (1 + (n - 1) u), u = 2^-24; S, the same terms summed in double in
+// whatever order the atomics arrive, is within n 2^-53 R of R.  So F lies in [S (1 - d), S (1 + d)], d = n u (1 + 1e-3) + 1e-12
+// -- 0.09 % at 15.7 k keypoints -- and a hypothesis whose interval lies wholly above the lowest upper end is not a minimum.
+// On the headline the second-best hypothesis of a pair is 0.7 - 8 % above the best (scripts/sacia_price.py,
+// profiles/r06_sacia_price.txt): ONE candidate is left and no chain runs at all.  A hypothesis all of whose terms are 1.0f
+// (no source keypoint lands within range of a target keypoint: maps that do not overlap) has F = n exactly.  What is left
+// takes the chain (k_sacia_chain), and the first minimum among the candidates is the CPU path's pick: every minimum of F is a
+// candidate, ties included.
+__global__ void __launch_bounds__(256) k_sacia_select(const SacJob *__restrict__ jobs, int H)
 {
-  const float *__restrict__ E = jobs[blockIdx.y].E;
-  const int ns = jobs[blockIdx.y].ns, ns_pad = jobs[blockIdx.y].ns_pad;
-  float *__restrict__ err = jobs[blockIdx.y].err;
-  // row stride = tile + 36 floats: lane r's 16-byte reads land on banks 36 r mod 64 (all distinct), and
-  // the zeroed tail lets the chain prefetch two groups past the end without a branch
-  __shared__ __attribute__((aligned(16))) float buf[2][kSumRows][kSumTile + kSumPad];
-  const int h0 = blockIdx.x * kSumRows;
-  for (int e = threadIdx.x; e < 2 * kSumRows * kSumPad; e += blockDim.x)
-    buf[e / (kSumRows * kSumPad)][(e / kSumPad) % kSumRows][kSumTile + e % kSumPad] = 0.0f;
-  const int rows = min(kSumRows, H - h0);
-  const int ntiles = (ns + kSumTile - 1) / kSumTile;
-  auto stage = [&](int t, int b) {
-    // kSumRows x kSumTile floats = 2048 float4, staged by waves 1..3 only (after the first tile): wave 0
-    // carries the add chains and must not sit on a global-memory wait between tiles
-    const int first = t == 0 ? 0 : kWave;
-    for (int e = (int)threadIdx.x - first; e >= 0 && e < kSumRows * (kSumTile / 4); e += (int)blockDim.x - first) {
-      const int r = e / (kSumTile / 4), c4 = e % (kSumTile / 4);
-      const int i = t * kSumTile + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < rows && i < ns_pad) v = *reinterpret_cast<const float4 *>(E + (size_t)(h0 + r) * ns_pad + i);
-      // everything past the row's end becomes +0: e + 0 == e, so the chain below can run in whole
-      // groups of 16 without a tail
-      if (i + 1 >= ns) v.y = 0.f;
-      if (i + 2 >= ns) v.z = 0.f;
-      if (i + 3 >= ns) v.w = 0.f;
-      if (i >= ns) v.x = 0.f;
-      *reinterpret_cast<float4 *>(&buf[b][r][c4 * 4]) = v;
-    }
-  };
-  float e = 0.0f;
-  stage(0, 0);
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
-    if ((int)threadIdx.x < rows) {
-      const int cnt = min(kSumTile, ns - t * kSumTile);
-      const float4 *row = reinterpret_cast<const float4 *>(buf[t & 1][threadIdx.x]);
-      const int groups = (cnt + 15) >> 4;
-      // The add chain is the critical path (one dependent v_add_f32 after another).  Two register
-      // sets of 16 values leapfrog: while one is being added the other is in flight from LDS.  Groups
-      // past the end are zeros (+0 leaves the sum unchanged).
-      float4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
-      float4 b0 = row[4], b1 = row[5], b2 = row[6], b3 = row[7];
-#pragma unroll 1
-      for (int gi = 0; gi < groups; gi += 2) {
-        e += a0.x; e += a0.y; e += a0.z; e += a0.w;
-        e += a1.x; e += a1.y; e += a1.z; e += a1.w;
-        e += a2.x; e += a2.y; e += a2.z; e += a2.w;
-        e += a3.x; e += a3.y; e += a3.z; e += a3.w;
-        a0 = row[gi * 4 + 8]; a1 = row[gi * 4 + 9]; a2 = row[gi * 4 + 10]; a3 = row[gi * 4 + 11];
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch HERE: the scheduler otherwise sinks it to its first use
-        e += b0.x; e += b0.y; e += b0.z; e += b0.w;
-        e += b1.x; e += b1.y; e += b1.z; e += b1.w;
-        e += b2.x; e += b2.y; e += b2.z; e += b2.w;
-        e += b3.x; e += b3.y; e += b3.z; e += b3.w;
-        b0 = row[gi * 4 + 12]; b1 = row[gi * 4 + 13]; b2 = row[gi * 4 + 14]; b3 = row[gi * 4 + 15];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __syncthreads();
+  const SacJob &J = jobs[blockIdx.x];
+  const double *__restrict__ S = J.S;
+  const int *__restrict__ n_part = J.n_part;
+  const double n = (double)J.ns;
+  const double d = n * 5.9604644775390625e-8 * 1.001 + 1e-12;
+  __shared__ double s_min[4];
+  __shared__ int s_cnt[4], s_chain[4], s_first[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the lowest upper end (a sum that is not a number compares false everywhere: no candidate at all -> everything is one)
+  double up = INFINITY;
+  for (int h = threadIdx.x; h < H; h += blockDim.x) {
+    const double hi = n_part[h] == 0 ? n : S[h] * (1.0 + d);
+    up = hi < up ? hi : up;
   }
-  if ((int)threadIdx.x < rows) err[h0 + threadIdx.x] = e;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(up, o, kWave); up = t < up ? t : up; }
+  if (lane == 0) s_min[wave] = up;
+  __syncthreads();
+  up = fmin(fmin(s_min[0], s_min[1]), fmin(s_min[2], s_min[3]));
+  int cnt = 0, chain = 0, first = 0x7fffffff;
+  for (int h = threadIdx.x; h < H; h += blockDim.x) {
+    const bool exact = n_part[h] == 0;
+    const double lo = exact ? n : S[h] * (1.0 - d);
+    const bool cand = lo <= up;
+    J.cls[h] = cand ? (exact ? 2 : 1) : 0;
+    if (exact) J.err[h] = (float)J.ns;                  // n ones add up to n without a rounding (n < 2^24)
+    cnt += cand ? 1 : 0;
+    chain += (cand && !exact) ? 1 : 0;
+    if (cand) first = min(first, h);
+  }
+  cnt = wave_sum(cnt); chain = wave_sum(chain); first = wave_min_int(first);
+  if (lane == 0) { s_cnt[wave] = cnt; s_chain[wave] = chain; s_first[wave] = first; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    chain = s_chain[0] + s_chain[1] + s_chain[2] + s_chain[3];
+    first = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
+    SacCtl c;
+    c.n_cand = cnt; c.n_chain = chain;
+    // one candidate: it is the minimum.  Candidates whose sums are all KNOWN and equal (every term of every one is 1.0f):
+    // the first of them.  No candidate (a sum that is not a number): every hypothesis takes the chain.
+    c.decided = (cnt == 1 || (cnt > 0 && chain == 0)) ? 1 : 0;
+    c.winner = c.decided ? first : -1;
+    *J.ctl = c;
+  }
+  __syncthreads();
+  const SacCtl c = *J.ctl;
+  if (c.n_cand == 0)
+    for (int h = threadIdx.x; h < H; h += blockDim.x) J.cls[h] = 1;
+  if (c.decided && threadIdx.x < 16) J.T_best[threadIdx.x] = J.T_all[(size_t)c.winner * 16 + threadIdx.x];
 }
+
+// error += e in source-keypoint order, float -- the chain the CPU path evaluates, bit for bit -- for the hypotheses the
+// certificate left open (cls 1): one lane per hypothesis, its row streamed from global memory four 16-byte loads ahead of the
+// additions.  No LDS: the launch is there for every batch and nearly always finds nothing to do, and a block that needs no
+// LDS does not queue for it behind the other streams' kernels.
+__global__ void __launch_bounds__(64) k_sacia_chain(const SacJob *__restrict__ jobs, int H)
+{
+  const SacJob &J = jobs[blockIdx.y];
+  if (J.ctl->decided) return;
+  const int h = blockIdx.x * 64 + threadIdx.x;
+  if (h >= H || J.cls[h] != 1) return;
+  const int ns = J.ns, ns_pad = J.ns_pad;
+  const float4 *__restrict__ row = reinterpret_cast<const float4 *>(J.E + (size_t)h * ns_pad);
+  const int groups = ns_pad >> 2;
+  float e = 0.0f;
+  float4 a0 = row[0], a1 = row[min(1, groups - 1)], a2 = row[min(2, groups - 1)], a3 = row[min(3, groups - 1)];
+  for (int g0 = 0; g0 < groups; g0 += 4) {
+    const float4 v0 = a0, v1 = a1, v2 = a2, v3 = a3;
+    const int nx = g0 + 4;
+    a0 = row[min(nx, groups - 1)]; a1 = row[min(nx + 1, groups - 1)]; a2 = row[min(nx + 2, groups - 1)]; a3 = row[min(nx + 3, groups - 1)];
+    const float t[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    const int base = g0 * 4;
+    if (base + 16 <= ns) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) e += t[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (base + k < ns) e += t[k];                   // (entries past the row's end -- the padding, a clamped re-read -- are left out)
+    }
+  }
+  J.err[h] = e;
+}
+
 
 // the target-side search structure of SAC-IA scoring (cached on the keypoint cloud)
 static const Grid &sacia_target_grid(Context *c, const mm3d_cloud *tgt_kp, float corr_thresh)
@@ -255,6 +310,16 @@ void prepare_sacia_target(Context *c, const mm3d_cloud *kp, float corr_thresh)
 
 __global__ void k_sacia_pick(const SacJob *__restrict__ jobs, int H);
 
+// process-wide statistics of the certified pick (mm3d_debug_sacia_stats; collected only while switched on: it costs a wait
+// per batch): 0 pairs, 1 pairs decided without a chain, 2 candidates left by the intervals, 3 chains run
+static std::atomic<long long> g_sacia_stats[4];
+static std::atomic<int> g_sacia_collect{0};
+void debug_sacia_stats(long long out[4], int reset, int collect)
+{
+  for (int i = 0; i < 4; ++i) { out[i] = g_sacia_stats[i].load(); if (reset) g_sacia_stats[i] = 0; }
+  if (collect >= 0) g_sacia_collect = collect;
+}
+
 // Models, errors, error sums and the pick for a batch of pairs: four launches whatever the batch size.
 // pairs[i].samp / corr_ref / nn and .T_best (16 floats) are device memory of the caller's; T_all, E and err are
 // scratch of this call (pool buffers of this context: whoever gets them next is enqueued behind these kernels).
@@ -264,6 +329,10 @@ void sacia_score_batch(Context *c, const SacPair *pairs, int n, int H, float cor
   const float radius = std::sqrt(corr_thresh > 0.f ? corr_thresh : 0.f);
   std::vector<DevBuf<float>> bufs;
   bufs.reserve((size_t)n * 3);
+  // the certified pick's words, one fill for the batch: per pair S [H doubles] | n_part [H ints] | ctl [16 B] | cls [H bytes]
+  const size_t per_pair = (((size_t)H * 13 + sizeof(SacCtl)) + 15) & ~(size_t)15;
+  DevBuf<unsigned char> cert(c, per_pair * (size_t)n);
+  MM3D_HIP(hipMemsetAsync(cert.get(), 0, per_pair * (size_t)n, c->stream));
   SacJob *hj = (SacJob *)c->pin(sizeof(SacJob) * (size_t)n);
   int max_ns = 0;
   double err_bytes = 0.0, sum_bytes = 0.0;
@@ -291,6 +360,11 @@ void sacia_score_batch(Context *c, const SacPair *pairs, int n, int H, float cor
     q.ns = ns; q.ns_pad = ns_pad;
     q.g = g.view();
     q.E = E; q.err = err; q.T_best = P.T_best;
+    unsigned char *cp = cert.get() + per_pair * (size_t)i;
+    q.S = reinterpret_cast<double *>(cp);
+    q.n_part = reinterpret_cast<int *>(cp + (size_t)H * 8);
+    q.ctl = reinterpret_cast<SacCtl *>(cp + (size_t)H * 12);
+    q.cls = cp + (size_t)H * 12 + sizeof(SacCtl);
     hj[i] = q;
     max_ns = std::max(max_ns, ns);
     err_bytes += (double)ns * H * 4.0 + ns * 16.0;
@@ -304,23 +378,42 @@ void sacia_score_batch(Context *c, const SacPair *pairs, int n, int H, float cor
     const int hn = std::min(65535, H - h0);
     MM3D_LAUNCH(c, "sacia_err", err_bytes * hn / H, k_sacia_err, dim3(div_up(max_ns, 256), hn, n), dim3(256), 0, dj, h0, corr_thresh, radius);
   }
-  MM3D_LAUNCH(c, "sacia_seq_sum", sum_bytes, k_seq_sum, dim3(div_up(H, kSumRows), n), dim3(256), 0, dj, H);
-  // "if (i_iter == 0 || error < lowest_error)": the first minimum, picked on the device
-  MM3D_LAUNCH(c, "sacia_pick", n * (H * 4.0 + 128.0), k_sacia_pick, dim3(n), dim3(64), 0, dj, H);
+  // "if (i_iter == 0 || error < lowest_error)": the first minimum, picked on the device -- certified from the sums in
+  // double where that decides it (nearly always: one candidate, no chain), from the CPU path's float chains of the
+  // candidates where it does not
+  MM3D_LAUNCH(c, "sacia_select", n * (H * 12.0 + 128.0), k_sacia_select, dim3(n), dim3(256), 0, dj, H);
+  MM3D_LAUNCH(c, "sacia_seq_sum", 0.0, k_sacia_chain, dim3(div_up(H, 64), n), dim3(64), 0, dj, H);
+  MM3D_LAUNCH(c, "sacia_pick", n * 128.0, k_sacia_pick, dim3(n), dim3(64), 0, dj, H);
+  (void)sum_bytes;
+  static const bool env_collect = getenv("MM3D_SACIA_STATS") != nullptr;
+  if (env_collect || g_sacia_collect.load()) {
+    SacCtl *hc = (SacCtl *)c->pin(sizeof(SacCtl) * (size_t)n);
+    for (int i = 0; i < n; ++i)
+      MM3D_HIP(hipMemcpyAsync(hc + i, hj[i].ctl, sizeof(SacCtl), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    for (int i = 0; i < n; ++i) {
+      g_sacia_stats[0] += 1; g_sacia_stats[1] += hc[i].decided ? 1 : 0;
+      g_sacia_stats[2] += hc[i].n_cand; g_sacia_stats[3] += hc[i].decided ? 0 : (hc[i].n_cand ? hc[i].n_chain : H);
+    }
+  }
 }
 
 // "if (i == 0 || error < lowest_error) keep": the first minimum, by one wave.  A NaN never wins a
 // '<', and a NaN at i == 0 is never beaten.
 __global__ void __launch_bounds__(64) k_sacia_pick(const SacJob *__restrict__ jobs, int H)
 {
+  if (jobs[blockIdx.x].ctl->decided) return;          // (k_sacia_select has written the winner's model)
   const float *__restrict__ err = jobs[blockIdx.x].err;
+  const unsigned char *__restrict__ cls = jobs[blockIdx.x].cls;
   const float *__restrict__ T_all = jobs[blockIdx.x].T_all;
   float *__restrict__ T_best = jobs[blockIdx.x].T_best;
   const int lane = threadIdx.x;
-  const float e0 = err[0];
+  // (hypothesis 0 is always a candidate or beaten by one; its sum is a number: every term is)
+  const float e0 = cls[0] ? err[0] : 0.0f;
   unsigned long long best = ~0ull;
   if (e0 == e0) {
     for (int i = lane; i < H; i += kWave) {
+      if (!cls[i]) continue;                            // certainly not a minimum
       const float e = err[i];
       if (e == e) {
         // e >= 0 (sums of non-negative terms) or -0: order the bits as values, ties to the lower index

@@ -268,6 +268,7 @@ struct SacPair {
   float *T_best;          // out: the winning model, 16 floats
 };
 void sacia_score_batch(Context *c, const SacPair *pairs, int n, int H, float corr_thresh);
+void debug_sacia_stats(long long out[4], int reset, int collect);
 // build (and cache on the clouds) every search structure pair estimates with these parameters read
 void prepare_pair_search(Context *c, const mm3d_cloud *points, double max_corr_dist, double score_max_distance);
 void prepare_sacia_target(Context *c, const mm3d_cloud *kp, float corr_thresh);

@@ -176,6 +176,9 @@ void mo_sac_ia(const mo_point *src_kp, const float *src_desc, int ns,
                double min_sample_distance, double max_correspondence_distance,
                int max_iterations, float T[16], int *best_iter_out,
                float *best_err_out);
+/* study hook (scripts/sacia_price.py): while `sink` is not NULL, mo_sac_ia also leaves the float error sum of hypothesis i
+ * (computeErrorMetric, ia_ransac.hpp) in sink[i] for i < capacity and the same sum in double in sink64[i] */
+void mo_sac_ia_error_sink(float *sink, double *sink64, int capacity);
 /* estimateTransformICP: R/src/matching.cpp:196-221. iters_out optional. */
 void mo_icp(const mo_point *src, int ns, const mo_point *tgt, int nt,
             const float guess[16], double max_correspondence_distance,

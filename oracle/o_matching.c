@@ -249,6 +249,14 @@ int mo_ransac(const mo_point *src_kp, int ns, const mo_point *tgt_kp, int nt, co
 /* SAC-IA */
 static inline int get_random_index(int n) { return (int)(n * (mo_rand() / (2147483647 + 1.0))); }
 
+static float *g_sacia_sink = NULL;
+static double *g_sacia_sink64 = NULL;
+static int g_sacia_sink_cap = 0;
+void mo_sac_ia_error_sink(float *sink, double *sink64, int capacity)
+{
+  g_sacia_sink = sink; g_sacia_sink64 = sink64; g_sacia_sink_cap = sink ? capacity : 0;
+}
+
 void mo_sac_ia(const mo_point *src_kp, const float *src_desc, int ns, const mo_point *tgt_kp,
                const float *tgt_desc, int nt, int dim, double min_sample_distance_d,
                double max_correspondence_distance, int max_iterations, float T[16],
@@ -333,6 +341,12 @@ void mo_sac_ia(const mo_point *src_kp, const float *src_desc, int ns, const mo_p
     }
     float error = 0.0f;
     for (int i = 0; i < ns; ++i) error += err_of[i];
+    if (it < g_sacia_sink_cap) {
+      double e64 = 0.0;
+      for (int i = 0; i < ns; ++i) e64 += (double)err_of[i];
+      g_sacia_sink[it] = error;
+      if (g_sacia_sink64) g_sacia_sink64[it] = e64;
+    }
     if (it == 0 || error < lowest_error) {
       lowest_error = error;
       memcpy(best, Tm, sizeof(best));

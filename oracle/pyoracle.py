@@ -319,6 +319,18 @@ def sac_ia(src_kp, src_desc, tgt_kp, tgt_desc, min_sample_distance, max_corr_dis
     return T.reshape(4, 4).T.copy(), bi.value, be.value
 
 
+def sac_ia_errors(src_kp, src_desc, tgt_kp, tgt_desc, min_sample_distance, max_corr_dist, max_iterations):
+    """sac_ia + every hypothesis' error sum: the CPU path's float chain and the same terms summed in double (study hook)."""
+    ef = np.zeros(int(max_iterations), dtype=np.float32)
+    ed = np.zeros(int(max_iterations), dtype=np.float64)
+    lib().mo_sac_ia_error_sink(_p(ef), _p(ed), int(max_iterations))
+    try:
+        T, bi, be = sac_ia(src_kp, src_desc, tgt_kp, tgt_desc, min_sample_distance, max_corr_dist, max_iterations)
+    finally:
+        lib().mo_sac_ia_error_sink(None, None, 0)
+    return T, bi, be, ef, ed
+
+
 def icp(src, tgt, guess, max_corr_dist, outlier_thr, max_iterations, eps):
     src, tgt = _pts(src), _pts(tgt)
     g = np.ascontiguousarray(np.asarray(guess, dtype=np.float32).T.reshape(16))

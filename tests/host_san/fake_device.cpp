@@ -150,6 +150,7 @@ mm3d_desc *compute_shot(Context *c, const mm3d_cloud *, const mm3d_normals *, mm
 void debug_libm(Context *, int, const float *x, const float *, int n, float *out) { for (int i = 0; i < n; ++i) out[i] = x[i]; }
 size_t debug_sift_cert_octave(Context *, const mm3d_cloud *, double, int, float *, float *, size_t) { return 0; }
 void debug_sift_cert_stats(long long *out, int) { for (int i = 0; i < 8; ++i) out[i] = 0; }
+void debug_sacia_stats(long long out[4], int, int) { for (int i = 0; i < 4; ++i) out[i] = 0; }
 void debug_sift_cert_min(int) {}
 void debug_float_chain(Context *, const float *incr, const unsigned *hits, int n, float *out)
 {

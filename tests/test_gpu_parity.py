@@ -488,6 +488,40 @@ def test_sac_ia_more_hypotheses_than_a_grid_dimension(ctx, po, scene):
     assert np.array_equal(T.view(np.uint32), T_ref.view(np.uint32))
 
 
+def test_sac_ia_certified_pick_in_all_its_cases(ctx, po, mm, scene):
+    """SAC-IA's winner is certified from the hypotheses' error sums in double (csrc/registration.hip::k_sacia_select); the CPU
+    path's float chain runs only for what the intervals leave open.  The cases: one candidate (the usual one: no chain at all);
+    nothing in range (every term of every hypothesis is 1.0f, every sum is n exactly: the FIRST hypothesis, no chain);
+    few keypoints, so that many hypotheses draw the same triples and tie exactly (the chains decide, the first minimum wins);
+    and a range so small that most hypotheses are all-ones and a few are not.  Same transform bits as the oracle in each."""
+    a, b = scene
+
+    def both(ka, da, kb, db, msd, corr, H, seed):
+        po.srand(seed)
+        T_ref, best_it, _ = po.sac_ia(ka, da, kb, db, msd, corr, H)
+        ctx.srand(seed)
+        mm.sacia_stats(reset=True, collect=1)
+        T = ctx.estimateTransformFromDescriptorsSets(ctx.cloud(ka), ctx.descriptors(da), ctx.cloud(kb), ctx.descriptors(db), msd, corr, H)
+        st = mm.sacia_stats(collect=0)
+        assert np.array_equal(T.view(np.uint32), T_ref.view(np.uint32)), (st, best_it)
+        return st, best_it
+
+    st, _ = both(a["kp"], a["desc"], b["kp"], b["desc"], 0.5, 1.0, 500, 1)
+    print("usual:", st)
+    assert st[0] == 1 and st[1] == 1 and st[2] == 1 and st[3] == 0
+    # (a hypothesis carries its three samples onto their partners, so it is a range below the rounding of that fit -- d2 <=
+    # 1e-14 -- that makes every term 1.0f)
+    st, it = both(a["kp"], a["desc"], b["kp"], b["desc"], 0.5, 1e-14, 300, 2)
+    print("nothing in range:", st, it)
+    assert st[1] == 1 and st[2] == 300 and st[3] == 0 and it == 0
+    ka, da, kb, db = a["kp"][:5], a["desc"][:5], b["kp"][:4], b["desc"][:4]
+    st, _ = both(ka, da, kb, db, 0.05, 1.0, 400, 3)
+    print("ties:", st)
+    assert st[2] > 1
+    st, _ = both(a["kp"][:300], a["desc"][:300], b["kp"][:300], b["desc"][:300], 0.5, 0.01, 500, 4)
+    print("small range:", st)
+
+
 def _small_rot(ax, ay, az, t):
     cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
     Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
