@@ -54,7 +54,7 @@ VALU_PEAK_WINSTR_S = 8.4e11
 VALU_PEAK_NOMINAL_WINSTR_S = 256 * 4 * 2.4e9 / 2
 # profile name (MM3D_LAUNCH) of the kernels whose C++ symbol differs from it (scripts/pmc_summary.py prints symbols)
 KERNEL_OF_SYMBOL = {"k_sift_dog_lds": "sift_dog", "k_sift_dog_lds_dense": "sift_dog_dense", "k_sift_dog_lds_exact": "sift_dog_exact", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_spfh": "spfh", "k_normals": "normals_radius_big",
-                    "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_sacia_chain": "sacia_seq_sum", "k_sacia_select": "sacia_select", "k_sift_dog_fast": "sift_dog_fast", "k_sift_reject": "sift_reject",
+                    "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce", "k_sacia_err": "sacia_err", "k_sacia_exact": "sacia_seq_sum", "k_sacia_select": "sacia_select", "k_sift_dog_fast": "sift_dog_fast", "k_sift_reject": "sift_reject",
                     "k_sift_extrema_one": "sift_extrema_one",
                     "k_fpfh_weight": "fpfh_weight", "k_knn_mfma": "desc_knn_mfma", "k_knn_mfma_wide_bf": "desc_knn_mfma_bf16", "k_knn_rerank": "desc_knn_rerank",
                     "k_radius_count": "radius_outlier_count"}
@@ -102,7 +102,7 @@ KERNEL_SYMBOLS = {
     "sift_dog": r"k_sift_dog_lds", "sift_dog_exact": r"k_sift_dog_lds", "sift_dog_fast": r"k_sift_dog_fast", "sift_reject": r"k_sift_reject",
     "sift_extrema_one": r"k_sift_extrema_one", "normals_radius": r"k_normals_lds", "spfh": r"k_spfh", "fpfh_weight": r"k_fpfh_weight",
     "fpfh_mark": r"k_fpfh_mark", "icp_corr_reduce": r"k_nn_waveILi0", "score_nn_reduce": r"k_nn_waveILi1", "sacia_err": r"k_sacia_err",
-    "sacia_seq_sum": r"k_sacia_chain", "sacia_select": r"k_sacia_select", "desc_knn_mfma": r"k_knn_(mfma|filter)", "desc_knn_mfma_bf16": r"k_knn_mfma_wide_bf", "desc_knn_rerank": r"k_knn_rerank",
+    "sacia_seq_sum": r"k_sacia_exact", "sacia_select": r"k_sacia_select", "desc_knn_mfma": r"k_knn_(mfma|filter)", "desc_knn_mfma_bf16": r"k_knn_mfma_wide_bf", "desc_knn_rerank": r"k_knn_rerank",
     "radius_outlier_count": r"k_radius_count", "voxel_centroid": r"k_voxel_centroid",
 }
 _ISA_CACHE = {}

@@ -64,16 +64,17 @@ struct SacJob {
   const float4 *skp, *tkp;       // keypoints in reference order (the models' samples)
   const int *samp, *corr_ref, *nn;
   float *T_all;                  // [H][16]
-  const float4 *skp_q;           // the queries of the error kernel (any order; .w = keypoint index when `permuted`)
-  int permuted, ns, ns_pad;
+  const float4 *skp_q;           // the queries of the error kernel (any order: the certificate's sums are order-free)
+  int ns;
   GridView g;                    // target keypoint grid with merged 3x3x3 lists
-  float *E;                      // [H][ns_pad]
-  float *err;                    // [H]
+  float *err;                    // [H]: the float chains' results of the hypotheses that needed one (k_sacia_exact)
   float *T_best;                 // [16]
   // the certified pick (below): per hypothesis the terms' sum in double and the number of terms that are not 1.0f (both
-  // zeroed), its class (0 out, 1 the chain decides, 2 its float sum is known), and the pair's verdict
+  // zeroed), its class (0 out, 1 the chain decides, 2 its float sum is known), the list of the class-1 hypotheses, and the
+  // pair's verdict
   double *S;                     // [H]
   int *n_part;                   // [H]
+  int *chain_list;               // [H]
   unsigned char *cls;            // [H]
   struct SacCtl *ctl;
 };
@@ -100,32 +101,13 @@ __global__ void k_sacia_models(const SacJob *__restrict__ jobs, int H)
 }
 
 // ---------------------------------------------------------------- SAC-IA hypothesis scoring
-// E[h][i] = TruncatedError(d2 of (T_h * src_i) to its nearest target keypoint); rows padded to a
-// multiple of 4 floats so the summation kernel can stream them with 16-byte loads.
+// One term of computeErrorMetric: TruncatedError(d2 of (T * s) to its nearest target keypoint).
 #ifndef MM3D_SAC_SUB
 #define MM3D_SAC_SUB 1
 #endif
 constexpr int kSacSub = MM3D_SAC_SUB;
-__global__ void __launch_bounds__(256)
-k_sacia_err(const SacJob *__restrict__ jobs, int h_first, float thresh, float radius)
+__device__ __forceinline__ float sacia_term(const GridView &g, const float *Tl, const float4 s, float thresh, float radius)
 {
-  const SacJob &J = jobs[blockIdx.z];
-  const float4 *__restrict__ skp = J.skp_q;
-  const int permuted = J.permuted, ns = J.ns, ns_pad = J.ns_pad;
-  const GridView g = J.g;
-  const float *__restrict__ T_all = J.T_all;
-  float *__restrict__ E = J.E;
-  if ((int)(blockIdx.x * blockDim.x) >= ns) return;   // (the grid is as wide as the batch's largest pair)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < ns;
-  const int h = h_first + (int)blockIdx.y;            // uniform: the model sits in scalar registers
-  const float *T = T_all + (size_t)h * 16;
-  float Tl[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) Tl[k] = T[k];
-  float e_term = 0.0f;
-  if (valid) {
-  const float4 s = skp[i];
   const float3 p = xform(Tl, s.x, s.y, s.z);
   float best = INFINITY;
   // 500 x K_s queries per pair against the same K_t targets: the stencil walk is taken out of the
@@ -166,12 +148,28 @@ k_sacia_err(const SacJob *__restrict__ jobs, int h_first, float thresh, float ra
       return true;
     });
   }
-  // the queries run in the source keypoints' Hilbert order (neighbouring lanes land in neighbouring target
-  // cells: similar span lengths, shared cache lines); the summation order is the keypoint index order
-  const int slot = permuted ? __float_as_int(s.w) : i;
-  e_term = (best <= thresh) ? best / thresh : 1.0f;
-  E[(size_t)h * ns_pad + slot] = e_term;
-  }
+  return (best <= thresh) ? best / thresh : 1.0f;
+}
+
+// Every (hypothesis, keypoint) term, summed per hypothesis in double and counted when it is not 1.0f: what the certified pick
+// below decides from.  The queries run in the source keypoints' Hilbert order (neighbouring lanes land in neighbouring target
+// cells: similar span lengths, shared cache lines).  Until round 6 the terms were WRITTEN, E[h][i], 31 MB per headline pair
+// in scattered 4-byte stores, for the float chains to read back; the chains that still run recompute theirs (k_sacia_exact):
+// the kernel alone 0.55 -> 0.42 ms per batch of three headline pairs, the headline + 3 %.
+__global__ void __launch_bounds__(256)
+k_sacia_err(const SacJob *__restrict__ jobs, int h_first, float thresh, float radius)
+{
+  const SacJob &J = jobs[blockIdx.z];
+  const int ns = J.ns;
+  if ((int)(blockIdx.x * blockDim.x) >= ns) return;   // (the grid is as wide as the batch's largest pair)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < ns;
+  const int h = h_first + (int)blockIdx.y;            // uniform: the model sits in scalar registers
+  const float *T = J.T_all + (size_t)h * 16;
+  float Tl[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) Tl[k] = T[k];
+  const float e_term = valid ? sacia_term(J.g, Tl, J.skp_q[i], thresh, radius) : 0.0f;
   // for the certified pick: the terms' sum in double (any order) and how many terms are not exactly 1.0f
   __shared__ double s_sum[4];
   __shared__ int s_part[4];
@@ -230,6 +228,7 @@ __global__ void __launch_bounds__(256) k_sacia_select(const SacJob *__restrict__
     cnt += cand ? 1 : 0;
     chain += (cand && !exact) ? 1 : 0;
     if (cand) first = min(first, h);
+    if (cand && !exact) J.chain_list[atomicAdd(&J.ctl->n_chain, 1)] = h;       // (ctl arrives zeroed; any order)
   }
   cnt = wave_sum(cnt); chain = wave_sum(chain); first = wave_min_int(first);
   if (lane == 0) { s_cnt[wave] = cnt; s_chain[wave] = chain; s_first[wave] = first; }
@@ -239,7 +238,7 @@ __global__ void __launch_bounds__(256) k_sacia_select(const SacJob *__restrict__
     chain = s_chain[0] + s_chain[1] + s_chain[2] + s_chain[3];
     first = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
     SacCtl c;
-    c.n_cand = cnt; c.n_chain = chain;
+    c.n_cand = cnt; c.n_chain = cnt == 0 ? H : chain;
     // one candidate: it is the minimum.  Candidates whose sums are all KNOWN and equal (every term of every one is 1.0f):
     // the first of them.  No candidate (a sum that is not a number): every hypothesis takes the chain.
     c.decided = (cnt == 1 || (cnt > 0 && chain == 0)) ? 1 : 0;
@@ -249,43 +248,46 @@ __global__ void __launch_bounds__(256) k_sacia_select(const SacJob *__restrict__
   __syncthreads();
   const SacCtl c = *J.ctl;
   if (c.n_cand == 0)
-    for (int h = threadIdx.x; h < H; h += blockDim.x) J.cls[h] = 1;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) { J.cls[h] = 1; J.chain_list[h] = h; }
   if (c.decided && threadIdx.x < 16) J.T_best[threadIdx.x] = J.T_all[(size_t)c.winner * 16 + threadIdx.x];
 }
 
 // error += e in source-keypoint order, float -- the chain the CPU path evaluates, bit for bit -- for the hypotheses the
-// certificate left open (cls 1): one lane per hypothesis, its row streamed from global memory four 16-byte loads ahead of the
-// additions.  No LDS: the launch is there for every batch and nearly always finds nothing to do, and a block that needs no
-// LDS does not queue for it behind the other streams' kernels.
-__global__ void __launch_bounds__(64) k_sacia_chain(const SacJob *__restrict__ jobs, int H)
+// certificate left open (chain_list): a block per hypothesis computes the terms of 256 keypoints at a time, in INDEX order,
+// into LDS, and one lane adds them up in that order.  ~250 us for a hypothesis of 15.7 k keypoints, a few of them in one pair
+// in forty; the launch is there for every batch and nearly always finds nothing to do (1 KB of LDS: it queues for none).
+constexpr int kSacExactBlocks = 8;       // blocks per pair; more open hypotheses than that are worked off in turns
+__global__ void __launch_bounds__(256) k_sacia_exact(const SacJob *__restrict__ jobs, float thresh, float radius)
 {
   const SacJob &J = jobs[blockIdx.y];
   if (J.ctl->decided) return;
-  const int h = blockIdx.x * 64 + threadIdx.x;
-  if (h >= H || J.cls[h] != 1) return;
-  const int ns = J.ns, ns_pad = J.ns_pad;
-  const float4 *__restrict__ row = reinterpret_cast<const float4 *>(J.E + (size_t)h * ns_pad);
-  const int groups = ns_pad >> 2;
-  float e = 0.0f;
-  float4 a0 = row[0], a1 = row[min(1, groups - 1)], a2 = row[min(2, groups - 1)], a3 = row[min(3, groups - 1)];
-  for (int g0 = 0; g0 < groups; g0 += 4) {
-    const float4 v0 = a0, v1 = a1, v2 = a2, v3 = a3;
-    const int nx = g0 + 4;
-    a0 = row[min(nx, groups - 1)]; a1 = row[min(nx + 1, groups - 1)]; a2 = row[min(nx + 2, groups - 1)]; a3 = row[min(nx + 3, groups - 1)];
-    const float t[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-    const int base = g0 * 4;
-    if (base + 16 <= ns) {
+  const int n_chain = J.ctl->n_chain, ns = J.ns;
+  __shared__ __attribute__((aligned(16))) float s_e[256];
+  for (int k = blockIdx.x; k < n_chain; k += gridDim.x) {
+    const int h = J.chain_list[k];
+    const float *T = J.T_all + (size_t)h * 16;
+    float Tl[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) e += t[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (base + k < ns) e += t[k];                   // (entries past the row's end -- the padding, a clamped re-read -- are left out)
+    for (int q = 0; q < 16; ++q) Tl[q] = T[q];
+    float e = 0.0f;
+    for (int i0 = 0; i0 < ns; i0 += 256) {
+      const int i = i0 + (int)threadIdx.x;
+      // (+0 past the end: e + 0 == e)
+      s_e[threadIdx.x] = i < ns ? sacia_term(J.g, Tl, J.skp[i], thresh, radius) : 0.0f;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const float4 *row = reinterpret_cast<const float4 *>(s_e);
+#pragma unroll 4
+        for (int g4 = 0; g4 < 64; ++g4) {
+          const float4 v = row[g4];
+          e += v.x; e += v.y; e += v.z; e += v.w;
+        }
+      }
+      __syncthreads();
     }
+    if (threadIdx.x == 0) J.err[h] = e;
   }
-  J.err[h] = e;
 }
-
 
 // the target-side search structure of SAC-IA scoring (cached on the keypoint cloud)
 static const Grid &sacia_target_grid(Context *c, const mm3d_cloud *tgt_kp, float corr_thresh)
@@ -320,8 +322,9 @@ void debug_sacia_stats(long long out[4], int reset, int collect)
   if (collect >= 0) g_sacia_collect = collect;
 }
 
-// Models, errors, error sums and the pick for a batch of pairs: four launches whatever the batch size.
-// pairs[i].samp / corr_ref / nn and .T_best (16 floats) are device memory of the caller's; T_all, E and err are
+// Models, errors and their sums, the certified pick (select, the float chains of what it leaves open, pick) for a batch of pairs:
+// five launches whatever the batch size.
+// pairs[i].samp / corr_ref / nn and .T_best (16 floats) are device memory of the caller's; T_all, err and the certificate's words are
 // scratch of this call (pool buffers of this context: whoever gets them next is enqueued behind these kernels).
 void sacia_score_batch(Context *c, const SacPair *pairs, int n, int H, float corr_thresh)
 {
@@ -329,24 +332,22 @@ void sacia_score_batch(Context *c, const SacPair *pairs, int n, int H, float cor
   const float radius = std::sqrt(corr_thresh > 0.f ? corr_thresh : 0.f);
   std::vector<DevBuf<float>> bufs;
   bufs.reserve((size_t)n * 3);
-  // the certified pick's words, one fill for the batch: per pair S [H doubles] | n_part [H ints] | ctl [16 B] | cls [H bytes]
-  const size_t per_pair = (((size_t)H * 13 + sizeof(SacCtl)) + 15) & ~(size_t)15;
+  // the certified pick's words, one fill for the batch: per pair S [H doubles] | n_part [H ints] | chain_list [H ints] |
+  // ctl [16 B] | cls [H bytes]
+  const size_t per_pair = (((size_t)H * 17 + sizeof(SacCtl)) + 15) & ~(size_t)15;
   DevBuf<unsigned char> cert(c, per_pair * (size_t)n);
   MM3D_HIP(hipMemsetAsync(cert.get(), 0, per_pair * (size_t)n, c->stream));
   SacJob *hj = (SacJob *)c->pin(sizeof(SacJob) * (size_t)n);
   int max_ns = 0;
-  double err_bytes = 0.0, sum_bytes = 0.0;
+  double err_bytes = 0.0;
   for (int i = 0; i < n; ++i) {
     const SacPair &P = pairs[i];
     const int ns = (int)P.src_kp->n;
-    const int ns_pad = (ns + 3) & ~3;
     const Grid &g = sacia_target_grid(c, P.tgt_kp, corr_thresh);
     cloud_hilbert(c, P.src_kp);                    // cached on the cloud (prepare_sacia_target)
     const bool permuted = P.src_kp->hil_pts.get() && P.src_kp->n_finite == P.src_kp->n;
     bufs.emplace_back(c, (size_t)H * 16);
     float *T_all = bufs.back().get();
-    bufs.emplace_back(c, (size_t)ns_pad * H);
-    float *E = bufs.back().get();
     bufs.emplace_back(c, (size_t)H);
     float *err = bufs.back().get();
     SacJob q;
@@ -356,19 +357,18 @@ void sacia_score_batch(Context *c, const SacPair *pairs, int n, int H, float cor
     q.samp = P.samp; q.corr_ref = P.corr_ref; q.nn = P.nn;
     q.T_all = T_all;
     q.skp_q = permuted ? (const float4 *)P.src_kp->hil_pts.get() : (const float4 *)P.src_kp->pts.get();
-    q.permuted = permuted ? 1 : 0;
-    q.ns = ns; q.ns_pad = ns_pad;
+    q.ns = ns;
     q.g = g.view();
-    q.E = E; q.err = err; q.T_best = P.T_best;
+    q.err = err; q.T_best = P.T_best;
     unsigned char *cp = cert.get() + per_pair * (size_t)i;
     q.S = reinterpret_cast<double *>(cp);
     q.n_part = reinterpret_cast<int *>(cp + (size_t)H * 8);
-    q.ctl = reinterpret_cast<SacCtl *>(cp + (size_t)H * 12);
-    q.cls = cp + (size_t)H * 12 + sizeof(SacCtl);
+    q.chain_list = reinterpret_cast<int *>(cp + (size_t)H * 12);
+    q.ctl = reinterpret_cast<SacCtl *>(cp + (size_t)H * 16);
+    q.cls = cp + (size_t)H * 16 + sizeof(SacCtl);
     hj[i] = q;
     max_ns = std::max(max_ns, ns);
-    err_bytes += (double)ns * H * 4.0 + ns * 16.0;
-    sum_bytes += (double)ns * H * 4.0;
+    err_bytes += (double)ns * H * 4.0 + ns * 16.0;          // (SURVEY 8d's figure: 4 B per (hypothesis, keypoint))
   }
   DevBuf<SacJob> d_jobs(c, (size_t)n);
   MM3D_HIP(hipMemcpyAsync(d_jobs.get(), hj, sizeof(SacJob) * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -382,9 +382,8 @@ void sacia_score_batch(Context *c, const SacPair *pairs, int n, int H, float cor
   // double where that decides it (nearly always: one candidate, no chain), from the CPU path's float chains of the
   // candidates where it does not
   MM3D_LAUNCH(c, "sacia_select", n * (H * 12.0 + 128.0), k_sacia_select, dim3(n), dim3(256), 0, dj, H);
-  MM3D_LAUNCH(c, "sacia_seq_sum", 0.0, k_sacia_chain, dim3(div_up(H, 64), n), dim3(64), 0, dj, H);
+  MM3D_LAUNCH(c, "sacia_seq_sum", 0.0, k_sacia_exact, dim3(kSacExactBlocks, n), dim3(256), 0, dj, corr_thresh, radius);
   MM3D_LAUNCH(c, "sacia_pick", n * 128.0, k_sacia_pick, dim3(n), dim3(64), 0, dj, H);
-  (void)sum_bytes;
   static const bool env_collect = getenv("MM3D_SACIA_STATS") != nullptr;
   if (env_collect || g_sacia_collect.load()) {
     SacCtl *hc = (SacCtl *)c->pin(sizeof(SacCtl) * (size_t)n);

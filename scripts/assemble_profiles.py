@@ -17,7 +17,7 @@ sys.path.insert(0, root)
 import bench  # noqa: E402  (KERNEL_SYMBOLS / kernel_source_hash: what makes a committed counter stale -- the machine code in THIS tree's libmm3d.so, which must be the library the GPU run used: do not rebuild between the run and this script)
 names = {"k_sift_dog_lds": "sift_dog", "k_sift_dog_lds_exact": "sift_dog_exact", "k_sift_dog_fast": "sift_dog_fast", "k_sift_reject": "sift_reject", "k_sift_extrema_one": "sift_extrema_one", "k_normals_lds": "normals_radius", "k_sift_dog": "sift_dog_big", "k_spfh": "spfh", "k_sacia_err": "sacia_err", "k_nn_wave": ["icp_corr_reduce", "score_nn_reduce"],
          "k_nn_wave<0>": "icp_corr_reduce", "k_nn_wave<1>": "score_nn_reduce",
-         "k_sacia_chain": "sacia_seq_sum", "k_sacia_select": "sacia_select", "k_knn_mfma": "desc_knn_mfma", "k_knn_rerank": "desc_knn_rerank",
+         "k_sacia_exact": "sacia_seq_sum", "k_sacia_select": "sacia_select", "k_knn_mfma": "desc_knn_mfma", "k_knn_rerank": "desc_knn_rerank",
          "k_fpfh_weight": "fpfh_weight", "k_fpfh_mark": "fpfh_mark", "k_normals": "normals_radius_big",
          "k_radius_count": "radius_outlier_count", "k_voxel_centroid": "voxel_centroid", "trampoline_kernel": "rocprim_radix_sort_pairs"}
 out, rows = {}, []
