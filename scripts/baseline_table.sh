@@ -15,8 +15,9 @@ run() {   # run <cfg> <bench args...>       (ONLY="5 1": just those rows)
   python3 -c "import json; d=json.load(open('gpurun_out/${TAG}_table_cfg$cfg.json')); print('cfg$cfg', d['value'], (d.get('cpu_baseline') or {}).get('value'), (d.get('cpu_baseline_all_cores') or {}).get('value'), (d.get('parity_check') or {}).get('ok'), d.get('icp_iterations_histogram'), d.get('gt_error', {}).get('recovered_within_0.5'))" \
     || { echo "cfg$cfg failed:"; tail -5 "/tmp/table_cfg$cfg.err"; }
 }
-run 1 --maps 2 --points 10000 --steps 10 --warmup 2
-run 2 --maps 4 --points 200000 --steps 5 --warmup 1
+# (steps of 4 and 14 ms: enough of them that one late host thread does not show -- five steps of row 2 gave 358 ... 435)
+run 1 --maps 2 --points 10000 --steps 30 --warmup 3
+run 2 --maps 4 --points 200000 --steps 15 --warmup 3
 run 3
 run 5 --maps 64 --points 50000 --steps 5 --warmup 1
 run 4 --maps 8 --points 2000000 --descriptor SHOT --steps 2 --warmup 1
