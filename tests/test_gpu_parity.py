@@ -520,6 +520,12 @@ def test_sac_ia_certified_pick_in_all_its_cases(ctx, po, mm, scene):
     assert st[2] > 1
     st, _ = both(a["kp"][:300], a["desc"][:300], b["kp"][:300], b["desc"][:300], 0.5, 0.01, 500, 4)
     print("small range:", st)
+    # three source keypoints and one target: every hypothesis carries the same triple, in one of six orders, onto the same point
+    # -- sums that differ by an ulp or not at all: far more candidates than the chain kernel has blocks per pair (it works them
+    # off in turns)
+    st, _ = both(a["kp"][:3], a["desc"][:3], b["kp"][:1], b["desc"][:1], 0.01, 1.0, 300, 5)
+    print("one triple:", st)
+    assert st[2] > 8
 
 
 def _small_rot(ax, ay, az, t):
