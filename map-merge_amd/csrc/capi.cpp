@@ -804,7 +804,7 @@ static void pairs_estimate_batch(mm3d_ctx *ctx, PairWork *w, size_t n, const mm3
   }
   if (!prepared.empty()) {
     // the sampled rows of every pair with the same target go through one descriptor search, and the hypotheses of
-    // all the batch's pairs are scored by the same four launches
+    // all the batch's pairs are scored by the same five launches
     std::stable_sort(prepared.begin(), prepared.end(), [](const SacPrepared &a, const SacPrepared &b) { return a.td < b.td; });
     std::vector<DevBuf<int>> nn_owners;
     std::vector<DevBuf<float>> nd_owners;
