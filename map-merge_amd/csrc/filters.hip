@@ -186,7 +186,7 @@ mm3d_cloud *downsample(Context *c, const mm3d_cloud *in_, double resolution)
   // by counting sort (grid.hip), or by rocPRIM's radix sort when some bin of the counting sort is very long
   DevBuf<int> too_long(c, 1);
   counting_sort_pairs_u32(c, keys.get(), n, (uint64_t)div_b[0] * (uint64_t)div_b[1] * (uint64_t)div_b[2], keys2.get(), vals2.get(),
-                          too_long.get());
+                          too_long.get(), in->n_finite == in->n);
   // One wait for the whole filter: the centroid launch is sized by its bound and reads the voxel count on the device, so the
   // count, the counting sort's "bin too long" word and the centroids' bounding box come back together (the new cloud needs no
   // k_bbox launch and no wait of its own).

@@ -717,8 +717,10 @@ __global__ void k_cs_place(const uint32_t *__restrict__ keys, const int *__restr
 
 // keys_out / idx_out: n entries; entries beyond the finite keys read 0xFFFFFFFF / are unspecified.  too_long (device)
 // must be checked by the caller after its next synchronisation.
+// no_invalid_keys: the caller knows that no key is 0xFFFFFFFF (every point finite) -- every output entry is written and the fill of
+// keys_out (n words: the largest of a map's fills) is left out.
 void counting_sort_pairs_u32(Context *c, const uint32_t *keys, int n, uint64_t key_range, uint32_t *keys_out, uint32_t *idx_out,
-                             int *too_long)
+                             int *too_long, bool no_invalid_keys)
 {
   uint32_t divisor = (uint32_t)((key_range + ((uint64_t)1 << 22) - 1) >> 22);
   if (divisor == 0) divisor = 1;
@@ -727,7 +729,7 @@ void counting_sort_pairs_u32(Context *c, const uint32_t *keys, int n, uint64_t k
   DevBuf<uint32_t> ranks(c, (size_t)n);
   MM3D_HIP(hipMemsetAsync(counts.get(), 0, ((size_t)nbins + 1) * sizeof(int), c->stream));
   MM3D_HIP(hipMemsetAsync(too_long, 0, sizeof(int), c->stream));
-  MM3D_HIP(hipMemsetAsync(keys_out, 0xFF, (size_t)n * sizeof(uint32_t), c->stream));
+  if (!no_invalid_keys) MM3D_HIP(hipMemsetAsync(keys_out, 0xFF, (size_t)n * sizeof(uint32_t), c->stream));
   MM3D_LAUNCH(c, "count_sort", n * 12.0, k_cs_count, dim3(div_up(n, 256)), dim3(256), 0, keys, n, divisor, counts.get(), ranks.get());
   exclusive_scan_int(c, counts.get(), bin_start.get(), (size_t)nbins + 1);
   MM3D_LAUNCH(c, "count_sort", n * 16.0, k_cs_scatter, dim3(div_up(n, 256)), dim3(256), 0, keys, (const uint32_t *)ranks.get(),

@@ -164,7 +164,7 @@ constexpr int kScanItems = 16, kScanTile = 256 * kScanItems;
 struct ScanLaunchState { unsigned long long *status; unsigned *ticket; unsigned ticket_base, epoch, tiles; };
 ScanLaunchState scan_prepare(Context *c, size_t n);
 void counting_sort_pairs_u32(Context *c, const uint32_t *keys, int n, uint64_t key_range, uint32_t *keys_out, uint32_t *idx_out,
-                             int *too_long);
+                             int *too_long, bool no_invalid_keys = false);
 void sort_pairs_u32(Context *c, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
                     size_t n, int end_bit);
 
